@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""Generate golden input/output vectors by running the REFERENCE's own source
+(/root/reference, read-only) on CPU.  TEST INFRASTRUCTURE ONLY.
+
+The reference ships no tests or known-answer vectors, so these
+files are the pins: they are produced by `models/dgl/pna_layer.py` (executed unmodified
+over oracle/dgl_standin.py) and by `models/pytorch/pna/layer.py` (imported unmodified).
+
+Run in the build container only (the GPU box has no /root/reference):
+    python oracle/make_golden.py            # writes tests/golden/*.npz
+The committed fixtures were produced with torch 2.10.0 (CPU path), seeds below.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import dgl_standin  # noqa: E402
+
+dgl_standin.install()
+from models.dgl.pna_layer import PNALayer as RefDGLLayer, PNASimpleLayer as RefSimpleLayer  # noqa: E402
+from models.pytorch.pna.layer import PNALayer as RefDenseLayer  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+AGG4 = "mean max min std"
+SCA3 = "identity amplification attenuation"
+
+
+def powerlaw_graph(rng, N, E, min_in_degree=1):
+    """Small multigraph with a skewed in/out-degree profile; every node gets >= min_in_degree
+    in-edges (the reference datasets have no isolated nodes)."""
+    w = (np.arange(N) + 1.0) ** -0.6
+    w /= w.sum()
+    perm = rng.permutation(N)
+    src = perm[rng.choice(N, size=E, p=w)]
+    dst = perm[rng.choice(N, size=E, p=w)]
+    extra_dst = np.repeat(np.arange(N), min_in_degree)
+    extra_src = rng.integers(0, N, size=extra_dst.size)
+    src = np.concatenate([src, extra_src])
+    dst = np.concatenate([dst, extra_dst])
+    p = rng.permutation(src.size)
+    return src[p].astype(np.int64), dst[p].astype(np.int64)
+
+
+def molecule_batch(rng, n_graphs, mean_nodes=23.2):
+    """ZINC-like batch: random spanning tree + ~10% ring closures, symmetrised."""
+    srcs, dsts, sizes, off = [], [], [], 0
+    for _ in range(n_graphs):
+        n = int(np.clip(round(rng.normal(mean_nodes, 4.3)), 9, 38))
+        u = np.arange(1, n)
+        v = np.array([rng.integers(0, i) for i in u])
+        k = max(1, n // 10)
+        ru, rv = rng.integers(0, n, k), rng.integers(0, n, k)
+        keep = ru != rv
+        a = np.concatenate([u, ru[keep]]) + off
+        b = np.concatenate([v, rv[keep]]) + off
+        srcs += [a, b]
+        dsts += [b, a]
+        sizes.append(n)
+        off += n
+    return np.concatenate(srcs).astype(np.int64), np.concatenate(dsts).astype(np.int64), sizes
+
+
+def randomise(module, gen):
+    """Replace the reference's tiny xavier(gain=1/in) init with weights ~ N(0, 1/fan_in) (activations
+    stay O(1)) and O(0.3) biases so that parity checks have teeth; BatchNorm affine parameters and
+    running stats are made non-trivial too."""
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if "batchnorm" in name:
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.3 + (1.0 if name.endswith("weight") else 0.0))
+            elif p.dim() == 2:
+                p.copy_(torch.randn(p.shape, generator=gen) / p.shape[1] ** 0.5)
+            else:
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.3)
+        for name, b in module.named_buffers():
+            if name.endswith("running_mean"):
+                b.copy_(torch.randn(b.shape, generator=gen) * 0.2)
+            if name.endswith("running_var"):
+                b.copy_(torch.rand(b.shape, generator=gen) + 0.5)
+
+
+def save(name, meta, arrays, module):
+    sd = {"sd/" + k: v.detach().cpu().numpy() for k, v in module.state_dict().items()}
+    arrays = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()}
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, meta=json.dumps(meta), **arrays, **sd)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB  out={arrays['out'].shape}")
+
+
+def golden_simple(name, seed, N, E, F, out_dim, aggregators=AGG4, scalers=SCA3, residual=True,
+                  default_init=False, posttrans_layers=1):
+    rng = np.random.default_rng(seed)
+    gen = torch.Generator().manual_seed(seed)
+    src, dst = powerlaw_graph(rng, N, E)
+    deg = np.bincount(dst, minlength=N)
+    avg_log = torch.tensor(float(np.mean(np.log(deg + 1))), dtype=torch.float32)
+    layer = RefSimpleLayer(F, out_dim, aggregators, scalers, {"log": avg_log}, 0.0, True, residual,
+                           posttrans_layers=posttrans_layers).eval()
+    if not default_init:
+        randomise(layer, gen)
+    h = torch.randn(N, F, generator=gen)
+    g = dgl_standin.StandinGraph(src, dst, N)
+    with torch.no_grad():
+        out = layer(g, h)
+        # the (V, A*S*F) tensor the reduce step leaves in ndata['h'] (pna_layer.py:194,:203)
+        g2 = dgl_standin.StandinGraph(src, dst, N)
+        g2.ndata["h"] = h
+        import dgl.function as fn
+        g2.update_all(fn.copy_u("h", "m"), layer.reduce_func)
+        agg = g2.ndata["h"]
+    meta = dict(kind="dgl_simple", seed=seed, N=N, F=F, out_dim=out_dim, aggregators=aggregators,
+                scalers=scalers, residual=residual, batch_norm=True, posttrans_layers=posttrans_layers)
+    save(name, meta, dict(src=src, dst=dst, h=h, avg_log=avg_log, agg=agg, out=out), layer)
+
+
+def golden_tower(name, seed, in_dim, out_dim, towers, divide_input, edge_dim=0, pretrans_layers=1,
+                 posttrans_layers=1, n_graphs=6, graph_norm=True, batch_norm=True, residual=True,
+                 aggregators=AGG4, scalers=SCA3):
+    rng = np.random.default_rng(seed)
+    gen = torch.Generator().manual_seed(seed)
+    src, dst, sizes = molecule_batch(rng, n_graphs)
+    N = int(sum(sizes))
+    deg = np.bincount(dst, minlength=N)
+    avg_log = torch.tensor(float(np.mean(np.log(deg + 1))), dtype=torch.float32)
+    layer = RefDGLLayer(in_dim, out_dim, aggregators, scalers, {"log": avg_log}, 0.0, graph_norm, batch_norm,
+                        towers=towers, pretrans_layers=pretrans_layers, posttrans_layers=posttrans_layers,
+                        divide_input=divide_input, residual=residual, edge_features=edge_dim > 0,
+                        edge_dim=edge_dim).eval()
+    randomise(layer, gen)
+    h = torch.randn(N, in_dim, generator=gen)
+    e = torch.randn(src.size, edge_dim, generator=gen) if edge_dim > 0 else torch.zeros(src.size, 0)
+    snorm_n = torch.cat([torch.full((s, 1), 1.0 / s) for s in sizes]).sqrt()   # data/molecules.py:157-159
+    g = dgl_standin.StandinGraph(src, dst, N)
+    with torch.no_grad():
+        out = layer(g, h, e if edge_dim > 0 else None, snorm_n)
+    meta = dict(kind="dgl_tower", seed=seed, N=N, in_dim=in_dim, out_dim=out_dim, towers=towers,
+                divide_input=divide_input, edge_dim=edge_dim, pretrans_layers=pretrans_layers,
+                posttrans_layers=posttrans_layers, graph_norm=graph_norm, batch_norm=batch_norm,
+                residual=residual, aggregators=aggregators, scalers=scalers, sizes=sizes)
+    save(name, meta, dict(src=src, dst=dst, h=h, e=e, snorm_n=snorm_n, avg_log=avg_log, out=out), layer)
+
+
+def golden_dense(name, seed, B, N, in_f, out_f, towers, divide_input, scalers, aggregators=("mean", "max", "min", "std"),
+                 self_loop=False, symmetric=True, p=0.3):
+    gen = torch.Generator().manual_seed(seed)
+    adj = (torch.rand(B, N, N, generator=gen) < p).float()
+    adj = adj * (1 - torch.eye(N))
+    if symmetric:                                           # benchmark graphs are symmetric 0/1
+        adj = torch.maximum(adj, adj.transpose(1, 2))
+    ring = torch.zeros(N, N)
+    idx = torch.arange(N)
+    ring[idx, (idx + 1) % N] = 1
+    ring[(idx + 1) % N, idx] = 1                            # no isolated nodes, rows AND columns non-empty
+    adj = torch.maximum(adj, ring.unsqueeze(0))
+    D = adj.sum(-1)
+    avg_d = dict(lin=torch.mean(D), exp=torch.mean(torch.exp(torch.div(1, D)) - 1), log=torch.mean(torch.log(D + 1)))
+    layer = RefDenseLayer(in_f, out_f, list(aggregators), list(scalers), avg_d, towers=towers, self_loop=self_loop,
+                          divide_input=divide_input).eval()
+    randomise(layer, gen)
+    x = torch.randn(B, N, in_f, generator=gen)
+    with torch.no_grad():
+        out = layer(x, adj)
+    meta = dict(kind="dense", seed=seed, B=B, N=N, in_features=in_f, out_features=out_f, towers=towers,
+                divide_input=divide_input, scalers=list(scalers), aggregators=list(aggregators),
+                self_loop=self_loop, symmetric=symmetric)
+    save(name, meta, dict(x=x, adj=adj, avg_lin=avg_d["lin"], avg_log=avg_d["log"], out=out), layer)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(1)
+    # --- PNASimpleLayer (MolHIV path, models/dgl/pna_layer.py:151-216) ---
+    golden_simple("simple_f75", 1234, N=96, E=900, F=75, out_dim=75)               # the roofline width
+    golden_simple("simple_f80_hiv", 42, N=64, E=200, F=80, out_dim=80)               # README.md:45 widths
+    golden_simple("simple_f20_order", 7, N=90, E=700, F=20, out_dim=12,
+                  aggregators="max std sum mean var min", scalers="attenuation identity", residual=False)
+    golden_simple("simple_f16_default_init", 41, N=50, E=300, F=16, out_dim=16, default_init=True)
+    golden_simple("simple_f33_post2", 3, N=70, E=400, F=33, out_dim=20, posttrans_layers=2, residual=False)
+    # --- PNALayer with towers (ZINC path, models/dgl/pna_layer.py:17-148) ---
+    golden_tower("tower_zinc_first", 41, in_dim=30, out_dim=30, towers=5, divide_input=False)
+    golden_tower("tower_zinc_last", 43, in_dim=30, out_dim=25, towers=5, divide_input=True)
+    golden_tower("tower_edgefeat", 44, in_dim=24, out_dim=24, towers=4, divide_input=True, edge_dim=6)
+    golden_tower("tower_deep_mlps", 45, in_dim=16, out_dim=16, towers=2, divide_input=False, pretrans_layers=2,
+                 posttrans_layers=2, graph_norm=False)
+    golden_tower("tower_f75", 46, in_dim=75, out_dim=70, towers=5, divide_input=False, n_graphs=3)
+    # --- dense variant (multitask path, models/pytorch/pna/layer.py) ---
+    golden_dense("dense_multitask_mid", 1234, B=6, N=14, in_f=16, out_f=16, towers=4, divide_input=True,
+                 scalers=("identity",))
+    golden_dense("dense_multitask_first", 42, B=5, N=11, in_f=2, out_f=16, towers=4, divide_input=False,
+                 scalers=("identity", "amplification", "attenuation"))
+    golden_dense("dense_linear_scalers", 5, B=3, N=9, in_f=8, out_f=8, towers=2, divide_input=True,
+                 scalers=("identity", "linear", "inverse_linear"), aggregators=("mean", "sum", "max", "min", "std", "var"))
+    golden_dense("dense_directed", 6, B=4, N=10, in_f=8, out_f=8, towers=2, divide_input=True,
+                 scalers=("identity", "amplification", "attenuation"), symmetric=False)
+    golden_dense("dense_self_loop", 8, B=3, N=8, in_f=8, out_f=4, towers=1, divide_input=True,
+                 scalers=("identity", "amplification"), self_loop=True)
+
+
+if __name__ == "__main__":
+    main()
