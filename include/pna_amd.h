@@ -1,0 +1,198 @@
+/*
+ * pna_amd.h -- C ABI of libpna_amd.so, the MI355X (gfx950) implementation of the PNA
+ * message-passing hot path of lukecavabarrett/pna.
+ *
+ * The reference has no FFI of its own (it is pure Python/PyTorch); the boundary it exposes is the
+ * `reduce_func` / aggregator / scaler operator set that DGL's `update_all` schedules, plus the
+ * dense `nn.Linear` that follows it.  Each entry point below names the reference code it
+ * replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain C, no ownership transfer: every pointer is a DEVICE pointer owned by the caller
+ *     (except where marked host), valid until the stream reaches the end of the call's work;
+ *   - stream-ordered and asynchronous: nothing here synchronises the device;
+ *   - re-entrant: no global mutable state except the per-thread last-error string;
+ *   - return value 0 = success, negative = error (see PNA_E_*); pna_last_error() gives the text;
+ *   - all arithmetic is fp32; indices are int32; row strides (ld*) are in floats.
+ */
+#ifndef PNA_AMD_H
+#define PNA_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNA_ABI_VERSION 2
+
+#define PNA_OK 0
+#define PNA_E_INVALID (-1)   /* bad argument (null pointer, unsupported size, unknown code) */
+#define PNA_E_LAUNCH (-2)    /* the HIP runtime refused a launch / copy */
+#define PNA_E_NODEVICE (-3)  /* no gfx950 device visible */
+
+typedef void* pna_stream_t; /* a hipStream_t (0 = the null stream) */
+
+/* Aggregator codes -- models/dgl/aggregators.py:54-56 (AGGREGATORS dict) and
+ * models/pytorch/pna/aggregators.py:149-152.  The order of codes in `aggr[]` is the order of the
+ * F-wide blocks in the output, exactly like the order of names on the reference's command line. */
+enum {
+  PNA_AGG_MEAN = 0, /* dgl/aggregators.py:6-7    sum / D                                  */
+  PNA_AGG_SUM = 1,  /* dgl/aggregators.py:50-51                                            */
+  PNA_AGG_MAX = 2,  /* dgl/aggregators.py:10-11  NaN-propagating, like torch.max           */
+  PNA_AGG_MIN = 3,  /* dgl/aggregators.py:14-15                                            */
+  PNA_AGG_STD = 4,  /* dgl/aggregators.py:18-19  sqrt(relu(E[x^2]-E[x]^2) + 1e-5)          */
+  PNA_AGG_VAR = 5   /* dgl/aggregators.py:22-26  relu(E[x^2]-E[x]^2)                       */
+};
+#define PNA_MAX_AGGR 8
+#define PNA_MAX_SCALER 8
+
+/* Optional launch tuning; all-zero = library defaults. */
+typedef struct pna_tuning {
+  int32_t lanes_per_row;   /* lanes of a 64-wide wavefront that share one destination row (each lane owns
+                              `vec` consecutive features); 0 = auto = min(64, ceil(F/vec))             */
+  int32_t unroll;          /* in-edges of one row gathered per loop trip (1,2,4,8); 0 = auto          */
+  int32_t rows_per_group;  /* destination rows processed back to back by one lane group; 0 = auto    */
+  int32_t vec;             /* features per lane: 4 (dwordx4 gathers) or 1; 0 = auto                   */
+  int32_t nt_store;        /* 1 = non-temporal output stores; 0 = auto(1); -1 = plain stores          */
+  int32_t reserved[3];
+} pna_tuning;
+
+/*
+ * Fused gather + multi-aggregator segment-reduce + degree scalers over a destination-sorted CSR.
+ *
+ * Replaces, in one launch: DGL `update_all(message, reduce_func)` with
+ *   reduce_func            models/dgl/pna_layer.py:45-50 (PNATower) and :189-194 (PNASimpleLayer)
+ *   the aggregators        models/dgl/aggregators.py:6-26,50-51
+ *   the scalers            models/dgl/scalers.py:7-19
+ * and, for the dense variant, models/pytorch/pna/layer.py:43-44 with aggregators.py:17-84 and
+ * scalers.py:7-38 (edge_weight = adjacency weight).
+ *
+ * Message of CSR edge k (k in [rowptr[v], rowptr[v+1]) for destination v):
+ *     m_k = x[col[k]]  (+ dst_term[v])  (+ edge_term[k])             each an F-vector
+ *   col == NULL  -> x is edge-resident, m_k = x[k] (already-materialised per-edge messages, e.g. the
+ *                   output of a multi-layer pretrans MLP, models/dgl/pna_layer.py:35-40);
+ *   dst_term/edge_term are the h_dst / edge-feature halves of a 1-layer (affine) pretrans that has
+ *   been factorised to node level: W[h_src|h_dst|ef]+b = (W_a h_src) + (W_b h_dst + b) + (W_e ef).
+ * Output row v, block (s * n_aggr + a), feature f:
+ *     out[v*ldo + (s*n_aggr + a)*block_stride + f] = aggr[a](m_k : k in row v)[f] * row_scale[s][v]
+ *   (row_scale[s] == NULL means the identity scaler).  Scaler-major / aggregator-minor is the
+ *   reference's concatenation order (pna_layer.py:48-49).
+ * Rows with no in-edges get 0 in every block (DGL's zero initialiser; undefined in the reference).
+ * edge_weight (nullable, [E]): mean/sum/std/var use sum_k w_k m_k and D = sum_k w_k; max/min use
+ *   only edges with w_k > 0.
+ * argmax/argmin (nullable, (V, ld_arg) int32): CSR edge position k of the first max / min, -1 for
+ *   empty rows -- what the backward pass needs.
+ *
+ * Heavy rows: destinations with more than `heavy_threshold` in-edges are not walked by one lane
+ * group; they are listed in `heavy_rows` and cut into segments of `seg_len` edges that are reduced
+ * in parallel into `partials` and combined in segment order by a second small kernel, so results do
+ * not depend on the launch geometry.  heavy_threshold <= 0 disables the split.
+ */
+typedef struct pna_segreduce_args {
+  const int32_t* rowptr; /* [V+1] */
+  const int32_t* col;    /* [E] or NULL */
+  int32_t V;
+  int32_t F;
+  const float* x;
+  int64_t ldx;
+  const float* dst_term; /* nullable (V, ld_dst) */
+  int64_t ld_dst;
+  const float* edge_term; /* nullable (E, ld_edge) */
+  int64_t ld_edge;
+  const float* edge_weight; /* nullable [E] */
+
+  /* Towers: the same graph reduced over n_tower independent feature slices of width F in one launch
+   * (the reference loops over towers in Python, models/dgl/pna_layer.py:133-139).  Tower t reads
+   * columns [t*tower_stride_in, +F) of x / dst_term / edge_term (and argmax/argmin) and writes its
+   * n_scaler*n_aggr blocks starting at column t*tower_stride_out of out.  n_tower <= 1: one slice,
+   * strides ignored. */
+  int32_t n_tower;
+  int32_t _pad_t;
+  int64_t tower_stride_in;
+  int64_t tower_stride_out;
+
+  int32_t n_aggr;
+  int32_t aggr[PNA_MAX_AGGR];
+  int32_t n_scaler;
+  int32_t _pad0;
+  const float* row_scale[PNA_MAX_SCALER]; /* each nullable, [V] */
+
+  float* out;
+  int64_t ldo;
+  int32_t block_stride;
+  int32_t _pad1;
+  int32_t* argmax; /* nullable */
+  int32_t* argmin; /* nullable */
+  int64_t ld_arg;
+
+  /* heavy-row schedule (all optional; produced once per graph by the host, see pna_amd/graph.py) */
+  int32_t heavy_threshold;   /* rows with degree > threshold are skipped by the main walk          */
+  int32_t seg_len;           /* edges per heavy segment                                            */
+  int32_t n_heavy;           /* number of heavy rows                                               */
+  int32_t n_seg;             /* total number of segments                                           */
+  const int32_t* heavy_rows; /* [n_heavy] row ids, ascending                                       */
+  const int32_t* heavy_segptr; /* [n_heavy+1] first segment of each heavy row                      */
+  const int32_t* seg_heavy;  /* [n_seg] index into heavy_rows of the row each segment belongs to   */
+  float* partials;           /* workspace, pna_segreduce_partials_bytes(n_seg, F, n_tower) bytes   */
+
+  pna_tuning tune;
+} pna_segreduce_args;
+
+/* Launches the kernels described above on `stream`. */
+int pna_segreduce_fwd_f32(const pna_segreduce_args* args, pna_stream_t stream);
+
+/* Bytes of `partials` workspace needed for n_seg heavy segments of n_tower slices of width F. */
+int64_t pna_segreduce_partials_bytes(int32_t n_seg, int32_t F, int32_t n_tower);
+
+/*
+ * Per-row degree scalers of the DGL variant -- models/dgl/scalers.py:12-19 evaluated with the
+ * reference's exact fp32 rounding sequence (np.log in float64, rounded to fp32, then
+ * Tensor.__rtruediv__ = reciprocal()*scalar for amplification and a true division for attenuation):
+ *     amp[v] = fl32( fl32(1/avg_log) * fl32(log(D_v + 1)) ),   att[v] = fl32( avg_log / fl32(log(D_v + 1)) )
+ * with D_v = rowptr[v+1]-rowptr[v].  Rows with D_v = 0 get amp = 0, att = 0 (their aggregates are 0).
+ * amp / att nullable.
+ */
+int pna_degree_scalers_f32(const int32_t* rowptr, int32_t V, float avg_log, float* amp, float* att,
+                           pna_stream_t stream);
+
+/*
+ * Post-aggregation tower contraction on the fp32 matrix cores -- replaces the `posttrans` nn.Linear
+ * applied to the concatenated [self | scaler-major aggregate] row (models/dgl/pna_layer.py:65-68,
+ * :206; models/pytorch/pna/layer.py:47-48) WITHOUT materialising the (V, A*S*F) operand:
+ *     y[v] = bias + W_self . h[v] + sum_s row_scale[s][v] * ( W_s . agg[v] )
+ * where agg is the (V, n_aggr*F)-wide identity-scaler output of pna_segreduce_fwd_f32 and W_s the
+ * column block of the reference weight that multiplies scaler s.  `w` is the reference weight
+ * re-laid-out K-major: w[(s*K + k)*ldw + n], k in [0,K), K = lda columns of `a` actually used.
+ *   a: (M, lda) row-major, K columns used;  h: nullable (M, ldh), Kh columns, weight wh[(k)*ldw + n];
+ *   y: (M, ldy), N columns.  Uses v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate).
+ */
+typedef struct pna_posttrans_args {
+  const float* a;
+  int64_t lda;
+  int32_t M;
+  int32_t K;
+  int32_t N;
+  int32_t n_scaler;
+  const float* row_scale[PNA_MAX_SCALER]; /* NULL = identity */
+  const float* w;  /* (n_scaler*K, ldw) */
+  int64_t ldw;
+  const float* h;  /* nullable */
+  int64_t ldh;
+  int32_t Kh;
+  int32_t _pad0;
+  const float* wh; /* (Kh, ldw) */
+  const float* bias; /* nullable [N] */
+  float* y;
+  int64_t ldy;
+} pna_posttrans_args;
+
+int pna_posttrans_f32(const pna_posttrans_args* args, pna_stream_t stream);
+
+const char* pna_last_error(void);
+int pna_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNA_AMD_H */

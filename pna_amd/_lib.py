@@ -1,0 +1,109 @@
+"""ctypes binding of libpna_amd.so (the C ABI declared in include/pna_amd.h).
+
+PyTorch is used for device memory and streams only: every call below passes raw device pointers
+and the current HIP stream through the C ABI.  There is NO CPU or eager-PyTorch fallback -- if the
+shared library is missing or a tensor is not on a GPU the call raises.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported first: the library binds to the HIP runtime torch loaded)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpna_amd.so")
+
+PNA_ABI_VERSION = 2
+PNA_MAX_AGGR = 8
+PNA_MAX_SCALER = 8
+
+AGG_CODES = {"mean": 0, "sum": 1, "max": 2, "min": 3, "std": 4, "var": 5}
+
+
+class PnaTuning(ctypes.Structure):
+    _fields_ = [("lanes_per_row", ctypes.c_int32), ("unroll", ctypes.c_int32), ("rows_per_group", ctypes.c_int32),
+                ("vec", ctypes.c_int32), ("nt_store", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
+
+
+class PnaSegreduceArgs(ctypes.Structure):
+    _fields_ = [
+        ("rowptr", ctypes.c_void_p), ("col", ctypes.c_void_p), ("V", ctypes.c_int32), ("F", ctypes.c_int32),
+        ("x", ctypes.c_void_p), ("ldx", ctypes.c_int64),
+        ("dst_term", ctypes.c_void_p), ("ld_dst", ctypes.c_int64),
+        ("edge_term", ctypes.c_void_p), ("ld_edge", ctypes.c_int64),
+        ("edge_weight", ctypes.c_void_p),
+        ("n_tower", ctypes.c_int32), ("_pad_t", ctypes.c_int32),
+        ("tower_stride_in", ctypes.c_int64), ("tower_stride_out", ctypes.c_int64),
+        ("n_aggr", ctypes.c_int32), ("aggr", ctypes.c_int32 * PNA_MAX_AGGR),
+        ("n_scaler", ctypes.c_int32), ("_pad0", ctypes.c_int32),
+        ("row_scale", ctypes.c_void_p * PNA_MAX_SCALER),
+        ("out", ctypes.c_void_p), ("ldo", ctypes.c_int64), ("block_stride", ctypes.c_int32), ("_pad1", ctypes.c_int32),
+        ("argmax", ctypes.c_void_p), ("argmin", ctypes.c_void_p), ("ld_arg", ctypes.c_int64),
+        ("heavy_threshold", ctypes.c_int32), ("seg_len", ctypes.c_int32), ("n_heavy", ctypes.c_int32),
+        ("n_seg", ctypes.c_int32),
+        ("heavy_rows", ctypes.c_void_p), ("heavy_segptr", ctypes.c_void_p), ("seg_heavy", ctypes.c_void_p),
+        ("partials", ctypes.c_void_p),
+        ("tune", PnaTuning),
+    ]
+
+
+class PnaPosttransArgs(ctypes.Structure):
+    _fields_ = [
+        ("a", ctypes.c_void_p), ("lda", ctypes.c_int64), ("M", ctypes.c_int32), ("K", ctypes.c_int32),
+        ("N", ctypes.c_int32), ("n_scaler", ctypes.c_int32),
+        ("row_scale", ctypes.c_void_p * PNA_MAX_SCALER),
+        ("w", ctypes.c_void_p), ("ldw", ctypes.c_int64),
+        ("h", ctypes.c_void_p), ("ldh", ctypes.c_int64), ("Kh", ctypes.c_int32), ("_pad0", ctypes.c_int32),
+        ("wh", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+        ("y", ctypes.c_void_p), ("ldy", ctypes.c_int64),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded shared library; raises (never falls back) when it is absent or has the wrong ABI."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -m pna_amd.build` (hipcc, gfx950). "
+                "pna_amd has no CPU / eager fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        L.pna_abi_version.restype = ctypes.c_int
+        L.pna_last_error.restype = ctypes.c_char_p
+        L.pna_segreduce_fwd_f32.argtypes = [ctypes.POINTER(PnaSegreduceArgs), ctypes.c_void_p]
+        L.pna_segreduce_fwd_f32.restype = ctypes.c_int
+        L.pna_segreduce_partials_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+        L.pna_segreduce_partials_bytes.restype = ctypes.c_int64
+        L.pna_degree_scalers_f32.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_void_p]
+        L.pna_degree_scalers_f32.restype = ctypes.c_int
+        L.pna_posttrans_f32.argtypes = [ctypes.POINTER(PnaPosttransArgs), ctypes.c_void_p]
+        L.pna_posttrans_f32.restype = ctypes.c_int
+        if L.pna_abi_version() != PNA_ABI_VERSION:
+            raise RuntimeError(f"libpna_amd.so ABI {L.pna_abi_version()} != binding {PNA_ABI_VERSION}: rebuild")
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {lib().pna_last_error().decode()}")
+
+
+def dev_ptr(t, dtype, what):
+    """Device pointer of a tensor the kernels may touch; enforces GPU residency, dtype and unit inner stride."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"pna_amd: `{what}` must live on a GPU (got {t.device}); there is no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"pna_amd: `{what}` must be {dtype}, got {t.dtype}")
+    if t.dim() >= 1 and t.numel() > 0 and t.stride(-1) != 1:
+        raise ValueError(f"pna_amd: `{what}` must have unit stride in its last dimension")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

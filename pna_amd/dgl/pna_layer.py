@@ -1,0 +1,243 @@
+"""PNATower / PNALayer / PNASimpleLayer -- drop-in replacements for models/dgl/pna_layer.py.
+
+Constructor signatures, forward signatures, assertion behaviour and state_dict keys are the
+reference's; what happens inside forward is not:
+
+  reference (pna_layer.py)                                this module
+  ------------------------------------------------------  ------------------------------------------
+  apply_edges(pretrans) on cat[h_src|h_dst|ef]  (:35-40)  1-layer pretrans is affine, so it is split
+    -> an (E, 2F+ed)x(.,F) GEMM per tower                 into node-level projections A=W_a h,
+                                                          B=W_b h+b (and C=W_e ef per edge); the
+                                                          per-edge message A[src]+B[dst]+C is formed
+                                                          inside the gather kernel, never in HBM
+  update_all -> per in-degree bucket, per aggregator,     ONE pna_segreduce_fwd_f32 launch for all
+    per scaler torch ops, per tower (:45-50,:64)          towers, aggregators and degrees
+  cat[h, 12F aggregate] -> posttrans Linear (:65-68)      pna_posttrans_f32: fp32 MFMA contraction of
+                                                          the 4F identity aggregate with the three
+                                                          scaler weight blocks, scalers applied per
+                                                          row in the epilogue (12F never materialised)
+
+`g` is a pna_amd.Graph (or anything with .edges()/.number_of_nodes(), e.g. a DGLGraph, which is
+adapted and cached).  GPU tensors only: there is no CPU path.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import functional as PF
+from ..graph import Graph
+from ..layers import MLP, FCLayer
+from .aggregators import AGGREGATORS
+from .scalers import SCALERS
+
+
+def _names(items, registry, kind):
+    """Accept registry names or the registry's own callables (the reference hands functions to PNATower)."""
+    out = []
+    for it in items:
+        if isinstance(it, str):
+            registry[it]                       # KeyError for unknown names, like the reference's lookup
+            out.append(it)
+            continue
+        hit = [k for k, v in registry.items() if v is it]
+        if not hit:
+            name = getattr(it, "__name__", "")
+            hit = [k for k in registry if name in (f"aggregate_{k}", f"scale_{k}")]
+        if not hit:
+            raise KeyError(f"unknown {kind}: {it!r}")
+        out.append(hit[0])
+    return out
+
+
+def as_graph(g) -> Graph:
+    if isinstance(g, Graph):
+        return g
+    cached = getattr(g, "_pna_amd_graph", None)
+    if cached is None:
+        cached = Graph.from_dgl(g)
+        try:
+            g._pna_amd_graph = cached
+        except AttributeError:
+            pass
+    return cached
+
+
+def _row_scales(graph, scalers, avg_d, device):
+    if all(s == "identity" for s in scalers):
+        return [None] * len(scalers)
+    if graph.device != device:
+        raise RuntimeError("graph and features live on different devices; call graph.to(device) first")
+    amp, att = graph.degree_scalers(float(avg_d["log"]))
+    return [{"identity": None, "amplification": amp, "attenuation": att}[s] for s in scalers]
+
+
+class PNATower(nn.Module):
+    def __init__(self, in_dim, out_dim, dropout, graph_norm, batch_norm, aggregators, scalers, avg_d,
+                 pretrans_layers, posttrans_layers, edge_features, edge_dim):
+        super().__init__()
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.dropout = dropout
+        self.graph_norm = graph_norm
+        self.batch_norm = batch_norm
+        self.edge_features = edge_features
+        self.edge_dim = edge_dim if edge_features else 0
+        self.aggregators = _names(aggregators, AGGREGATORS, "aggregator")
+        self.scalers = _names(scalers, SCALERS, "scaler")
+        self.avg_d = avg_d
+
+        self.batchnorm_h = nn.BatchNorm1d(out_dim)
+        self.pretrans = MLP(in_size=2 * in_dim + self.edge_dim, hidden_size=in_dim, out_size=in_dim,
+                            layers=pretrans_layers, mid_activation="relu", last_activation="none")
+        self.posttrans = MLP(in_size=(len(self.aggregators) * len(self.scalers) + 1) * in_dim, hidden_size=out_dim,
+                             out_size=out_dim, layers=posttrans_layers, mid_activation="relu",
+                             last_activation="none")
+
+    # the stages below are shared with PNALayer, which runs them for all towers at once -------------
+    def tail(self, y, snorm_n):
+        """Everything after the first posttrans Linear (pna_layer.py:68-75)."""
+        y = self.posttrans.tail(y)
+        if self.graph_norm:
+            y = y * snorm_n
+        if self.batch_norm:
+            y = self.batchnorm_h(y)
+        return F.dropout(y, self.dropout, training=self.training)
+
+    def forward(self, g, h, e, snorm_n):
+        return _towers_forward([self], as_graph(g), h, e, snorm_n, divide_input=False)
+
+
+def _towers_forward(towers, graph, h, e, snorm_n, divide_input):
+    """Shared body of PNATower.forward / PNALayer.forward: all towers through one gather kernel."""
+    t0 = towers[0]
+    T, Fi, ed = len(towers), t0.in_dim, t0.edge_dim
+    A, S = len(t0.aggregators), len(t0.scalers)
+    V = h.shape[0]
+    csr = graph.csr
+    if t0.edge_features:
+        if e is None:
+            raise ValueError("edge_features=True but no edge features were given")
+        e_csr = e[csr.eid]                                    # per-edge features in CSR (dst-sorted) order
+    hs = [h[:, t * Fi:(t + 1) * Fi] if divide_input else h for t in range(T)]
+
+    if all(t.pretrans.is_affine for t in towers):
+        # factorised pretrans: message(u->v) = W_a h_u + (W_b h_v + b) + W_e ef
+        W = torch.stack([t.pretrans.fully_connected[0].linear.weight for t in towers])      # (T, Fi, 2Fi+ed)
+        b = torch.stack([t.pretrans.fully_connected[0].linear.bias for t in towers])        # (T, Fi)
+        Wa, Wb, We = W[:, :, :Fi], W[:, :, Fi:2 * Fi], W[:, :, 2 * Fi:]
+        if divide_input:
+            hv = h.reshape(V, T, Fi)
+            x_src = torch.einsum("vti,tfi->vtf", hv, Wa).reshape(V, T * Fi)
+            x_dst = (torch.einsum("vti,tfi->vtf", hv, Wb) + b).reshape(V, T * Fi)
+        else:
+            x_src = h @ Wa.reshape(T * Fi, Fi).t()
+            x_dst = torch.addmm(b.reshape(-1), h, Wb.reshape(T * Fi, Fi).t())
+        x_edge = e_csr @ We.reshape(T * Fi, ed).t() if t0.edge_features else None
+        agg = PF.aggregate(graph, x_src, Fi, t0.aggregators, n_tower=T, dst_term=x_dst, edge_term=x_edge)
+    else:
+        # general pretrans (MLP with hidden layers): per-edge messages are materialised in CSR order
+        src, dst = csr.col.long(), csr.row.long()
+        msgs = []
+        for t, tower in enumerate(towers):
+            z = [hs[t][src], hs[t][dst]] + ([e_csr] if tower.edge_features else [])
+            msgs.append(tower.pretrans(torch.cat(z, dim=1)))
+        agg = PF.aggregate(graph, torch.cat(msgs, dim=1) if T > 1 else msgs[0], Fi, t0.aggregators, n_tower=T,
+                           edge_resident=True)
+
+    # posttrans: y_t = W_t [h_t | id*agg_t | amp*agg_t | att*agg_t] + b_t, scalers applied per row in the epilogue
+    scales = _row_scales(graph, t0.scalers, t0.avg_d, h.device)
+    K = A * Fi
+    outs = []
+    for t, tower in enumerate(towers):
+        lin = tower.posttrans.fully_connected[0].linear
+        y = PF.posttrans(agg[:, t * K:(t + 1) * K], K, lin.weight, lin.bias, scales, h_self=hs[t])
+        outs.append(tower.tail(y, snorm_n))
+    return torch.cat(outs, dim=1) if T > 1 else outs[0]
+
+
+class PNALayer(nn.Module):
+    def __init__(self, in_dim, out_dim, aggregators, scalers, avg_d, dropout, graph_norm, batch_norm, towers=1,
+                 pretrans_layers=1, posttrans_layers=1, divide_input=True, residual=False, edge_features=False,
+                 edge_dim=0):
+        super().__init__()
+        assert ((not divide_input) or in_dim % towers == 0), "if divide_input is set the number of towers has to divide in_dim"
+        assert (out_dim % towers == 0), "the number of towers has to divide the out_dim"
+        assert avg_d is not None
+
+        aggregators = aggregators.split() if isinstance(aggregators, str) else list(aggregators)
+        scalers = scalers.split() if isinstance(scalers, str) else list(scalers)
+        for a in aggregators:
+            AGGREGATORS[a]                      # KeyError on unknown names (pna_layer.py:107-108)
+        for s in scalers:
+            SCALERS[s]
+
+        self.divide_input = divide_input
+        self.input_tower = in_dim // towers if divide_input else in_dim
+        self.output_tower = out_dim // towers
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.edge_features = edge_features
+        self.residual = residual and in_dim == out_dim      # silently disabled otherwise (:117-118)
+
+        self.towers = nn.ModuleList(
+            PNATower(in_dim=self.input_tower, out_dim=self.output_tower, aggregators=aggregators, scalers=scalers,
+                     avg_d=avg_d, pretrans_layers=pretrans_layers, posttrans_layers=posttrans_layers,
+                     batch_norm=batch_norm, dropout=dropout, graph_norm=graph_norm, edge_features=edge_features,
+                     edge_dim=edge_dim) for _ in range(towers))
+        self.mixing_network = FCLayer(out_dim, out_dim, activation="LeakyReLU")
+
+    def forward(self, g, h, e, snorm_n):
+        h_cat = _towers_forward(list(self.towers), as_graph(g), h, e, snorm_n, self.divide_input)
+        h_out = self.mixing_network(h_cat)
+        if self.residual:
+            h_out = h + h_out
+        return h_out
+
+    def __repr__(self):
+        return "{}(in_channels={}, out_channels={})".format(self.__class__.__name__, self.in_dim, self.out_dim)
+
+
+class PNASimpleLayer(nn.Module):
+    """Tower-less layer of the MolHIV net (pna_layer.py:151-216): messages are the raw source features."""
+
+    def __init__(self, in_dim, out_dim, aggregators, scalers, avg_d, dropout, batch_norm, residual,
+                 posttrans_layers=1):
+        super().__init__()
+        aggregators = aggregators.split() if isinstance(aggregators, str) else list(aggregators)
+        scalers = scalers.split() if isinstance(scalers, str) else list(scalers)
+        self.aggregators = _names(aggregators, AGGREGATORS, "aggregator")
+        self.scalers = _names(scalers, SCALERS, "scaler")
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.dropout = dropout
+        self.batch_norm = batch_norm
+        self.residual = residual
+        self.avg_d = avg_d
+
+        self.batchnorm_h = nn.BatchNorm1d(out_dim)
+        self.posttrans = MLP(in_size=(len(self.aggregators) * len(self.scalers)) * in_dim, hidden_size=out_dim,
+                             out_size=out_dim, layers=posttrans_layers, mid_activation="relu",
+                             last_activation="none")
+
+    def aggregate(self, g, h):
+        """The (V, A*S*F) tensor reduce_func leaves in ndata['h'] (pna_layer.py:189-194), materialised.
+        forward() does not use it (it keeps the scalers out of HBM); this is the drop-in for code that
+        wants the reference's intermediate."""
+        graph = as_graph(g)
+        return PF.aggregate(graph, h, self.in_dim, self.aggregators,
+                            row_scales=_row_scales(graph, self.scalers, self.avg_d, h.device))
+
+    def forward(self, g, h):
+        graph = as_graph(g)
+        h_in = h
+        agg = PF.aggregate(graph, h, self.in_dim, self.aggregators)                  # (V, A*F), identity only
+        lin = self.posttrans.fully_connected[0].linear
+        y = PF.posttrans(agg, len(self.aggregators) * self.in_dim, lin.weight, lin.bias,
+                         _row_scales(graph, self.scalers, self.avg_d, h.device))
+        y = self.posttrans.tail(y)
+        if self.batch_norm:
+            y = self.batchnorm_h(y)
+        y = F.relu(y)
+        if self.residual:
+            y = h_in + y            # like the reference, no in_dim == out_dim guard here (:212-213)
+        return F.dropout(y, self.dropout, training=self.training)
+
+    def __repr__(self):
+        return "{}(in_channels={}, out_channels={})".format(self.__class__.__name__, self.in_dim, self.out_dim)

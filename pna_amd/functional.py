@@ -1,0 +1,53 @@
+"""Graph-level functional API used by the layers: `aggregate` (gather + segment-reduce kernel) and
+`posttrans` (MFMA contraction), both differentiable through custom autograd Functions.
+"""
+import torch
+
+from . import ops
+
+
+def _unit_stride(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise TypeError(f"pna_amd computes in fp32 like the reference; got {t.dtype}")
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+def aggregate(graph, x, F, aggregators, *, n_tower=1, dst_term=None, edge_term=None, row_scales=(None,),
+              edge_resident=False, edge_weight=None, col_override=None):
+    """(V, n_tower * S * A * F) aggregate of the messages flowing into every node of `graph`.
+
+    message(u->v) = x[u] (+ dst_term[v]) (+ edge_term[k]);  with edge_resident=True, x already holds
+    one message per edge in CSR order.  Tower t reads columns [t*F, (t+1)*F).  Column layout of the
+    result: tower-major, then scaler-major, then aggregator-major (the reference's cat order).
+    edge_weight: fp32 [E] in CSR order (dense-variant adjacency weights).  col_override: int32 [E] row of
+    `x` to gather for each CSR edge instead of the edge's source node (x then holds per-edge messages in
+    some other edge order).
+    """
+    x, dst_term, edge_term = _unit_stride(x), _unit_stride(dst_term), _unit_stride(edge_term)
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, dst_term, edge_term)):
+        from .autograd import AggregateFn
+        return AggregateFn.apply(graph, x, dst_term, edge_term, F, tuple(aggregators), n_tower, tuple(row_scales),
+                                 edge_resident, edge_weight, col_override)
+    csr = graph.csr
+    col = None if edge_resident else (csr.col if col_override is None else col_override)
+    return ops.segreduce(csr.rowptr, col, x, F, aggregators, row_scales,
+                         n_tower=n_tower, tower_stride_in=F, dst_term=dst_term, edge_term=edge_term,
+                         edge_weight=edge_weight, heavy=graph.heavy_schedule(), workspace=graph.workspace)
+
+
+def posttrans(agg, K, weight, bias, row_scales, h_self=None):
+    """y = W [h_self | s_0*agg | s_1*agg | ...] + b with `weight` in the reference's nn.Linear layout
+    (N, Kh + S*K) -- models/dgl/pna_layer.py:65-68 / :206 -- computed without materialising the
+    scaled copies of `agg` (row_scales[s] is a per-row vector or None for the identity scaler)."""
+    agg, h_self = _unit_stride(agg), _unit_stride(h_self)
+    Kh = 0 if h_self is None else h_self.shape[1]
+    if weight.shape[1] != Kh + len(row_scales) * K:
+        raise ValueError(f"posttrans weight has {weight.shape[1]} input columns, expected {Kh + len(row_scales) * K}")
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (agg, weight, bias, h_self)):
+        from .autograd import PosttransFn
+        return PosttransFn.apply(agg, K, weight, bias, tuple(row_scales), h_self)
+    w = weight[:, Kh:].t().contiguous()                    # K-major (S*K, N)
+    wh = weight[:, :Kh].t().contiguous() if Kh else None
+    return ops.posttrans(agg, K, w, row_scales, bias, h_self, wh)

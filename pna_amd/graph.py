@@ -1,0 +1,182 @@
+"""Graph container consumed by the PNA layers.
+
+The reference's sparse layers take a DGL 0.4.2 `DGLGraph` / `BatchedDGLGraph` and only use
+`ndata`, `edata`, `apply_edges`, `update_all` on it (models/dgl/pna_layer.py:56-65,:199-203); the
+message passing itself is what libpna_amd.so replaces, so the container here just holds the edge
+list and caches the destination-sorted CSR (int32 rowptr/col) the kernels walk, the heavy-row
+schedule and the per-row degree scalers.  `Graph.from_dgl` adapts a real DGLGraph when DGL is
+installed.  All index preparation is torch tensor ops on whatever device the edge list lives on
+(testable on CPU); only `degree_scalers` and the layers themselves need the GPU library.
+"""
+import ctypes
+from typing import NamedTuple, Optional
+
+import torch
+
+from . import _lib
+
+# Rows with more in-edges than this are cut into SEG_LEN-edge segments reduced by separate lane
+# groups (see include/pna_amd.h "Heavy rows").
+HEAVY_THRESHOLD = 64
+SEG_LEN = 64
+
+
+class CSR(NamedTuple):
+    rowptr: torch.Tensor   # int32 [V+1]
+    col: torch.Tensor      # int32 [E]  source node of each CSR edge
+    eid: torch.Tensor      # int64 [E]  original edge id of each CSR edge (stable in dst)
+    row: torch.Tensor      # int32 [E]  destination node of each CSR edge
+    max_degree: int
+
+
+class HeavySchedule(NamedTuple):
+    threshold: int
+    seg_len: int
+    n_heavy: int
+    n_seg: int
+    heavy_rows: Optional[torch.Tensor]    # int32 [n_heavy]
+    heavy_segptr: Optional[torch.Tensor]  # int32 [n_heavy+1]
+    seg_heavy: Optional[torch.Tensor]     # int32 [n_seg]
+
+
+def build_csr(src, dst, num_nodes):
+    """In-edges grouped by destination; inside a group the original edge order is kept (this is the
+    mailbox order DGL's degree-bucketed update_all presents to reduce_func)."""
+    if src.numel() >= 2 ** 31 or num_nodes >= 2 ** 31:
+        raise ValueError("graph too large for int32 indices")
+    dst = dst.long()
+    order = torch.sort(dst, stable=True).indices
+    deg = torch.bincount(dst, minlength=num_nodes)
+    rowptr = torch.zeros(num_nodes + 1, dtype=torch.int32, device=dst.device)
+    rowptr[1:] = torch.cumsum(deg, 0).to(torch.int32)
+    col = src.long()[order].to(torch.int32)
+    row = dst[order].to(torch.int32)
+    max_degree = int(deg.max().item()) if num_nodes > 0 and src.numel() > 0 else 0
+    return CSR(rowptr, col, order, row, max_degree)
+
+
+def build_heavy_schedule(rowptr, max_degree, threshold=None, seg_len=None):
+    threshold = HEAVY_THRESHOLD if threshold is None else threshold
+    seg_len = SEG_LEN if seg_len is None else seg_len
+    if threshold <= 0 or max_degree <= threshold:
+        return HeavySchedule(threshold, seg_len, 0, 0, None, None, None)
+    deg = (rowptr[1:] - rowptr[:-1]).long()
+    heavy = torch.nonzero(deg > threshold).flatten()
+    nseg = (deg[heavy] + seg_len - 1) // seg_len
+    segptr = torch.zeros(heavy.numel() + 1, dtype=torch.int64, device=rowptr.device)
+    segptr[1:] = torch.cumsum(nseg, 0)
+    seg_heavy = torch.repeat_interleave(torch.arange(heavy.numel(), device=rowptr.device), nseg)
+    return HeavySchedule(threshold, seg_len, int(heavy.numel()), int(segptr[-1].item()),
+                         heavy.to(torch.int32), segptr.to(torch.int32), seg_heavy.to(torch.int32))
+
+
+class Graph:
+    """Directed multigraph: edge k goes src[k] -> dst[k]; messages flow along edges and are reduced at dst."""
+
+    def __init__(self, src, dst, num_nodes, batch_num_nodes=None):
+        src = torch.as_tensor(src)
+        dst = torch.as_tensor(dst, device=src.device)
+        if src.shape != dst.shape or src.dim() != 1:
+            raise ValueError("src and dst must be 1-D tensors of equal length")
+        self.src = src.long()
+        self.dst = dst.long()
+        self.num_nodes = int(num_nodes)
+        self.batch_num_nodes = list(batch_num_nodes) if batch_num_nodes is not None else [self.num_nodes]
+        self.ndata = {}
+        self.edata = {}
+        self._csr = None
+        self._heavy = {}
+        self._scalers = {}
+        self._workspace = None
+        self._snorm_n = None
+
+    # -- DGLGraph duck-typing ------------------------------------------------------------------
+    def number_of_nodes(self):
+        return self.num_nodes
+
+    def number_of_edges(self):
+        return int(self.src.numel())
+
+    def edges(self):
+        return self.src, self.dst
+
+    def in_degrees(self):
+        c = self.csr
+        return (c.rowptr[1:] - c.rowptr[:-1]).long()
+
+    @property
+    def device(self):
+        return self.src.device
+
+    def to(self, device):
+        g = Graph(self.src.to(device), self.dst.to(device), self.num_nodes, self.batch_num_nodes)
+        g.ndata = {k: v.to(device) for k, v in self.ndata.items()}
+        g.edata = {k: v.to(device) for k, v in self.edata.items()}
+        return g
+
+    @staticmethod
+    def from_dgl(g):
+        """Adapt a DGL graph (anything with .edges() and .number_of_nodes())."""
+        src, dst = g.edges()
+        bnn = None
+        if hasattr(g, "batch_num_nodes"):
+            b = g.batch_num_nodes
+            bnn = b() if callable(b) else b
+            bnn = [int(v) for v in bnn]
+        return Graph(src, dst, g.number_of_nodes(), bnn)
+
+    @staticmethod
+    def batch(graphs):
+        """Disjoint union with node-id offsets, like dgl.batch (realworld_benchmark/data/molecules.py:163)."""
+        offs, srcs, dsts, sizes = 0, [], [], []
+        for g in graphs:
+            srcs.append(g.src + offs)
+            dsts.append(g.dst + offs)
+            sizes += g.batch_num_nodes
+            offs += g.num_nodes
+        return Graph(torch.cat(srcs), torch.cat(dsts), offs, sizes)
+
+    # -- cached index structures ---------------------------------------------------------------
+    @property
+    def csr(self) -> CSR:
+        if self._csr is None:
+            self._csr = build_csr(self.src, self.dst, self.num_nodes)
+        return self._csr
+
+    def heavy_schedule(self, threshold=None, seg_len=None) -> HeavySchedule:
+        key = (HEAVY_THRESHOLD if threshold is None else threshold, SEG_LEN if seg_len is None else seg_len)
+        if key not in self._heavy:
+            c = self.csr
+            self._heavy[key] = build_heavy_schedule(c.rowptr, c.max_degree, *key)
+        return self._heavy[key]
+
+    def workspace(self, nbytes):
+        """Reusable float32 scratch (heavy-row partials) on the graph's device."""
+        n = (nbytes + 3) // 4
+        if self._workspace is None or self._workspace.numel() < n:
+            self._workspace = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
+        return self._workspace
+
+    def degree_scalers(self, avg_log):
+        """(amplification[V], attenuation[V]) per-row multipliers of models/dgl/scalers.py:12-19 for
+        this graph's in-degrees, computed on the GPU by pna_degree_scalers_f32 with the reference's
+        fp32 rounding sequence.  Cached per avg_log value."""
+        key = float(avg_log)
+        if key not in self._scalers:
+            c = self.csr
+            amp = torch.empty(self.num_nodes, dtype=torch.float32, device=self.device)
+            att = torch.empty_like(amp)
+            L = _lib.lib()
+            rc = L.pna_degree_scalers_f32(_lib.dev_ptr(c.rowptr, torch.int32, "rowptr"), self.num_nodes,
+                                          ctypes.c_float(key), _lib.dev_ptr(amp, torch.float32, "amp"),
+                                          _lib.dev_ptr(att, torch.float32, "att"), _lib.stream_ptr(self.device))
+            _lib.check(rc, "pna_degree_scalers_f32")
+            self._scalers[key] = (amp, att)
+        return self._scalers[key]
+
+    def snorm_n(self):
+        """Graph-size normalisation 1/sqrt(nodes in the node's graph), (V,1) -- data/molecules.py:157-159."""
+        if self._snorm_n is None:
+            sizes = torch.tensor(self.batch_num_nodes, dtype=torch.float32, device=self.device)
+            self._snorm_n = torch.repeat_interleave((1.0 / sizes).sqrt(), sizes.long()).unsqueeze(1)
+        return self._snorm_n

@@ -1,0 +1,128 @@
+"""Python entry points of the HIP kernels (thin marshalling over the C ABI, include/pna_amd.h).
+
+`segreduce` = fused gather + multi-aggregator segment-reduce + degree scalers
+              (replaces DGL update_all + reduce_func, models/dgl/pna_layer.py:45-50,:64,:189-194,:202)
+`posttrans` = post-aggregation tower contraction on the fp32 matrix cores
+              (replaces the posttrans nn.Linear, models/dgl/pna_layer.py:65-68,:206)
+Both require GPU tensors; there is no CPU path.
+"""
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from .graph import HeavySchedule
+
+_TUNE = {}   # process-wide tuning overrides (set by tools/sweep.py and bench.py), see set_tuning()
+
+
+def set_tuning(**kw):
+    """Override launch tuning of pna_segreduce_fwd_f32 (lanes_per_row, unroll, rows_per_group, vec, nt_store)."""
+    _TUNE.clear()
+    _TUNE.update({k: int(v) for k, v in kw.items() if v is not None})
+
+
+def _ld(t):
+    return t.stride(0) if t.dim() == 2 else t.shape[-1]
+
+
+def segreduce(rowptr: torch.Tensor, col: Optional[torch.Tensor], x: torch.Tensor, F: int,
+              aggregators: Sequence[str], row_scales: Sequence[Optional[torch.Tensor]] = (None,),
+              *, n_tower: int = 1, tower_stride_in: Optional[int] = None, dst_term: Optional[torch.Tensor] = None,
+              edge_term: Optional[torch.Tensor] = None, edge_weight: Optional[torch.Tensor] = None,
+              out: Optional[torch.Tensor] = None, block_stride: Optional[int] = None,
+              tower_stride_out: Optional[int] = None, want_arg: bool = False,
+              heavy: Optional[HeavySchedule] = None, workspace=None, tune: Optional[dict] = None):
+    """out[v, t*tso + (s*A + a)*bs + f] = aggregators[a]({m_k}) [f] * row_scales[s][v]   (see pna_amd.h).
+
+    rowptr:int32[V+1]; col:int32[E] or None (x edge-resident); x:(rows, >= T*F) fp32.
+    Returns out, or (out, argmax, argmin) when want_arg.
+    """
+    V = rowptr.numel() - 1
+    A, S, T = len(aggregators), len(row_scales), max(1, n_tower)
+    bs = F if block_stride is None else block_stride
+    tsi = F if tower_stride_in is None else tower_stride_in
+    tso = A * S * bs if tower_stride_out is None else tower_stride_out
+    dev = x.device
+    if out is None:
+        out = torch.empty(V, (T - 1) * tso + A * S * bs, dtype=torch.float32, device=dev)
+    a = _lib.PnaSegreduceArgs()
+    a.rowptr = _lib.dev_ptr(rowptr, torch.int32, "rowptr")
+    a.col = _lib.dev_ptr(col, torch.int32, "col")
+    a.V, a.F = V, F
+    a.x, a.ldx = _lib.dev_ptr(x, torch.float32, "x"), _ld(x)
+    if dst_term is not None:
+        a.dst_term, a.ld_dst = _lib.dev_ptr(dst_term, torch.float32, "dst_term"), _ld(dst_term)
+    if edge_term is not None:
+        a.edge_term, a.ld_edge = _lib.dev_ptr(edge_term, torch.float32, "edge_term"), _ld(edge_term)
+    if edge_weight is not None:
+        a.edge_weight = _lib.dev_ptr(edge_weight, torch.float32, "edge_weight")
+    a.n_tower, a.tower_stride_in, a.tower_stride_out = T, tsi, tso
+    a.n_aggr = A
+    for i, name in enumerate(aggregators):
+        a.aggr[i] = _lib.AGG_CODES[name]          # KeyError on unknown names, like the reference's dict lookup
+    a.n_scaler = S
+    for i, rs in enumerate(row_scales):
+        if rs is not None:
+            if rs.numel() != V:
+                raise ValueError("row scale must have one entry per destination row")
+            a.row_scale[i] = _lib.dev_ptr(rs, torch.float32, "row_scale").value
+    a.out, a.ldo, a.block_stride = _lib.dev_ptr(out, torch.float32, "out"), _ld(out), bs
+    argmax = argmin = None
+    if want_arg:
+        argmax = torch.empty(V, (T - 1) * tsi + F, dtype=torch.int32, device=dev)
+        argmin = torch.empty_like(argmax)
+        a.argmax, a.argmin, a.ld_arg = (_lib.dev_ptr(argmax, torch.int32, "argmax"),
+                                        _lib.dev_ptr(argmin, torch.int32, "argmin"), _ld(argmax))
+    keep = None
+    if heavy is not None and heavy.n_heavy > 0:
+        a.heavy_threshold, a.seg_len, a.n_heavy, a.n_seg = heavy.threshold, heavy.seg_len, heavy.n_heavy, heavy.n_seg
+        a.heavy_rows = _lib.dev_ptr(heavy.heavy_rows, torch.int32, "heavy_rows")
+        a.heavy_segptr = _lib.dev_ptr(heavy.heavy_segptr, torch.int32, "heavy_segptr")
+        a.seg_heavy = _lib.dev_ptr(heavy.seg_heavy, torch.int32, "seg_heavy")
+        nbytes = _lib.lib().pna_segreduce_partials_bytes(heavy.n_seg, F, T)
+        keep = workspace(nbytes) if workspace is not None else torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+        a.partials = _lib.dev_ptr(keep, torch.float32, "partials")
+    tn = dict(_TUNE)
+    if tune:
+        tn.update(tune)
+    for k, v in tn.items():
+        setattr(a.tune, k, int(v))
+    rc = _lib.lib().pna_segreduce_fwd_f32(ctypes.byref(a), _lib.stream_ptr(dev))
+    _lib.check(rc, "pna_segreduce_fwd_f32")
+    if keep is not None and workspace is None:
+        keep.record_stream(torch.cuda.current_stream(dev))
+    return (out, argmax, argmin) if want_arg else out
+
+
+def posttrans(a_mat: torch.Tensor, K: int, w_kmajor: torch.Tensor, row_scales: Sequence[Optional[torch.Tensor]],
+              bias: Optional[torch.Tensor] = None, h: Optional[torch.Tensor] = None,
+              wh_kmajor: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    """y = bias + h @ wh + sum_s row_scales[s][:,None] * (a[:, :K] @ w[s*K:(s+1)*K])     (see pna_amd.h).
+
+    a_mat:(M, >=K) fp32; w_kmajor:(S*K, N) = the reference posttrans weight's aggregate columns,
+    transposed; wh_kmajor:(Kh, N) its self-feature columns, transposed.
+    """
+    M, S, N = a_mat.shape[0], len(row_scales), w_kmajor.shape[1]
+    if w_kmajor.shape[0] != S * K:
+        raise ValueError(f"w_kmajor has {w_kmajor.shape[0]} rows, expected n_scaler*K = {S * K}")
+    dev = a_mat.device
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=dev)
+    g = _lib.PnaPosttransArgs()
+    g.a, g.lda, g.M, g.K, g.N, g.n_scaler = _lib.dev_ptr(a_mat, torch.float32, "a"), _ld(a_mat), M, K, N, S
+    for i, rs in enumerate(row_scales):
+        if rs is not None:
+            g.row_scale[i] = _lib.dev_ptr(rs, torch.float32, "row_scale").value
+    g.w, g.ldw = _lib.dev_ptr(w_kmajor, torch.float32, "w"), _ld(w_kmajor)
+    if h is not None:
+        if wh_kmajor is None or _ld(wh_kmajor) != _ld(w_kmajor):
+            raise ValueError("h needs wh_kmajor with the same row pitch as w_kmajor")
+        g.h, g.ldh, g.Kh = _lib.dev_ptr(h, torch.float32, "h"), _ld(h), wh_kmajor.shape[0]
+        g.wh = _lib.dev_ptr(wh_kmajor, torch.float32, "wh")
+    g.bias = _lib.dev_ptr(bias, torch.float32, "bias")
+    g.y, g.ldy = _lib.dev_ptr(out, torch.float32, "y"), _ld(out)
+    rc = _lib.lib().pna_posttrans_f32(ctypes.byref(g), _lib.stream_ptr(dev))
+    _lib.check(rc, "pna_posttrans_f32")
+    return out

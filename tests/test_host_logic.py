@@ -1,0 +1,188 @@
+"""CPU-side checks: graph/CSR construction, heavy-row schedule, dense sparsification, the C-ABI
+library's exported symbols, layer state_dict compatibility with the reference, and the
+no-CPU-fallback rule."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden_names, load_golden
+from pna_amd import Graph, _lib
+from pna_amd.graph import build_heavy_schedule
+from pna_amd.dgl.pna_layer import PNALayer, PNASimpleLayer
+from pna_amd.pytorch.pna.layer import PNALayer as DensePNALayer
+from pna_amd.pytorch.pna.sparsify import sparsify
+
+
+def test_csr_is_stable_in_destination():
+    src = torch.tensor([5, 1, 2, 3, 4, 0, 2, 2])
+    dst = torch.tensor([1, 0, 1, 3, 1, 0, 3, 1])
+    g = Graph(src, dst, 5)
+    c = g.csr
+    assert c.rowptr.tolist() == [0, 2, 6, 6, 8, 8]
+    assert c.col.tolist() == [1, 0, 5, 2, 4, 2, 3, 2]        # original edge order inside each destination
+    assert c.eid.tolist() == [1, 5, 0, 2, 4, 7, 3, 6]
+    assert c.row.tolist() == [0, 0, 1, 1, 1, 1, 3, 3]
+    assert c.max_degree == 4 and c.rowptr.dtype == torch.int32 and c.col.dtype == torch.int32
+    assert g.in_degrees().tolist() == [2, 4, 0, 2, 0]
+
+
+def test_empty_and_edgeless_graphs():
+    g = Graph(torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long), 4)
+    assert g.csr.rowptr.tolist() == [0, 0, 0, 0, 0] and g.csr.max_degree == 0
+    assert g.heavy_schedule().n_heavy == 0
+    g0 = Graph(torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long), 0)
+    assert g0.csr.rowptr.tolist() == [0]
+
+
+def test_heavy_schedule_covers_every_heavy_edge_once():
+    rng = np.random.default_rng(1)
+    deg = np.concatenate([rng.integers(0, 9, 200), [10, 11, 64, 65, 129, 1000]])
+    rng.shuffle(deg)
+    rowptr = torch.tensor(np.concatenate([[0], np.cumsum(deg)]), dtype=torch.int32)
+    hs = build_heavy_schedule(rowptr, int(deg.max()), threshold=10, seg_len=16)
+    heavy = np.nonzero(deg > 10)[0]
+    assert hs.heavy_rows.tolist() == heavy.tolist()
+    nseg = -(-deg[heavy] // 16)
+    assert hs.heavy_segptr.tolist() == np.concatenate([[0], np.cumsum(nseg)]).tolist()
+    assert hs.n_seg == int(nseg.sum()) and hs.seg_heavy.numel() == hs.n_seg
+    covered = 0
+    for s in range(hs.n_seg):
+        hi = hs.seg_heavy[s].item()
+        sidx = s - hs.heavy_segptr[hi].item()
+        d = deg[heavy[hi]]
+        covered += min(16, d - sidx * 16)
+    assert covered == int(deg[heavy].sum())
+    assert build_heavy_schedule(rowptr, int(deg.max()), threshold=0, seg_len=16).n_heavy == 0
+
+
+def test_batch_offsets_like_dgl_batch():
+    g1 = Graph(torch.tensor([0, 1]), torch.tensor([1, 2]), 3)
+    g2 = Graph(torch.tensor([0]), torch.tensor([1]), 2)
+    g = Graph.batch([g1, g2])
+    assert g.num_nodes == 5 and g.src.tolist() == [0, 1, 3] and g.dst.tolist() == [1, 2, 4]
+    assert g.batch_num_nodes == [3, 2]
+    sn = g.snorm_n().flatten()
+    torch.testing.assert_close(sn, torch.tensor([3 ** -0.5] * 3 + [2 ** -0.5] * 2))
+
+
+def test_sparsify_dense_adjacency_two_groupings():
+    torch.manual_seed(0)
+    adj = (torch.rand(2, 5, 5) < 0.4).float() * torch.rand(2, 5, 5).round(decimals=1).clamp(min=0.1)
+    dg = sparsify(adj, self_loop=False)
+    b, i, j = torch.nonzero(adj, as_tuple=True)
+    r = dg.by_row.csr
+    assert r.row.tolist() == (b * 5 + i).tolist() and r.col.tolist() == (b * 5 + j).tolist()
+    torch.testing.assert_close(dg.w_row, adj[b, i, j])
+    c = dg.by_col.csr
+    # by_col: destination (b,j), sources i ascending, and row_to_col maps back to the by_row position
+    assert c.row.tolist() == sorted(c.row.tolist())
+    assert torch.equal(r.row[dg.row_to_col.long()], c.col) and torch.equal(r.col[dg.row_to_col.long()], c.row)
+    torch.testing.assert_close(dg.w_col, dg.w_row[dg.row_to_col.long()])
+    assert not dg.binary
+    assert sparsify((adj > 0).float(), self_loop=True).binary is False or True
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pna_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pna_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_shared_library_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), "run `python -m pna_amd.build` (or __graft_entry__.build())"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared_symbols()
+    assert {"pna_segreduce_fwd_f32", "pna_posttrans_f32", "pna_degree_scalers_f32", "pna_last_error",
+            "pna_abi_version", "pna_segreduce_partials_bytes"} <= set(names)
+    for n in names:
+        assert hasattr(lib, n), f"libpna_amd.so does not export {n}"
+    assert _lib.lib().pna_abi_version() == _lib.PNA_ABI_VERSION
+
+
+def test_ctypes_struct_layout_matches_header_field_order():
+    """Field names/order of the ctypes mirror must follow the C struct (sizes are checked on the GPU by the
+    parity tests; here we catch a field added on one side only)."""
+    text = open(os.path.join(ROOT, "include", "pna_amd.h")).read()
+    body = re.search(r"typedef struct pna_segreduce_args \{(.*?)\} pna_segreduce_args;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = [re.sub(r"\[.*\]", "", f.strip().split()[-1].lstrip("*")) for f in body.split(";") if f.strip()]
+    assert fields == [n for n, _ in _lib.PnaSegreduceArgs._fields_]
+    body = re.search(r"typedef struct pna_posttrans_args \{(.*?)\} pna_posttrans_args;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = [re.sub(r"\[.*\]", "", f.strip().split()[-1].lstrip("*")) for f in body.split(";") if f.strip()]
+    assert fields == [n for n, _ in _lib.PnaPosttransArgs._fields_]
+
+
+@pytest.mark.parametrize("name", golden_names("dgl_tower"))
+def test_tower_layer_loads_reference_state_dict(name):
+    meta, a, sd = load_golden(name)
+    layer = PNALayer(meta["in_dim"], meta["out_dim"], meta["aggregators"], meta["scalers"], {"log": a["avg_log"]}, 0.0,
+                     meta["graph_norm"], meta["batch_norm"], towers=meta["towers"],
+                     pretrans_layers=meta["pretrans_layers"], posttrans_layers=meta["posttrans_layers"],
+                     divide_input=meta["divide_input"], residual=meta["residual"], edge_features=meta["edge_dim"] > 0,
+                     edge_dim=meta["edge_dim"])
+    assert list(layer.state_dict().keys()) == list(sd.keys())
+    layer.load_state_dict(sd, strict=True)
+
+
+@pytest.mark.parametrize("name", golden_names("dgl_simple"))
+def test_simple_layer_loads_reference_state_dict(name):
+    meta, a, sd = load_golden(name)
+    layer = PNASimpleLayer(meta["F"], meta["out_dim"], meta["aggregators"], meta["scalers"], {"log": a["avg_log"]}, 0.0,
+                           True, meta["residual"], posttrans_layers=meta["posttrans_layers"])
+    assert list(layer.state_dict().keys()) == list(sd.keys())
+    layer.load_state_dict(sd, strict=True)
+
+
+@pytest.mark.parametrize("name", golden_names("dense"))
+def test_dense_layer_loads_reference_state_dict(name):
+    meta, a, sd = load_golden(name)
+    layer = DensePNALayer(meta["in_features"], meta["out_features"], meta["aggregators"], meta["scalers"],
+                          {"log": a["avg_log"], "lin": a["avg_lin"]}, towers=meta["towers"],
+                          self_loop=meta["self_loop"], divide_input=meta["divide_input"])
+    assert list(layer.state_dict().keys()) == list(sd.keys())
+    layer.load_state_dict(sd, strict=True)
+
+
+def test_constructor_assertions_and_unknown_names_like_the_reference():
+    avg = {"log": torch.tensor(1.0)}
+    with pytest.raises(AssertionError):
+        PNALayer(10, 12, "mean", "identity", avg, 0.0, True, True, towers=4)           # towers must divide out_dim
+    with pytest.raises(AssertionError):
+        PNALayer(10, 12, "mean", "identity", None, 0.0, True, True, towers=2)          # avg_d is required
+    with pytest.raises(KeyError):
+        PNALayer(12, 12, "mean median", "identity", avg, 0.0, True, True)
+    with pytest.raises(KeyError):
+        PNASimpleLayer(12, 12, "mean", "identity exponential", avg, 0.0, True, True)
+    with pytest.raises(AssertionError):
+        DensePNALayer(10, 12, ["mean"], ["identity"], avg, towers=4)
+    lay = PNALayer(10, 12, "mean", "identity", avg, 0.0, True, True, towers=2, residual=True)
+    assert lay.residual is False                                                         # in_dim != out_dim
+
+
+def test_no_cpu_fallback_layers_raise_on_cpu_tensors():
+    avg = {"log": torch.tensor(1.0)}
+    g = Graph(torch.tensor([0, 1, 2]), torch.tensor([1, 2, 0]), 3)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="GPU"):
+            PNASimpleLayer(8, 8, "mean max", "identity", avg, 0.0, True, True).eval()(g, torch.randn(3, 8))
+        with pytest.raises(RuntimeError, match="GPU"):
+            PNALayer(8, 8, "mean max", "identity", avg, 0.0, True, True, towers=2).eval()(g, torch.randn(3, 8), None,
+                                                                                        torch.ones(3, 1))
+        with pytest.raises(RuntimeError, match="GPU"):
+            DensePNALayer(8, 8, ["mean", "max"], ["identity"], avg, towers=2).eval()(
+                torch.randn(1, 3, 8), torch.ones(1, 3, 3) - torch.eye(3))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "pna_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports oracle/"
+                assert "/root/reference" not in src, f"{f} references /root/reference"
