@@ -1,0 +1,231 @@
+#!/usr/bin/env python
+"""bench.py -- PNA-layer forward edges/sec on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], "roofline config"): synthetic power-law graph,
+|V| = 1M and |E| = 10M directed edges PER GPU, F = 75, fp32; one step = one PNASimpleLayer forward
+(models/dgl/pna_layer.py:197-216: gather + mean/max/min/std + identity/amplification/attenuation +
+posttrans Linear(12F->F) + BatchNorm(eval) + ReLU + residual), eval mode, inputs resident in HBM.
+With N > 1 the graph has N x the nodes/edges (weak scaling), is sharded by destination range, and each
+step includes the RCCL halo all-to-all of source rows.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the fused segment-reduce kernel vs the 8 TB/s HBM roofline, ALGORITHMIC bytes
+                  E*(4F+4) + 4(V+1) + V*16F per launch / its measured mean duration
+  cpu_baseline -- the oracle's C port (oracle/pna_oracle.c, OpenMP) + torch CPU Linear/BN of the same
+                  layer, timed on this box's host cores on a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+V_PER_GPU = 1_000_000
+E_PER_GPU = 10_000_000
+F = 75
+AGGREGATORS = "mean max min std"
+SCALERS = "identity amplification attenuation"
+HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md
+MFMA_F32_PEAK = 157.3e12   # FLOP/s
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--nodes-per-gpu", type=int, default=V_PER_GPU)
+    p.add_argument("--edges-per-gpu", type=int, default=E_PER_GPU)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample-rows", type=int, default=250_000)
+    p.add_argument("--kernel-iters", type=int, default=20, help="launches used for the per-kernel HIP-event timing")
+    return p.parse_args()
+
+
+def event_time_ms(fn, iters, warmup=3):
+    """Mean duration of fn() over `iters` back-to-back launches, HIP events on torch's current stream
+    (the stream every pna_amd kernel is launched on)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def cpu_baseline(src, dst, V, h, layer_sd, avg_log, sample_rows):
+    """Reference-formulation layer forward on the host: C port of reduce_func (materialises the (V,12F)
+    aggregate like the reference) + torch CPU Linear / BatchNorm / ReLU / residual, on rows [0, sample_rows)."""
+    import numpy as np
+    from oracle import c_oracle
+    from pna_amd.graph import build_csr
+    torch.set_num_threads(os.cpu_count())
+    csr = build_csr(src.cpu(), dst.cpu(), V)
+    n = min(sample_rows, V)
+    rp = csr.rowptr[:n + 1].numpy().copy()
+    e_n = int(rp[-1])
+    col = csr.col[:e_n].numpy().copy()
+    x = h.cpu().numpy()
+    amp, att = c_oracle.degree_scalers(rp, float(avg_log))
+    sd = {k: v.cpu() for k, v in layer_sd.items()}
+    W, b = sd["posttrans.fully_connected.0.linear.weight"], sd["posttrans.fully_connected.0.linear.bias"]
+    out = np.empty((n, 12 * F), np.float32)
+    out[:] = 0                                                   # fault the pages in outside the clock
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        c_oracle.segreduce(rp, col, x, F, AGGREGATORS.split(), [None, amp, att], out=out)
+        y = torch.nn.functional.linear(torch.from_numpy(out), W, b)
+        y = torch.nn.functional.batch_norm(y, sd["batchnorm_h.running_mean"], sd["batchnorm_h.running_var"],
+                                           sd["batchnorm_h.weight"], sd["batchnorm_h.bias"], False)
+        y = torch.from_numpy(x[:n]) + torch.relu(y)
+        times.append(time.perf_counter() - t0)
+    t = min(times)
+    return {"value": e_n / t, "unit": "edges/s", "cores": os.cpu_count(), "kind": "port",
+            "threads": {"openmp": c_oracle.num_threads(), "torch": torch.get_num_threads()},
+            "sample": f"destination rows [0,{n}) of the same graph = {e_n} edges, 1 layer forward, best of 2 "
+                      f"({t:.2f} s); C/OpenMP port of reduce_func + torch CPU Linear/BN/ReLU"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from pna_amd import Graph
+    from pna_amd.dgl.pna_layer import PNASimpleLayer
+    from pna_amd.shard import shard_graph
+    from pna_amd.synth import powerlaw_graph
+    from pna_amd import ops, functional as PF
+
+    V, E = args.nodes_per_gpu * world, args.edges_per_gpu * world
+    src, dst = powerlaw_graph(V, E, seed=1234, device=dev)          # identical on every rank
+    deg = torch.bincount(dst, minlength=V)
+    avg_log = torch.log(deg.double() + 1).mean().float()            # avg_d['log'] of this graph (main_HIV.py:240-244)
+    if world > 1:
+        g = shard_graph(src, dst, V)
+        lo, hi = g.lo, g.hi
+    else:
+        g = Graph(src, dst, V)
+        lo, hi = 0, V
+    n_local = hi - lo
+    e_local = int(g.csr.rowptr[-1].item())
+    hs = g.heavy_schedule()
+    h_all = torch.randn(V, F, generator=torch.Generator().manual_seed(1234))   # x ~ N(0,1), seed 1234
+    h = h_all[lo:hi].to(dev)
+
+    torch.manual_seed(0)
+    layer = PNASimpleLayer(F, F, AGGREGATORS, SCALERS, {"log": avg_log}, 0.0, True, True)
+    with torch.no_grad():                                            # random-init weights of the architecture, O(1) activations
+        for p in layer.parameters():
+            p.copy_(torch.randn_like(p) / (p.shape[-1] ** 0.5 if p.dim() == 2 else 3.0))
+    layer_sd = {k: v.clone() for k, v in layer.state_dict().items()}
+    layer = layer.to(dev).eval()
+    g.degree_scalers(float(avg_log))
+
+    def step():
+        with torch.no_grad():
+            return layer(g, h)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = E / (dt / args.steps)
+
+    # ---- per-kernel timing of the dominant kernels (HIP events, this rank) ------------------------------
+    csr = g.csr
+    with torch.no_grad():
+        x_ext = g.source_features(h)
+        t_seg = event_time_ms(lambda: PF.aggregate(g, x_ext, F, AGGREGATORS.split()), args.kernel_iters)
+        agg = PF.aggregate(g, x_ext, F, AGGREGATORS.split())
+        lin = layer.posttrans.fully_connected[0].linear
+        amp, att = g.degree_scalers(float(avg_log))
+        t_post = event_time_ms(lambda: PF.posttrans(agg, 4 * F, lin.weight, lin.bias, [None, amp, att]), args.kernel_iters)
+        t_halo = event_time_ms(lambda: g.source_features(h), args.kernel_iters) if world > 1 else 0.0
+    alg_read = e_local * (4 * F + 4) + 4 * (n_local + 1)
+    alg_write = n_local * 16 * F
+    alg_bytes = alg_read + alg_write
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")      # PMC-derived HBM bytes per launch, if collected
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("pna_segreduce_c3", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "k_segreduce<4,U,false> (pna_segreduce_fwd_f32)",
+                "achieved": alg_bytes / (t_seg * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": alg_bytes / (t_seg * 1e-3) / HBM_PEAK, "traffic": traffic,
+                "ms_per_launch": t_seg, "algorithmic_bytes_per_launch": alg_bytes,
+                "read_only_frac": alg_read / (t_seg * 1e-3) / HBM_PEAK,
+                "edges_per_s_kernel_only": e_local / (t_seg * 1e-3),
+                "heavy_rows": hs.n_heavy, "heavy_segments": hs.n_seg}
+    flops = 2.0 * n_local * (12 * F) * F
+    roofline_post = {"bound": "mfma", "kernel": "k_posttrans<3,false> (pna_posttrans_f32)", "achieved": flops / (t_post * 1e-3) / 1e12,
+                     "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s", "frac": flops / (t_post * 1e-3) / MFMA_F32_PEAK,
+                     "ms_per_launch": t_post}
+
+    rec = {
+        "metric": "PNA-layer fwd edges/sec (F=75, 4 aggr x 3 scalers)", "value": value, "unit": "edges/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[2]: synthetic power-law graph |V|=1M |E|=10M per GPU, F=75, "
+                               "single PNA (simple) layer fwd: 4 aggregators x 3 scalers + posttrans Linear(900->75) + BN + ReLU + residual",
+                   "V": V, "E": E, "F": F, "aggregators": AGGREGATORS, "scalers": SCALERS,
+                   "parallelism": f"dst-range shard x{world}, halo all-to-all" if world > 1 else "single GPU",
+                   "max_in_degree": int(csr.max_degree), "halo_rows_rank0": getattr(g, "n_halo", 0)},
+        "roofline": roofline, "roofline_posttrans": roofline_post,
+        "kernel_ms": {"segreduce": t_seg, "posttrans": t_post, "halo_all_to_all": t_halo},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            rec["cpu_baseline"] = cpu_baseline(src, dst, V, h_all, layer_sd, avg_log, args.cpu_sample_rows)
+        except Exception as ex:                                     # the baseline must never sink the GPU number
+            rec["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": f"failed: {ex!r}"}
+    if rank == 0:
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -34,59 +34,84 @@ int pna_oracle_segreduce(const float* x, int64_t ldx, const int32_t* rowptr, con
                          const float* const* row_scale, float* out, int64_t ldo, int32_t block_stride,
                          int32_t acc_double) {
   int bad = 0;
-#pragma omp parallel for schedule(dynamic, 64)
-  for (int32_t v = 0; v < V; ++v) {
-    const int32_t beg = rowptr[v], end = rowptr[v + 1];
-    for (int32_t f = 0; f < F; ++f) {
-      float s32 = 0.f, q32 = 0.f, w32 = 0.f;
-      double s64 = 0.0, q64 = 0.0, w64 = 0.0;
-      float mx = -INFINITY, mn = INFINITY;
+  for (int32_t a = 0; a < n_aggr; ++a)
+    if (aggr[a] < AGG_MEAN || aggr[a] > AGG_VAR) return -1;
+#pragma omp parallel
+  {
+    /* per-thread accumulators, one slot per feature; edges are folded in CSR order (k outer, f inner) so
+     * every feature sees exactly the sequential sum s = ((m_1 + m_2) + m_3) + ... */
+    float* s32 = (float*)malloc(sizeof(float) * F * 4);
+    double* s64 = (double*)malloc(sizeof(double) * F * 2);
+    float *q32 = s32 + F, *mx = s32 + 2 * F, *mn = s32 + 3 * F;
+    double* q64 = s64 + F;
+#pragma omp for schedule(dynamic, 64)
+    for (int32_t v = 0; v < V; ++v) {
+      const int32_t beg = rowptr[v], end = rowptr[v + 1];
+      float w32 = 0.f;
+      double w64 = 0.0;
+      for (int32_t f = 0; f < F; ++f) { s32[f] = 0.f; q32[f] = 0.f; mx[f] = -INFINITY; mn[f] = INFINITY; s64[f] = 0.0; q64[f] = 0.0; }
       for (int32_t k = beg; k < end; ++k) {
         const int64_t r = col ? col[k] : k;
-        float m = x[r * ldx + f];
-        if (dst_term) m = m + dst_term[(int64_t)v * ld_dst + f];
-        if (edge_term) m = m + edge_term[(int64_t)k * ld_edge + f];
+        const float* xr = x + r * ldx;
+        const float* dt = dst_term ? dst_term + (int64_t)v * ld_dst : 0;
+        const float* et = edge_term ? edge_term + (int64_t)k * ld_edge : 0;
         const float w = edge_weight ? edge_weight[k] : 1.f;
-        if (acc_double) {
-          s64 += (double)m * w; q64 += (double)m * m * w; w64 += w;
-        } else if (edge_weight) {
-          s32 = s32 + m * w; q32 = q32 + (m * m) * w; w32 = w32 + w;
-        } else {
-          s32 = s32 + m; q32 = q32 + m * m; w32 = w32 + 1.f;
-        }
-        if (w > 0.f) {
-          if (m > mx || (m != m && mx == mx)) mx = m;
-          if (m < mn || (m != m && mn == mn)) mn = m;
-        }
-      }
-      float mean, var, sum;
-      if (acc_double) {
-        const double me = s64 / w64, t = q64 / w64 - me * me;
-        mean = (float)me; var = (float)(t < 0.0 ? 0.0 : t); sum = (float)s64;
-      } else {
-        mean = s32 / w32;
-        const float msq = q32 / w32;
-        const float t = msq - mean * mean;
-        var = t < 0.f ? 0.f : t; sum = s32;
-      }
-      const float sd = acc_double ? (float)sqrt((double)var + 1e-5) : sqrtf(var + 1e-5f);
-      for (int32_t s = 0; s < n_scaler; ++s) {
-        const float sc = row_scale[s] ? row_scale[s][v] : 1.f;
-        for (int32_t a = 0; a < n_aggr; ++a) {
-          float val;
-          switch (aggr[a]) {
-            case AGG_MEAN: val = mean; break;
-            case AGG_SUM: val = sum; break;
-            case AGG_MAX: val = mx; break;
-            case AGG_MIN: val = mn; break;
-            case AGG_STD: val = sd; break;
-            case AGG_VAR: val = var; break;
-            default: val = 0.f; bad = 1; break;
+        if (acc_double) w64 += w; else w32 = w32 + w;
+        if (!acc_double && !edge_weight && !dt && !et) {
+          /* common case (PNASimpleLayer, pna_layer.py:202: message = raw source features), branch-free */
+          for (int32_t f = 0; f < F; ++f) {
+            const float m = xr[f];
+            s32[f] = s32[f] + m;
+            q32[f] = q32[f] + m * m;
+            mx[f] = (m > mx[f] || m != m) ? m : mx[f];
+            mn[f] = (m < mn[f] || m != m) ? m : mn[f];
           }
-          out[(int64_t)v * ldo + (int64_t)(s * n_aggr + a) * block_stride + f] = (end > beg) ? val * sc : 0.f;
+          continue;
+        }
+        for (int32_t f = 0; f < F; ++f) {
+          float m = xr[f];
+          if (dt) m = m + dt[f];
+          if (et) m = m + et[f];
+          if (acc_double) { s64[f] += (double)m * w; q64[f] += (double)m * m * w; }
+          else if (edge_weight) { s32[f] = s32[f] + m * w; q32[f] = q32[f] + (m * m) * w; }
+          else { s32[f] = s32[f] + m; q32[f] = q32[f] + m * m; }
+          if (w > 0.f) {
+            if (m > mx[f] || (m != m && mx[f] == mx[f])) mx[f] = m;
+            if (m < mn[f] || (m != m && mn[f] == mn[f])) mn[f] = m;
+          }
+        }
+      }
+      for (int32_t f = 0; f < F; ++f) {
+        float mean, var, sum;
+        if (acc_double) {
+          const double me = s64[f] / w64, t = q64[f] / w64 - me * me;
+          mean = (float)me; var = (float)(t < 0.0 ? 0.0 : t); sum = (float)s64[f];
+        } else {
+          mean = s32[f] / w32;
+          const float msq = q32[f] / w32;
+          const float t = msq - mean * mean;
+          var = t < 0.f ? 0.f : t; sum = s32[f];
+        }
+        const float sd = acc_double ? (float)sqrt((double)var + 1e-5) : sqrtf(var + 1e-5f);
+        for (int32_t sc_i = 0; sc_i < n_scaler; ++sc_i) {
+          const float sc = row_scale[sc_i] ? row_scale[sc_i][v] : 1.f;
+          for (int32_t a = 0; a < n_aggr; ++a) {
+            float val;
+            switch (aggr[a]) {
+              case AGG_MEAN: val = mean; break;
+              case AGG_SUM: val = sum; break;
+              case AGG_MAX: val = mx[f]; break;
+              case AGG_MIN: val = mn[f]; break;
+              case AGG_STD: val = sd; break;
+              default: val = var; break;
+            }
+            out[(int64_t)v * ldo + (int64_t)(sc_i * n_aggr + a) * block_stride + f] = (end > beg) ? val * sc : 0.f;
+          }
         }
       }
     }
+    free(s32);
+    free(s64);
   }
   return bad ? -1 : 0;
 }

@@ -132,13 +132,14 @@ def _towers_forward(towers, graph, h, e, snorm_n, divide_input):
             x_src = h @ Wa.reshape(T * Fi, Fi).t()
             x_dst = torch.addmm(b.reshape(-1), h, Wb.reshape(T * Fi, Fi).t())
         x_edge = e_csr @ We.reshape(T * Fi, ed).t() if t0.edge_features else None
+        x_src = graph.source_features(x_src)                  # multi-GPU: halo exchange of the PROJECTED rows
         agg = PF.aggregate(graph, x_src, Fi, t0.aggregators, n_tower=T, dst_term=x_dst, edge_term=x_edge)
     else:
         # general pretrans (MLP with hidden layers): per-edge messages are materialised in CSR order
         src, dst = csr.col.long(), csr.row.long()
         msgs = []
         for t, tower in enumerate(towers):
-            z = [hs[t][src], hs[t][dst]] + ([e_csr] if tower.edge_features else [])
+            z = [graph.source_features(hs[t])[src], hs[t][dst]] + ([e_csr] if tower.edge_features else [])
             msgs.append(tower.pretrans(torch.cat(z, dim=1)))
         agg = PF.aggregate(graph, torch.cat(msgs, dim=1) if T > 1 else msgs[0], Fi, t0.aggregators, n_tower=T,
                            edge_resident=True)
@@ -221,13 +222,13 @@ class PNASimpleLayer(nn.Module):
         forward() does not use it (it keeps the scalers out of HBM); this is the drop-in for code that
         wants the reference's intermediate."""
         graph = as_graph(g)
-        return PF.aggregate(graph, h, self.in_dim, self.aggregators,
+        return PF.aggregate(graph, graph.source_features(h), self.in_dim, self.aggregators,
                             row_scales=_row_scales(graph, self.scalers, self.avg_d, h.device))
 
     def forward(self, g, h):
         graph = as_graph(g)
         h_in = h
-        agg = PF.aggregate(graph, h, self.in_dim, self.aggregators)                  # (V, A*F), identity only
+        agg = PF.aggregate(graph, graph.source_features(h), self.in_dim, self.aggregators)   # (V, A*F), identity only
         lin = self.posttrans.fully_connected[0].linear
         y = PF.posttrans(agg, len(self.aggregators) * self.in_dim, lin.weight, lin.bias,
                          _row_scales(graph, self.scalers, self.avg_d, h.device))

@@ -136,6 +136,11 @@ class Graph:
             offs += g.num_nodes
         return Graph(torch.cat(srcs), torch.cat(dsts), offs, sizes)
 
+    def source_features(self, h):
+        """Feature table the gather kernel indexes with the CSR's source ids.  Identity for a whole graph;
+        pna_amd.shard.HaloGraph overrides it with the halo all-to-all ([local rows | halo rows])."""
+        return h
+
     # -- cached index structures ---------------------------------------------------------------
     @property
     def csr(self) -> CSR:

@@ -1,0 +1,213 @@
+"""GPU parity of the HIP kernels, called through the C ABI, against the CPU oracle (oracle/).
+
+Bar (BASELINE.json north_star): max/min and degree-derived values BIT-EXACT; mean/sum/std/var and the
+MLP within 1e-5 relative (fp32; plus the absolute floor that fp32 cancellation in E[x^2]-E[x]^2 and in
+GEMM dot products makes unavoidable -- both stated next to each assert)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from pna_amd import Graph, ops
+from pna_amd.graph import build_heavy_schedule
+
+pytestmark = pytest.mark.gpu
+
+ALL_AGG = ["mean", "max", "min", "std", "sum", "var"]
+
+
+def _rand_graph(rng, V, E, hub=0):
+    dst = rng.integers(0, V, E)
+    if hub:
+        dst[:hub] = rng.integers(0, 3, hub)            # a few very heavy destinations
+    src = rng.integers(0, V, E)
+    return torch.from_numpy(src), torch.from_numpy(dst)
+
+
+def _check_blocks(got, ref, ref64, aggs, n_scaler, F, what=""):
+    """max/min bit-exact; others: |got-ref| <= 1e-5*|ref| + atol, where atol covers fp32 summation-order
+    noise: for std/var it is amplified by the cancellation in E[x^2]-E[x]^2, so we bound the GPU
+    error against the float64 ground truth by the CPU fp32 oracle's own error (x4) instead."""
+    A = len(aggs)
+    for s in range(n_scaler):
+        for i, ag in enumerate(aggs):
+            blk = slice((s * A + i) * F, (s * A + i + 1) * F)
+            g, r, r64 = got[:, blk], ref[:, blk], ref64[:, blk]
+            if ag in ("max", "min"):
+                assert np.array_equal(g, r), f"{what} {ag} s={s}: not bit-exact"
+            else:
+                tol = 1e-5 * np.abs(r64) + np.maximum(4 * np.abs(r - r64), 1e-6 * (1 + np.abs(r64)))
+                bad = np.abs(g - r64) > tol
+                assert not bad.any(), f"{what} {ag} s={s}: max err {np.abs(g - r64).max():.3e} at {np.argwhere(bad)[:3]}"
+
+
+@pytest.mark.parametrize("F", [1, 2, 3, 4, 5, 7, 16, 33, 75, 80, 128, 260])
+def test_segreduce_widths(cuda_device, F):
+    rng = np.random.default_rng(F)
+    V, E = 700, 6000
+    src, dst = _rand_graph(rng, V, E)
+    g = Graph(src, dst, V).to(cuda_device)
+    c = g.csr
+    x = torch.randn(V, F, generator=torch.Generator().manual_seed(F))
+    amp, att = g.degree_scalers(1.7)
+    got = ops.segreduce(c.rowptr, c.col, x.to(cuda_device), F, ALL_AGG, [None, amp, att]).cpu().numpy()
+    rp, col = c.rowptr.cpu().numpy(), c.col.cpu().numpy()
+    amp_o, att_o = c_oracle.degree_scalers(rp, 1.7)
+    assert np.array_equal(amp.cpu().numpy(), amp_o) and np.array_equal(att.cpu().numpy(), att_o)
+    ref = c_oracle.segreduce(rp, col, x.numpy(), F, ALL_AGG, [None, amp_o, att_o])
+    ref64 = c_oracle.segreduce(rp, col, x.numpy(), F, ALL_AGG, [None, amp_o, att_o], acc_double=True)
+    _check_blocks(got, ref, ref64, ALL_AGG, 3, F, f"F={F}")
+    # rows without in-edges are zero in every block
+    empty = (rp[1:] == rp[:-1])
+    assert empty.any() and not got[empty].any()
+
+
+@pytest.mark.parametrize("ld_extra,tune", [(0, {}), (5, {}), (0, dict(vec=1)), (1, dict(unroll=1)), (0, dict(unroll=2)),
+                                           (3, dict(unroll=8)), (0, dict(lanes_per_row=32)), (0, dict(lanes_per_row=10)),
+                                           (0, dict(rows_per_group=1)), (0, dict(rows_per_group=16, nt_store=-1))])
+def test_segreduce_tunings_and_strides_agree_bitwise(cuda_device, ld_extra, tune):
+    """Every launch geometry computes bit-identical results (sequential edge order per row)."""
+    rng = np.random.default_rng(3)
+    V, E, F = 900, 9000, 75
+    src, dst = _rand_graph(rng, V, E)
+    g = Graph(src, dst, V).to(cuda_device)
+    c = g.csr
+    xs = torch.randn(V, F + ld_extra, generator=torch.Generator().manual_seed(1)).to(cuda_device)
+    x = xs[:, :F]
+    base = ops.segreduce(c.rowptr, c.col, x.contiguous(), F, ALL_AGG)
+    got = ops.segreduce(c.rowptr, c.col, x, F, ALL_AGG, tune=tune)
+    assert torch.equal(base, got)
+
+
+def test_segreduce_heavy_rows_split(cuda_device):
+    rng = np.random.default_rng(11)
+    V, E, F = 500, 30000, 75
+    src, dst = _rand_graph(rng, V, E, hub=12000)
+    g = Graph(src, dst, V).to(cuda_device)
+    c = g.csr
+    assert c.max_degree > 2000
+    x = torch.randn(V, F, generator=torch.Generator().manual_seed(5))
+    rp, col = c.rowptr.cpu().numpy(), c.col.cpu().numpy()
+    ref = c_oracle.segreduce(rp, col, x.numpy(), F, ALL_AGG)
+    ref64 = c_oracle.segreduce(rp, col, x.numpy(), F, ALL_AGG, acc_double=True)
+    xd = x.to(cuda_device)
+    outs = []
+    for thr, seg in [(64, 64), (16, 8), (100, 37), (0, 0)]:
+        hs = build_heavy_schedule(c.rowptr, c.max_degree, thr, seg) if thr else None
+        got = ops.segreduce(c.rowptr, c.col, xd, F, ALL_AGG, heavy=hs).cpu().numpy()
+        _check_blocks(got, ref, ref64, ALL_AGG, 1, F, f"thr={thr}")
+        outs.append(got)
+    # same schedule, different launch geometry -> bit-identical (segment order is fixed)
+    hs = build_heavy_schedule(c.rowptr, c.max_degree, 64, 64)
+    a = ops.segreduce(c.rowptr, c.col, xd, F, ALL_AGG, heavy=hs, tune=dict(unroll=2, rows_per_group=2))
+    assert np.array_equal(a.cpu().numpy(), outs[0])
+
+
+@pytest.mark.parametrize("T,F", [(1, 75), (5, 15), (5, 75), (4, 4), (3, 2), (2, 130)])
+def test_segreduce_towers_terms_weights_args(cuda_device, T, F):
+    """n_tower slices + dst_term + edge_term + edge_weight + argmax/argmin (the EXTRA kernel path)."""
+    rng = np.random.default_rng(T * 100 + F)
+    V, E = 300, 5000
+    src, dst = _rand_graph(rng, V, E, hub=900)
+    g = Graph(src, dst, V).to(cuda_device)
+    c = g.csr
+    gen = torch.Generator().manual_seed(7)
+    x, dt = torch.randn(V, T * F, generator=gen), torch.randn(V, T * F, generator=gen)
+    et = torch.randn(E, T * F, generator=gen)
+    w = (torch.rand(E, generator=gen) * 3).round() * 0.5           # weights incl. zeros
+    hs = build_heavy_schedule(c.rowptr, c.max_degree, 32, 16)
+    rp, col = c.rowptr.cpu().numpy(), c.col.cpu().numpy()
+    for use_w in (False, True):
+        got, amx, amn = ops.segreduce(c.rowptr, c.col, x.to(cuda_device), F, ALL_AGG, n_tower=T, tower_stride_in=F,
+                                      dst_term=dt.to(cuda_device), edge_term=et.to(cuda_device),
+                                      edge_weight=w.to(cuda_device) if use_w else None, want_arg=True, heavy=hs)
+        got, amx, amn = got.cpu().numpy(), amx.cpu().numpy(), amn.cpu().numpy()
+        A = len(ALL_AGG)
+        for t in range(T):
+            kw = dict(dst_term=dt.numpy(), edge_term=et.numpy(), edge_weight=w.numpy() if use_w else None, col_offset=t * F)
+            ref = c_oracle.segreduce(rp, col, x.numpy(), F, ALL_AGG, **kw)
+            ref64 = c_oracle.segreduce(rp, col, x.numpy(), F, ALL_AGG, acc_double=True, **kw)
+            sl = got[:, t * A * F:(t + 1) * A * F]
+            ok = np.isfinite(ref64).all(axis=1)                    # weighted rows with sum(w)=0 are NaN in both
+            if use_w:
+                assert np.array_equal(np.isnan(sl), np.isnan(ref))
+            _check_blocks(sl[ok], ref[ok], ref64[ok], ALL_AGG, 1, F, f"t={t} w={use_w}")
+            # argmax / argmin point at a CSR edge whose message equals the max / min
+            msg = x.numpy()[col][:, t * F:(t + 1) * F] + dt.numpy()[np.repeat(np.arange(V), np.diff(rp))][:, t * F:(t + 1) * F] \
+                + et.numpy()[:, t * F:(t + 1) * F]
+            ax, an = amx[:, t * F:(t + 1) * F], amn[:, t * F:(t + 1) * F]
+            has = (ax >= 0)
+            rows, cols = np.nonzero(has)
+            assert np.array_equal(msg[ax[rows, cols], cols], sl[rows, cols + 1 * F])      # block 1 = max
+            assert np.array_equal(msg[an[rows, cols], cols], sl[rows, cols + 2 * F])      # block 2 = min
+            assert ((ax[rows, cols] >= rp[rows]) & (ax[rows, cols] < rp[rows + 1])).all()
+
+
+def test_segreduce_edge_resident_messages(cuda_device):
+    rng = np.random.default_rng(5)
+    V, E, F = 400, 3000, 20
+    src, dst = _rand_graph(rng, V, E)
+    g = Graph(src, dst, V).to(cuda_device)
+    c = g.csr
+    m = torch.randn(E, F, generator=torch.Generator().manual_seed(2))
+    got = ops.segreduce(c.rowptr, None, m.to(cuda_device), F, ["max", "mean", "min"]).cpu().numpy()
+    ref = c_oracle.segreduce(c.rowptr.cpu().numpy(), None, m.numpy(), F, ["max", "mean", "min"])
+    ref64 = c_oracle.segreduce(c.rowptr.cpu().numpy(), None, m.numpy(), F, ["max", "mean", "min"], acc_double=True)
+    _check_blocks(got, ref, ref64, ["max", "mean", "min"], 1, F)
+
+
+def test_segreduce_nan_inf_propagation(cuda_device):
+    V, F = 6, 8
+    src = torch.tensor([0, 1, 2, 3, 4, 5, 0, 1])
+    dst = torch.tensor([0, 0, 0, 1, 1, 2, 3, 3])
+    x = torch.randn(V, F)
+    x[1, 2] = float("nan"); x[4, 0] = float("inf"); x[0, 5] = float("-inf")
+    g = Graph(src, dst, V).to(cuda_device)
+    c = g.csr
+    got = ops.segreduce(c.rowptr, c.col, x.to(cuda_device), F, ["max", "min", "mean"]).cpu()
+    from oracle import torch_oracle as O
+    ref = O.reduce_bucketed(x[src], src, dst, V, ["max", "min", "mean"], ["identity"], torch.tensor(1.0))
+    assert torch.equal(torch.isnan(got), torch.isnan(ref))
+    ok = ~torch.isnan(ref)
+    torch.testing.assert_close(got[ok], ref[ok], rtol=1e-6, atol=0)
+
+
+def test_segreduce_argument_validation(cuda_device):
+    g = Graph(torch.tensor([0, 1]), torch.tensor([1, 0]), 2).to(cuda_device)
+    c = g.csr
+    x = torch.randn(2, 8, device=cuda_device)
+    with pytest.raises(KeyError):
+        ops.segreduce(c.rowptr, c.col, x, 8, ["median"])
+    with pytest.raises(RuntimeError, match="leading dimensions"):
+        ops.segreduce(c.rowptr, c.col, x, 16, ["mean"])
+    with pytest.raises(RuntimeError, match="unroll"):
+        ops.segreduce(c.rowptr, c.col, x, 8, ["mean"], tune=dict(unroll=3))
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.segreduce(c.rowptr, c.col, x.cpu(), 8, ["mean"])
+    with pytest.raises(TypeError):
+        ops.segreduce(c.rowptr, c.col, x.double(), 8, ["mean"])
+
+
+@pytest.mark.parametrize("M,K,N,S,Kh", [(1000, 300, 75, 3, 0), (777, 300, 15, 3, 75), (64, 16, 16, 1, 0), (65, 17, 5, 2, 3),
+                                        (300, 60, 14, 3, 15), (129, 20, 100, 5, 4), (50, 8, 4, 1, 2), (2000, 320, 80, 3, 0)])
+def test_posttrans_mfma_vs_float64(cuda_device, M, K, N, S, Kh):
+    gen = torch.Generator().manual_seed(M + K)
+    a = torch.randn(M, K + 3, generator=gen)[:, :K]                    # non-trivial lda
+    W = torch.randn(N, Kh + S * K, generator=gen) / (K ** 0.5)
+    b = torch.randn(N, generator=gen)
+    h = torch.randn(M, Kh, generator=gen) if Kh else None
+    scales = [None] + [torch.rand(M, generator=gen) + 0.5 for _ in range(S - 1)]
+    from pna_amd import functional as PF
+    dev = cuda_device
+    got = PF.posttrans(a.to(dev), K, W.to(dev), b.to(dev), [None if s is None else s.to(dev) for s in scales],
+                       None if h is None else h.to(dev)).cpu()
+    # float64 reference of the reference's formulation: Linear(cat[h, s0*a, s1*a, ...])
+    ad = a.double()
+    cat = ([h.double()] if Kh else []) + [ad if s is None else ad * s.double().unsqueeze(1) for s in scales]
+    z = torch.cat(cat, dim=1)
+    ref = z @ W.double().t() + b.double()
+    mag = z.abs() @ W.double().abs().t() + b.double().abs()             # sum of |terms| of every dot product
+    err = (got.double() - ref).abs()
+    # fp32 fma-chain bound: relative to the dot product's absolute mass (the quantity rounding scales with)
+    assert (err <= 1e-5 * ref.abs() + 2e-6 * mag).all(), f"max err {err.max():.3e}"
+    assert (err / mag).max() < 3e-6

@@ -1,0 +1,122 @@
+"""GPU parity of the drop-in layers against the golden vectors produced by the reference's own source
+(tests/golden/, see oracle/make_golden.py).  Tolerance: 1e-5 relative (north_star) plus an absolute floor
+of 1e-5 on O(1)-O(10) activations for the dot products' cancellation (the CPU reference itself moves by
+that much when its GEMM runs with a different thread count, tests/test_oracle_golden.py)."""
+import pytest
+import torch
+
+from conftest import golden_names, load_golden
+from pna_amd import Graph
+from pna_amd.dgl.pna_layer import PNALayer, PNASimpleLayer
+from pna_amd.dgl.aggregators import AGGREGATORS as DGL_AGG
+from pna_amd.dgl.scalers import SCALERS as DGL_SCALERS
+from pna_amd.pytorch.pna.layer import PNALayer as DensePNALayer
+from pna_amd.pytorch.pna.aggregators import AGGREGATORS as DENSE_AGG
+from pna_amd.pytorch.pna.scalers import SCALERS as DENSE_SCALERS
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", golden_names("dgl_simple"))
+def test_simple_layer_golden(cuda_device, name):
+    meta, a, sd = load_golden(name)
+    layer = PNASimpleLayer(meta["F"], meta["out_dim"], meta["aggregators"], meta["scalers"], {"log": a["avg_log"]}, 0.0,
+                           True, meta["residual"], posttrans_layers=meta["posttrans_layers"])
+    layer.load_state_dict(sd)
+    layer = layer.to(cuda_device).eval()
+    g = Graph(a["src"], a["dst"], meta["N"]).to(cuda_device)
+    with torch.no_grad():
+        out = layer(g, a["h"].to(cuda_device)).cpu()
+        agg = layer.aggregate(g, a["h"].to(cuda_device)).cpu()
+    # the (V, A*S*F) tensor of reduce_func: max/min blocks (all scalers) bit-exact, rest 1e-5
+    aggs, F = meta["aggregators"].split(), meta["F"]
+    A = len(aggs)
+    for s in range(len(meta["scalers"].split())):
+        for i, ag in enumerate(aggs):
+            blk = slice((s * A + i) * F, (s * A + i + 1) * F)
+            if ag in ("max", "min"):
+                assert torch.equal(agg[:, blk], a["agg"][:, blk]), f"{ag} block of scaler {s} not bit-exact"
+            else:
+                torch.testing.assert_close(agg[:, blk], a["agg"][:, blk], rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(out, a["out"], **TOL)
+
+
+@pytest.mark.parametrize("name", golden_names("dgl_tower"))
+def test_tower_layer_golden(cuda_device, name):
+    meta, a, sd = load_golden(name)
+    layer = PNALayer(meta["in_dim"], meta["out_dim"], meta["aggregators"], meta["scalers"], {"log": a["avg_log"]}, 0.0,
+                     meta["graph_norm"], meta["batch_norm"], towers=meta["towers"],
+                     pretrans_layers=meta["pretrans_layers"], posttrans_layers=meta["posttrans_layers"],
+                     divide_input=meta["divide_input"], residual=meta["residual"], edge_features=meta["edge_dim"] > 0,
+                     edge_dim=meta["edge_dim"])
+    layer.load_state_dict(sd)
+    layer = layer.to(cuda_device).eval()
+    g = Graph(a["src"], a["dst"], meta["N"], meta["sizes"]).to(cuda_device)
+    e = a["e"].to(cuda_device) if meta["edge_dim"] > 0 else None
+    with torch.no_grad():
+        out = layer(g, a["h"].to(cuda_device), e, a["snorm_n"].to(cuda_device)).cpu()
+        torch.testing.assert_close(g.snorm_n().cpu(), a["snorm_n"])
+    torch.testing.assert_close(out, a["out"], **TOL)
+
+
+@pytest.mark.parametrize("name", golden_names("dense"))
+def test_dense_layer_golden(cuda_device, name):
+    meta, a, sd = load_golden(name)
+    avg_d = {"log": a["avg_log"].to(cuda_device), "lin": a["avg_lin"].to(cuda_device)}
+    layer = DensePNALayer(meta["in_features"], meta["out_features"], meta["aggregators"], meta["scalers"], avg_d,
+                          towers=meta["towers"], self_loop=meta["self_loop"], divide_input=meta["divide_input"],
+                          device=cuda_device)
+    layer.load_state_dict(sd)
+    layer = layer.to(cuda_device).eval()
+    with torch.no_grad():
+        out = layer(a["x"].to(cuda_device), a["adj"].to(cuda_device)).cpu()
+    torch.testing.assert_close(out, a["out"], **TOL)
+
+
+def test_dgl_registry_operators_on_a_mailbox(cuda_device):
+    from oracle import torch_oracle as O
+    h = torch.randn(37, 6, 20, generator=torch.Generator().manual_seed(0))
+    for name, fn in DGL_AGG.items():
+        got = fn(h.to(cuda_device)).cpu()
+        ref = O.MAILBOX_AGGREGATORS[name](h)
+        if name in ("max", "min"):
+            assert torch.equal(got, ref)
+        else:
+            torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-6)
+    avg = {"log": torch.tensor(1.3, device=cuda_device)}
+    x = torch.randn(5, 8, device=cuda_device)
+    for name, fn in DGL_SCALERS.items():
+        ref = O.mailbox_scale(name, x.cpu(), 6, torch.tensor(1.3))
+        assert torch.equal(fn(x, D=6, avg_d=avg).cpu(), ref)
+
+
+def test_dense_registry_operators(cuda_device):
+    from oracle import torch_oracle as O
+    gen = torch.Generator().manual_seed(1)
+    B, N, F = 3, 7, 5
+    X = torch.randn(B, N, N, F, generator=gen)
+    adj = (torch.rand(B, N, N, generator=gen) < 0.5).float()
+    adj = torch.maximum(adj, torch.eye(N).roll(1, 0).unsqueeze(0))        # every row and column non-empty
+    adj = torch.maximum(adj, torch.eye(N).roll(1, 1).unsqueeze(0))
+    for name, fn in DENSE_AGG.items():
+        for sl in (False, True):
+            got = fn(X.to(cuda_device), adj.to(cuda_device), self_loop=sl, device=cuda_device).cpu()
+            ref = O.DENSE_AGGREGATORS[name](X, adj + torch.eye(N).unsqueeze(0) if sl else adj)
+            if name in ("max", "min"):
+                assert torch.equal(got, ref), name
+            else:
+                torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-6)
+    avg_d = {"log": torch.tensor(1.4), "lin": torch.tensor(3.1)}
+    m = torch.randn(B, N, 12, generator=gen)
+    for name, fn in DENSE_SCALERS.items():
+        got = fn(m.to(cuda_device), adj.to(cuda_device), {k: v.to(cuda_device) for k, v in avg_d.items()}).cpu()
+        torch.testing.assert_close(got, O.dense_scale(name, m, adj, avg_d), rtol=1e-6, atol=1e-7)
+
+
+def test_training_mode_raises_until_backward_exists(cuda_device):
+    layer = PNASimpleLayer(8, 8, "mean max", "identity", {"log": torch.tensor(1.0)}, 0.0, True, True).to(cuda_device)
+    g = Graph(torch.tensor([0, 1, 2]), torch.tensor([1, 2, 0]), 3).to(cuda_device)
+    h = torch.randn(3, 8, device=cuda_device, requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        layer(g, h)

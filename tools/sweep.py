@@ -1,0 +1,114 @@
+#!/usr/bin/env python
+"""Tuning sweep of the fused segment-reduce kernel on the roofline workload (one GPU call, many
+variants, interleaved rounds, min and median per variant).  Writes gpurun_out/sweep_<tag>.json.
+
+    python tools/sweep.py --tag r01 [--V 1000000 --E 10000000 --F 75]
+"""
+import argparse
+import itertools
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pna_amd import Graph, ops  # noqa: E402
+from pna_amd.graph import build_heavy_schedule  # noqa: E402
+from pna_amd.synth import powerlaw_graph  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tag", default="r01")
+    ap.add_argument("--V", type=int, default=1_000_000)
+    ap.add_argument("--E", type=int, default=10_000_000)
+    ap.add_argument("--F", type=int, default=75)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    V, E, F = args.V, args.E, args.F
+    src, dst = powerlaw_graph(V, E, seed=1234, device=dev)
+    g = Graph(src, dst, V)
+    c = g.csr
+    amp, att = g.degree_scalers(2.2488)
+    xs = {}
+    base = torch.randn(V, F, generator=torch.Generator().manual_seed(1234)).to(dev)
+    for ld in (75, 76, 80, 96):
+        buf = torch.zeros(V, ld, device=dev)
+        buf[:, :F] = base
+        xs[ld] = buf[:, :F]
+    heavy = {0: None}
+    for thr, seg in ((32, 32), (64, 64), (128, 64), (128, 128), (256, 128), (512, 256)):
+        heavy[(thr, seg)] = build_heavy_schedule(c.rowptr, c.max_degree, thr, seg)
+    aggs = ["mean", "max", "min", "std"]
+    alg_bytes = E * (4 * F + 4) + 4 * (V + 1) + V * 16 * F
+
+    variants = []
+    # 1. tuning grid at ld=75, default heavy (64,64), 4F output
+    for U, R, L in itertools.product((2, 4, 8), (1, 2, 4, 8), (19, 20)):
+        variants.append(dict(ld=75, heavy=(64, 64), S=1, tune=dict(unroll=U, rows_per_group=R, lanes_per_row=L)))
+    # 2. leading dimension of x
+    for ld in (76, 80, 96):
+        for U in (4, 8):
+            variants.append(dict(ld=ld, heavy=(64, 64), S=1, tune=dict(unroll=U, rows_per_group=4)))
+    # 3. heavy schedule
+    for hk in heavy:
+        if hk != (64, 64):
+            variants.append(dict(ld=75, heavy=hk, S=1, tune=dict(unroll=4, rows_per_group=4)))
+    # 4. store policy, materialised 12F output, scalar path
+    variants.append(dict(ld=75, heavy=(64, 64), S=1, tune=dict(unroll=4, rows_per_group=4, nt_store=-1)))
+    variants.append(dict(ld=75, heavy=(64, 64), S=3, tune=dict(unroll=4, rows_per_group=4)))
+    variants.append(dict(ld=75, heavy=(64, 64), S=3, tune=dict(unroll=4, rows_per_group=4, nt_store=-1)))
+    variants.append(dict(ld=75, heavy=(64, 64), S=1, tune=dict(unroll=4, rows_per_group=4, vec=1)))
+    variants.append(dict(ld=80, heavy=(64, 64), S=1, tune=dict(unroll=4, rows_per_group=4, lanes_per_row=32)))
+    if args.quick:
+        variants = variants[::6]
+
+    outs = {}
+    for S in (1, 3):
+        outs[S] = torch.empty(V, 4 * S * F, device=dev)
+
+    def run(v):
+        scales = [None] if v["S"] == 1 else [None, amp, att]
+        hk = v["heavy"]
+        return ops.segreduce(c.rowptr, c.col, xs[v["ld"]], F, aggs, scales, out=outs[v["S"]], heavy=heavy[hk if hk else 0],
+                             workspace=g.workspace, tune=v["tune"])
+
+    ref = run(variants[0]).clone()
+    times = [[] for _ in variants]
+    for i, v in enumerate(variants):                       # correctness of every variant first (4F part bit-identical
+        o = run(v)                                         # for variants sharing the heavy schedule)
+        if v["heavy"] == variants[0]["heavy"]:
+            assert torch.equal(o[:, :4 * F], ref), v
+    for r in range(args.rounds):
+        for i, v in enumerate(variants):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            run(v)
+            a.record()
+            for _ in range(args.iters):
+                run(v)
+            b.record()
+            torch.cuda.synchronize()
+            times[i].append(a.elapsed_time(b) / args.iters)
+    res = []
+    for v, t in zip(variants, times):
+        t = sorted(t)
+        res.append(dict(v, heavy=list(v["heavy"]) if v["heavy"] else None, ms_min=t[0], ms_med=t[len(t) // 2],
+                        frac_hbm_min=alg_bytes / (t[0] * 1e-3) / 8e12, gedges_s=E / (t[0] * 1e-3) / 1e9))
+    res.sort(key=lambda r: r["ms_med"])
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    path = os.path.join(ROOT, "gpurun_out", f"sweep_{args.tag}.json")
+    json.dump(dict(V=V, E=E, F=F, alg_bytes=alg_bytes, results=res), open(path, "w"), indent=1)
+    for r in res[:12]:
+        print(json.dumps(r))
+    print("...")
+    for r in res[-4:]:
+        print(json.dumps(r))
+
+
+if __name__ == "__main__":
+    main()
