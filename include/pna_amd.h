@@ -51,11 +51,13 @@ enum {
 typedef struct pna_tuning {
   int32_t lanes_per_row;   /* lanes of a 64-wide wavefront that share one destination row (each lane owns
                               `vec` consecutive features); 0 = auto = min(64, ceil(F/vec))             */
-  int32_t unroll;          /* in-edges of one row gathered per loop trip (1,2,4,8); 0 = auto          */
+  int32_t unroll;          /* in-edges of one row gathered per loop trip (2,4,8); 0 = auto            */
   int32_t rows_per_group;  /* destination rows processed back to back by one lane group; 0 = auto    */
   int32_t vec;             /* features per lane: 4 (dwordx4 gathers) or 1; 0 = auto                   */
   int32_t nt_store;        /* 1 = non-temporal output stores; 0 = auto(1); -1 = plain stores          */
-  int32_t reserved[3];
+  int32_t prefetch;        /* 1 = fetch the next row's source ids one row ahead; 0 = auto(1); -1 = off */
+  int32_t reserved[2];     /* [0]: debug bits for bench experiments (bit0 = skip output stores);
+                              [1]: 1 = force the compiler-scheduled kernel instead of the hand-scheduled one */
 } pna_tuning;
 
 /*
@@ -96,6 +98,7 @@ typedef struct pna_segreduce_args {
   int32_t F;
   const float* x;
   int64_t ldx;
+  int64_t x_rows;        /* rows of x (source nodes, or E when col == NULL); 0 = unknown (64-bit addressing) */
   const float* dst_term; /* nullable (V, ld_dst) */
   int64_t ld_dst;
   const float* edge_term; /* nullable (E, ld_edge) */

@@ -21,13 +21,14 @@ AGG_CODES = {"mean": 0, "sum": 1, "max": 2, "min": 3, "std": 4, "var": 5}
 
 class PnaTuning(ctypes.Structure):
     _fields_ = [("lanes_per_row", ctypes.c_int32), ("unroll", ctypes.c_int32), ("rows_per_group", ctypes.c_int32),
-                ("vec", ctypes.c_int32), ("nt_store", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
+                ("vec", ctypes.c_int32), ("nt_store", ctypes.c_int32), ("prefetch", ctypes.c_int32),
+                ("debug", ctypes.c_int32), ("generic", ctypes.c_int32)]
 
 
 class PnaSegreduceArgs(ctypes.Structure):
     _fields_ = [
         ("rowptr", ctypes.c_void_p), ("col", ctypes.c_void_p), ("V", ctypes.c_int32), ("F", ctypes.c_int32),
-        ("x", ctypes.c_void_p), ("ldx", ctypes.c_int64),
+        ("x", ctypes.c_void_p), ("ldx", ctypes.c_int64), ("x_rows", ctypes.c_int64),
         ("dst_term", ctypes.c_void_p), ("ld_dst", ctypes.c_int64),
         ("edge_term", ctypes.c_void_p), ("ld_edge", ctypes.c_int64),
         ("edge_weight", ctypes.c_void_p),

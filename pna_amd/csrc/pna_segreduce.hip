@@ -49,7 +49,7 @@ struct KArgs {
   int V, F, n_aggr, n_scaler, block_stride;
   int aggr[PNA_MAX_AGGR];
   int heavy_threshold, seg_len, n_heavy, n_seg;
-  int L, G, R, n_heavy_blocks, pstride, nt, T, tiles;
+  int L, G, R, n_heavy_blocks, pstride, nt, T, tiles, pf, dbg;
 };
 
 template <int VEC> struct Ld;
@@ -90,17 +90,32 @@ template <int VEC, bool EXTRA> struct Acc {
   }
 };
 
+// Single-instruction max/min (no canonicalisation prologue; a quiet-NaN operand is ignored).
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmin(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // One message m (already gathered) of CSR edge position e folded into the accumulators.
 template <int VEC, bool EXTRA>
 __device__ __forceinline__ void fold(Acc<VEC, EXTRA>& a, const float (&m)[VEC], int e, float w, bool has_w) {
   if constexpr (!EXTRA) {
+    // Hot path: 14 VALU per dwordx4 (2 pk_add, 2 pk_mul, 2 pk_add, 4 v_max, 4 v_min).  v_max/v_min drop
+    // NaN operands; torch.max/min propagate them, so NaN is restored at the end of the row from the sum
+    // of squares (q is NaN iff some message is NaN: its terms are >= 0, so inf never cancels) -- see nan_fix().
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       const float v = m[k];
       a.s[k] = a.s[k] + v;
       a.q[k] = a.q[k] + v * v;
-      a.mx[k] = (v > a.mx[k] || v != v) ? v : a.mx[k];   // NaN-propagating like torch.max
-      a.mn[k] = (v < a.mn[k] || v != v) ? v : a.mn[k];
+      a.mx[k] = vmax(a.mx[k], v);
+      a.mn[k] = vmin(a.mn[k], v);
     }
   } else {
     const bool on = !has_w || w > 0.f;                     // max/min: adjacency is a mask (A.5)
@@ -124,31 +139,65 @@ __device__ __forceinline__ void fold(Acc<VEC, EXTRA>& a, const float (&m)[VEC], 
 }
 
 // B consecutive edges [e0, e0+B) of one row: issue every gather first, then fold in edge order.
-template <int VEC, int B, bool EXTRA>
+// PARTIAL: only the first `nvalid` (1 <= nvalid < B) edges exist; the other slots re-load the last valid
+// edge (same cache lines, so no extra memory traffic and -- unlike loads under a branch -- all B loads
+// still issue back to back) and are not folded.
+template <int VEC, int B, bool EXTRA, bool PARTIAL, bool IDX32>
 __device__ __forceinline__ void batch(const KArgs& a, Acc<VEC, EXTRA>& acc, int myidx, int src_lane0, int e0,
-                                      long off, const float (&dterm)[VEC]) {
+                                      long off, const float (&dterm)[VEC], int nvalid, bool gather) {
   int id[B];
+  int ee[B];
   float v[B][VEC];
 #pragma unroll
-  for (int u = 0; u < B; ++u) id[u] = a.col ? __shfl(myidx, src_lane0 + u) : (e0 + u);
+  for (int u = 0; u < B; ++u) {
+    const int uu = PARTIAL ? min(u, nvalid - 1) : u;
+    ee[u] = e0 + uu;
+    id[u] = __shfl(myidx, src_lane0 + uu);          // (edge-resident x: myidx already holds cb + lane)
+  }
+  (void)gather;
+  if constexpr (IDX32) {
+    // feature table < 4 GiB: 32-bit byte offsets against the wave-uniform base (global_load ... v_off, s[base])
+    const unsigned ldb = (unsigned)a.ldx * 4u, offb = (unsigned)off * 4u;
 #pragma unroll
-  for (int u = 0; u < B; ++u) Ld<VEC>::load(a.x + (size_t)id[u] * a.ldx + off, v[u]);
+    for (int u = 0; u < B; ++u)
+      Ld<VEC>::load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x) + ((unsigned)id[u] * ldb + offb)), v[u]);
+  } else {
+#pragma unroll
+    for (int u = 0; u < B; ++u) Ld<VEC>::load(a.x + (size_t)id[u] * a.ldx + off, v[u]);
+  }
   if constexpr (!EXTRA) {
 #pragma unroll
-    for (int u = 0; u < B; ++u) fold<VEC, false>(acc, v[u], e0 + u, 1.f, false);
+    for (int u = 0; u < B; ++u) {
+      if constexpr (PARTIAL) {
+        // Branch-free tail: an empty slot holds a copy of the last valid edge.  Folding that copy into
+        // max/min is idempotent; for sum / sum-of-squares it is replaced by +0 (v*v of 0 is 0).
+        const bool on = u < nvalid;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          const float vm = on ? v[u][k] : 0.f;
+          acc.s[k] = acc.s[k] + vm;
+          acc.q[k] = acc.q[k] + vm * vm;
+          acc.mx[k] = vmax(acc.mx[k], v[u][k]);
+          acc.mn[k] = vmin(acc.mn[k], v[u][k]);
+        }
+      } else {
+        fold<VEC, false>(acc, v[u], ee[u], 1.f, false);
+      }
+    }
   } else {
     float et[B][VEC];
     float w[B];
     if (a.edge_term) {
 #pragma unroll
-      for (int u = 0; u < B; ++u) Ld<VEC>::load(a.edge_term + (size_t)(e0 + u) * a.ld_edge + off, et[u]);
+      for (int u = 0; u < B; ++u) Ld<VEC>::load(a.edge_term + (size_t)ee[u] * a.ld_edge + off, et[u]);
     }
     if (a.ew) {
 #pragma unroll
-      for (int u = 0; u < B; ++u) w[u] = a.ew[e0 + u];
+      for (int u = 0; u < B; ++u) w[u] = a.ew[ee[u]];
     }
 #pragma unroll
     for (int u = 0; u < B; ++u) {
+      if (PARTIAL && u >= nvalid) continue;
       float m[VEC];
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
@@ -156,15 +205,16 @@ __device__ __forceinline__ void batch(const KArgs& a, Acc<VEC, EXTRA>& acc, int 
         if (a.dst_term) m[k] = m[k] + dterm[k];
         if (a.edge_term) m[k] = m[k] + et[u][k];
       }
-      fold<VEC, true>(acc, m, e0 + u, a.ew ? w[u] : 1.f, a.ew != nullptr);
+      fold<VEC, true>(acc, m, ee[u], a.ew ? w[u] : 1.f, a.ew != nullptr);
     }
   }
 }
 
-// All lanes of a group walk CSR positions [beg, end) of destination `row`.
-template <int VEC, int U, bool EXTRA>
+// All lanes of a group walk CSR positions [beg, end) of destination `row`.  `pref` holds the row's first
+// L source ids (lane c: col[beg + c]) when `have_pref` -- fetched one row ahead by the caller.
+template <int VEC, int U, bool EXTRA, bool IDX32>
 __device__ __forceinline__ void walk(const KArgs& a, Acc<VEC, EXTRA>& acc, int row, int beg, int end, int c,
-                                     int grp_lane0, long off) {
+                                     int grp_lane0, long off, int pref, bool have_pref) {
   float dterm[VEC];
 #pragma unroll
   for (int k = 0; k < VEC; ++k) dterm[k] = 0.f;
@@ -172,13 +222,14 @@ __device__ __forceinline__ void walk(const KArgs& a, Acc<VEC, EXTRA>& acc, int r
   const int L = a.L;
   for (int cb = beg; cb < end; cb += L) {
     const int nidx = min(L, end - cb);
-    int myidx = 0;
-    if (a.col && c < nidx) myidx = a.col[cb + c];
+    int myidx = pref;
+    if (!(have_pref && cb == beg)) {
+      myidx = cb + c;                                   // edge-resident x: message row = CSR position
+      if (a.col) myidx = c < nidx ? a.col[cb + c] : 0;
+    }
     int j = 0;
-    for (; j + U <= nidx; j += U) batch<VEC, U, EXTRA>(a, acc, myidx, grp_lane0 + j, cb + j, off, dterm);
-    if (U >= 8 && nidx - j >= 4) { batch<VEC, 4, EXTRA>(a, acc, myidx, grp_lane0 + j, cb + j, off, dterm); j += 4; }
-    if (U >= 4 && nidx - j >= 2) { batch<VEC, 2, EXTRA>(a, acc, myidx, grp_lane0 + j, cb + j, off, dterm); j += 2; }
-    if (U >= 2 && nidx - j >= 1) { batch<VEC, 1, EXTRA>(a, acc, myidx, grp_lane0 + j, cb + j, off, dterm); j += 1; }
+    for (; j + U <= nidx; j += U) batch<VEC, U, EXTRA, false, IDX32>(a, acc, myidx, grp_lane0 + j, cb + j, off, dterm, U, true);
+    if (j < nidx) batch<VEC, U, EXTRA, true, IDX32>(a, acc, myidx, grp_lane0 + j, cb + j, off, dterm, nidx - j, true);
   }
 }
 
@@ -187,16 +238,23 @@ __device__ __forceinline__ void walk(const KArgs& a, Acc<VEC, EXTRA>& acc, int r
 template <int VEC, bool EXTRA>
 __device__ __forceinline__ void finalize_store(const KArgs& a, const Acc<VEC, EXTRA>& acc, int row, int deg,
                                                long offi, long offo) {
-  float mean[VEC], var[VEC], sd[VEC];
+  float mean[VEC], var[VEC], sd[VEC], mx[VEC], mn[VEC];
   const bool empty = deg <= 0;
   const float D = (EXTRA && a.ew) ? acc.wsum : (float)deg;
+  // one IEEE division per row; mean = s * (1/D) is within 1 ulp of the reference's s / D (exact for
+  // D = 1, 2, 4, ...), far inside the fp32 summation-order noise the 1e-5 parity bar allows for mean/std
+  const float invD = 1.0f / D;
 #pragma unroll
   for (int k = 0; k < VEC; ++k) {
-    mean[k] = acc.s[k] / D;                               // torch.mean = sum / n
-    const float msq = acc.q[k] / D;
+    mean[k] = acc.s[k] * invD;
+    const float msq = acc.q[k] * invD;
     const float t = msq - mean[k] * mean[k];
     var[k] = (t < 0.f) ? 0.f : t;                         // relu (keeps NaN)
     sd[k] = sqrtf(var[k] + 1e-5f);
+    // the fast fold's v_max/v_min ignore NaN; q != q <=> the row holds a NaN message (torch propagates it)
+    const bool has_nan = !EXTRA && acc.q[k] != acc.q[k];
+    mx[k] = has_nan ? acc.q[k] : acc.mx[k];
+    mn[k] = has_nan ? acc.q[k] : acc.mn[k];
   }
   for (int s = 0; s < a.n_scaler; ++s) {
     const float sc = a.row_scale[s] ? a.row_scale[s][row] : 1.f;
@@ -209,8 +267,8 @@ __device__ __forceinline__ void finalize_store(const KArgs& a, const Acc<VEC, EX
         switch (code) {
           case PNA_AGG_MEAN: v = mean[k]; break;
           case PNA_AGG_SUM: v = acc.s[k]; break;
-          case PNA_AGG_MAX: v = acc.mx[k]; break;
-          case PNA_AGG_MIN: v = acc.mn[k]; break;
+          case PNA_AGG_MAX: v = mx[k]; break;
+          case PNA_AGG_MIN: v = mn[k]; break;
           case PNA_AGG_STD: v = sd[k]; break;
           default: v = var[k]; break;
         }
@@ -225,7 +283,7 @@ __device__ __forceinline__ void finalize_store(const KArgs& a, const Acc<VEC, EX
   }
 }
 
-template <int VEC, int U, bool EXTRA>
+template <int VEC, int U, bool EXTRA, bool IDX32>
 __global__ __launch_bounds__(kBlock) void k_segreduce(const KArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -257,7 +315,7 @@ __global__ __launch_bounds__(kBlock) void k_segreduce(const KArgs a) {
     const int beg = rbeg + sidx * a.seg_len;
     const int end = min(beg + a.seg_len, rend);
     acc.init();
-    walk<VEC, U, EXTRA>(a, acc, row, beg, end, c, grp_lane0, offi);
+    walk<VEC, U, EXTRA, IDX32>(a, acc, row, beg, end, c, grp_lane0, offi, 0, false);
     if (lane_ok) {
       float* p = a.partials + ((size_t)seg * a.T + tower) * kNQ * a.pstride + off;
       Ld<VEC>::store(p, acc.s, false);
@@ -273,17 +331,266 @@ __global__ __launch_bounds__(kBlock) void k_segreduce(const KArgs a) {
     return;
   }
   // ---- ordinary rows: R rows per lane group, interleaved across the block's groups -------------
-  const long base = (long)(blockIdx.x - a.n_heavy_blocks) * NG * a.R;
+  // Software pipeline across rows: while row k is being gathered, the first L source ids of row k+1
+  // and the rowptr pair of row k+2 are already in flight, so the dependent chain per row is just its
+  // gathers (rowptr -> col -> x would otherwise be three serial memory latencies for ~10 edges).
+  const long base = (long)(blockIdx.x - a.n_heavy_blocks) * NG * a.R + gid;
+  const int thr = a.heavy_threshold;
+  const bool pf = a.pf != 0 && a.col != nullptr;
+  if (base >= a.V) return;
+  int beg_c = a.rowptr[base], end_c = a.rowptr[base + 1];
+  int idx_c = 0;
+  {
+    const int d = end_c - beg_c;
+    if (pf && c < d && !(thr > 0 && d > thr)) idx_c = a.col[beg_c + c];
+  }
+  int beg_n = 0, end_n = 0;
+  if (a.R > 1 && base + NG < a.V) { beg_n = a.rowptr[base + NG]; end_n = a.rowptr[base + NG + 1]; }
   for (int r = 0; r < a.R; ++r) {
-    const long row_l = base + (long)r * NG + gid;
+    const long row_l = base + (long)r * NG;
     if (row_l >= a.V) break;
     const int row = (int)row_l;
-    const int beg = a.rowptr[row], end = a.rowptr[row + 1];
-    const int deg = end - beg;
-    if (a.heavy_threshold > 0 && deg > a.heavy_threshold) continue;   // done by the segment blocks
+    // prefetch for the rows to come (issued before this row's gathers)
+    int idx_n = 0, beg_nn = 0, end_nn = 0;
+    const bool vn = r + 1 < a.R && row_l + NG < a.V;
+    if (vn && pf) {
+      const int dn = end_n - beg_n;
+      if (c < dn && !(thr > 0 && dn > thr)) idx_n = a.col[beg_n + c];
+    }
+    if (r + 2 < a.R && row_l + 2 * NG < a.V) { beg_nn = a.rowptr[row_l + 2 * NG]; end_nn = a.rowptr[row_l + 2 * NG + 1]; }
+    const int deg = end_c - beg_c;
+    if (!(thr > 0 && deg > thr)) {                           // heavy rows are done by the segment blocks
+      acc.init();
+      walk<VEC, U, EXTRA, IDX32>(a, acc, row, beg_c, end_c, c, grp_lane0, offi, idx_c, pf);
+      if (lane_ok && !((a.dbg & 1) && acc.s[0] != 12345.678f)) finalize_store<VEC, EXTRA>(a, acc, row, deg, offi, offo);
+    }
+    idx_c = idx_n; beg_c = beg_n; end_c = end_n; beg_n = beg_nn; end_n = end_nn;
+  }
+}
+
+// ================================================================================================
+// Hand-scheduled hot path: VEC = 4, plain gather (col != NULL, no dst/edge terms, weights or arg
+// outputs), feature table < 4 GiB and < 2^24 rows (32-bit byte offsets, v_mad_u32_u24 addressing).
+//
+// hipcc's own s_waitcnt placement cannot know that the prefetched source ids / rowptr pair of the
+// NEXT row have landed (they were issued before the current row's gathers, and VMEM returns in
+// order), so it drains the queue -- including the previous row's output stores -- with vmcnt(0)
+// before every first ds_bpermute.  Here every load of the row loop is issued through inline asm and
+// waited for with counted s_waitcnt, so that per row the wave only ever waits on its gathers, with
+// the previous row's store acknowledgements and the next rows' prefetches in flight underneath.
+// Rules kept (cdna_hip_programming.md 5.7): an asm-loaded register is only consumed through the
+// "+v" operand of the asm statement that waits for it (or anchors it), so the compiler can neither
+// hoist a use above the wait nor recycle the register early.
+// ================================================================================================
+typedef int i2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void aload32(int& dst, const void* base, unsigned voff) {
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ void aload64(i2& dst, const void* base, unsigned voff) {
+  asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ void aload128(f4& dst, const void* base, unsigned voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
+}
+template <int N> __device__ __forceinline__ void await(f4& v) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void await(int& v) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N) : "memory");
+}
+
+struct AccF {   // fast-path accumulators of one lane: 4 features
+  f4 s, q, mx, mn;
+  __device__ __forceinline__ void init() {
+    s = (f4){0.f, 0.f, 0.f, 0.f}; q = s;
+    mx = (f4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    mn = (f4){INFINITY, INFINITY, INFINITY, INFINITY};
+  }
+  __device__ __forceinline__ void fold(const f4 v) {
+    s = s + v;
+    q = q + v * v;
+    mx.x = vmax(mx.x, v.x); mx.y = vmax(mx.y, v.y); mx.z = vmax(mx.z, v.z); mx.w = vmax(mx.w, v.w);
+    mn.x = vmin(mn.x, v.x); mn.y = vmin(mn.y, v.y); mn.z = vmin(mn.z, v.z); mn.w = vmin(mn.w, v.w);
+  }
+  __device__ __forceinline__ void fold_masked(const f4 v, bool on) {   // empty slot = copy of a folded edge
+    const f4 z = (f4){0.f, 0.f, 0.f, 0.f};
+    const f4 vm = on ? v : z;
+    s = s + vm;
+    q = q + vm * vm;
+    mx.x = vmax(mx.x, v.x); mx.y = vmax(mx.y, v.y); mx.z = vmax(mx.z, v.z); mx.w = vmax(mx.w, v.w);
+    mn.x = vmin(mn.x, v.x); mn.y = vmin(mn.y, v.y); mn.z = vmin(mn.z, v.z); mn.w = vmin(mn.w, v.w);
+  }
+};
+
+template <int I, int U> struct Drain {   // wait for gather I of U (U-1-I younger ones may stay in flight), fold it
+  static __device__ __forceinline__ void run(AccF& acc, f4 (&v)[U], int nvalid, bool partial) {
+    await<U - 1 - I>(v[I]);
+    if (partial) acc.fold_masked(v[I], I < nvalid); else acc.fold(v[I]);
+    Drain<I + 1, U>::run(acc, v, nvalid, partial);
+  }
+};
+template <int U> struct Drain<U, U> {
+  static __device__ __forceinline__ void run(AccF&, f4 (&)[U], int, bool) {}
+};
+
+// U gathers of one row issued back to back from the ids held by the group's lanes, then folded in order.
+template <int U, bool PARTIAL>
+__device__ __forceinline__ void fast_batch(const KArgs& a, AccF& acc, int idx, int src_lane0, unsigned ldb,
+                                           unsigned offb, int nvalid) {
+  int id[U];
+  f4 v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) id[u] = __shfl(idx, src_lane0 + (PARTIAL ? min(u, nvalid - 1) : u));
+#pragma unroll
+  for (int u = 0; u < U; ++u) aload128(v[u], a.x, __umul24((unsigned)id[u], ldb) + offb);
+  Drain<0, U>::run(acc, v, nvalid, PARTIAL);
+}
+
+__device__ __forceinline__ void fast_finalize_store(const KArgs& a, const AccF& acc, int row, int deg, long offo) {
+  float* const orow = a.out + (size_t)row * a.ldo + offo;
+  const unsigned bs = (unsigned)a.block_stride;
+  const bool nt = a.nt != 0;
+  typedef f4 f4a4 __attribute__((aligned(4)));
+  auto put = [&](unsigned blk, const f4 v) {
+    f4a4* p = reinterpret_cast<f4a4*>(orow + blk * bs);
+    if (nt) __builtin_nontemporal_store(v, p); else *p = v;
+  };
+  const int A = a.n_aggr, S = a.n_scaler;
+  if (deg <= 0) {                                          // no in-edges: every block is 0
+    const f4 z = (f4){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < A * S; ++b) put(b, z);
+    return;
+  }
+  const float invD = 1.0f / (float)deg;                    // one IEEE division per row (see finalize_store)
+  const f4 mean = acc.s * invD;
+  f4 var = acc.q * invD - mean * mean;
+  var.x = var.x < 0.f ? 0.f : var.x; var.y = var.y < 0.f ? 0.f : var.y;
+  var.z = var.z < 0.f ? 0.f : var.z; var.w = var.w < 0.f ? 0.f : var.w;
+  for (int i = 0; i < A; ++i) {
+    f4 v;
+    switch (a.aggr[i]) {
+      case PNA_AGG_MEAN: v = mean; break;
+      case PNA_AGG_SUM: v = acc.s; break;
+      case PNA_AGG_MAX:   // v_max drops NaN; q is NaN iff the row holds a NaN message (torch propagates it)
+        v.x = acc.q.x != acc.q.x ? acc.q.x : acc.mx.x; v.y = acc.q.y != acc.q.y ? acc.q.y : acc.mx.y;
+        v.z = acc.q.z != acc.q.z ? acc.q.z : acc.mx.z; v.w = acc.q.w != acc.q.w ? acc.q.w : acc.mx.w;
+        break;
+      case PNA_AGG_MIN:
+        v.x = acc.q.x != acc.q.x ? acc.q.x : acc.mn.x; v.y = acc.q.y != acc.q.y ? acc.q.y : acc.mn.y;
+        v.z = acc.q.z != acc.q.z ? acc.q.z : acc.mn.z; v.w = acc.q.w != acc.q.w ? acc.q.w : acc.mn.w;
+        break;
+      case PNA_AGG_STD:
+        v.x = sqrtf(var.x + 1e-5f); v.y = sqrtf(var.y + 1e-5f); v.z = sqrtf(var.z + 1e-5f); v.w = sqrtf(var.w + 1e-5f);
+        break;
+      default: v = var; break;
+    }
+    for (int s = 0; s < S; ++s) {
+      const float* rs = a.row_scale[s];
+      put((unsigned)(s * A + i), rs ? v * rs[row] : v);
+    }
+  }
+}
+
+template <int U>
+__global__ __launch_bounds__(kBlock) void k_segreduce_fast(const KArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int L = a.L;
+  const int grp = lane / L;
+  if (grp >= a.G) return;
+  const int c = lane - grp * L;
+  const int grp_lane0 = grp * L;
+  const int nchunks = (a.F + 3) / 4;
+  const int tower = blockIdx.y / a.tiles;
+  const int chunk = (blockIdx.y - tower * a.tiles) * L + c;
+  const bool lane_ok = chunk < nchunks;
+  const int off = min(min(chunk, nchunks - 1) * 4, a.F - 4);
+  const long offi = (long)tower * a.ts_in + off;
+  const long offo = (long)tower * a.ts_out + off;
+  const int NG = kWaves * a.G;
+  const int gid = wave * a.G + grp;
+  if ((int)blockIdx.x < a.n_heavy_blocks) {
+    // heavy segments: compiler-scheduled generic walk, raw partials to the workspace
+    const int seg = blockIdx.x * NG + gid;
+    if (seg >= a.n_seg) return;
+    const int hi = a.seg_heavy[seg];
+    const int row = a.heavy_rows[hi];
+    const int sidx = seg - a.heavy_segptr[hi];
+    const int rbeg = a.rowptr[row], rend = a.rowptr[row + 1];
+    const int beg = rbeg + sidx * a.seg_len;
+    const int end = min(beg + a.seg_len, rend);
+    Acc<4, false> acc;
     acc.init();
-    walk<VEC, U, EXTRA>(a, acc, row, beg, end, c, grp_lane0, offi);
-    if (lane_ok) finalize_store<VEC, EXTRA>(a, acc, row, deg, offi, offo);
+    walk<4, U, false, true>(a, acc, row, beg, end, c, grp_lane0, offi, 0, false);
+    if (lane_ok) {
+      float* p = a.partials + ((size_t)seg * a.T + tower) * kNQ * a.pstride + off;
+      Ld<4>::store(p, acc.s, false);
+      Ld<4>::store(p + a.pstride, acc.q, false);
+      Ld<4>::store(p + 2 * a.pstride, acc.mx, false);
+      Ld<4>::store(p + 3 * a.pstride, acc.mn, false);
+    }
+    return;
+  }
+  const long base = (long)(blockIdx.x - a.n_heavy_blocks) * NG * a.R + gid;
+  if (base >= a.V) return;
+  const int thr = a.heavy_threshold;
+  const unsigned ldb = (unsigned)a.ldx * 4u;
+  const unsigned offb = (unsigned)offi * 4u;
+
+  // prologue: rowptr pair of row 0 -> its first ids and the rowptr pair of row 1
+  i2 b0;
+  aload64(b0, a.rowptr, (unsigned)base * 4u);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(b0) : : "memory");
+  int beg_c = b0.x, end_c = b0.y;
+  int idx_c = 0;
+  {
+    const int d = end_c - beg_c;
+    if (c < d && !(thr > 0 && d > thr)) aload32(idx_c, a.col, (unsigned)(beg_c + c) * 4u);
+  }
+  i2 bn = (i2){0, 0};
+  if (a.R > 1 && base + NG < a.V) aload64(bn, a.rowptr, (unsigned)(base + NG) * 4u);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(idx_c), "+v"(bn) : : "memory");
+  int beg_n = bn.x, end_n = bn.y;
+
+  AccF acc;
+  for (int r = 0; r < a.R; ++r) {
+    const long row_l = base + (long)r * NG;
+    if (row_l >= a.V) break;
+    const int row = (int)row_l;
+    // ---- prefetch: first L source ids of row r+1, rowptr pair of row r+2 (issued BEFORE this row's gathers)
+    int idx_n = 0;
+    i2 bnn = (i2){0, 0};
+    if (r + 1 < a.R && row_l + NG < a.V) {
+      const int dn = end_n - beg_n;
+      if (c < dn && !(thr > 0 && dn > thr)) aload32(idx_n, a.col, (unsigned)(beg_n + c) * 4u);
+    }
+    if (r + 2 < a.R && row_l + 2 * NG < a.V) aload64(bnn, a.rowptr, (unsigned)(row + 2 * NG) * 4u);
+    // ---- this row
+    const int deg = end_c - beg_c;
+    bool gathered = false;
+    if (!(thr > 0 && deg > thr)) {
+      acc.init();
+      int idx = idx_c;
+      for (int cb = beg_c; cb < end_c; cb += L) {
+        const int nidx = min(L, end_c - cb);
+        if (cb != beg_c) {                                  // rows longer than one id chunk (rare): fetch + wait
+          idx = 0;
+          if (c < nidx) aload32(idx, a.col, (unsigned)(cb + c) * 4u);
+          await<0>(idx);
+        }
+        int j = 0;
+        for (; j + U <= nidx; j += U) fast_batch<U, false>(a, acc, idx, grp_lane0 + j, ldb, offb, U);
+        if (j < nidx) fast_batch<U, true>(a, acc, idx, grp_lane0 + j, ldb, offb, nidx - j);
+      }
+      gathered = deg > 0;
+      if (lane_ok && !((a.dbg & 1) && acc.s.x != 12345.678f)) fast_finalize_store(a, acc, row, deg, offo);
+    }
+    // The prefetches were issued before this row's gathers, so once the wave has waited for any gather they
+    // have landed (VMEM returns in order).  Only if no lane group of the wave gathered anything: drain.
+    if (__builtin_amdgcn_ballot_w64(gathered) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(idx_n), "+v"(bnn));              // anchor: consumers cannot move above this point
+    idx_c = idx_n; beg_c = beg_n; end_c = end_n; beg_n = bnn.x; end_n = bnn.y;
   }
 }
 
@@ -311,33 +618,42 @@ __global__ __launch_bounds__(kBlock) void k_heavy_finalize(const KArgs a) {
   const int s0 = a.heavy_segptr[hi], s1 = a.heavy_segptr[hi + 1];
   Acc<VEC, EXTRA> acc;
   acc.init();
-  for (int seg = s0; seg < s1; ++seg) {
-    const float* p = a.partials + ((size_t)seg * a.T + tower) * kNQ * a.pstride + off;
-    float ps[VEC], pq[VEC], pmx[VEC], pmn[VEC];
-    Ld<VEC>::load(p, ps);
-    Ld<VEC>::load(p + a.pstride, pq);
-    Ld<VEC>::load(p + 2 * a.pstride, pmx);
-    Ld<VEC>::load(p + 3 * a.pstride, pmn);
-    int pax[VEC], pan[VEC];
-    if constexpr (EXTRA) {
-      float t[VEC];
-      Ld<VEC>::load(p + 4 * a.pstride, t);
+  // Partials are independent loads: fetch PB segments' worth before folding (a hub row has ~60 segments;
+  // one-at-a-time would be 60 serial memory latencies), then fold strictly in segment order.
+  constexpr int PB = 4;
+  for (int sb = s0; sb < s1; sb += PB) {
+    float ps[PB][VEC], pq[PB][VEC], pmx[PB][VEC], pmn[PB][VEC], pax[PB][VEC], pan[PB][VEC], pw[PB];
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) pax[k] = __float_as_int(t[k]);
-      Ld<VEC>::load(p + 5 * a.pstride, t);
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) pan[k] = __float_as_int(t[k]);
-      acc.wsum = acc.wsum + p[6 * a.pstride - off];
+    for (int i = 0; i < PB; ++i) {
+      const int seg = min(sb + i, s1 - 1);
+      const float* p = a.partials + ((size_t)seg * a.T + tower) * kNQ * a.pstride + off;
+      Ld<VEC>::load(p, ps[i]);
+      Ld<VEC>::load(p + a.pstride, pq[i]);
+      Ld<VEC>::load(p + 2 * a.pstride, pmx[i]);
+      Ld<VEC>::load(p + 3 * a.pstride, pmn[i]);
+      if constexpr (EXTRA) {
+        Ld<VEC>::load(p + 4 * a.pstride, pax[i]);
+        Ld<VEC>::load(p + 5 * a.pstride, pan[i]);
+        pw[i] = p[6 * a.pstride - off];
+      }
     }
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-      acc.s[k] = acc.s[k] + ps[k];
-      acc.q[k] = acc.q[k] + pq[k];
-      const bool gx = pmx[k] > acc.mx[k] || (pmx[k] != pmx[k] && acc.mx[k] == acc.mx[k]);
-      const bool gn = pmn[k] < acc.mn[k] || (pmn[k] != pmn[k] && acc.mn[k] == acc.mn[k]);
-      acc.mx[k] = gx ? pmx[k] : acc.mx[k];
-      acc.mn[k] = gn ? pmn[k] : acc.mn[k];
-      if constexpr (EXTRA) { acc.amx[k] = gx ? pax[k] : acc.amx[k]; acc.amn[k] = gn ? pan[k] : acc.amn[k]; }
+    for (int i = 0; i < PB; ++i) {
+      if (sb + i >= s1) break;
+      if constexpr (EXTRA) acc.wsum = acc.wsum + pw[i];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        acc.s[k] = acc.s[k] + ps[i][k];
+        acc.q[k] = acc.q[k] + pq[i][k];
+        const bool gx = pmx[i][k] > acc.mx[k] || (pmx[i][k] != pmx[i][k] && acc.mx[k] == acc.mx[k]);
+        const bool gn = pmn[i][k] < acc.mn[k] || (pmn[i][k] != pmn[i][k] && acc.mn[k] == acc.mn[k]);
+        acc.mx[k] = gx ? pmx[i][k] : acc.mx[k];
+        acc.mn[k] = gn ? pmn[i][k] : acc.mn[k];
+        if constexpr (EXTRA) {
+          acc.amx[k] = gx ? __float_as_int(pax[i][k]) : acc.amx[k];
+          acc.amn[k] = gn ? __float_as_int(pan[i][k]) : acc.amn[k];
+        }
+      }
     }
   }
   finalize_store<VEC, EXTRA>(a, acc, row, a.rowptr[row + 1] - a.rowptr[row], offi, offo);
@@ -359,19 +675,23 @@ __global__ void k_degree_scalers(const int32_t* rowptr, int V, float avg_log, fl
 }
 
 template <int VEC, int U>
-int launch_u(const KArgs& k, bool extra, dim3 grid, hipStream_t st) {
-  if (extra) hipLaunchKernelGGL((k_segreduce<VEC, U, true>), grid, dim3(kBlock), 0, st, k);
-  else hipLaunchKernelGGL((k_segreduce<VEC, U, false>), grid, dim3(kBlock), 0, st, k);
+int launch_u(const KArgs& k, bool extra, bool idx32, dim3 grid, hipStream_t st) {
+  if (extra) {
+    if (idx32) hipLaunchKernelGGL((k_segreduce<VEC, U, true, true>), grid, dim3(kBlock), 0, st, k);
+    else hipLaunchKernelGGL((k_segreduce<VEC, U, true, false>), grid, dim3(kBlock), 0, st, k);
+  } else {
+    if (idx32) hipLaunchKernelGGL((k_segreduce<VEC, U, false, true>), grid, dim3(kBlock), 0, st, k);
+    else hipLaunchKernelGGL((k_segreduce<VEC, U, false, false>), grid, dim3(kBlock), 0, st, k);
+  }
   return 0;
 }
 
-template <int VEC>
-int launch_v(const KArgs& k, int U, bool extra, dim3 grid, hipStream_t st) {
+int launch_any(const KArgs& k, int vec, int U, bool extra, bool idx32, dim3 grid, hipStream_t st) {
+  if (vec == 1) return launch_u<1, 4>(k, extra, idx32, grid, st);      // scalar path: one unroll only
   switch (U) {
-    case 1: return launch_u<VEC, 1>(k, extra, grid, st);
-    case 2: return launch_u<VEC, 2>(k, extra, grid, st);
-    case 4: return launch_u<VEC, 4>(k, extra, grid, st);
-    case 8: return launch_u<VEC, 8>(k, extra, grid, st);
+    case 2: return launch_u<4, 2>(k, extra, idx32, grid, st);
+    case 4: return launch_u<4, 4>(k, extra, idx32, grid, st);
+    case 8: return launch_u<4, 8>(k, extra, idx32, grid, st);
   }
   return -1;
 }
@@ -439,9 +759,11 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
   }
   k.L = L; k.G = 64 / L; k.T = T; k.tiles = tiles; k.ts_in = ts_in; k.ts_out = ts_out;
   int U = t.unroll ? t.unroll : 4;
-  if (U != 1 && U != 2 && U != 4 && U != 8) return pna_set_error(PNA_E_INVALID, "pna_segreduce_fwd_f32: tune.unroll must be 1,2,4,8");
+  if (U != 2 && U != 4 && U != 8) return pna_set_error(PNA_E_INVALID, "pna_segreduce_fwd_f32: tune.unroll must be 2, 4 or 8");
   k.R = t.rows_per_group > 0 ? t.rows_per_group : 4;
   k.nt = t.nt_store >= 0 ? 1 : 0;
+  k.pf = t.prefetch >= 0 ? 1 : 0;
+  k.dbg = t.reserved[0];   // bit0: skip the output stores (bench experiments only; results are then undefined)
   k.pstride = (p->F + 3) / 4 * 4;
   const int NG = kWaves * k.G;
   k.n_heavy_blocks = heavy ? (k.n_seg + NG - 1) / NG : 0;
@@ -451,7 +773,21 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
   const bool extra = p->dst_term || p->edge_term || p->edge_weight || p->argmax || p->argmin;
   dim3 grid((unsigned)(light_blocks + k.n_heavy_blocks), (unsigned)(tiles * T));
   hipStream_t st = (hipStream_t)stream;
-  int rc = vec == 4 ? launch_v<4>(k, U, extra, grid, st) : launch_v<1>(k, U, extra, grid, st);
+  // 32-bit gather offsets when the whole feature table is addressable with them
+  const bool idx32 = p->x_rows > 0 && (double)p->x_rows * (double)p->ldx * 4.0 < 4294967296.0 && p->ldx < (1 << 28);
+  // hand-scheduled kernel for the common configuration (see k_segreduce_fast)
+  const bool fast_ok = vec == 4 && !extra && p->col != nullptr && idx32 && p->x_rows < (1 << 24) && p->ldx * 4 < (1 << 24) &&
+                       p->V < (1 << 30) && t.reserved[1] == 0;
+  int rc = 0;
+  if (fast_ok) {
+    switch (U) {
+      case 2: hipLaunchKernelGGL((k_segreduce_fast<2>), grid, dim3(kBlock), 0, st, k); break;
+      case 4: hipLaunchKernelGGL((k_segreduce_fast<4>), grid, dim3(kBlock), 0, st, k); break;
+      default: hipLaunchKernelGGL((k_segreduce_fast<8>), grid, dim3(kBlock), 0, st, k); break;
+    }
+  } else {
+    rc = launch_any(k, vec, U, extra, idx32, grid, st);
+  }
   if (rc != 0) return pna_set_error(PNA_E_INVALID, "pna_segreduce_fwd_f32: no kernel for this tuning");
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));

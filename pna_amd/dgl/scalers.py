@@ -10,11 +10,18 @@ import numpy as np
 
 
 def degree_factor(name, D, avg_d):
-    """Scalar (0-dim fp32 tensor) the scaler `name` multiplies a bucket of in-degree D with."""
+    """The fp32 value (as a Python float) the scaler `name` multiplies a bucket of in-degree D with.
+
+    The reference evaluates `np.log(D+1) / avg` as avg.reciprocal() * fp32(log(D+1)) and
+    `avg / np.log(D+1)` as a true fp32 division (torch's scalar dispatch).  The same sequence is done
+    here in numpy float32 on the host so that the factor is identical whether avg_d['log'] lives on the
+    CPU or on a GPU (a device-side reciprocal may differ from the CPU's by one ulp)."""
+    avg = np.float32(float(avg_d["log"]))
+    lg = np.float32(np.log(D + 1))
     if name == "amplification":
-        return np.log(D + 1) / avg_d["log"]       # -> avg.reciprocal() * fp32(log(D+1))
+        return float(np.float32(np.float32(1.0) / avg) * lg)
     if name == "attenuation":
-        return avg_d["log"] / np.log(D + 1)       # -> avg / fp32(log(D+1))
+        return float(avg / lg)
     raise KeyError(name)
 
 

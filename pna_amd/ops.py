@@ -51,7 +51,7 @@ def segreduce(rowptr: torch.Tensor, col: Optional[torch.Tensor], x: torch.Tensor
     a.rowptr = _lib.dev_ptr(rowptr, torch.int32, "rowptr")
     a.col = _lib.dev_ptr(col, torch.int32, "col")
     a.V, a.F = V, F
-    a.x, a.ldx = _lib.dev_ptr(x, torch.float32, "x"), _ld(x)
+    a.x, a.ldx, a.x_rows = _lib.dev_ptr(x, torch.float32, "x"), _ld(x), x.shape[0]
     if dst_term is not None:
         a.dst_term, a.ld_dst = _lib.dev_ptr(dst_term, torch.float32, "dst_term"), _ld(dst_term)
     if edge_term is not None:

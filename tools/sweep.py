@@ -44,13 +44,26 @@ def main():
     heavy = {0: None}
     for thr, seg in ((32, 32), (64, 64), (128, 64), (128, 128), (256, 128), (512, 256)):
         heavy[(thr, seg)] = build_heavy_schedule(c.rowptr, c.max_degree, thr, seg)
+    cols = {"real": c.col, "l2": (c.col % 4096).contiguous(),                       # every gather hits L2: issue-bound floor
+            "seq": (torch.arange(E, device=dev, dtype=torch.int32) % V).contiguous()}  # streaming sources
     aggs = ["mean", "max", "min", "std"]
     alg_bytes = E * (4 * F + 4) + 4 * (V + 1) + V * 16 * F
 
     variants = []
+    # 0. memory-system experiments: same instruction stream, different source locality
+    for cm in ("l2", "seq"):
+        for U in (4, 8):
+            variants.append(dict(ld=75, heavy=(64, 64), S=1, col=cm, tune=dict(unroll=U, rows_per_group=4)))
+    for cm in ("real", "l2"):
+        variants.append(dict(ld=75, heavy=(64, 64), S=1, col=cm, nocheck=1, tune=dict(unroll=4, rows_per_group=4, debug=1)))
     # 1. tuning grid at ld=75, default heavy (64,64), 4F output
-    for U, R, L in itertools.product((2, 4, 8), (1, 2, 4, 8), (19, 20)):
-        variants.append(dict(ld=75, heavy=(64, 64), S=1, tune=dict(unroll=U, rows_per_group=R, lanes_per_row=L)))
+    for U, R in itertools.product((4,), (4, 8, 16)):
+        variants.append(dict(ld=75, heavy=(64, 64), S=1, tune=dict(unroll=U, rows_per_group=R)))
+    for U in (2, 4):
+        variants.append(dict(ld=75, heavy=(64, 64), S=1, tune=dict(unroll=U, rows_per_group=4, generic=1)))
+    for hk in ((64, 64), (128, 128)):
+        for ld in (75, 80):
+            variants.append(dict(ld=ld, heavy=hk, S=1, tune=dict(unroll=4, rows_per_group=8)))
     # 2. leading dimension of x
     for ld in (76, 80, 96):
         for U in (4, 8):
@@ -71,18 +84,29 @@ def main():
     outs = {}
     for S in (1, 3):
         outs[S] = torch.empty(V, 4 * S * F, device=dev)
+    big = torch.empty(V, 4 * 96, device=dev)
+    for bs in (76, 80, 96):
+        variants.append(dict(ld=80, heavy=(128, 128), S=1, bs=bs, nocheck=1, tune=dict(unroll=4, rows_per_group=8)))
+    for na in (1, 2, 3):
+        variants.append(dict(ld=80, heavy=(128, 128), S=1, na=na, nocheck=1, tune=dict(unroll=4, rows_per_group=8)))
 
     def run(v):
         scales = [None] if v["S"] == 1 else [None, amp, att]
         hk = v["heavy"]
-        return ops.segreduce(c.rowptr, c.col, xs[v["ld"]], F, aggs, scales, out=outs[v["S"]], heavy=heavy[hk if hk else 0],
-                             workspace=g.workspace, tune=v["tune"])
+        ag = aggs[:v.get("na", 4)]
+        if "bs" in v:
+            o, bs = big[:, :4 * v["bs"]], v["bs"]
+        else:
+            o, bs = outs[v["S"]][:, :len(ag) * v["S"] * F], F
+        return ops.segreduce(c.rowptr, cols[v.get("col", "real")], xs[v["ld"]], F, ag, scales, out=o, block_stride=bs,
+                             heavy=heavy[hk if hk else 0], workspace=g.workspace, tune=v["tune"])
 
-    ref = run(variants[0]).clone()
+    ref_v = dict(ld=75, heavy=(64, 64), S=1, tune=dict(unroll=4, rows_per_group=4))
+    ref = run(ref_v).clone()
     times = [[] for _ in variants]
     for i, v in enumerate(variants):                       # correctness of every variant first (4F part bit-identical
         o = run(v)                                         # for variants sharing the heavy schedule)
-        if v["heavy"] == variants[0]["heavy"]:
+        if v["heavy"] == ref_v["heavy"] and v.get("col", "real") == "real" and not v.get("nocheck"):
             assert torch.equal(o[:, :4 * F], ref), v
     for r in range(args.rounds):
         for i, v in enumerate(variants):
@@ -97,17 +121,14 @@ def main():
     res = []
     for v, t in zip(variants, times):
         t = sorted(t)
-        res.append(dict(v, heavy=list(v["heavy"]) if v["heavy"] else None, ms_min=t[0], ms_med=t[len(t) // 2],
+        res.append(dict(v, col=v.get("col", "real"), heavy=list(v["heavy"]) if v["heavy"] else None, ms_min=t[0], ms_med=t[len(t) // 2],
                         frac_hbm_min=alg_bytes / (t[0] * 1e-3) / 8e12, gedges_s=E / (t[0] * 1e-3) / 1e9))
     res.sort(key=lambda r: r["ms_med"])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     path = os.path.join(ROOT, "gpurun_out", f"sweep_{args.tag}.json")
     json.dump(dict(V=V, E=E, F=F, alg_bytes=alg_bytes, results=res), open(path, "w"), indent=1)
-    for r in res[:12]:
-        print(json.dumps(r))
-    print("...")
-    for r in res[-4:]:
-        print(json.dumps(r))
+    for r in res:
+        print(f"{r['ms_med']:.3f} {r['ms_min']:.3f} col={r['col']} ld={r['ld']} heavy={r['heavy']} S={r['S']} bs={r.get('bs')} na={r.get('na')} {r['tune']}")
 
 
 if __name__ == "__main__":
