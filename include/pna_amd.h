@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PNA_ABI_VERSION 2
+#define PNA_ABI_VERSION 3
 
 #define PNA_OK 0
 #define PNA_E_INVALID (-1)   /* bad argument (null pointer, unsupported size, unknown code) */
@@ -149,6 +149,64 @@ int pna_segreduce_fwd_f32(const pna_segreduce_args* args, pna_stream_t stream);
 int64_t pna_segreduce_partials_bytes(int32_t n_seg, int32_t F, int32_t n_tower);
 
 /*
+ * Backward of pna_segreduce_fwd_f32 (what autograd derives through the reference's per-bucket torch ops,
+ * models/dgl/aggregators.py:6-26).  `gagg` is the gradient w.r.t. the UNSCALED aggregates in the forward's
+ * identity-scaler layout: row v, tower t, aggregator i (aggr[i]) at column t*tower_stride_g + i*F of an
+ * (V, ld_g) matrix (the caller folds the degree scalers in: G_i = sum_s row_scale[s] * dOut[s, i]).
+ * The kernel rebuilds every message m_k = x[col[k]] (+ dst_term[v]) (+ edge_term[k]) and scatters
+ *     dL/dm_k = G_mean/D + G_sum + [k = argmax] G_max + [k = argmin] G_min
+ *             + (G_var + G_std/(2 std)) [var > 0] (2/D) (m_k - mean)
+ * into grad_x[col[k]] (fp32 hardware atomics: zero-fill grad_x first; plain stores when col == NULL),
+ * grad_dst[v] (sum over the row's edges; zero-fill first) and grad_edge[k].  Any of the three may be NULL.
+ * mean / stdv / var are the forward results (identity-scaled), (V, ld_stat) with tower stride
+ * tower_stride_stat -- needed only when std or var is among aggr[] (stdv or var, one is enough);
+ * argmax / argmin are the forward's (V, ld_arg) outputs, tower stride tower_stride_in.
+ * x / dst_term / edge_term are only read when std or var is among aggr[].
+ */
+typedef struct pna_segreduce_bwd_args {
+  const int32_t* rowptr;
+  const int32_t* col; /* nullable: x edge-resident */
+  int32_t V;
+  int32_t F;
+  const float* x;
+  int64_t ldx;
+  const float* dst_term;
+  int64_t ld_dst;
+  const float* edge_term;
+  int64_t ld_edge;
+  int32_t n_tower;
+  int32_t n_aggr;
+  int64_t tower_stride_in;
+  int32_t aggr[PNA_MAX_AGGR];
+  const float* gagg;
+  int64_t ld_g;
+  int64_t tower_stride_g;
+  const float* mean;
+  const float* stdv;
+  const float* var;
+  int64_t ld_stat;
+  int64_t tower_stride_stat;
+  const int32_t* argmax;
+  const int32_t* argmin;
+  int64_t ld_arg;
+  float* grad_x;
+  int64_t ld_gx;
+  float* grad_dst;
+  int64_t ld_gd;
+  float* grad_edge;
+  int64_t ld_ge;
+  int32_t heavy_threshold;
+  int32_t seg_len;
+  int32_t n_heavy;
+  int32_t n_seg;
+  const int32_t* heavy_rows;
+  const int32_t* heavy_segptr;
+  const int32_t* seg_heavy;
+} pna_segreduce_bwd_args;
+
+int pna_segreduce_bwd_f32(const pna_segreduce_bwd_args* args, pna_stream_t stream);
+
+/*
  * Per-row degree scalers of the DGL variant -- models/dgl/scalers.py:12-19 evaluated with the
  * reference's exact fp32 rounding sequence (np.log in float64, rounded to fp32, then
  * Tensor.__rtruediv__ = reciprocal()*scalar for amplification and a true division for attenuation):
@@ -162,31 +220,47 @@ int pna_degree_scalers_f32(const int32_t* rowptr, int32_t V, float avg_log, floa
 /*
  * Post-aggregation tower contraction on the fp32 matrix cores -- replaces the `posttrans` nn.Linear
  * applied to the concatenated [self | scaler-major aggregate] row (models/dgl/pna_layer.py:65-68,
- * :206; models/pytorch/pna/layer.py:47-48) WITHOUT materialising the (V, A*S*F) operand:
- *     y[v] = bias + W_self . h[v] + sum_s row_scale[s][v] * ( W_s . agg[v] )
- * where agg is the (V, n_aggr*F)-wide identity-scaler output of pna_segreduce_fwd_f32 and W_s the
- * column block of the reference weight that multiplies scaler s.  `w` is the reference weight
- * re-laid-out K-major: w[(s*K + k)*ldw + n], k in [0,K), K = lda columns of `a` actually used.
- *   a: (M, lda) row-major, K columns used;  h: nullable (M, ldh), Kh columns, weight wh[(k)*ldw + n];
- *   y: (M, ldy), N columns.  Uses v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate).
+ * :206; models/pytorch/pna/layer.py:47-48) WITHOUT materialising the (V, A*S*F) operand, and -- in
+ * eval mode -- the elementwise tail that follows it (graph-norm :71-72, BatchNorm with running stats
+ * :73-74 / :209-210, ReLU :211, residual :212-213):
+ *     z[v]  = bias + W_self . h[v] + sum_s row_scale[s][v] * ( W_s . a[v] )
+ *     y[v]  = residual[v] + act( (z[v] * row_post[v]) * col_scale + col_shift )
+ * where `a` is the (M, K = n_aggr*F)-wide identity-scaler output of pna_segreduce_fwd_f32 and W_s the
+ * column block of the reference weight that multiplies scaler s; row_post / col_scale+col_shift /
+ * relu / residual are each optional (NULL / 0 = skipped).  Uses v_mfma_f32_16x16x4_f32 (exact fp32
+ * products, fp32 accumulate).
+ *
+ * The weight is consumed in a packed, zero-padded tile image produced once per weight update by
+ * pna_posttrans_pack_f32 from the reference layout: w_ref is the nn.Linear weight, (N, ldw_ref)
+ * row-major, input columns ordered [h (Kh) | scaler 0 (K) | scaler 1 (K) | ...] exactly as the
+ * reference concatenates them (pna_layer.py:48-49,:65).  pna_posttrans_packed_floats returns the
+ * number of floats of w_img (and of wh_img through *wh_floats).
  */
+int64_t pna_posttrans_packed_floats(int32_t K, int32_t N, int32_t n_scaler, int32_t Kh, int64_t* wh_floats);
+int pna_posttrans_pack_f32(const float* w_ref, int64_t ldw_ref, int32_t N, int32_t K, int32_t n_scaler, int32_t Kh,
+                           float* w_img, float* wh_img /* nullable when Kh == 0 */, pna_stream_t stream);
+
 typedef struct pna_posttrans_args {
-  const float* a;
+  const float* a;   /* (M, lda), K columns used */
   int64_t lda;
   int32_t M;
   int32_t K;
   int32_t N;
-  int32_t n_scaler;
-  const float* row_scale[PNA_MAX_SCALER]; /* NULL = identity */
-  const float* w;  /* (n_scaler*K, ldw) */
-  int64_t ldw;
-  const float* h;  /* nullable */
+  int32_t n_scaler; /* 1..5 */
+  const float* row_scale[PNA_MAX_SCALER]; /* each [M] or NULL = identity */
+  const float* w_img;  /* packed aggregate weight */
+  const float* h;      /* nullable (M, ldh): the node's own features (tower variant) */
   int64_t ldh;
   int32_t Kh;
-  int32_t _pad0;
-  const float* wh; /* (Kh, ldw) */
-  const float* bias; /* nullable [N] */
-  float* y;
+  int32_t relu;        /* 1 = ReLU after the affine column map */
+  const float* wh_img; /* packed self weight (when h != NULL) */
+  const float* bias;   /* nullable [N] */
+  const float* row_post;  /* nullable [M]: graph-norm factor snorm_n */
+  const float* col_scale; /* nullable [N]: gamma / sqrt(running_var + eps)            (eval BatchNorm) */
+  const float* col_shift; /* nullable [N]: beta - running_mean * col_scale            (with col_scale) */
+  const float* residual;  /* nullable (M, ld_res): added after the activation */
+  int64_t ld_res;
+  float* y;            /* (M, ldy), N columns */
   int64_t ldy;
 } pna_posttrans_args;
 

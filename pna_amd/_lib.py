@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to the HI
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpna_amd.so")
 
-PNA_ABI_VERSION = 2
+PNA_ABI_VERSION = 3
 PNA_MAX_AGGR = 8
 PNA_MAX_SCALER = 8
 
@@ -47,14 +47,37 @@ class PnaSegreduceArgs(ctypes.Structure):
     ]
 
 
+class PnaSegreduceBwdArgs(ctypes.Structure):
+    _fields_ = [
+        ("rowptr", ctypes.c_void_p), ("col", ctypes.c_void_p), ("V", ctypes.c_int32), ("F", ctypes.c_int32),
+        ("x", ctypes.c_void_p), ("ldx", ctypes.c_int64),
+        ("dst_term", ctypes.c_void_p), ("ld_dst", ctypes.c_int64),
+        ("edge_term", ctypes.c_void_p), ("ld_edge", ctypes.c_int64),
+        ("n_tower", ctypes.c_int32), ("n_aggr", ctypes.c_int32), ("tower_stride_in", ctypes.c_int64),
+        ("aggr", ctypes.c_int32 * PNA_MAX_AGGR),
+        ("gagg", ctypes.c_void_p), ("ld_g", ctypes.c_int64), ("tower_stride_g", ctypes.c_int64),
+        ("mean", ctypes.c_void_p), ("stdv", ctypes.c_void_p), ("var", ctypes.c_void_p),
+        ("ld_stat", ctypes.c_int64), ("tower_stride_stat", ctypes.c_int64),
+        ("argmax", ctypes.c_void_p), ("argmin", ctypes.c_void_p), ("ld_arg", ctypes.c_int64),
+        ("grad_x", ctypes.c_void_p), ("ld_gx", ctypes.c_int64),
+        ("grad_dst", ctypes.c_void_p), ("ld_gd", ctypes.c_int64),
+        ("grad_edge", ctypes.c_void_p), ("ld_ge", ctypes.c_int64),
+        ("heavy_threshold", ctypes.c_int32), ("seg_len", ctypes.c_int32), ("n_heavy", ctypes.c_int32),
+        ("n_seg", ctypes.c_int32),
+        ("heavy_rows", ctypes.c_void_p), ("heavy_segptr", ctypes.c_void_p), ("seg_heavy", ctypes.c_void_p),
+    ]
+
+
 class PnaPosttransArgs(ctypes.Structure):
     _fields_ = [
         ("a", ctypes.c_void_p), ("lda", ctypes.c_int64), ("M", ctypes.c_int32), ("K", ctypes.c_int32),
         ("N", ctypes.c_int32), ("n_scaler", ctypes.c_int32),
         ("row_scale", ctypes.c_void_p * PNA_MAX_SCALER),
-        ("w", ctypes.c_void_p), ("ldw", ctypes.c_int64),
-        ("h", ctypes.c_void_p), ("ldh", ctypes.c_int64), ("Kh", ctypes.c_int32), ("_pad0", ctypes.c_int32),
-        ("wh", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+        ("w_img", ctypes.c_void_p),
+        ("h", ctypes.c_void_p), ("ldh", ctypes.c_int64), ("Kh", ctypes.c_int32), ("relu", ctypes.c_int32),
+        ("wh_img", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+        ("row_post", ctypes.c_void_p), ("col_scale", ctypes.c_void_p), ("col_shift", ctypes.c_void_p),
+        ("residual", ctypes.c_void_p), ("ld_res", ctypes.c_int64),
         ("y", ctypes.c_void_p), ("ldy", ctypes.c_int64),
     ]
 
@@ -75,6 +98,8 @@ def lib():
         L.pna_last_error.restype = ctypes.c_char_p
         L.pna_segreduce_fwd_f32.argtypes = [ctypes.POINTER(PnaSegreduceArgs), ctypes.c_void_p]
         L.pna_segreduce_fwd_f32.restype = ctypes.c_int
+        L.pna_segreduce_bwd_f32.argtypes = [ctypes.POINTER(PnaSegreduceBwdArgs), ctypes.c_void_p]
+        L.pna_segreduce_bwd_f32.restype = ctypes.c_int
         L.pna_segreduce_partials_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
         L.pna_segreduce_partials_bytes.restype = ctypes.c_int64
         L.pna_degree_scalers_f32.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p,
@@ -82,6 +107,12 @@ def lib():
         L.pna_degree_scalers_f32.restype = ctypes.c_int
         L.pna_posttrans_f32.argtypes = [ctypes.POINTER(PnaPosttransArgs), ctypes.c_void_p]
         L.pna_posttrans_f32.restype = ctypes.c_int
+        L.pna_posttrans_packed_floats.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                  ctypes.POINTER(ctypes.c_int64)]
+        L.pna_posttrans_packed_floats.restype = ctypes.c_int64
+        L.pna_posttrans_pack_f32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                             ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.pna_posttrans_pack_f32.restype = ctypes.c_int
         if L.pna_abi_version() != PNA_ABI_VERSION:
             raise RuntimeError(f"libpna_amd.so ABI {L.pna_abi_version()} != binding {PNA_ABI_VERSION}: rebuild")
         _lib = L

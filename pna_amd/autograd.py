@@ -1,20 +1,155 @@
 """Backward passes of the fused operators.
 
-Not implemented in this round: the forward kernels are the scoped hot path; training through them
-raises instead of silently falling back to an eager implementation.
+`AggregateFn`  : forward = pna_segreduce_fwd_f32 (with argmax/argmin recorded), backward =
+                 pna_segreduce_bwd_f32 (re-gather + fp32 atomic scatter; see include/pna_amd.h).
+`PosttransFn`  : forward = pna_posttrans_f32; its backward is three plain GEMMs (grad_agg, grad_weight,
+                 grad_h) -- library matmuls through torch (rocBLAS/hipBLASLt), like the other non-hot
+                 linears of the path.
+No CPU or eager fallback for the forward; gradients of the degree scalers themselves are not needed
+(they depend on the graph only).
 """
+import ctypes
+
 import torch
+
+from . import _lib, ops
+
+_STAT_AGGS = ("std", "var")
 
 
 class AggregateFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, *args):
-        raise NotImplementedError("pna_amd: backward of the fused aggregation is not implemented yet; "
-                                  "run under torch.no_grad() (forward / inference only)")
+    def forward(ctx, graph, x, dst_term, edge_term, F, aggregators, n_tower, row_scales, edge_resident,
+                edge_weight, col_override):
+        if edge_weight is not None:
+            raise NotImplementedError("pna_amd: backward through weighted (non 0/1 adjacency) aggregation is not implemented")
+        if len(set(aggregators)) != len(aggregators):
+            raise NotImplementedError("pna_amd: backward needs distinct aggregators")
+        csr = graph.csr
+        col = None if edge_resident else (csr.col if col_override is None else col_override)
+        aggs = list(aggregators)
+        # the backward of std / var needs the forward mean (and std): make sure they are computed
+        extra = []
+        if any(a in _STAT_AGGS for a in aggs):
+            if "mean" not in aggs:
+                extra.append("mean")
+            if "std" not in aggs:
+                extra.append("std")
+        all_aggs = aggs + extra
+        want_arg = any(a in ("max", "min") for a in aggs)
+        res = ops.segreduce(csr.rowptr, col, x, F, all_aggs, [None], n_tower=n_tower, tower_stride_in=F,
+                            dst_term=dst_term, edge_term=edge_term, want_arg=want_arg,
+                            heavy=graph.heavy_schedule(), workspace=graph.workspace)
+        ident, amx, amn = res if want_arg else (res, None, None)       # (V, T*A'*F) identity-scaled
+        V, T, A, A2, S = ident.shape[0], max(1, n_tower), len(aggs), len(all_aggs), len(row_scales)
+        iv = ident.view(V, T, A2, F)
+        if S == 1 and row_scales[0] is None and not extra:
+            out = ident
+        else:
+            blocks = [iv[:, :, :A] if rs is None else iv[:, :, :A] * rs.view(V, 1, 1, 1) for rs in row_scales]
+            out = torch.stack(blocks, dim=2).reshape(V, T * S * A * F)  # tower-major, scaler-major, aggregator-major
+        ctx.graph, ctx.F, ctx.aggs, ctx.all_aggs, ctx.T, ctx.col = graph, F, aggs, all_aggs, T, col
+        ctx.row_scales = row_scales
+        ctx.needs = (x.requires_grad, dst_term is not None and dst_term.requires_grad,
+                     edge_term is not None and edge_term.requires_grad)
+        ctx.save_for_backward(x, dst_term, edge_term, ident, amx, amn)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, dst_term, edge_term, ident, amx, amn = ctx.saved_tensors
+        graph, F, aggs, all_aggs, T = ctx.graph, ctx.F, ctx.aggs, ctx.all_aggs, ctx.T
+        V, A, A2, S = ident.shape[0], len(aggs), len(all_aggs), len(ctx.row_scales)
+        go = grad_out.reshape(V, T, S, A, F)
+        # fold the degree scalers into the gradient of the unscaled aggregates: G_a = sum_s scale_s * dOut[s, a]
+        gagg = None
+        for s, rs in enumerate(ctx.row_scales):
+            term = go[:, :, s] if rs is None else go[:, :, s] * rs.view(V, 1, 1, 1)
+            gagg = term if gagg is None else gagg + term
+        gagg = gagg.contiguous().view(V, T * A * F)
+        csr = graph.csr
+        dev = x.device
+        need_x, need_d, need_e = ctx.needs
+        b = _lib.PnaSegreduceBwdArgs()
+        b.rowptr = _lib.dev_ptr(csr.rowptr, torch.int32, "rowptr")
+        b.col = _lib.dev_ptr(ctx.col, torch.int32, "col")
+        b.V, b.F = V, F
+        b.x, b.ldx = _lib.dev_ptr(x, torch.float32, "x"), x.stride(0)
+        if dst_term is not None:
+            b.dst_term, b.ld_dst = _lib.dev_ptr(dst_term, torch.float32, "dst_term"), dst_term.stride(0)
+        if edge_term is not None:
+            b.edge_term, b.ld_edge = _lib.dev_ptr(edge_term, torch.float32, "edge_term"), edge_term.stride(0)
+        b.n_tower, b.n_aggr, b.tower_stride_in = T, A, F
+        for i, name in enumerate(aggs):
+            b.aggr[i] = _lib.AGG_CODES[name]
+        b.gagg, b.ld_g, b.tower_stride_g = _lib.dev_ptr(gagg, torch.float32, "gagg"), gagg.stride(0), A * F
+        if any(a in _STAT_AGGS for a in aggs):
+            base = ident.data_ptr()
+            b.mean = ctypes.c_void_p(base + 4 * all_aggs.index("mean") * F)
+            b.stdv = ctypes.c_void_p(base + 4 * all_aggs.index("std") * F)
+            if "var" in all_aggs:
+                b.var = ctypes.c_void_p(base + 4 * all_aggs.index("var") * F)
+            b.ld_stat, b.tower_stride_stat = ident.stride(0), A2 * F
+        if amx is not None:
+            b.argmax, b.argmin, b.ld_arg = (_lib.dev_ptr(amx, torch.int32, "argmax"),
+                                            _lib.dev_ptr(amn, torch.int32, "argmin"), amx.stride(0))
+        gx = gd = ge = None
+        if need_x:
+            gx = torch.zeros(x.shape[0], T * F, dtype=torch.float32, device=dev) if ctx.col is not None else \
+                torch.empty(x.shape[0], T * F, dtype=torch.float32, device=dev)
+            b.grad_x, b.ld_gx = _lib.dev_ptr(gx, torch.float32, "grad_x"), gx.stride(0)
+        if need_d:
+            gd = torch.zeros(V, T * F, dtype=torch.float32, device=dev)
+            b.grad_dst, b.ld_gd = _lib.dev_ptr(gd, torch.float32, "grad_dst"), gd.stride(0)
+        if need_e:
+            ge = torch.empty(edge_term.shape[0], T * F, dtype=torch.float32, device=dev)
+            b.grad_edge, b.ld_ge = _lib.dev_ptr(ge, torch.float32, "grad_edge"), ge.stride(0)
+        hs = graph.heavy_schedule()
+        if hs.n_heavy > 0:
+            b.heavy_threshold, b.seg_len, b.n_heavy, b.n_seg = hs.threshold, hs.seg_len, hs.n_heavy, hs.n_seg
+            b.heavy_rows = _lib.dev_ptr(hs.heavy_rows, torch.int32, "heavy_rows")
+            b.heavy_segptr = _lib.dev_ptr(hs.heavy_segptr, torch.int32, "heavy_segptr")
+            b.seg_heavy = _lib.dev_ptr(hs.seg_heavy, torch.int32, "seg_heavy")
+        if need_x or need_d or need_e:
+            rc = _lib.lib().pna_segreduce_bwd_f32(ctypes.byref(b), _lib.stream_ptr(dev))
+            _lib.check(rc, "pna_segreduce_bwd_f32")
+        if gx is not None and x.shape[1] != T * F:
+            full = torch.zeros_like(x)
+            full[:, :T * F] = gx
+            gx = full
+        return (None, gx, gd, ge, None, None, None, None, None, None, None)
 
 
 class PosttransFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, *args):
-        raise NotImplementedError("pna_amd: backward of the fused posttrans contraction is not implemented yet; "
-                                  "run under torch.no_grad() (forward / inference only)")
+    def forward(ctx, agg, K, weight, bias, row_scales, h_self):
+        w = weight if weight.stride(-1) == 1 else weight.contiguous()
+        y = ops.posttrans(agg, K, w, row_scales, bias, h_self)
+        ctx.K, ctx.row_scales = K, row_scales
+        ctx.save_for_backward(agg, weight, h_self)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        agg, weight, h_self = ctx.saved_tensors
+        K, scales = ctx.K, ctx.row_scales
+        S = len(scales)
+        Kh = 0 if h_self is None else h_self.shape[1]
+        a = agg[:, :K]
+        gys = [gy if rs is None else gy * rs.unsqueeze(1) for rs in scales]         # scale_s (.) gy
+        g_agg = g_w = g_b = g_h = None
+        if ctx.needs_input_grad[0]:
+            g_agg = torch.cat(gys, dim=1) @ torch.cat([weight[:, Kh + s * K:Kh + (s + 1) * K] for s in range(S)], dim=0)
+            if agg.shape[1] != K:
+                full = torch.zeros_like(agg)
+                full[:, :K] = g_agg
+                g_agg = full
+        if ctx.needs_input_grad[2]:
+            parts = ([gy.t() @ h_self] if Kh else []) + [g.t() @ a for g in gys]
+            g_w = torch.cat(parts, dim=1)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            g_b = gy.sum(0)
+        if Kh and ctx.needs_input_grad[5]:
+            g_h = gy @ weight[:, :Kh]
+        return g_agg, None, g_w, g_b, None, g_h

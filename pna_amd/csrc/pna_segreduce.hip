@@ -462,6 +462,9 @@ __device__ __forceinline__ void fast_finalize_store(const KArgs& a, const AccF& 
     for (int b = 0; b < A * S; ++b) put(b, z);
     return;
   }
+  float sc[PNA_MAX_SCALER];                                // all row scalers requested up front (one wait)
+#pragma unroll
+  for (int s = 0; s < PNA_MAX_SCALER; ++s) sc[s] = (s < S && a.row_scale[s]) ? a.row_scale[s][row] : 1.f;
   const float invD = 1.0f / (float)deg;                    // one IEEE division per row (see finalize_store)
   const f4 mean = acc.s * invD;
   f4 var = acc.q * invD - mean * mean;
@@ -485,10 +488,9 @@ __device__ __forceinline__ void fast_finalize_store(const KArgs& a, const AccF& 
         break;
       default: v = var; break;
     }
-    for (int s = 0; s < S; ++s) {
-      const float* rs = a.row_scale[s];
-      put((unsigned)(s * A + i), rs ? v * rs[row] : v);
-    }
+#pragma unroll
+    for (int s = 0; s < PNA_MAX_SCALER; ++s)
+      if (s < S) put((unsigned)(s * A + i), a.row_scale[s] ? v * sc[s] : v);
   }
 }
 
@@ -594,7 +596,9 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const KArgs a) {
   }
 }
 
-// Fold the per-segment partials of each heavy row in segment order and finish the row.
+// Fold the per-segment partials of each heavy row and finish the row.  One wavefront per heavy row: lane
+// group g folds segments g, g+G, g+2G, ... in order, then the G group results are combined in group order
+// (a fixed association, so results stay independent of the launch geometry of the main kernel).
 template <int VEC, bool EXTRA>
 __global__ __launch_bounds__(kBlock) void k_heavy_finalize(const KArgs a) {
   const int lane = threadIdx.x & 63;
@@ -606,57 +610,85 @@ __global__ __launch_bounds__(kBlock) void k_heavy_finalize(const KArgs a) {
   const int nchunks = (a.F + VEC - 1) / VEC;
   const int tower = blockIdx.y / a.tiles;
   const int chunk = (blockIdx.y - tower * a.tiles) * L + c;
-  if (chunk >= nchunks) return;
-  int off = chunk * VEC;
+  int off = min(chunk, nchunks - 1) * VEC;
   if (VEC == 4) off = min(off, a.F - 4);
   const long offi = (long)tower * a.ts_in + off;
   const long offo = (long)tower * a.ts_out + off;
-  const int NG = kWaves * a.G;
-  const int hi = blockIdx.x * NG + wave * a.G + grp;
+  const int hi = blockIdx.x * kWaves + wave;
   if (hi >= a.n_heavy) return;
   const int row = a.heavy_rows[hi];
   const int s0 = a.heavy_segptr[hi], s1 = a.heavy_segptr[hi + 1];
   Acc<VEC, EXTRA> acc;
   acc.init();
-  // Partials are independent loads: fetch PB segments' worth before folding (a hub row has ~60 segments;
-  // one-at-a-time would be 60 serial memory latencies), then fold strictly in segment order.
+  auto merge = [&](const float (&ps)[VEC], const float (&pq)[VEC], const float (&pmx)[VEC], const float (&pmn)[VEC],
+                   const int (&pax)[VEC], const int (&pan)[VEC], float pw) {
+    if constexpr (EXTRA) acc.wsum = acc.wsum + pw;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      acc.s[k] = acc.s[k] + ps[k];
+      acc.q[k] = acc.q[k] + pq[k];
+      // ties keep the earlier edge (smaller CSR position), NaN is sticky
+      bool gx = pmx[k] > acc.mx[k] || (pmx[k] != pmx[k] && acc.mx[k] == acc.mx[k]);
+      bool gn = pmn[k] < acc.mn[k] || (pmn[k] != pmn[k] && acc.mn[k] == acc.mn[k]);
+      if constexpr (EXTRA) {
+        gx = gx || (pmx[k] == acc.mx[k] && pax[k] >= 0 && (acc.amx[k] < 0 || pax[k] < acc.amx[k]));
+        gn = gn || (pmn[k] == acc.mn[k] && pan[k] >= 0 && (acc.amn[k] < 0 || pan[k] < acc.amn[k]));
+        acc.amx[k] = gx ? pax[k] : acc.amx[k];
+        acc.amn[k] = gn ? pan[k] : acc.amn[k];
+      }
+      acc.mx[k] = gx ? pmx[k] : acc.mx[k];
+      acc.mn[k] = gn ? pmn[k] : acc.mn[k];
+    }
+  };
+  // Partials are independent loads: fetch PB segments' worth before folding.
   constexpr int PB = 4;
-  for (int sb = s0; sb < s1; sb += PB) {
-    float ps[PB][VEC], pq[PB][VEC], pmx[PB][VEC], pmn[PB][VEC], pax[PB][VEC], pan[PB][VEC], pw[PB];
+  const int G = a.G;
+  for (int sb = s0 + grp; sb < s1; sb += PB * G) {
+    float ps[PB][VEC], pq[PB][VEC], pmx[PB][VEC], pmn[PB][VEC], pw[PB];
+    int pax[PB][VEC], pan[PB][VEC];
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-      const int seg = min(sb + i, s1 - 1);
+      const int seg = min(sb + i * G, s1 - 1);
       const float* p = a.partials + ((size_t)seg * a.T + tower) * kNQ * a.pstride + off;
       Ld<VEC>::load(p, ps[i]);
       Ld<VEC>::load(p + a.pstride, pq[i]);
       Ld<VEC>::load(p + 2 * a.pstride, pmx[i]);
       Ld<VEC>::load(p + 3 * a.pstride, pmn[i]);
+      pw[i] = 0.f;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) { pax[i][k] = -1; pan[i][k] = -1; }
       if constexpr (EXTRA) {
-        Ld<VEC>::load(p + 4 * a.pstride, pax[i]);
-        Ld<VEC>::load(p + 5 * a.pstride, pan[i]);
+        float t[VEC];
+        Ld<VEC>::load(p + 4 * a.pstride, t);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) pax[i][k] = __float_as_int(t[k]);
+        Ld<VEC>::load(p + 5 * a.pstride, t);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) pan[i][k] = __float_as_int(t[k]);
         pw[i] = p[6 * a.pstride - off];
       }
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-      if (sb + i >= s1) break;
-      if constexpr (EXTRA) acc.wsum = acc.wsum + pw[i];
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) {
-        acc.s[k] = acc.s[k] + ps[i][k];
-        acc.q[k] = acc.q[k] + pq[i][k];
-        const bool gx = pmx[i][k] > acc.mx[k] || (pmx[i][k] != pmx[i][k] && acc.mx[k] == acc.mx[k]);
-        const bool gn = pmn[i][k] < acc.mn[k] || (pmn[i][k] != pmn[i][k] && acc.mn[k] == acc.mn[k]);
-        acc.mx[k] = gx ? pmx[i][k] : acc.mx[k];
-        acc.mn[k] = gn ? pmn[i][k] : acc.mn[k];
-        if constexpr (EXTRA) {
-          acc.amx[k] = gx ? __float_as_int(pax[i][k]) : acc.amx[k];
-          acc.amn[k] = gn ? __float_as_int(pan[i][k]) : acc.amn[k];
-        }
-      }
+      if (sb + i * G >= s1) break;
+      merge(ps[i], pq[i], pmx[i], pmn[i], pax[i], pan[i], pw[i]);
     }
   }
-  finalize_store<VEC, EXTRA>(a, acc, row, a.rowptr[row + 1] - a.rowptr[row], offi, offo);
+  // combine the lane groups' results into group 0, in group order
+  for (int g2 = 1; g2 < G; ++g2) {
+    float ps[VEC], pq[VEC], pmx[VEC], pmn[VEC];
+    int pax[VEC], pan[VEC];
+    const int src = lane + g2 * L;                          // only meaningful for lanes of group 0
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      ps[k] = __shfl(acc.s[k], src); pq[k] = __shfl(acc.q[k], src);
+      pmx[k] = __shfl(acc.mx[k], src); pmn[k] = __shfl(acc.mn[k], src);
+      pax[k] = EXTRA ? __shfl(acc.amx[k], src) : -1; pan[k] = EXTRA ? __shfl(acc.amn[k], src) : -1;
+    }
+    const float pw = EXTRA ? __shfl(acc.wsum, src) : 0.f;
+    if (grp == 0) merge(ps, pq, pmx, pmn, pax, pan, pw);
+  }
+  if (grp == 0 && chunk < nchunks) finalize_store<VEC, EXTRA>(a, acc, row, a.rowptr[row + 1] - a.rowptr[row], offi, offo);
 }
 
 // models/dgl/scalers.py:12-19 with the reference's rounding sequence (see pna_amd.h).
@@ -760,7 +792,7 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
   k.L = L; k.G = 64 / L; k.T = T; k.tiles = tiles; k.ts_in = ts_in; k.ts_out = ts_out;
   int U = t.unroll ? t.unroll : 4;
   if (U != 2 && U != 4 && U != 8) return pna_set_error(PNA_E_INVALID, "pna_segreduce_fwd_f32: tune.unroll must be 2, 4 or 8");
-  k.R = t.rows_per_group > 0 ? t.rows_per_group : 4;
+  k.R = t.rows_per_group > 0 ? t.rows_per_group : (p->V >= (1 << 18) ? 8 : 4);
   k.nt = t.nt_store >= 0 ? 1 : 0;
   k.pf = t.prefetch >= 0 ? 1 : 0;
   k.dbg = t.reserved[0];   // bit0: skip the output stores (bench experiments only; results are then undefined)
@@ -792,7 +824,7 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
   if (heavy) {
-    dim3 g2((unsigned)((k.n_heavy + NG - 1) / NG), (unsigned)(tiles * T));
+    dim3 g2((unsigned)((k.n_heavy + kWaves - 1) / kWaves), (unsigned)(tiles * T));
     if (vec == 4) {
       if (extra) hipLaunchKernelGGL((k_heavy_finalize<4, true>), g2, dim3(kBlock), 0, st, k);
       else hipLaunchKernelGGL((k_heavy_finalize<4, false>), g2, dim3(kBlock), 0, st, k);

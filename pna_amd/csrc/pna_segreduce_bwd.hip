@@ -1,0 +1,284 @@
+// pna_segreduce_bwd.hip -- backward of the fused gather + multi-aggregator segment-reduce.
+// Implements pna_segreduce_bwd_f32 of include/pna_amd.h.
+//
+// The reference gets this gradient from autograd through its per-bucket torch ops (torch.mean / max / min /
+// sqrt(relu(E[x^2]-E[x]^2)+eps), models/dgl/aggregators.py:6-26).  With G_a[v,f] the gradient w.r.t. the
+// UNSCALED aggregate a of destination v (the caller folds the degree scalers in: G_a = sum_s scale_s * dOut_sa),
+// D the in-degree and m_k the message of in-edge k:
+//     dL/dm_k = G_mean/D + G_sum + [k = argmax] G_max + [k = argmin] G_min
+//             + (G_var + G_std / (2 std)) * [var > 0] * (2/D) * (m_k - mean)
+// (relu'(0) = 0 and max/min route the gradient to the single index torch.max/min return).  m_k = x[col_k]
+// + dst_term[v] + edge_term[k] is rebuilt by re-gathering; dL/dm_k is then scattered:
+//     grad_x[col_k] += dL/dm_k   (hardware fp32 atomics; plain store when x is edge-resident)
+//     grad_dst[v]   += sum_k dL/dm_k,    grad_edge[k] = dL/dm_k.
+// Same lane mapping as the forward kernel (G lane groups per wavefront, one destination row per group, 4
+// features per lane) and the same heavy-row segmentation, so hub rows are spread over many lane groups.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "pna_amd.h"
+#include "pna_internal.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) f4u { f4 v; };
+typedef int i4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) i4u { i4 v; };
+
+constexpr int kBlock = 256;
+constexpr int kWaves = 4;
+
+struct BArgs {
+  const int32_t* rowptr; const int32_t* col;
+  const float* x; const float* dst_term; const float* edge_term;
+  const float* g[6];                 // gradient block per aggregator CODE (mean,sum,max,min,std,var) or null
+  const float* mean; const float* stdv; const float* var;
+  const int32_t* argmax; const int32_t* argmin;
+  float* grad_x; float* grad_dst; float* grad_edge;
+  const int32_t* heavy_rows; const int32_t* heavy_segptr; const int32_t* seg_heavy;
+  long ldx, ld_dst, ld_edge, ld_g, ld_stat, ld_arg, ld_gx, ld_gd, ld_ge, ts_in, ts_g, ts_stat;
+  int V, F, heavy_threshold, seg_len, n_heavy, n_seg, L, G, R, n_heavy_blocks, T, tiles;
+};
+
+template <int VEC> struct V;
+template <> struct V<4> {
+  static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
+    f4 t = reinterpret_cast<const f4u*>(p)->v; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  static __device__ __forceinline__ void ldi(const int32_t* p, int (&v)[4]) {
+    i4 t = reinterpret_cast<const i4u*>(p)->v; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  static __device__ __forceinline__ void st(float* p, const float (&v)[4]) {
+    f4 t = {v[0], v[1], v[2], v[3]}; reinterpret_cast<f4u*>(p)->v = t;
+  }
+};
+template <> struct V<1> {
+  static __device__ __forceinline__ void ld(const float* p, float (&v)[1]) { v[0] = *p; }
+  static __device__ __forceinline__ void ldi(const int32_t* p, int (&v)[1]) { v[0] = *p; }
+  static __device__ __forceinline__ void st(float* p, const float (&v)[1]) { *p = v[0]; }
+};
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_segreduce_bwd(const BArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int L = a.L;
+  const int grp = lane / L;
+  if (grp >= a.G) return;
+  const int c = lane - grp * L;
+  const int grp_lane0 = grp * L;
+  const int nchunks = (a.F + VEC - 1) / VEC;
+  const int tower = blockIdx.y / a.tiles;
+  const int chunk = (blockIdx.y - tower * a.tiles) * L + c;
+  // The sliding last window overlaps its neighbour: lanes must not double-count overlapped features.  Feature
+  // ownership: a lane owns component k iff its global feature index is >= VEC*chunk (its nominal start).
+  const bool lane_ok = chunk < nchunks;
+  int off = min(chunk, nchunks - 1) * VEC;
+  const int nominal = off;
+  if (VEC == 4) off = min(off, a.F - 4);
+  const int skipk = lane_ok ? nominal - off : VEC;          // components [0, skipk) belong to the previous lane
+  const long oin = (long)tower * a.ts_in + off;
+  const long og = (long)tower * a.ts_g + off;
+  const long ostat = (long)tower * a.ts_stat + off;
+  const int NG = kWaves * a.G;
+  const int gid = wave * a.G + grp;
+
+  int row, beg, end;
+  bool heavy_item = false;
+  auto process = [&]() {
+    const int rbeg = a.rowptr[row], rend = a.rowptr[row + 1];
+    const float D = (float)(rend - rbeg);
+    float base[VEC], cvar[VEC], mean[VEC], gmx[VEC], gmn[VEC], gd[VEC];
+    int amx[VEC], amn[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { base[k] = 0.f; cvar[k] = 0.f; mean[k] = 0.f; gmx[k] = 0.f; gmn[k] = 0.f; gd[k] = 0.f; amx[k] = -1; amn[k] = -1; }
+    float t[VEC];
+    const size_t grow = (size_t)row * a.ld_g + og;
+    if (a.g[PNA_AGG_MEAN]) { V<VEC>::ld(a.g[PNA_AGG_MEAN] + grow, t);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) base[k] = t[k] / D; }
+    if (a.g[PNA_AGG_SUM]) { V<VEC>::ld(a.g[PNA_AGG_SUM] + grow, t);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) base[k] = base[k] + t[k]; }
+    if (a.g[PNA_AGG_MAX]) { V<VEC>::ld(a.g[PNA_AGG_MAX] + grow, gmx); V<VEC>::ldi(a.argmax + (size_t)row * a.ld_arg + oin, amx); }
+    if (a.g[PNA_AGG_MIN]) { V<VEC>::ld(a.g[PNA_AGG_MIN] + grow, gmn); V<VEC>::ldi(a.argmin + (size_t)row * a.ld_arg + oin, amn); }
+    if (a.g[PNA_AGG_STD] || a.g[PNA_AGG_VAR]) {
+      const size_t srow = (size_t)row * a.ld_stat + ostat;
+      V<VEC>::ld(a.mean + srow, mean);
+      float sd[VEC], vr[VEC], gs[VEC], gv[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) { sd[k] = 1.f; vr[k] = 0.f; gs[k] = 0.f; gv[k] = 0.f; }
+      if (a.stdv) V<VEC>::ld(a.stdv + srow, sd);
+      if (a.var) V<VEC>::ld(a.var + srow, vr);
+      if (a.g[PNA_AGG_STD]) V<VEC>::ld(a.g[PNA_AGG_STD] + grow, gs);
+      if (a.g[PNA_AGG_VAR]) V<VEC>::ld(a.g[PNA_AGG_VAR] + grow, gv);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const float v = a.var ? vr[k] : sd[k] * sd[k] - 1e-5f;        // relu'(raw var): 0 at and below 0
+        const float gsv = a.g[PNA_AGG_STD] ? gs[k] / (2.f * sd[k]) : 0.f;
+        cvar[k] = v > 0.f ? (gv[k] + gsv) * (2.f / D) : 0.f;
+      }
+    }
+    float dterm[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) dterm[k] = 0.f;
+    if (a.dst_term) V<VEC>::ld(a.dst_term + (size_t)row * a.ld_dst + oin, dterm);
+    const bool need_m = a.g[PNA_AGG_STD] || a.g[PNA_AGG_VAR];
+    for (int cb = beg; cb < end; cb += L) {
+      const int nidx = min(L, end - cb);
+      int myidx = cb + c;
+      if (a.col) myidx = c < nidx ? a.col[cb + c] : 0;
+      for (int j = 0; j < nidx; j += 4) {
+        int id[4];
+        float m[4][VEC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) id[u] = __shfl(myidx, grp_lane0 + min(j + u, nidx - 1));
+        if (need_m) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) V<VEC>::ld(a.x + (size_t)id[u] * a.ldx + oin, m[u]);
+          if (a.edge_term) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              float e[VEC];
+              V<VEC>::ld(a.edge_term + (size_t)(cb + min(j + u, nidx - 1)) * a.ld_edge + oin, e);
+#pragma unroll
+              for (int k = 0; k < VEC; ++k) m[u][k] = (m[u][k] + dterm[k]) + e[k];
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int k = 0; k < VEC; ++k) m[u][k] = m[u][k] + dterm[k];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (j + u >= nidx) break;
+          const int e = cb + j + u;
+          float gm[VEC];
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) {
+            float v = base[k];
+            if (need_m) v = v + cvar[k] * (m[u][k] - mean[k]);
+            if (e == amx[k]) v = v + gmx[k];
+            if (e == amn[k]) v = v + gmn[k];
+            gm[k] = v;
+            gd[k] = gd[k] + v;
+          }
+          if (lane_ok) {
+            if (a.grad_edge) {
+              // overlapped components carry identical values; both lanes may store them
+              V<VEC>::st(a.grad_edge + (size_t)e * a.ld_ge + oin, gm);
+            }
+            if (a.grad_x) {
+              float* px = a.grad_x + (size_t)id[u] * a.ld_gx + oin;
+              if (a.col) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k)
+                  if (k >= skipk) unsafeAtomicAdd(px + k, gm[k]);
+              } else {
+                V<VEC>::st(px, gm);
+              }
+            }
+          }
+        }
+      }
+    }
+    if (a.grad_dst && lane_ok) {
+      float* pd = a.grad_dst + (size_t)row * a.ld_gd + oin;
+      if (heavy_item) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+          if (k >= skipk) unsafeAtomicAdd(pd + k, gd[k]);
+      } else {
+        V<VEC>::st(pd, gd);
+      }
+    }
+  };
+
+  if ((int)blockIdx.x < a.n_heavy_blocks) {
+    const int seg = blockIdx.x * NG + gid;
+    if (seg >= a.n_seg) return;
+    const int hi = a.seg_heavy[seg];
+    row = a.heavy_rows[hi];
+    const int sidx = seg - a.heavy_segptr[hi];
+    beg = a.rowptr[row] + sidx * a.seg_len;
+    end = min(beg + a.seg_len, a.rowptr[row + 1]);
+    heavy_item = true;
+    process();
+    return;
+  }
+  const long base_row = (long)(blockIdx.x - a.n_heavy_blocks) * NG * a.R + gid;
+  for (int r = 0; r < a.R; ++r) {
+    const long row_l = base_row + (long)r * NG;
+    if (row_l >= a.V) break;
+    row = (int)row_l;
+    beg = a.rowptr[row]; end = a.rowptr[row + 1];
+    if (a.heavy_threshold > 0 && end - beg > a.heavy_threshold) continue;
+    if (end == beg) {
+      if (a.grad_dst && lane_ok) {
+        float z[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) z[k] = 0.f;
+        V<VEC>::st(a.grad_dst + (size_t)row * a.ld_gd + oin, z);
+      }
+      continue;
+    }
+    process();
+  }
+}
+
+}  // namespace
+
+extern "C" int pna_segreduce_bwd_f32(const pna_segreduce_bwd_args* p, pna_stream_t stream) {
+  if (!p) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: null args");
+  if (p->V < 0 || p->F <= 0) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: bad V/F");
+  if (p->V == 0) return PNA_OK;
+  if (!p->rowptr || !p->gagg) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: rowptr/gagg must be non-null");
+  if (p->n_aggr <= 0 || p->n_aggr > PNA_MAX_AGGR) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: n_aggr out of range");
+  BArgs k;
+  memset(&k, 0, sizeof(k));
+  const int T = p->n_tower > 1 ? p->n_tower : 1;
+  bool need_stat = false, need_x = false;
+  for (int i = 0; i < p->n_aggr; ++i) {
+    const int code = p->aggr[i];
+    if (code < PNA_AGG_MEAN || code > PNA_AGG_VAR) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: unknown aggregator code");
+    if (k.g[code]) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: duplicate aggregator");
+    k.g[code] = p->gagg + (int64_t)i * p->F;
+    if (code == PNA_AGG_STD || code == PNA_AGG_VAR) need_stat = need_x = true;
+    if (code == PNA_AGG_MAX && !p->argmax) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: max needs argmax");
+    if (code == PNA_AGG_MIN && !p->argmin) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: min needs argmin");
+  }
+  if (need_stat && (!p->mean || !(p->stdv || p->var) || (k.g[PNA_AGG_STD] && !p->stdv)))
+    return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: std/var need the forward mean and std (or var)");
+  if (need_x && !p->x) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: std/var need the forward input x");
+  const bool heavy = p->heavy_threshold > 0 && p->n_heavy > 0;
+  if (heavy && (!p->heavy_rows || !p->heavy_segptr || !p->seg_heavy || p->seg_len <= 0 || p->n_seg <= 0))
+    return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: incomplete heavy-row schedule");
+  k.rowptr = p->rowptr; k.col = p->col; k.x = p->x; k.dst_term = need_x ? p->dst_term : nullptr;
+  k.edge_term = need_x ? p->edge_term : nullptr;
+  k.mean = p->mean; k.stdv = p->stdv; k.var = p->var; k.argmax = p->argmax; k.argmin = p->argmin;
+  k.grad_x = p->grad_x; k.grad_dst = p->grad_dst; k.grad_edge = p->grad_edge;
+  k.heavy_rows = p->heavy_rows; k.heavy_segptr = p->heavy_segptr; k.seg_heavy = p->seg_heavy;
+  k.ldx = p->ldx; k.ld_dst = p->ld_dst; k.ld_edge = p->ld_edge; k.ld_g = p->ld_g; k.ld_stat = p->ld_stat; k.ld_arg = p->ld_arg;
+  k.ld_gx = p->ld_gx; k.ld_gd = p->ld_gd; k.ld_ge = p->ld_ge;
+  k.ts_in = T > 1 ? p->tower_stride_in : 0; k.ts_g = T > 1 ? p->tower_stride_g : 0; k.ts_stat = T > 1 ? p->tower_stride_stat : 0;
+  k.V = p->V; k.F = p->F; k.T = T;
+  k.heavy_threshold = heavy ? p->heavy_threshold : 0; k.seg_len = p->seg_len; k.n_heavy = heavy ? p->n_heavy : 0;
+  k.n_seg = heavy ? p->n_seg : 0;
+  const int vec = p->F >= 4 ? 4 : 1;
+  const int nchunks = (p->F + vec - 1) / vec;
+  const int tiles = (nchunks + 63) / 64;
+  k.L = (nchunks + tiles - 1) / tiles; k.G = 64 / k.L; k.tiles = tiles; k.R = 4;
+  const int NG = kWaves * k.G;
+  k.n_heavy_blocks = heavy ? (k.n_seg + NG - 1) / NG : 0;
+  const long light_blocks = (p->V + (long)NG * k.R - 1) / ((long)NG * k.R);
+  dim3 grid((unsigned)(light_blocks + k.n_heavy_blocks), (unsigned)(tiles * T));
+  if (vec == 4) hipLaunchKernelGGL((k_segreduce_bwd<4>), grid, dim3(kBlock), 0, (hipStream_t)stream, k);
+  else hipLaunchKernelGGL((k_segreduce_bwd<1>), grid, dim3(kBlock), 0, (hipStream_t)stream, k);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
+  return PNA_OK;
+}

@@ -147,6 +147,19 @@ def _towers_forward(towers, graph, h, e, snorm_n, divide_input):
     # posttrans: y_t = W_t [h_t | id*agg_t | amp*agg_t | att*agg_t] + b_t, scalers applied per row in the epilogue
     scales = _row_scales(graph, t0.scalers, t0.avg_d, h.device)
     K = A * Fi
+    # inference: graph-norm, eval BatchNorm (and dropout = identity) fold into the contraction's epilogue and each
+    # tower writes its slice of the concatenated output directly
+    fuse = (not torch.is_grad_enabled() or not any(p.requires_grad for p in t0.parameters())) and \
+        all((not t.training) and t.posttrans.is_affine for t in towers) and not h.requires_grad
+    if fuse:
+        No = t0.out_dim
+        h_cat = torch.empty(V, T * No, dtype=torch.float32, device=h.device)
+        for t, tower in enumerate(towers):
+            lin = tower.posttrans.fully_connected[0].linear
+            PF.posttrans(agg[:, t * K:(t + 1) * K], K, lin.weight, lin.bias, scales, h_self=hs[t],
+                         row_post=snorm_n if tower.graph_norm else None,
+                         bn=tower.batchnorm_h if tower.batch_norm else None, out=h_cat[:, t * No:(t + 1) * No])
+        return h_cat
     outs = []
     for t, tower in enumerate(towers):
         lin = tower.posttrans.fully_connected[0].linear
@@ -230,8 +243,17 @@ class PNASimpleLayer(nn.Module):
         h_in = h
         agg = PF.aggregate(graph, graph.source_features(h), self.in_dim, self.aggregators)   # (V, A*F), identity only
         lin = self.posttrans.fully_connected[0].linear
-        y = PF.posttrans(agg, len(self.aggregators) * self.in_dim, lin.weight, lin.bias,
-                         _row_scales(graph, self.scalers, self.avg_d, h.device))
+        scales = _row_scales(graph, self.scalers, self.avg_d, h.device)
+        K = len(self.aggregators) * self.in_dim
+        if not self.training and self.posttrans.is_affine and not (torch.is_grad_enabled() and (
+                h.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            # inference: BatchNorm (running stats), ReLU and the residual fold into the contraction's epilogue
+            if self.residual and h_in.shape[1] != self.out_dim:
+                raise RuntimeError(f"The size of tensor a ({h_in.shape[1]}) must match the size of tensor b "
+                                   f"({self.out_dim}) at non-singleton dimension 1")   # same failure as the reference (:213)
+            return PF.posttrans(agg, K, lin.weight, lin.bias, scales, bn=self.batchnorm_h if self.batch_norm else None,
+                                relu=True, residual=h_in if self.residual else None)
+        y = PF.posttrans(agg, K, lin.weight, lin.bias, scales)
         y = self.posttrans.tail(y)
         if self.batch_norm:
             y = self.batchnorm_h(y)

@@ -37,17 +37,33 @@ def aggregate(graph, x, F, aggregators, *, n_tower=1, dst_term=None, edge_term=N
                          edge_weight=edge_weight, heavy=graph.heavy_schedule(), workspace=graph.workspace)
 
 
-def posttrans(agg, K, weight, bias, row_scales, h_self=None):
+def posttrans(agg, K, weight, bias, row_scales, h_self=None, *, row_post=None, bn=None, relu=False, residual=None,
+              out=None):
     """y = W [h_self | s_0*agg | s_1*agg | ...] + b with `weight` in the reference's nn.Linear layout
     (N, Kh + S*K) -- models/dgl/pna_layer.py:65-68 / :206 -- computed without materialising the
-    scaled copies of `agg` (row_scales[s] is a per-row vector or None for the identity scaler)."""
+    scaled copies of `agg` (row_scales[s] is a per-row vector or None for the identity scaler).
+
+    Optional fused tail (inference): row_post = snorm_n (V,1)/(V,), bn = an nn.BatchNorm1d in eval mode (folded
+    to a per-column affine map), relu, residual -- applied in the reference's order
+    (pna_layer.py:71-75 / :209-213)."""
     agg, h_self = _unit_stride(agg), _unit_stride(h_self)
     Kh = 0 if h_self is None else h_self.shape[1]
     if weight.shape[1] != Kh + len(row_scales) * K:
         raise ValueError(f"posttrans weight has {weight.shape[1]} input columns, expected {Kh + len(row_scales) * K}")
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (agg, weight, bias, h_self)):
         from .autograd import PosttransFn
+        if row_post is not None or bn is not None or relu or residual is not None:
+            raise RuntimeError("the fused posttrans tail is inference-only")
         return PosttransFn.apply(agg, K, weight, bias, tuple(row_scales), h_self)
-    w = weight[:, Kh:].t().contiguous()                    # K-major (S*K, N)
-    wh = weight[:, :Kh].t().contiguous() if Kh else None
-    return ops.posttrans(agg, K, w, row_scales, bias, h_self, wh)
+    col_scale = col_shift = None
+    if bn is not None:
+        if bn.training:
+            raise RuntimeError("only an eval-mode BatchNorm (running statistics) can be folded into the epilogue")
+        col_scale = (bn.weight if bn.weight is not None else 1.0) * torch.rsqrt(bn.running_var + bn.eps)
+        col_shift = (bn.bias if bn.bias is not None else 0.0) - bn.running_mean * col_scale
+        col_scale, col_shift = col_scale.contiguous(), col_shift.contiguous()
+    if row_post is not None:
+        row_post = row_post.reshape(-1).contiguous()
+    w = weight if weight.stride(-1) == 1 else weight.contiguous()
+    return ops.posttrans(agg, K, w, row_scales, bias, h_self, out=out, row_post=row_post, col_scale=col_scale,
+                         col_shift=col_shift, relu=relu, residual=_unit_stride(residual))

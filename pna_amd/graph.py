@@ -16,9 +16,10 @@ import torch
 from . import _lib
 
 # Rows with more in-edges than this are cut into SEG_LEN-edge segments reduced by separate lane
-# groups (see include/pna_amd.h "Heavy rows").
-HEAVY_THRESHOLD = 64
-SEG_LEN = 64
+# groups (see include/pna_amd.h "Heavy rows"); 128/128 measured best on the 10 M-edge power-law graph
+# (tools/sweep.py, profiles/).
+HEAVY_THRESHOLD = 128
+SEG_LEN = 128
 
 
 class CSR(NamedTuple):

@@ -96,18 +96,47 @@ def segreduce(rowptr: torch.Tensor, col: Optional[torch.Tensor], x: torch.Tensor
     return (out, argmax, argmin) if want_arg else out
 
 
-def posttrans(a_mat: torch.Tensor, K: int, w_kmajor: torch.Tensor, row_scales: Sequence[Optional[torch.Tensor]],
-              bias: Optional[torch.Tensor] = None, h: Optional[torch.Tensor] = None,
-              wh_kmajor: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
-    """y = bias + h @ wh + sum_s row_scales[s][:,None] * (a[:, :K] @ w[s*K:(s+1)*K])     (see pna_amd.h).
+_PACK_CACHE = {}
 
-    a_mat:(M, >=K) fp32; w_kmajor:(S*K, N) = the reference posttrans weight's aggregate columns,
-    transposed; wh_kmajor:(Kh, N) its self-feature columns, transposed.
+
+def pack_posttrans_weight(weight: torch.Tensor, K: int, n_scaler: int, Kh: int):
+    """(w_img, wh_img) tile images of a reference-layout posttrans weight (N, Kh + n_scaler*K); cached per
+    weight version, so inference packs once and training re-packs after every optimizer step."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.stride(0), K, n_scaler, Kh, weight.device)
+    hit = _PACK_CACHE.get(key)
+    if hit is not None:
+        return hit
+    L = _lib.lib()
+    N = weight.shape[0]
+    nh = ctypes.c_int64(0)
+    nw = L.pna_posttrans_packed_floats(K, N, n_scaler, Kh, ctypes.byref(nh))
+    w_img = torch.empty(nw, dtype=torch.float32, device=weight.device)
+    wh_img = torch.empty(max(nh.value, 1), dtype=torch.float32, device=weight.device) if Kh else None
+    rc = L.pna_posttrans_pack_f32(_lib.dev_ptr(weight, torch.float32, "weight"), _ld(weight), N, K, n_scaler, Kh,
+                                  _lib.dev_ptr(w_img, torch.float32, "w_img"), _lib.dev_ptr(wh_img, torch.float32, "wh_img"),
+                                  _lib.stream_ptr(weight.device))
+    _lib.check(rc, "pna_posttrans_pack_f32")
+    if len(_PACK_CACHE) > 64:
+        _PACK_CACHE.clear()
+    _PACK_CACHE[key] = (w_img, wh_img)
+    return w_img, wh_img
+
+
+def posttrans(a_mat: torch.Tensor, K: int, weight: torch.Tensor, row_scales: Sequence[Optional[torch.Tensor]],
+              bias: Optional[torch.Tensor] = None, h: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+              row_post: Optional[torch.Tensor] = None, col_scale: Optional[torch.Tensor] = None,
+              col_shift: Optional[torch.Tensor] = None, relu: bool = False, residual: Optional[torch.Tensor] = None):
+    """y = residual + act(((bias + h@Wh^T + sum_s row_scales[s][:,None] * (a[:, :K] @ W_s^T)) * row_post[:,None]) *
+    col_scale + col_shift)                                                                      (see pna_amd.h).
+
+    a_mat:(M, >=K) fp32; weight:(N, Kh + S*K) in the reference nn.Linear layout (columns [h | scaler blocks]).
     """
-    M, S, N = a_mat.shape[0], len(row_scales), w_kmajor.shape[1]
-    if w_kmajor.shape[0] != S * K:
-        raise ValueError(f"w_kmajor has {w_kmajor.shape[0]} rows, expected n_scaler*K = {S * K}")
+    M, S, N = a_mat.shape[0], len(row_scales), weight.shape[0]
+    Kh = 0 if h is None else h.shape[1]
+    if weight.shape[1] != Kh + S * K:
+        raise ValueError(f"weight has {weight.shape[1]} input columns, expected Kh + n_scaler*K = {Kh + S * K}")
     dev = a_mat.device
+    w_img, wh_img = pack_posttrans_weight(weight, K, S, Kh)
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=dev)
     g = _lib.PnaPosttransArgs()
@@ -115,13 +144,20 @@ def posttrans(a_mat: torch.Tensor, K: int, w_kmajor: torch.Tensor, row_scales: S
     for i, rs in enumerate(row_scales):
         if rs is not None:
             g.row_scale[i] = _lib.dev_ptr(rs, torch.float32, "row_scale").value
-    g.w, g.ldw = _lib.dev_ptr(w_kmajor, torch.float32, "w"), _ld(w_kmajor)
+    g.w_img = _lib.dev_ptr(w_img, torch.float32, "w_img")
     if h is not None:
-        if wh_kmajor is None or _ld(wh_kmajor) != _ld(w_kmajor):
-            raise ValueError("h needs wh_kmajor with the same row pitch as w_kmajor")
-        g.h, g.ldh, g.Kh = _lib.dev_ptr(h, torch.float32, "h"), _ld(h), wh_kmajor.shape[0]
-        g.wh = _lib.dev_ptr(wh_kmajor, torch.float32, "wh")
+        g.h, g.ldh, g.Kh = _lib.dev_ptr(h, torch.float32, "h"), _ld(h), Kh
+        g.wh_img = _lib.dev_ptr(wh_img, torch.float32, "wh_img")
     g.bias = _lib.dev_ptr(bias, torch.float32, "bias")
+    if row_post is not None:
+        if row_post.numel() != M:
+            raise ValueError("row_post must have one entry per row")
+        g.row_post = _lib.dev_ptr(row_post, torch.float32, "row_post")
+    g.col_scale = _lib.dev_ptr(col_scale, torch.float32, "col_scale")
+    g.col_shift = _lib.dev_ptr(col_shift, torch.float32, "col_shift")
+    g.relu = 1 if relu else 0
+    if residual is not None:
+        g.residual, g.ld_res = _lib.dev_ptr(residual, torch.float32, "residual"), _ld(residual)
     g.y, g.ldy = _lib.dev_ptr(out, torch.float32, "y"), _ld(out)
     rc = _lib.lib().pna_posttrans_f32(ctypes.byref(g), _lib.stream_ptr(dev))
     _lib.check(rc, "pna_posttrans_f32")

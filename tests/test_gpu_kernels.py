@@ -199,3 +199,26 @@ def test_posttrans_mfma_vs_float64(cuda_device, M, K, N, S, Kh):
     # fp32 fma-chain bound: relative to the dot product's absolute mass (the quantity rounding scales with)
     assert (err <= 1e-5 * ref.abs() + 2e-6 * mag).all(), f"max err {err.max():.3e}"
     assert (err / mag).max() < 3e-6
+
+
+def test_posttrans_fused_epilogue(cuda_device):
+    """graph-norm * eval-BatchNorm affine * ReLU + residual folded into the MFMA epilogue (pna_layer.py:71-75,:209-213)."""
+    from pna_amd import functional as PF
+    gen = torch.Generator().manual_seed(3)
+    M, K, N, S = 333, 40, 24, 3
+    a = torch.randn(M, K, generator=gen)
+    W = torch.randn(N, S * K, generator=gen) / (K ** 0.5)
+    b = torch.randn(N, generator=gen)
+    scales = [None, torch.rand(M, generator=gen) + 0.5, torch.rand(M, generator=gen) + 0.5]
+    snorm = torch.rand(M, 1, generator=gen) + 0.2
+    res = torch.randn(M, N, generator=gen)
+    bn = torch.nn.BatchNorm1d(N).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(N, generator=gen) + 0.5); bn.bias.copy_(torch.randn(N, generator=gen))
+        bn.running_mean.copy_(torch.randn(N, generator=gen)); bn.running_var.copy_(torch.rand(N, generator=gen) + 0.5)
+        z = torch.cat([a if s is None else a * s.unsqueeze(1) for s in scales], dim=1).double() @ W.double().t() + b.double()
+        ref = res.double() + torch.relu(bn.double()(z * snorm.double()))
+        dev = cuda_device
+        got = PF.posttrans(a.to(dev), K, W.to(dev), b.to(dev), [None if s is None else s.to(dev) for s in scales],
+                           row_post=snorm.to(dev), bn=bn.float().to(dev), relu=True, residual=res.to(dev)).cpu()
+    torch.testing.assert_close(got.double(), ref, rtol=1e-5, atol=2e-5)

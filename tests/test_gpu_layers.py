@@ -115,11 +115,3 @@ def test_dense_registry_operators(cuda_device):
     for name, fn in DENSE_SCALERS.items():
         got = fn(m.to(cuda_device), adj.to(cuda_device), {k: v.to(cuda_device) for k, v in avg_d.items()}).cpu()
         torch.testing.assert_close(got, O.dense_scale(name, m, adj, avg_d), rtol=1e-6, atol=1e-7)
-
-
-def test_training_mode_raises_until_backward_exists(cuda_device):
-    layer = PNASimpleLayer(8, 8, "mean max", "identity", {"log": torch.tensor(1.0)}, 0.0, True, True).to(cuda_device)
-    g = Graph(torch.tensor([0, 1, 2]), torch.tensor([1, 2, 0]), 3).to(cuda_device)
-    h = torch.randn(3, 8, device=cuda_device, requires_grad=True)
-    with pytest.raises(NotImplementedError):
-        layer(g, h)

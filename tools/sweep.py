@@ -107,7 +107,11 @@ def main():
     for i, v in enumerate(variants):                       # correctness of every variant first (4F part bit-identical
         o = run(v)                                         # for variants sharing the heavy schedule)
         if v["heavy"] == ref_v["heavy"] and v.get("col", "real") == "real" and not v.get("nocheck"):
-            assert torch.equal(o[:, :4 * F], ref), v
+            same_map = not ({"vec", "lanes_per_row"} & set(v["tune"]))     # heavy-row fold order depends on the lane mapping
+            if same_map:
+                assert torch.equal(o[:, :4 * F], ref), v
+            else:
+                torch.testing.assert_close(o[:, :4 * F], ref, rtol=1e-4, atol=1e-4)
     for r in range(args.rounds):
         for i, v in enumerate(variants):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
