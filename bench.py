@@ -48,6 +48,7 @@ def parse():
     p.add_argument("--edges-per-gpu", type=int, default=E_PER_GPU)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-rows", type=int, default=250_000)
+    p.add_argument("--x-pitch", type=int, default=80, help="row pitch (floats) of the resident feature matrix")
     p.add_argument("--kernel-iters", type=int, default=20, help="launches used for the per-kernel HIP-event timing")
     return p.parse_args()
 
@@ -135,7 +136,11 @@ def main():
     e_local = int(g.csr.rowptr[-1].item())
     hs = g.heavy_schedule()
     h_all = torch.randn(V, F, generator=torch.Generator().manual_seed(1234))   # x ~ N(0,1), seed 1234
-    h = h_all[lo:hi].to(dev)
+    # node features live in a 16-byte aligned row pitch (80 floats for F=75), the layout a multi-layer net keeps
+    # its activations in; the kernels accept any pitch (--x-pitch 75 = dense rows, ~3 % slower gather)
+    h_buf = torch.zeros(hi - lo, max(args.x_pitch, F), device=dev)
+    h = h_buf[:, :F]
+    h.copy_(h_all[lo:hi])
 
     torch.manual_seed(0)
     layer = PNASimpleLayer(F, F, AGGREGATORS, SCALERS, {"log": avg_log}, 0.0, True, True)
@@ -190,7 +195,7 @@ def main():
             traffic = json.load(open(tpath)).get("pna_segreduce_c3", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_segreduce<4,U,false> (pna_segreduce_fwd_f32)",
+    roofline = {"bound": "hbm", "kernel": "k_segreduce_fast<4> + k_heavy_finalize (pna_segreduce_fwd_f32)",
                 "achieved": alg_bytes / (t_seg * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": alg_bytes / (t_seg * 1e-3) / HBM_PEAK, "traffic": traffic,
                 "ms_per_launch": t_seg, "algorithmic_bytes_per_launch": alg_bytes,
@@ -198,7 +203,7 @@ def main():
                 "edges_per_s_kernel_only": e_local / (t_seg * 1e-3),
                 "heavy_rows": hs.n_heavy, "heavy_segments": hs.n_seg}
     flops = 2.0 * n_local * (12 * F) * F
-    roofline_post = {"bound": "mfma", "kernel": "k_posttrans<3,false> (pna_posttrans_f32)", "achieved": flops / (t_post * 1e-3) / 1e12,
+    roofline_post = {"bound": "mfma", "kernel": "k_posttrans<3,false,5> (pna_posttrans_f32)", "achieved": flops / (t_post * 1e-3) / 1e12,
                      "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s", "frac": flops / (t_post * 1e-3) / MFMA_F32_PEAK,
                      "ms_per_launch": t_post}
 
@@ -210,6 +215,7 @@ def main():
                                "single PNA (simple) layer fwd: 4 aggregators x 3 scalers + posttrans Linear(900->75) + BN + ReLU + residual",
                    "V": V, "E": E, "F": F, "aggregators": AGGREGATORS, "scalers": SCALERS,
                    "parallelism": f"dst-range shard x{world}, halo all-to-all" if world > 1 else "single GPU",
+                   "x_row_pitch_floats": max(args.x_pitch, F),
                    "max_in_degree": int(csr.max_degree), "halo_rows_rank0": getattr(g, "n_halo", 0)},
         "roofline": roofline, "roofline_posttrans": roofline_post,
         "kernel_ms": {"segreduce": t_seg, "posttrans": t_post, "halo_all_to_all": t_halo},
