@@ -139,6 +139,17 @@ typedef struct pna_segreduce_args {
   const int32_t* seg_heavy;  /* [n_seg] index into heavy_rows of the row each segment belongs to   */
   float* partials;           /* workspace, pna_segreduce_partials_bytes(n_seg, F, n_tower) bytes   */
 
+  /* Optional work list for the hand-scheduled kernel (used when the call is the plain 4-aggregator gather
+   * mean|max|min|std with the identity scaler): n_work_items records {row, beg, end, slot} (int32 x 4).  slot < 0:
+   * the record is a whole row [beg,end) = [rowptr[row], rowptr[row+1]) whose result is finalised and stored;
+   * slot >= 0: the record is heavy segment number `slot` (its partials go to partials[slot]; the segments of a
+   * heavy row must be the ones heavy_segptr describes).  Every row must be covered exactly once, either by one
+   * whole-row record or by its segments.  The host orders the records by length (pna_amd/graph.py) so that the
+   * lane groups of a wavefront walk equally long records; results do not depend on the order.  NULL = the
+   * compiler-scheduled kernel in natural row order. */
+  const int32_t* work_items;
+  int32_t n_work_items;
+  int32_t _pad2;
   pna_tuning tune;
 } pna_segreduce_args;
 

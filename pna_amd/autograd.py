@@ -39,7 +39,7 @@ class AggregateFn(torch.autograd.Function):
         want_arg = any(a in ("max", "min") for a in aggs)
         res = ops.segreduce(csr.rowptr, col, x, F, all_aggs, [None], n_tower=n_tower, tower_stride_in=F,
                             dst_term=dst_term, edge_term=edge_term, want_arg=want_arg,
-                            heavy=graph.heavy_schedule(), workspace=graph.workspace)
+                            heavy=graph.heavy_schedule(), workspace=graph.workspace, items=graph.work_items())
         ident, amx, amn = res if want_arg else (res, None, None)       # (V, T*A'*F) identity-scaled
         V, T, A, A2, S = ident.shape[0], max(1, n_tower), len(aggs), len(all_aggs), len(row_scales)
         iv = ident.view(V, T, A2, F)

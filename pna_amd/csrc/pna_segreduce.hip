@@ -434,20 +434,22 @@ template <int U> struct Drain<U, U> {
   static __device__ __forceinline__ void run(AccF&, f4 (&)[U], int, bool) {}
 };
 
-// U gathers of one row issued back to back from the ids held by the group's lanes, then folded in order.
-template <int U, bool PARTIAL>
-__device__ __forceinline__ void fast_batch(const KArgs& a, AccF& acc, int idx, int src_lane0, unsigned ldb,
-                                           unsigned offb, int nvalid) {
-  int id[U];
-  f4 v[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) id[u] = __shfl(idx, src_lane0 + (PARTIAL ? min(u, nvalid - 1) : u));
-#pragma unroll
-  for (int u = 0; u < U; ++u) aload128(v[u], a.x, __umul24((unsigned)id[u], ldb) + offb);
-  Drain<0, U>::run(acc, v, nvalid, PARTIAL);
-}
+// Slim argument block of the hand-scheduled kernel.  Everything the row loop touches fits in ~40 SGPRs; the full
+// KArgs (scaler pointers, aggregator codes, heavy-row arrays) made hipcc spill SGPRs into VGPR lanes, which cost
+// two waves per SIMD.  The kernel is therefore specialised to the configuration the layers issue -- aggregators
+// (mean, max, min, std), identity scaler only (the degree scalers are applied in the posttrans epilogue) -- and
+// everything else goes through the compiler-scheduled k_segreduce.
+struct FArgs {
+  const int32_t* items;   // [n_items][4] = {row, beg, end, slot}: slot < 0 -> whole row (finalise + store),
+                          //                 slot >= 0 -> heavy segment: raw partials to partials[slot]
+  const int32_t* col; const float* x; float* out; float* partials;
+  long ldo, ts_out;
+  unsigned ldb, ts_in_b;  // x row pitch / tower stride in bytes
+  int n_items, F, L, G, R, T, tiles, pstride, block_stride, nt, dbg;
+};
 
-__device__ __forceinline__ void fast_finalize_store(const KArgs& a, const AccF& acc, int row, int deg, long offo) {
+// mean | max | min | std blocks of one destination row (identity scaler), 4 features per lane.
+__device__ __forceinline__ void fast_finalize_store(const FArgs& a, const AccF& acc, int row, int deg, long offo) {
   float* const orow = a.out + (size_t)row * a.ldo + offo;
   const unsigned bs = (unsigned)a.block_stride;
   const bool nt = a.nt != 0;
@@ -456,46 +458,43 @@ __device__ __forceinline__ void fast_finalize_store(const KArgs& a, const AccF& 
     f4a4* p = reinterpret_cast<f4a4*>(orow + blk * bs);
     if (nt) __builtin_nontemporal_store(v, p); else *p = v;
   };
-  const int A = a.n_aggr, S = a.n_scaler;
   if (deg <= 0) {                                          // no in-edges: every block is 0
     const f4 z = (f4){0.f, 0.f, 0.f, 0.f};
-    for (int b = 0; b < A * S; ++b) put(b, z);
+    put(0, z); put(1, z); put(2, z); put(3, z);
     return;
   }
-  float sc[PNA_MAX_SCALER];                                // all row scalers requested up front (one wait)
-#pragma unroll
-  for (int s = 0; s < PNA_MAX_SCALER; ++s) sc[s] = (s < S && a.row_scale[s]) ? a.row_scale[s][row] : 1.f;
   const float invD = 1.0f / (float)deg;                    // one IEEE division per row (see finalize_store)
   const f4 mean = acc.s * invD;
   f4 var = acc.q * invD - mean * mean;
   var.x = var.x < 0.f ? 0.f : var.x; var.y = var.y < 0.f ? 0.f : var.y;
   var.z = var.z < 0.f ? 0.f : var.z; var.w = var.w < 0.f ? 0.f : var.w;
-  for (int i = 0; i < A; ++i) {
-    f4 v;
-    switch (a.aggr[i]) {
-      case PNA_AGG_MEAN: v = mean; break;
-      case PNA_AGG_SUM: v = acc.s; break;
-      case PNA_AGG_MAX:   // v_max drops NaN; q is NaN iff the row holds a NaN message (torch propagates it)
-        v.x = acc.q.x != acc.q.x ? acc.q.x : acc.mx.x; v.y = acc.q.y != acc.q.y ? acc.q.y : acc.mx.y;
-        v.z = acc.q.z != acc.q.z ? acc.q.z : acc.mx.z; v.w = acc.q.w != acc.q.w ? acc.q.w : acc.mx.w;
-        break;
-      case PNA_AGG_MIN:
-        v.x = acc.q.x != acc.q.x ? acc.q.x : acc.mn.x; v.y = acc.q.y != acc.q.y ? acc.q.y : acc.mn.y;
-        v.z = acc.q.z != acc.q.z ? acc.q.z : acc.mn.z; v.w = acc.q.w != acc.q.w ? acc.q.w : acc.mn.w;
-        break;
-      case PNA_AGG_STD:
-        v.x = sqrtf(var.x + 1e-5f); v.y = sqrtf(var.y + 1e-5f); v.z = sqrtf(var.z + 1e-5f); v.w = sqrtf(var.w + 1e-5f);
-        break;
-      default: v = var; break;
-    }
-#pragma unroll
-    for (int s = 0; s < PNA_MAX_SCALER; ++s)
-      if (s < S) put((unsigned)(s * A + i), a.row_scale[s] ? v * sc[s] : v);
-  }
+  // v_max/v_min drop NaN; q is NaN iff the row holds a NaN message (torch propagates it)
+  f4 mx, mn, sd;
+  mx.x = acc.q.x != acc.q.x ? acc.q.x : acc.mx.x; mx.y = acc.q.y != acc.q.y ? acc.q.y : acc.mx.y;
+  mx.z = acc.q.z != acc.q.z ? acc.q.z : acc.mx.z; mx.w = acc.q.w != acc.q.w ? acc.q.w : acc.mx.w;
+  mn.x = acc.q.x != acc.q.x ? acc.q.x : acc.mn.x; mn.y = acc.q.y != acc.q.y ? acc.q.y : acc.mn.y;
+  mn.z = acc.q.z != acc.q.z ? acc.q.z : acc.mn.z; mn.w = acc.q.w != acc.q.w ? acc.q.w : acc.mn.w;
+  sd.x = sqrtf(var.x + 1e-5f); sd.y = sqrtf(var.y + 1e-5f); sd.z = sqrtf(var.z + 1e-5f); sd.w = sqrtf(var.w + 1e-5f);
+  put(0, mean); put(1, mx); put(2, mn); put(3, sd);
 }
 
+// U gathers of one row issued back to back from the ids held by the group's lanes, then folded in order.
+template <int U, bool PARTIAL>
+__device__ __forceinline__ void fast_batch(const float* x, AccF& acc, int idx, int src_lane0, unsigned ldb,
+                                           unsigned offb, int nvalid) {
+  int id[U];
+  f4 v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) id[u] = __shfl(idx, src_lane0 + (PARTIAL ? min(u, nvalid - 1) : u));
+#pragma unroll
+  for (int u = 0; u < U; ++u) aload128(v[u], x, __umul24((unsigned)id[u], ldb) + offb);
+  Drain<0, U>::run(acc, v, nvalid, PARTIAL);
+}
+
+// The prefetch invariants: the first L source ids of item r+1 and the record of item r+2 are requested BEFORE
+// item r's gathers; VMEM returns in order, so once the wave has waited for any gather of item r they have landed.
 template <int U>
-__global__ __launch_bounds__(kBlock) void k_segreduce_fast(const KArgs a) {
+__global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int L = a.L;
@@ -508,91 +507,67 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const KArgs a) {
   const int chunk = (blockIdx.y - tower * a.tiles) * L + c;
   const bool lane_ok = chunk < nchunks;
   const int off = min(min(chunk, nchunks - 1) * 4, a.F - 4);
-  const long offi = (long)tower * a.ts_in + off;
   const long offo = (long)tower * a.ts_out + off;
   const int NG = kWaves * a.G;
-  const int gid = wave * a.G + grp;
-  if ((int)blockIdx.x < a.n_heavy_blocks) {
-    // heavy segments: compiler-scheduled generic walk, raw partials to the workspace
-    const int seg = blockIdx.x * NG + gid;
-    if (seg >= a.n_seg) return;
-    const int hi = a.seg_heavy[seg];
-    const int row = a.heavy_rows[hi];
-    const int sidx = seg - a.heavy_segptr[hi];
-    const int rbeg = a.rowptr[row], rend = a.rowptr[row + 1];
-    const int beg = rbeg + sidx * a.seg_len;
-    const int end = min(beg + a.seg_len, rend);
-    Acc<4, false> acc;
-    acc.init();
-    walk<4, U, false, true>(a, acc, row, beg, end, c, grp_lane0, offi, 0, false);
-    if (lane_ok) {
-      float* p = a.partials + ((size_t)seg * a.T + tower) * kNQ * a.pstride + off;
-      Ld<4>::store(p, acc.s, false);
-      Ld<4>::store(p + a.pstride, acc.q, false);
-      Ld<4>::store(p + 2 * a.pstride, acc.mx, false);
-      Ld<4>::store(p + 3 * a.pstride, acc.mn, false);
-    }
-    return;
-  }
-  const long base = (long)(blockIdx.x - a.n_heavy_blocks) * NG * a.R + gid;
-  if (base >= a.V) return;
-  const int thr = a.heavy_threshold;
-  const unsigned ldb = (unsigned)a.ldx * 4u;
-  const unsigned offb = (unsigned)offi * 4u;
+  const long NI = a.n_items;
+  const long base = (long)blockIdx.x * NG * a.R + wave * a.G + grp;
+  if (base >= NI) return;
+  const unsigned ldb = a.ldb;
+  const unsigned offb = (unsigned)tower * a.ts_in_b + (unsigned)off * 4u;
+  auto issue_item = [&](i4& dst, long k) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"((unsigned)k * 16u), "s"(a.items) : "memory");
+  };
 
-  // prologue: rowptr pair of row 0 -> its first ids and the rowptr pair of row 1
-  i2 b0;
-  aload64(b0, a.rowptr, (unsigned)base * 4u);
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(b0) : : "memory");
-  int beg_c = b0.x, end_c = b0.y;
+  // prologue: record of item 0 -> its first ids and the record of item 1
+  i4 cur;
+  issue_item(cur, base);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur) : : "memory");
   int idx_c = 0;
-  {
-    const int d = end_c - beg_c;
-    if (c < d && !(thr > 0 && d > thr)) aload32(idx_c, a.col, (unsigned)(beg_c + c) * 4u);
-  }
-  i2 bn = (i2){0, 0};
-  if (a.R > 1 && base + NG < a.V) aload64(bn, a.rowptr, (unsigned)(base + NG) * 4u);
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(idx_c), "+v"(bn) : : "memory");
-  int beg_n = bn.x, end_n = bn.y;
+  if (c < cur.z - cur.y) aload32(idx_c, a.col, (unsigned)(cur.y + c) * 4u);
+  i4 nxt = (i4){0, 0, 0, -1};
+  if (a.R > 1 && base + NG < NI) issue_item(nxt, base + NG);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(idx_c), "+v"(nxt) : : "memory");
 
   AccF acc;
   for (int r = 0; r < a.R; ++r) {
-    const long row_l = base + (long)r * NG;
-    if (row_l >= a.V) break;
-    const int row = (int)row_l;
-    // ---- prefetch: first L source ids of row r+1, rowptr pair of row r+2 (issued BEFORE this row's gathers)
+    const long item = base + (long)r * NG;
+    if (item >= NI) break;
+    // ---- prefetch (issued BEFORE this item's gathers)
     int idx_n = 0;
-    i2 bnn = (i2){0, 0};
-    if (r + 1 < a.R && row_l + NG < a.V) {
-      const int dn = end_n - beg_n;
-      if (c < dn && !(thr > 0 && dn > thr)) aload32(idx_n, a.col, (unsigned)(beg_n + c) * 4u);
-    }
-    if (r + 2 < a.R && row_l + 2 * NG < a.V) aload64(bnn, a.rowptr, (unsigned)(row + 2 * NG) * 4u);
-    // ---- this row
-    const int deg = end_c - beg_c;
-    bool gathered = false;
-    if (!(thr > 0 && deg > thr)) {
-      acc.init();
-      int idx = idx_c;
-      for (int cb = beg_c; cb < end_c; cb += L) {
-        const int nidx = min(L, end_c - cb);
-        if (cb != beg_c) {                                  // rows longer than one id chunk (rare): fetch + wait
-          idx = 0;
-          if (c < nidx) aload32(idx, a.col, (unsigned)(cb + c) * 4u);
-          await<0>(idx);
-        }
-        int j = 0;
-        for (; j + U <= nidx; j += U) fast_batch<U, false>(a, acc, idx, grp_lane0 + j, ldb, offb, U);
-        if (j < nidx) fast_batch<U, true>(a, acc, idx, grp_lane0 + j, ldb, offb, nidx - j);
+    i4 nn = (i4){0, 0, 0, -1};
+    if (r + 1 < a.R && item + NG < NI && c < nxt.z - nxt.y) aload32(idx_n, a.col, (unsigned)(nxt.y + c) * 4u);
+    if (r + 2 < a.R && item + 2 * NG < NI) issue_item(nn, item + 2 * NG);
+    // ---- this item
+    const int row = cur.x, beg = cur.y, end = cur.z, slot = cur.w;
+    acc.init();
+    int idx = idx_c;
+    for (int cb = beg; cb < end; cb += L) {
+      const int nidx = min(L, end - cb);
+      if (cb != beg) {                                       // longer than one id chunk (rare): fetch + wait
+        idx = 0;
+        if (c < nidx) aload32(idx, a.col, (unsigned)(cb + c) * 4u);
+        await<0>(idx);
       }
-      gathered = deg > 0;
-      if (lane_ok && !((a.dbg & 1) && acc.s.x != 12345.678f)) fast_finalize_store(a, acc, row, deg, offo);
+      int j = 0;
+      for (; j + U <= nidx; j += U) fast_batch<U, false>(a.x, acc, idx, grp_lane0 + j, ldb, offb, U);
+      if (j < nidx) fast_batch<U, true>(a.x, acc, idx, grp_lane0 + j, ldb, offb, nidx - j);
     }
-    // The prefetches were issued before this row's gathers, so once the wave has waited for any gather they
-    // have landed (VMEM returns in order).  Only if no lane group of the wave gathered anything: drain.
-    if (__builtin_amdgcn_ballot_w64(gathered) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("" : "+v"(idx_n), "+v"(bnn));              // anchor: consumers cannot move above this point
-    idx_c = idx_n; beg_c = beg_n; end_c = end_n; beg_n = bnn.x; end_n = bnn.y;
+    if (lane_ok && !((a.dbg & 1) && acc.s.x != 12345.678f)) {
+      if (slot < 0) {
+        fast_finalize_store(a, acc, row, end - beg, offo);
+      } else {                                               // heavy segment: raw (s, q, max, min) to the workspace
+        typedef f4 f4a4 __attribute__((aligned(4)));
+        float* p = a.partials + ((size_t)slot * a.T + tower) * kNQ * a.pstride + off;
+        *reinterpret_cast<f4a4*>(p) = acc.s;
+        *reinterpret_cast<f4a4*>(p + a.pstride) = acc.q;
+        *reinterpret_cast<f4a4*>(p + 2 * a.pstride) = acc.mx;
+        *reinterpret_cast<f4a4*>(p + 3 * a.pstride) = acc.mn;
+      }
+    }
+    // Only if no lane group of the wave gathered anything have the prefetches possibly not landed: drain.
+    if (__builtin_amdgcn_ballot_w64(end > beg) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(idx_n), "+v"(nn));                 // anchor: consumers cannot move above this point
+    idx_c = idx_n; cur = nxt; nxt = nn;
   }
 }
 
@@ -792,7 +767,7 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
   k.L = L; k.G = 64 / L; k.T = T; k.tiles = tiles; k.ts_in = ts_in; k.ts_out = ts_out;
   int U = t.unroll ? t.unroll : 4;
   if (U != 2 && U != 4 && U != 8) return pna_set_error(PNA_E_INVALID, "pna_segreduce_fwd_f32: tune.unroll must be 2, 4 or 8");
-  k.R = t.rows_per_group > 0 ? t.rows_per_group : (p->V >= (1 << 18) ? 8 : 4);
+  k.R = t.rows_per_group > 0 ? t.rows_per_group : 4;
   k.nt = t.nt_store >= 0 ? 1 : 0;
   k.pf = t.prefetch >= 0 ? 1 : 0;
   k.dbg = t.reserved[0];   // bit0: skip the output stores (bench experiments only; results are then undefined)
@@ -807,15 +782,26 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
   hipStream_t st = (hipStream_t)stream;
   // 32-bit gather offsets when the whole feature table is addressable with them
   const bool idx32 = p->x_rows > 0 && (double)p->x_rows * (double)p->ldx * 4.0 < 4294967296.0 && p->ldx < (1 << 28);
-  // hand-scheduled kernel for the common configuration (see k_segreduce_fast)
-  const bool fast_ok = vec == 4 && !extra && p->col != nullptr && idx32 && p->x_rows < (1 << 24) && p->ldx * 4 < (1 << 24) &&
-                       p->V < (1 << 30) && t.reserved[1] == 0;
+  // hand-scheduled kernel for the configuration the layers issue (see k_segreduce_fast / FArgs)
+  const bool std4 = p->n_aggr == 4 && p->aggr[0] == PNA_AGG_MEAN && p->aggr[1] == PNA_AGG_MAX && p->aggr[2] == PNA_AGG_MIN &&
+                    p->aggr[3] == PNA_AGG_STD && p->n_scaler == 1 && p->row_scale[0] == nullptr;
+  const bool fast_ok = vec == 4 && !extra && std4 && p->col != nullptr && idx32 && p->x_rows < (1 << 24) &&
+                       p->ldx * 4 < (1 << 24) && (int64_t)T * ts_in * 4 < (1 << 30) && p->work_items != nullptr &&
+                       p->n_work_items > 0 && p->n_work_items < (1 << 27) && t.reserved[1] == 0;
   int rc = 0;
   if (fast_ok) {
+    FArgs f;
+    memset(&f, 0, sizeof(f));
+    f.items = p->work_items; f.col = p->col; f.x = p->x; f.out = p->out; f.partials = p->partials;
+    f.ldo = p->ldo; f.ts_out = ts_out; f.ldb = (unsigned)(p->ldx * 4); f.ts_in_b = (unsigned)(ts_in * 4);
+    f.n_items = p->n_work_items; f.F = p->F; f.L = k.L; f.G = k.G; f.R = k.R; f.T = T; f.tiles = tiles;
+    f.pstride = k.pstride; f.block_stride = p->block_stride; f.nt = k.nt; f.dbg = k.dbg;
+    const long fb = (p->n_work_items + rows_per_block - 1) / rows_per_block;
+    dim3 fgrid((unsigned)fb, (unsigned)(tiles * T));
     switch (U) {
-      case 2: hipLaunchKernelGGL((k_segreduce_fast<2>), grid, dim3(kBlock), 0, st, k); break;
-      case 4: hipLaunchKernelGGL((k_segreduce_fast<4>), grid, dim3(kBlock), 0, st, k); break;
-      default: hipLaunchKernelGGL((k_segreduce_fast<8>), grid, dim3(kBlock), 0, st, k); break;
+      case 2: hipLaunchKernelGGL((k_segreduce_fast<2>), fgrid, dim3(kBlock), 0, st, f); break;
+      case 4: hipLaunchKernelGGL((k_segreduce_fast<4>), fgrid, dim3(kBlock), 0, st, f); break;
+      default: hipLaunchKernelGGL((k_segreduce_fast<8>), fgrid, dim3(kBlock), 0, st, f); break;
     }
   } else {
     rc = launch_any(k, vec, U, extra, idx32, grid, st);

@@ -34,7 +34,8 @@ def aggregate(graph, x, F, aggregators, *, n_tower=1, dst_term=None, edge_term=N
     col = None if edge_resident else (csr.col if col_override is None else col_override)
     return ops.segreduce(csr.rowptr, col, x, F, aggregators, row_scales,
                          n_tower=n_tower, tower_stride_in=F, dst_term=dst_term, edge_term=edge_term,
-                         edge_weight=edge_weight, heavy=graph.heavy_schedule(), workspace=graph.workspace)
+                         edge_weight=edge_weight, heavy=graph.heavy_schedule(), workspace=graph.workspace,
+                         items=graph.work_items())
 
 
 def posttrans(agg, K, weight, bias, row_scales, h_self=None, *, row_post=None, bn=None, relu=False, residual=None,

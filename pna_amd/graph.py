@@ -156,6 +156,46 @@ class Graph:
             self._heavy[key] = build_heavy_schedule(c.rowptr, c.max_degree, *key)
         return self._heavy[key]
 
+    def work_items(self, threshold=None, seg_len=None, order="natural", window=96):
+        """int32 (n, 4) work list {row, beg, end, slot} for the hand-scheduled kernel (include/pna_amd.h): first
+        the segments of the heavy rows (slot = segment number), then one whole-row record (slot = -1) per other
+        row.  order="degree": rows sorted by in-degree, descending and stable, so the lane groups of a wavefront
+        walk rows of equal length; order="window": ascending row id, but sorted by in-degree inside consecutive
+        windows of `window` rows; order="natural" (default): ascending row id, which keeps whatever locality the
+        node numbering has (neighbouring rows tend to share source rows and then hit in L1/L2).  On the 10 M-edge
+        power-law benchmark graph natural order is fastest although degree sorting removes a third of the
+        instructions -- the gather is bound by cache misses, not by issue (tools/sweep.py, profiles/)."""
+        hs = self.heavy_schedule(threshold, seg_len)
+        key = ("items", hs.threshold, hs.seg_len, order, window)
+        if key not in self._heavy:
+            c = self.csr
+            rp = c.rowptr.long()
+            deg = rp[1:] - rp[:-1]
+            dev = self.device
+            if hs.n_heavy > 0:
+                rows = torch.nonzero(deg <= hs.threshold).flatten()
+                hrow = hs.heavy_rows.long()[hs.seg_heavy.long()]
+                slot = torch.arange(hs.n_seg, device=dev)
+                sidx = slot - hs.heavy_segptr.long()[hs.seg_heavy.long()]
+                hbeg = rp[hrow] + sidx * hs.seg_len
+                hend = torch.minimum(hbeg + hs.seg_len, rp[hrow + 1])
+                heavy_items = torch.stack([hrow, hbeg, hend, slot], dim=1)
+            else:
+                rows = torch.arange(self.num_nodes, device=dev)
+                heavy_items = torch.zeros(0, 4, dtype=torch.long, device=dev)
+            if order == "degree":
+                rows = rows[torch.sort(deg[rows], descending=True, stable=True).indices]
+            elif order == "window":
+                # sort key = (window index ascending, degree descending): one stable sort of a combined key
+                w = torch.arange(rows.numel(), device=dev) // window
+                key2 = w * (int(deg.max().item()) + 1 if rows.numel() else 1) + (int(deg.max().item()) - deg[rows] if rows.numel() else 0)
+                rows = rows[torch.sort(key2, stable=True).indices]
+            elif order != "natural":
+                raise ValueError(order)
+            light = torch.stack([rows, rp[rows], rp[rows + 1], torch.full_like(rows, -1)], dim=1)
+            self._heavy[key] = torch.cat([heavy_items, light], dim=0).to(torch.int32).contiguous()
+        return self._heavy[key]
+
     def workspace(self, nbytes):
         """Reusable float32 scratch (heavy-row partials) on the graph's device."""
         n = (nbytes + 3) // 4

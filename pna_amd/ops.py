@@ -33,7 +33,8 @@ def segreduce(rowptr: torch.Tensor, col: Optional[torch.Tensor], x: torch.Tensor
               edge_term: Optional[torch.Tensor] = None, edge_weight: Optional[torch.Tensor] = None,
               out: Optional[torch.Tensor] = None, block_stride: Optional[int] = None,
               tower_stride_out: Optional[int] = None, want_arg: bool = False,
-              heavy: Optional[HeavySchedule] = None, workspace=None, tune: Optional[dict] = None):
+              heavy: Optional[HeavySchedule] = None, workspace=None, tune: Optional[dict] = None,
+              items: Optional[torch.Tensor] = None):
     """out[v, t*tso + (s*A + a)*bs + f] = aggregators[a]({m_k}) [f] * row_scales[s][v]   (see pna_amd.h).
 
     rowptr:int32[V+1]; col:int32[E] or None (x edge-resident); x:(rows, >= T*F) fp32.
@@ -87,6 +88,8 @@ def segreduce(rowptr: torch.Tensor, col: Optional[torch.Tensor], x: torch.Tensor
     tn = dict(_TUNE)
     if tune:
         tn.update(tune)
+    if items is not None and items.numel() > 0:
+        a.work_items, a.n_work_items = _lib.dev_ptr(items, torch.int32, "work_items"), items.shape[0]
     for k, v in tn.items():
         setattr(a.tune, k, int(v))
     rc = _lib.lib().pna_segreduce_fwd_f32(ctypes.byref(a), _lib.stream_ptr(dev))

@@ -186,3 +186,35 @@ def test_product_package_never_imports_the_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports oracle/"
                 assert "/root/reference" not in src, f"{f} references /root/reference"
+
+
+def test_work_items_cover_every_edge_once():
+    rng = np.random.default_rng(4)
+    V, E = 400, 5000
+    dst = rng.integers(0, V - 5, E)
+    dst[:1200] = rng.integers(0, 3, 1200)                    # three hubs
+    g = Graph(torch.from_numpy(rng.integers(0, V, E)), torch.from_numpy(dst), V)
+    deg = g.in_degrees()
+    rp = g.csr.rowptr.long()
+    for thr, seg, order in ((0, 0, "degree"), (16, 8, "degree"), (128, 128, "natural"), (30, 16, "degree"), (16, 8, "window")):
+        it = g.work_items(thr, seg, order, 32).long()
+        assert it.shape[1] == 4
+        hs = g.heavy_schedule(thr, seg)
+        whole = it[it[:, 3] < 0]
+        segs = it[it[:, 3] >= 0]
+        assert segs.shape[0] == hs.n_seg and torch.equal(segs[:, 3], torch.arange(hs.n_seg))
+        want = torch.arange(V) if hs.n_heavy == 0 else torch.nonzero(deg <= hs.threshold).flatten()
+        assert sorted(whole[:, 0].tolist()) == want.tolist()
+        assert torch.equal(whole[:, 1], rp[whole[:, 0]]) and torch.equal(whole[:, 2], rp[whole[:, 0] + 1])
+        d = (whole[:, 2] - whole[:, 1]).tolist()
+        if order == "degree":
+            assert d == sorted(d, reverse=True)
+        if order == "window":
+            for w0 in range(0, len(d), 32):
+                assert d[w0:w0 + 32] == sorted(d[w0:w0 + 32], reverse=True)
+                assert sorted(whole[w0:w0 + 32, 0].tolist()) == want[w0:w0 + 32].tolist()
+        covered = torch.zeros(E, dtype=torch.long)
+        for r, b, e, s_ in it.tolist():
+            covered[b:e] += 1
+            assert rp[r] <= b and e <= rp[r + 1]
+        assert (covered == 1).all()

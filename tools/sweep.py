@@ -63,6 +63,14 @@ def main():
         variants.append(dict(ld=75, heavy=(64, 64), S=1, tune=dict(unroll=U, rows_per_group=4, generic=1)))
     for hk in ((64, 64), (128, 128)):
         for ld in (75, 80):
+            for R in (4, 8):
+                variants.append(dict(ld=ld, heavy=hk, S=1, order="natural", tune=dict(unroll=4, rows_per_group=R)))
+    for order, window in (("degree", 0), ("window", 48), ("window", 96), ("window", 192), ("window", 384), ("window", 1536)):
+        for U in (2, 4):
+            variants.append(dict(ld=80, heavy=(128, 128), S=1, order=order, window=window, tune=dict(unroll=U, rows_per_group=4)))
+            variants.append(dict(ld=80, heavy=(128, 128), S=1, order=order, window=window, tune=dict(unroll=U, rows_per_group=8)))
+    for hk in ((64, 64), (128, 128)):
+        for ld in (75, 80):
             variants.append(dict(ld=ld, heavy=hk, S=1, tune=dict(unroll=4, rows_per_group=8)))
     # 2. leading dimension of x
     for ld in (76, 80, 96):
@@ -99,7 +107,8 @@ def main():
         else:
             o, bs = outs[v["S"]][:, :len(ag) * v["S"] * F], F
         return ops.segreduce(c.rowptr, cols[v.get("col", "real")], xs[v["ld"]], F, ag, scales, out=o, block_stride=bs,
-                             heavy=heavy[hk if hk else 0], workspace=g.workspace, tune=v["tune"])
+                             heavy=heavy[hk if hk else 0], workspace=g.workspace, tune=v["tune"],
+                             items=g.work_items(hk[0] if hk else 0, hk[1] if hk else 0, v.get("order", "natural"), v.get("window", 96)))
 
     ref_v = dict(ld=75, heavy=(64, 64), S=1, tune=dict(unroll=4, rows_per_group=4))
     ref = run(ref_v).clone()
@@ -107,7 +116,7 @@ def main():
     for i, v in enumerate(variants):                       # correctness of every variant first (4F part bit-identical
         o = run(v)                                         # for variants sharing the heavy schedule)
         if v["heavy"] == ref_v["heavy"] and v.get("col", "real") == "real" and not v.get("nocheck"):
-            same_map = not ({"vec", "lanes_per_row"} & set(v["tune"]))     # heavy-row fold order depends on the lane mapping
+            same_map = not ({"vec", "lanes_per_row", "generic"} & set(v["tune"]))     # heavy-row fold order depends on the lane mapping
             if same_map:
                 assert torch.equal(o[:, :4 * F], ref), v
             else:
@@ -132,7 +141,7 @@ def main():
     path = os.path.join(ROOT, "gpurun_out", f"sweep_{args.tag}.json")
     json.dump(dict(V=V, E=E, F=F, alg_bytes=alg_bytes, results=res), open(path, "w"), indent=1)
     for r in res:
-        print(f"{r['ms_med']:.3f} {r['ms_min']:.3f} col={r['col']} ld={r['ld']} heavy={r['heavy']} S={r['S']} bs={r.get('bs')} na={r.get('na')} {r['tune']}")
+        print(f"{r['ms_med']:.3f} {r['ms_min']:.3f} col={r['col']} ld={r['ld']} heavy={r['heavy']} S={r['S']} bs={r.get('bs')} na={r.get('na')} ord={r.get('order')}/{r.get('window')} {r['tune']}")
 
 
 if __name__ == "__main__":
