@@ -766,7 +766,7 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
   }
   k.L = L; k.G = 64 / L; k.T = T; k.tiles = tiles; k.ts_in = ts_in; k.ts_out = ts_out;
   int U = t.unroll ? t.unroll : 4;
-  if (U != 2 && U != 4 && U != 8) return pna_set_error(PNA_E_INVALID, "pna_segreduce_fwd_f32: tune.unroll must be 2, 4 or 8");
+  if (U < 2 || U > 8 || U == 7) return pna_set_error(PNA_E_INVALID, "pna_segreduce_fwd_f32: tune.unroll must be 2..6 or 8");
   k.R = t.rows_per_group > 0 ? t.rows_per_group : 4;
   k.nt = t.nt_store >= 0 ? 1 : 0;
   k.pf = t.prefetch >= 0 ? 1 : 0;
@@ -789,6 +789,7 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
                        p->ldx * 4 < (1 << 24) && (int64_t)T * ts_in * 4 < (1 << 30) && p->work_items != nullptr &&
                        p->n_work_items > 0 && p->n_work_items < (1 << 27) && t.reserved[1] == 0;
   int rc = 0;
+  if (!fast_ok && U != 2 && U != 4 && U != 8) U = 4;       // the compiler-scheduled kernel is built for 2, 4, 8
   if (fast_ok) {
     FArgs f;
     memset(&f, 0, sizeof(f));
@@ -800,7 +801,10 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
     dim3 fgrid((unsigned)fb, (unsigned)(tiles * T));
     switch (U) {
       case 2: hipLaunchKernelGGL((k_segreduce_fast<2>), fgrid, dim3(kBlock), 0, st, f); break;
+      case 3: hipLaunchKernelGGL((k_segreduce_fast<3>), fgrid, dim3(kBlock), 0, st, f); break;
       case 4: hipLaunchKernelGGL((k_segreduce_fast<4>), fgrid, dim3(kBlock), 0, st, f); break;
+      case 5: hipLaunchKernelGGL((k_segreduce_fast<5>), fgrid, dim3(kBlock), 0, st, f); break;
+      case 6: hipLaunchKernelGGL((k_segreduce_fast<6>), fgrid, dim3(kBlock), 0, st, f); break;
       default: hipLaunchKernelGGL((k_segreduce_fast<8>), fgrid, dim3(kBlock), 0, st, f); break;
     }
   } else {

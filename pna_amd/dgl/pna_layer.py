@@ -62,12 +62,26 @@ def as_graph(g) -> Graph:
     return cached
 
 
+def _avg_log_value(avg_d):
+    """avg_d['log'] as a Python float, read from the device ONCE per tensor object/version (a .item() per forward
+    would put a device->host synchronisation into every layer call and make the forward un-capturable in a
+    hipGraph).  The cache lives on the tensor object itself, never keyed by address (addresses are recycled)."""
+    t = avg_d["log"]
+    if not torch.is_tensor(t):
+        return float(t)
+    hit = getattr(t, "_pna_amd_float", None)
+    if hit is None or hit[0] != t._version:
+        hit = (t._version, float(t))
+        t._pna_amd_float = hit
+    return hit[1]
+
+
 def _row_scales(graph, scalers, avg_d, device):
     if all(s == "identity" for s in scalers):
         return [None] * len(scalers)
     if graph.device != device:
         raise RuntimeError("graph and features live on different devices; call graph.to(device) first")
-    amp, att = graph.degree_scalers(float(avg_d["log"]))
+    amp, att = graph.degree_scalers(_avg_log_value(avg_d))
     return [{"identity": None, "amplification": amp, "attenuation": att}[s] for s in scalers]
 
 

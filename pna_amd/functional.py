@@ -38,6 +38,21 @@ def aggregate(graph, x, F, aggregators, *, n_tower=1, dst_term=None, edge_term=N
                          items=graph.work_items())
 
 
+def _fold_batchnorm(bn):
+    """Eval-mode BatchNorm1d as y = x * col_scale + col_shift; cached ON the module per parameter/buffer version so
+    that an inference loop does not relaunch the five little fold kernels every forward."""
+    ts = [t for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var) if t is not None]
+    key = tuple((id(t), t._version) for t in ts) + (bn.eps,)
+    hit = bn.__dict__.get("_pna_amd_fold")
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            cs = (bn.weight if bn.weight is not None else 1.0) * torch.rsqrt(bn.running_var + bn.eps)
+            ct = (bn.bias if bn.bias is not None else 0.0) - bn.running_mean * cs
+        hit = (key, cs.contiguous(), ct.contiguous(), ts)      # `ts` keeps the keyed tensors alive (id() stays unique)
+        bn.__dict__["_pna_amd_fold"] = hit
+    return hit[1], hit[2]
+
+
 def posttrans(agg, K, weight, bias, row_scales, h_self=None, *, row_post=None, bn=None, relu=False, residual=None,
               out=None):
     """y = W [h_self | s_0*agg | s_1*agg | ...] + b with `weight` in the reference's nn.Linear layout
@@ -60,9 +75,7 @@ def posttrans(agg, K, weight, bias, row_scales, h_self=None, *, row_post=None, b
     if bn is not None:
         if bn.training:
             raise RuntimeError("only an eval-mode BatchNorm (running statistics) can be folded into the epilogue")
-        col_scale = (bn.weight if bn.weight is not None else 1.0) * torch.rsqrt(bn.running_var + bn.eps)
-        col_shift = (bn.bias if bn.bias is not None else 0.0) - bn.running_mean * col_scale
-        col_scale, col_shift = col_scale.contiguous(), col_shift.contiguous()
+        col_scale, col_shift = _fold_batchnorm(bn)
     if row_post is not None:
         row_post = row_post.reshape(-1).contiguous()
     w = weight if weight.stride(-1) == 1 else weight.contiguous()

@@ -99,16 +99,14 @@ def segreduce(rowptr: torch.Tensor, col: Optional[torch.Tensor], x: torch.Tensor
     return (out, argmax, argmin) if want_arg else out
 
 
-_PACK_CACHE = {}
-
-
 def pack_posttrans_weight(weight: torch.Tensor, K: int, n_scaler: int, Kh: int):
-    """(w_img, wh_img) tile images of a reference-layout posttrans weight (N, Kh + n_scaler*K); cached per
-    weight version, so inference packs once and training re-packs after every optimizer step."""
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.stride(0), K, n_scaler, Kh, weight.device)
-    hit = _PACK_CACHE.get(key)
-    if hit is not None:
-        return hit
+    """(w_img, wh_img) tile images of a reference-layout posttrans weight (N, Kh + n_scaler*K).  Cached on the weight
+    tensor object per version: inference packs once, training re-packs after every optimizer step.  (Never keyed by
+    address -- the allocator recycles addresses.)"""
+    key = (weight._version, tuple(weight.shape), weight.stride(0), K, n_scaler, Kh)
+    hit = getattr(weight, "_pna_amd_pack", None)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
     L = _lib.lib()
     N = weight.shape[0]
     nh = ctypes.c_int64(0)
@@ -119,9 +117,10 @@ def pack_posttrans_weight(weight: torch.Tensor, K: int, n_scaler: int, Kh: int):
                                   _lib.dev_ptr(w_img, torch.float32, "w_img"), _lib.dev_ptr(wh_img, torch.float32, "wh_img"),
                                   _lib.stream_ptr(weight.device))
     _lib.check(rc, "pna_posttrans_pack_f32")
-    if len(_PACK_CACHE) > 64:
-        _PACK_CACHE.clear()
-    _PACK_CACHE[key] = (w_img, wh_img)
+    try:
+        weight._pna_amd_pack = (key, w_img, wh_img)
+    except AttributeError:
+        pass
     return w_img, wh_img
 
 

@@ -24,14 +24,18 @@ class DenseGraphs(NamedTuple):
     binary: bool               # every kept weight is exactly 1 (then the weights need not be passed)
 
 
-_CACHE = {}
-
-
 def sparsify(adj: torch.Tensor, self_loop: bool) -> DenseGraphs:
-    key = (adj.data_ptr(), adj._version, tuple(adj.shape), adj.device, self_loop)
-    hit = _CACHE.get(key)
-    if hit is not None:
-        return hit
+    # cached on the adjacency tensor object (the N/2 layer calls of one GNN.forward pass the same object,
+    # gnn_framework.py:93-95) per in-place version; never keyed by address
+    cache = getattr(adj, "_pna_amd_sparse", None)
+    if cache is None or cache[0] != adj._version:
+        cache = (adj._version, {})
+        try:
+            adj._pna_amd_sparse = cache
+        except AttributeError:
+            pass
+    if self_loop in cache[1]:
+        return cache[1][self_loop]
     B, N, _ = adj.shape
     a = adj + torch.eye(N, device=adj.device, dtype=adj.dtype).unsqueeze(0) if self_loop else adj
     b, i, j = torch.nonzero(a, as_tuple=True)                 # lexicographic in (b, i, j)
@@ -45,7 +49,5 @@ def sparsify(adj: torch.Tensor, self_loop: bool) -> DenseGraphs:
     g_col = Graph((b * N + i)[perm], (b * N + j)[perm], V, [N] * B)
     out = DenseGraphs(g_row, g_col, w_row, w_row[perm].contiguous(), perm.to(torch.int32),
                       bool((w_row == 1).all().item()) if w_row.numel() else True)
-    if len(_CACHE) > 16:
-        _CACHE.clear()
-    _CACHE[key] = out
+    cache[1][self_loop] = out
     return out

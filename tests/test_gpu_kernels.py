@@ -169,7 +169,7 @@ def test_segreduce_argument_validation(cuda_device):
     with pytest.raises(RuntimeError, match="leading dimensions"):
         ops.segreduce(c.rowptr, c.col, x, 16, ["mean"])
     with pytest.raises(RuntimeError, match="unroll"):
-        ops.segreduce(c.rowptr, c.col, x, 8, ["mean"], tune=dict(unroll=3))
+        ops.segreduce(c.rowptr, c.col, x, 8, ["mean"], tune=dict(unroll=7))
     with pytest.raises(RuntimeError, match="GPU"):
         ops.segreduce(c.rowptr, c.col, x.cpu(), 8, ["mean"])
     with pytest.raises(TypeError):

@@ -1,0 +1,133 @@
+#!/usr/bin/env python
+"""Timing of the parity-test configurations of BASELINE.json (configs[0], [1], [3]) on one MI355X: eager launches
+vs hipGraph replay, next to the oracle's CPU restatement on this box's host cores.  These are not bench.py
+lines (bench.py reports configs[2]); the numbers go to profiles/r01_configs.json.
+
+    python tools/bench_configs.py > gpurun_out/configs.json
+"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import torch_oracle as O  # noqa: E402  (reported CPU baseline only)
+from pna_amd import Graph  # noqa: E402
+from pna_amd.capture import GraphedForward  # noqa: E402
+from pna_amd.dgl.pna_layer import PNALayer, PNASimpleLayer  # noqa: E402
+from pna_amd.pytorch.pna.layer import PNALayer as DensePNALayer  # noqa: E402
+from pna_amd.synth import molecule_batch  # noqa: E402
+
+dev = torch.device("cuda:0")
+AGG, SCA = "mean max min std", "identity amplification attenuation"
+
+
+def gpu_ms(fn, iters=50, warmup=5):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def cpu_ms(fn, iters=3):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def randomise(layer):
+    gen = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for n, p in layer.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=gen) / (p.shape[-1] ** 0.5 if p.dim() == 2 else 3.0) +
+                    (1.0 if "batchnorm" in n and n.endswith("weight") else 0.0))
+
+
+out = {"cpu_cores": os.cpu_count(), "torch_threads": torch.get_num_threads()}
+
+# ---- configs[1]: ZINC-shaped batch, PNALayer with 5 towers (realworld_benchmark/configs/...ZINC.json) ----
+src, dst, sizes = molecule_batch(128, seed=41)
+V, E = sum(sizes), src.numel()
+g = Graph(src, dst, V, sizes).to(dev)
+deg = g.in_degrees()
+avg = {"log": torch.log(deg.double() + 1).mean().float().cpu()}
+h = torch.randn(V, 75)
+layer = PNALayer(75, 75, AGG, SCA, avg, 0.0, True, True, towers=5, divide_input=False, residual=True).eval()
+randomise(layer)
+sd = {k: v.clone() for k, v in layer.state_dict().items()}
+snorm = g.snorm_n()
+lay = layer.to(dev)
+hd = h.to(dev)
+with torch.no_grad():
+    eager = gpu_ms(lambda: lay(g, hd, None, snorm))
+    gf = GraphedForward(lambda x: lay(g, x, None, snorm), hd)
+    graphed = gpu_ms(lambda: gf(hd))
+    ref = O.dgl_layer_forward(sd, src, dst, V, h, None, snorm.cpu(), AGG.split(), SCA.split(), avg["log"], 5, False, True, True,
+                              True, False)
+    err = (gf(hd).cpu() - ref).abs().max().item()
+    cpu = cpu_ms(lambda: O.dgl_layer_forward(sd, src, dst, V, h, None, snorm.cpu(), AGG.split(), SCA.split(), avg["log"], 5,
+                                             False, True, True, True, False))
+out["zinc_tower_layer"] = dict(graphs=128, V=V, E=E, hidden=75, towers=5, eager_ms=eager, hipgraph_ms=graphed,
+                               edges_per_s_hipgraph=E / graphed * 1e3, cpu_oracle_ms=cpu, max_abs_err_vs_oracle=err)
+
+# ---- configs[3]: MolHIV-shaped batch, PNASimpleLayer hidden 80, 2048 graphs ----
+src, dst, sizes = molecule_batch(2048, mean_nodes=25.5, sd_nodes=12, lo=6, hi=222, seed=41, lognormal=True)
+V, E = sum(sizes), src.numel()
+g = Graph(src, dst, V, sizes).to(dev)
+deg = g.in_degrees()
+avg = {"log": torch.log(deg.double() + 1).mean().float().cpu()}
+h = torch.randn(V, 80)
+layer = PNASimpleLayer(80, 80, AGG, SCA, avg, 0.0, True, True).eval()
+randomise(layer)
+sd = {k: v.clone() for k, v in layer.state_dict().items()}
+lay = layer.to(dev)
+hd = h.to(dev)
+with torch.no_grad():
+    eager = gpu_ms(lambda: lay(g, hd))
+    gf = GraphedForward(lambda x: lay(g, x), hd)
+    graphed = gpu_ms(lambda: gf(hd))
+    ref = O.simple_layer_forward(sd, src, dst, V, h, AGG.split(), SCA.split(), avg["log"])
+    err = (gf(hd).cpu() - ref).abs().max().item()
+    cpu = cpu_ms(lambda: O.simple_layer_forward(sd, src, dst, V, h, AGG.split(), SCA.split(), avg["log"]))
+out["molhiv_simple_layer"] = dict(graphs=2048, V=V, E=E, hidden=80, eager_ms=eager, hipgraph_ms=graphed,
+                                  edges_per_s_hipgraph=E / graphed * 1e3, cpu_oracle_ms=cpu, max_abs_err_vs_oracle=err)
+
+# ---- configs[0]: multitask dense layer, B=128 graphs of N=50 nodes, hidden 16, 4 towers ----
+gen = torch.Generator().manual_seed(1234)
+B, N = 128, 50
+adj = (torch.rand(B, N, N, generator=gen) < 0.1).float()
+adj = torch.maximum(adj, adj.transpose(1, 2)) * (1 - torch.eye(N))
+ring = torch.zeros(N, N)
+i = torch.arange(N)
+ring[i, (i + 1) % N] = 1
+ring[(i + 1) % N, i] = 1
+adj = torch.maximum(adj, ring.unsqueeze(0))
+D = adj.sum(-1)
+avg_d = dict(lin=D.mean(), log=torch.log(D + 1).mean())
+x = torch.randn(B, N, 16, generator=gen)
+layer = DensePNALayer(16, 16, AGG.split(), ["identity"], avg_d, towers=4, divide_input=True).eval()
+randomise(layer)
+sd = {k: v.clone() for k, v in layer.state_dict().items()}
+lay = layer.to(dev)
+xd, ad = x.to(dev), adj.to(dev)
+avg_dev = {k: v.to(dev) for k, v in avg_d.items()}
+for t in lay.towers:
+    t.avg_d = avg_dev
+with torch.no_grad():
+    eager = gpu_ms(lambda: lay(xd, ad))
+    ref = O.dense_layer_forward(sd, x, adj, AGG.split(), ["identity"], avg_d, 4, True)
+    err = (lay(xd, ad).cpu() - ref).abs().max().item()
+    cpu = cpu_ms(lambda: O.dense_layer_forward(sd, x, adj, AGG.split(), ["identity"], avg_d, 4, True))
+E = int(adj.sum().item())
+out["multitask_dense_layer"] = dict(B=B, N=N, hidden=16, towers=4, directed_edges=E, eager_ms=eager,
+                                    edges_per_s_eager=E / eager * 1e3, cpu_oracle_ms=cpu, max_abs_err_vs_oracle=err)
+print(json.dumps(out, indent=1))

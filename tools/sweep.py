@@ -42,7 +42,7 @@ def main():
         buf[:, :F] = base
         xs[ld] = buf[:, :F]
     heavy = {0: None}
-    for thr, seg in ((32, 32), (64, 64), (128, 64), (128, 128), (256, 128), (512, 256)):
+    for thr, seg in ((32, 32), (64, 64), (128, 64), (128, 128), (256, 128), (512, 256), (96, 96), (192, 96), (192, 192), (256, 256)):
         heavy[(thr, seg)] = build_heavy_schedule(c.rowptr, c.max_degree, thr, seg)
     cols = {"real": c.col, "l2": (c.col % 4096).contiguous(),                       # every gather hits L2: issue-bound floor
             "seq": (torch.arange(E, device=dev, dtype=torch.int32) % V).contiguous()}  # streaming sources
@@ -65,10 +65,11 @@ def main():
         for ld in (75, 80):
             for R in (4, 8):
                 variants.append(dict(ld=ld, heavy=hk, S=1, order="natural", tune=dict(unroll=4, rows_per_group=R)))
-    for order, window in (("degree", 0), ("window", 48), ("window", 96), ("window", 192), ("window", 384), ("window", 1536)):
-        for U in (2, 4):
-            variants.append(dict(ld=80, heavy=(128, 128), S=1, order=order, window=window, tune=dict(unroll=U, rows_per_group=4)))
-            variants.append(dict(ld=80, heavy=(128, 128), S=1, order=order, window=window, tune=dict(unroll=U, rows_per_group=8)))
+    for U in (2, 3, 4, 5, 6, 8):
+        for R in (2, 4):
+            variants.append(dict(ld=80, heavy=(128, 128), S=1, tune=dict(unroll=U, rows_per_group=R)))
+    for hk in ((96, 96), (192, 96), (192, 192), (256, 256)):
+        variants.append(dict(ld=80, heavy=hk, S=1, tune=dict(unroll=4, rows_per_group=4)))
     for hk in ((64, 64), (128, 128)):
         for ld in (75, 80):
             variants.append(dict(ld=ld, heavy=hk, S=1, tune=dict(unroll=4, rows_per_group=8)))
