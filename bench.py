@@ -135,12 +135,17 @@ def main():
     n_local = hi - lo
     e_local = int(g.csr.rowptr[-1].item())
     hs = g.heavy_schedule()
-    h_all = torch.randn(V, F, generator=torch.Generator().manual_seed(1234))   # x ~ N(0,1), seed 1234
+    # x ~ N(0,1), seed 1234.  N=1: generated on the host so the CPU baseline sees the same values; N>1:
+    # every rank draws only its own rows (per-rank seed) -- an 8M x 75 host tensor per rank would only slow start-up
+    h_all = torch.randn(V, F, generator=torch.Generator().manual_seed(1234)) if world == 1 else None
     # node features live in a 16-byte aligned row pitch (80 floats for F=75), the layout a multi-layer net keeps
     # its activations in; the kernels accept any pitch (--x-pitch 75 = dense rows, ~3 % slower gather)
     h_buf = torch.zeros(hi - lo, max(args.x_pitch, F), device=dev)
     h = h_buf[:, :F]
-    h.copy_(h_all[lo:hi])
+    if world == 1:
+        h.copy_(h_all)
+    else:
+        h.copy_(torch.randn(hi - lo, F, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank)))
 
     torch.manual_seed(0)
     layer = PNASimpleLayer(F, F, AGGREGATORS, SCALERS, {"log": avg_log}, 0.0, True, True)

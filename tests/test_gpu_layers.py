@@ -115,3 +115,29 @@ def test_dense_registry_operators(cuda_device):
     for name, fn in DENSE_SCALERS.items():
         got = fn(m.to(cuda_device), adj.to(cuda_device), {k: v.to(cuda_device) for k, v in avg_d.items()}).cpu()
         torch.testing.assert_close(got, O.dense_scale(name, m, adj, avg_d), rtol=1e-6, atol=1e-7)
+
+
+def test_sharded_layer_single_rank_rccl(cuda_device):
+    """The multi-GPU code path (dst-range shard, halo all-to-all over RCCL, layer over [local | halo]) on a
+    1-rank process group: exercises the NCCL/RCCL calls and shows the sharded layer equals the plain one."""
+    import os
+    import torch.distributed as dist
+    from pna_amd.shard import shard_graph
+    from pna_amd.synth import powerlaw_graph
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda_device)
+    try:
+        V, E, F = 3000, 30000, 20
+        src, dst = powerlaw_graph(V, E, seed=5, device=cuda_device)
+        gs = shard_graph(src, dst, V)
+        g = Graph(src, dst, V)
+        assert gs.n_halo == 0 and gs.num_nodes == V
+        layer = PNASimpleLayer(F, F, "mean max min std", "identity amplification attenuation", {"log": torch.tensor(2.0)},
+                               0.0, True, True).to(cuda_device).eval()
+        h = torch.randn(V, F, device=cuda_device)
+        with torch.no_grad():
+            assert torch.equal(layer(gs, h), layer(g, h))
+    finally:
+        dist.destroy_process_group()
