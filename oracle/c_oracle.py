@@ -46,6 +46,10 @@ def num_threads():
     return lib().pna_oracle_num_threads()
 
 
+def set_threads(n):
+    lib().pna_oracle_set_threads(ctypes.c_int(int(n)))
+
+
 def degree_scalers(rowptr, avg_log):
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
     V = rowptr.size - 1

@@ -35,6 +35,16 @@ def install():
         fn.copy_u = copy_u
         fn.copy_src = copy_u
         dgl.function = fn
+
+        # per-graph readouts of a batched graph (nets/*/pna_net.py:83-90): segments = batch_num_nodes
+        def _readout(op):
+            def f(g, key):
+                parts = torch.split(g.ndata[key], g.batch_num_nodes)
+                return torch.stack([op(p) for p in parts])
+            return f
+        dgl.sum_nodes = _readout(lambda p: p.sum(0))
+        dgl.mean_nodes = _readout(lambda p: p.mean(0))
+        dgl.max_nodes = _readout(lambda p: p.max(0)[0])
         sys.modules["dgl"] = dgl
         sys.modules["dgl.function"] = fn
     if REFERENCE_ROOT not in sys.path:
@@ -54,10 +64,11 @@ class _NodeBatch:
 class StandinGraph:
     """Minimal duck-type of a (batched) DGLGraph: directed multigraph src[k] -> dst[k]."""
 
-    def __init__(self, src, dst, num_nodes):
+    def __init__(self, src, dst, num_nodes, batch_num_nodes=None):
         self.src = torch.as_tensor(src, dtype=torch.int64)
         self.dst = torch.as_tensor(dst, dtype=torch.int64)
         self.N = int(num_nodes)
+        self.batch_num_nodes = list(batch_num_nodes) if batch_num_nodes is not None else [self.N]
         self.ndata = {}
         self.edata = {}
 

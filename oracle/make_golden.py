@@ -171,6 +171,37 @@ def golden_dense(name, seed, B, N, in_f, out_f, towers, divide_input, scalers, a
     save(name, meta, dict(x=x, adj=adj, avg_lin=avg_d["lin"], avg_log=avg_d["log"], out=out), layer)
 
 
+def golden_net(name, seed, hidden, out_dim, L, towers, edge_dim, readout, gru=False, n_graphs=7):
+    """The whole molecules PNANet (realworld_benchmark/nets/molecules_graph_regression/pna_net.py) -- SURVEY 8f N2."""
+    sys.path.insert(0, os.path.join(dgl_standin.REFERENCE_ROOT, "realworld_benchmark"))
+    from nets.molecules_graph_regression.pna_net import PNANet as RefNet
+    rng = np.random.default_rng(seed)
+    gen = torch.Generator().manual_seed(seed)
+    src, dst, sizes = molecule_batch(rng, n_graphs)
+    N = int(sum(sizes))
+    deg = np.bincount(dst, minlength=N)
+    avg_log = torch.tensor(float(np.mean(np.log(deg + 1))), dtype=torch.float32)
+    params = dict(num_atom_type=28, num_bond_type=4, hidden_dim=hidden, out_dim=out_dim, in_feat_dropout=0.0, dropout=0.0,
+                  L=L, readout=readout, graph_norm=True, batch_norm=True, residual=True, aggregators=AGG4, scalers=SCA3,
+                  avg_d={"log": avg_log}, towers=towers, divide_input_first=False, divide_input_last=True,
+                  edge_feat=edge_dim > 0, edge_dim=edge_dim, pretrans_layers=1, posttrans_layers=1, gru=gru, device="cpu")
+    net = RefNet(params).eval()
+    randomise(net, gen)
+    with torch.no_grad():
+        net.embedding_h.weight.copy_(torch.randn(net.embedding_h.weight.shape, generator=gen))
+        if edge_dim > 0:
+            net.embedding_e.weight.copy_(torch.randn(net.embedding_e.weight.shape, generator=gen))
+    atoms = torch.randint(0, 28, (N,), generator=gen)
+    bonds = torch.randint(0, 4, (src.size,), generator=gen)
+    snorm_n = torch.cat([torch.full((s, 1), 1.0 / s) for s in sizes]).sqrt()
+    g = dgl_standin.StandinGraph(src, dst, N, sizes)
+    with torch.no_grad():
+        out = net(g, atoms, bonds, snorm_n, None)
+    meta = dict(kind="net_molecules", seed=seed, N=N, sizes=sizes, hidden_dim=hidden, out_dim=out_dim, L=L, towers=towers,
+                edge_dim=edge_dim, readout=readout, gru=gru, aggregators=AGG4, scalers=SCA3)
+    save(name, meta, dict(src=src, dst=dst, atoms=atoms, bonds=bonds, snorm_n=snorm_n, avg_log=avg_log, out=out), net)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
@@ -188,6 +219,10 @@ def main():
     golden_tower("tower_deep_mlps", 45, in_dim=16, out_dim=16, towers=2, divide_input=False, pretrans_layers=2,
                  posttrans_layers=2, graph_norm=False)
     golden_tower("tower_f75", 46, in_dim=75, out_dim=70, towers=5, divide_input=False, n_graphs=3)
+    # --- whole molecules net incl. embeddings, graph readout, MLPReadout ---
+    golden_net("net_zinc_sum_edgefeat", 41, hidden=20, out_dim=20, L=3, towers=5, edge_dim=6, readout="sum")
+    golden_net("net_zinc_mean_gru", 42, hidden=16, out_dim=16, L=2, towers=4, edge_dim=0, readout="mean", gru=True)
+    golden_net("net_zinc_max", 43, hidden=12, out_dim=8, L=2, towers=2, edge_dim=0, readout="max")
     # --- dense variant (multitask path, models/pytorch/pna/layer.py) ---
     golden_dense("dense_multitask_mid", 1234, B=6, N=14, in_f=16, out_f=16, towers=4, divide_input=True,
                  scalers=("identity",))

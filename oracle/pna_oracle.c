@@ -129,6 +129,14 @@ void pna_oracle_degree_scalers(const int32_t* rowptr, int32_t V, float avg_log, 
   }
 }
 
+void pna_oracle_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int pna_oracle_num_threads(void) {
   int n = 1;
 #ifdef _OPENMP
