@@ -239,7 +239,8 @@ int pna_degree_scalers_f32(const int32_t* rowptr, int32_t V, float avg_log, floa
  * where `a` is the (M, K = n_aggr*F)-wide identity-scaler output of pna_segreduce_fwd_f32 and W_s the
  * column block of the reference weight that multiplies scaler s; row_post / col_scale+col_shift /
  * relu / residual are each optional (NULL / 0 = skipped).  Uses v_mfma_f32_16x16x4_f32 (exact fp32
- * products, fp32 accumulate).
+ * products, fp32 accumulate).  K >= 4 and (when h is given) Kh >= 4: narrower operands are padded with zero
+ * columns by the caller (pna_amd/functional.py does).
  *
  * The weight is consumed in a packed, zero-padded tile image produced once per weight update by
  * pna_posttrans_pack_f32 from the reference layout: w_ref is the nn.Linear weight, (N, ldw_ref)

@@ -106,21 +106,46 @@ __global__ __launch_bounds__(kBlock, (S + (HAS_H ? 1 : 0)) * NT <= 15 ? 4 : 2) v
   const f4* img_a = reinterpret_cast<const f4*>(g.w_img + (size_t)blockIdx.y * nca * S * kPanel);
   const f4* img_h = HAS_H ? reinterpret_cast<const f4*>(g.wh_img + (size_t)blockIdx.y * nch * kPanel) : nullptr;
 
+  // ---- staging of the next chunk -------------------------------------------------------------------------------
+  // !HAS_H (the simple layer, the hot case): every load of the next chunk (weight image + A fragment) is an
+  // UNCONDITIONAL inline-asm load waited for by hand right before it is written to LDS / rotated in.  hipcc cannot
+  // count loads issued under per-thread range checks and would put `s_waitcnt vmcnt(0)` in front of the first
+  // MFMA of every chunk, stalling the matrix pipe for a full L2/HBM round trip per chunk (1.38 -> 1.16 ms on C3).
+  // Rules that keep this safe: an asm-loaded register is written by asm on EVERY path (no control-flow merge with
+  // another definition -- the copy hipcc inserts at a merge would read the register before the load lands): range
+  // checks are replaced by clamped addresses (redundant loads), the last iteration re-loads the last chunk.
+  // HAS_H (tower variant, two images): compiler-scheduled loads, same structure.
+  constexpr int SH = (kPanel / 4 + kBlock - 1) / kBlock;
   f4 st[SV];                                   // staged image of the next chunk
+#pragma unroll
+  for (int i = 0; i < SV; ++i) st[i] = (f4){0.f, 0.f, 0.f, 0.f};
+  auto a_src = [&](int c, const float*& src, long& ld, int& kmax, int& k) {
+    if (c < nca) { src = g.a; ld = g.lda; kmax = g.K; k = c * kKC + 4 * lg; }
+    else { src = g.h; ld = g.ldh; kmax = g.Kh; k = (c - nca) * kKC + 4 * lg; }
+  };
   auto stage_load = [&](int c) {
-    if (c < nca) {
+    if constexpr (!HAS_H) {
       const f4* src = img_a + (size_t)c * (S * kPanel / 4);
 #pragma unroll
       for (int i = 0; i < SV; ++i) {
-        const int idx = threadIdx.x + i * kBlock;
-        if (idx < S * kPanel / 4) st[i] = src[idx];
+        const int idx = min((int)threadIdx.x + i * kBlock, S * kPanel / 4 - 1);
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(st[i]) : "v"((unsigned)idx * 16u), "s"(src) : "memory");
       }
-    } else if (HAS_H) {
-      const f4* src = img_h + (size_t)(c - nca) * (kPanel / 4);
+    } else {
+      if (c < nca) {
+        const f4* src = img_a + (size_t)c * (S * kPanel / 4);
 #pragma unroll
-      for (int i = 0; i < (kPanel / 4 + kBlock - 1) / kBlock; ++i) {
-        const int idx = threadIdx.x + i * kBlock;
-        if (idx < kPanel / 4) st[i] = src[idx];
+        for (int i = 0; i < SV; ++i) {
+          const int idx = threadIdx.x + i * kBlock;
+          if (idx < S * kPanel / 4) st[i] = src[idx];
+        }
+      } else {
+        const f4* src = img_h + (size_t)(c - nca) * (kPanel / 4);
+#pragma unroll
+        for (int i = 0; i < SH; ++i) {
+          const int idx = threadIdx.x + i * kBlock;
+          if (idx < kPanel / 4) st[i] = src[idx];
+        }
       }
     }
   };
@@ -135,35 +160,59 @@ __global__ __launch_bounds__(kBlock, (S + (HAS_H ? 1 : 0)) * NT <= 15 ? 4 : 2) v
     } else if (HAS_H) {
       f4* bh = base + S * kPanel / 4;
 #pragma unroll
-      for (int i = 0; i < (kPanel / 4 + kBlock - 1) / kBlock; ++i) {
+      for (int i = 0; i < SH; ++i) {
         const int idx = threadIdx.x + i * kBlock;
         if (idx < kPanel / 4) bh[idx] = st[i];
       }
     }
   };
-  auto load_a = [&](int c) -> f4 {
+  // A fragment of chunk c for this lane: floats [k, k+4) of its row, k = 16 c + 4 lg, read as ONE load from a
+  // window clamped inside the row (floats [kk, kk+4), kk = min(k, kmax-4); the launcher guarantees kmax >= 4);
+  // `fix_a` shifts / zero-fills after the wait.
+  auto load_a = [&](int c) -> f4 {                     // !HAS_H: async, only valid after wait_staged()
     const float* src; long ld; int kmax, k;
-    if (c < nca) { src = g.a; ld = g.lda; kmax = g.K; k = c * kKC + 4 * lg; }
-    else { src = g.h; ld = g.ldh; kmax = g.Kh; k = (c - nca) * kKC + 4 * lg; }
-    f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-    const float* p = src + (size_t)arow * ld + k;
-    if (k + 3 < kmax) v = reinterpret_cast<const f4u*>(p)->v;
-    else {
-      if (k < kmax) v.x = p[0];
-      if (k + 1 < kmax) v.y = p[1];
-      if (k + 2 < kmax) v.z = p[2];
-    }
+    a_src(c, src, ld, kmax, k);
+    const int kk = max(0, min(k, kmax - 4));
+    const float* p = src + (size_t)arow * ld + kk;
+    f4 v;
+    if constexpr (!HAS_H) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    else v = reinterpret_cast<const f4u*>(p)->v;
     return v;
+  };
+  auto fix_a = [&](int c, f4 t) -> f4 {                // window [kk,kk+4) -> elements [k,k+4), 0 beyond kmax
+    const float* src; long ld; int kmax, k;
+    a_src(c, src, ld, kmax, k);
+    const int d = k - max(0, min(k, kmax - 4));        // 0 except in the last, partial group of a row
+    f4 v;
+    v.x = d == 0 ? t.x : d == 1 ? t.y : d == 2 ? t.z : t.w;
+    v.y = d == 0 ? t.y : d == 1 ? t.z : t.w;
+    v.z = d == 0 ? t.z : t.w;
+    v.w = t.w;
+    v.x = (k < kmax && d <= 3) ? v.x : 0.f;
+    v.y = (k + 1 < kmax && d <= 2) ? v.y : 0.f;
+    v.z = (k + 2 < kmax && d <= 1) ? v.z : 0.f;
+    v.w = (k + 3 < kmax && d == 0) ? v.w : 0.f;
+    return v;
+  };
+  auto wait_staged = [&](f4& a_reg) {
+    if constexpr (!HAS_H) {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(a_reg) : : "memory");
+#pragma unroll
+      for (int i = 0; i < SV; ++i) asm volatile("" : "+v"(st[i]));
+    }
   };
 
   stage_load(0);
   f4 a_cur = load_a(0);
+  wait_staged(a_cur);
+  a_cur = fix_a(0, a_cur);
   stage_write(0, 0);
   __syncthreads();
   for (int c = 0; c < nc; ++c) {
     const int buf = c & 1;
-    f4 a_nxt = (f4){0.f, 0.f, 0.f, 0.f};
-    if (c + 1 < nc) { stage_load(c + 1); a_nxt = load_a(c + 1); }        // issue only; consumed after the MFMAs
+    const int cn = min(c + 1, nc - 1);                   // the last iteration re-loads its own chunk (never written)
+    stage_load(cn);                                      // issue only; consumed after the MFMAs
+    f4 a_nxt = load_a(cn);
     const float* base = lds + buf * P * kPanel;
     const bool is_h = c >= nca;
 #pragma unroll
@@ -182,6 +231,8 @@ __global__ __launch_bounds__(kBlock, (S + (HAS_H ? 1 : 0)) * NT <= 15 ? 4 : 2) v
           acc[P - 1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, brow[S * kPanel + n * 16], acc[P - 1][n], 0, 0, 0);
       }
     }
+    wait_staged(a_nxt);
+    a_nxt = fix_a(cn, a_nxt);
     if (c + 1 < nc) stage_write(c + 1, buf ^ 1);
     a_cur = a_nxt;
     __syncthreads();
@@ -271,6 +322,8 @@ extern "C" int pna_posttrans_f32(const pna_posttrans_args* p, pna_stream_t strea
   if (!p->a || !p->w_img || !p->y) return pna_set_error(PNA_E_INVALID, "pna_posttrans_f32: a/w_img/y must be non-null");
   if (p->n_scaler < 1 || p->n_scaler > 5) return pna_set_error(PNA_E_INVALID, "pna_posttrans_f32: n_scaler must be 1..5");
   if (p->lda < p->K || p->ldy < p->N) return pna_set_error(PNA_E_INVALID, "pna_posttrans_f32: leading dimensions too small");
+  if (p->K < 4 || (p->h != nullptr && p->Kh > 0 && p->Kh < 4))
+    return pna_set_error(PNA_E_INVALID, "pna_posttrans_f32: K and Kh must be >= 4 (pad the operand and the weight with zero columns)");
   const bool has_h = p->h != nullptr && p->Kh > 0;
   if (has_h && (!p->wh_img || p->ldh < p->Kh)) return pna_set_error(PNA_E_INVALID, "pna_posttrans_f32: h given without wh_img / ldh too small");
   if (p->residual && p->ld_res < p->N) return pna_set_error(PNA_E_INVALID, "pna_posttrans_f32: ld_res too small");

@@ -66,6 +66,18 @@ def posttrans(agg, K, weight, bias, row_scales, h_self=None, *, row_post=None, b
     Kh = 0 if h_self is None else h_self.shape[1]
     if weight.shape[1] != Kh + len(row_scales) * K:
         raise ValueError(f"posttrans weight has {weight.shape[1]} input columns, expected {Kh + len(row_scales) * K}")
+    if K < 4 or 0 < Kh < 4:
+        # the MFMA kernel reads its operands in 16-byte pieces: widen tiny operands (multitask layers: 2 features
+        # per tower) to 4 columns with zeros, and give the weight matching zero columns
+        S, N = len(row_scales), weight.shape[0]
+        Kp, Khp = max(K, 4), (max(Kh, 4) if Kh else 0)
+        wb = [weight[:, :Kh]] + [weight[:, Kh + s * K:Kh + (s + 1) * K] for s in range(S)]
+        wb = [torch.nn.functional.pad(w, (0, (Khp if i == 0 else Kp) - w.shape[1])) for i, w in enumerate(wb)]
+        weight = torch.cat(wb if Kh else wb[1:], dim=1)
+        agg = torch.nn.functional.pad(agg[:, :K], (0, Kp - K))
+        if Kh:
+            h_self = torch.nn.functional.pad(h_self, (0, Khp - Kh))
+        K, Kh = Kp, Khp
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (agg, weight, bias, h_self)):
         from .autograd import PosttransFn
         if row_post is not None or bn is not None or relu or residual is not None:
