@@ -150,6 +150,7 @@ typedef struct pna_segreduce_args {
   const int32_t* work_items;
   int32_t n_work_items;
   int32_t _pad2;
+  int64_t n_edges; /* = rowptr[V] (length of col); required with work_items */
   pna_tuning tune;
 } pna_segreduce_args;
 

@@ -44,6 +44,7 @@ class PnaSegreduceArgs(ctypes.Structure):
         ("heavy_rows", ctypes.c_void_p), ("heavy_segptr", ctypes.c_void_p), ("seg_heavy", ctypes.c_void_p),
         ("partials", ctypes.c_void_p),
         ("work_items", ctypes.c_void_p), ("n_work_items", ctypes.c_int32), ("_pad2", ctypes.c_int32),
+        ("n_edges", ctypes.c_int64),
         ("tune", PnaTuning),
     ]
 

@@ -445,7 +445,7 @@ struct FArgs {
   const int32_t* col; const float* x; float* out; float* partials;
   long ldo, ts_out;
   unsigned ldb, ts_in_b;  // x row pitch / tower stride in bytes
-  int n_items, F, L, G, R, T, tiles, pstride, block_stride, nt, dbg;
+  int n_items, n_edges, F, L, G, R, T, tiles, pstride, block_stride, nt, dbg;
 };
 
 // mean | max | min | std blocks of one destination row (identity scaler), 4 features per lane.
@@ -518,25 +518,36 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"((unsigned)k * 16u), "s"(a.items) : "memory");
   };
 
+  // Every asm-loaded register below is written by an asm load on EVERY path (addresses are clamped instead of
+  // guarded): an asm output that met another definition at a control-flow merge could be copied by the compiler
+  // before the load has landed.
+  const long last = NI - 1;
+  const unsigned e_last = (unsigned)a.n_edges - 1u;          // n_edges >= 1 (launcher)
+  auto ids_of = [&](int& dst, const i4 rec) {                // lane c <- col[beg + min(c, deg-1)], clamped into col[]
+    const int d = rec.z - rec.y;
+    const unsigned pos = (unsigned)rec.y + (unsigned)min(c, max(d - 1, 0));
+    aload32(dst, a.col, min(pos, e_last) * 4u);
+  };
+
   // prologue: record of item 0 -> its first ids and the record of item 1
   i4 cur;
   issue_item(cur, base);
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur) : : "memory");
-  int idx_c = 0;
-  if (c < cur.z - cur.y) aload32(idx_c, a.col, (unsigned)(cur.y + c) * 4u);
-  i4 nxt = (i4){0, 0, 0, -1};
-  if (a.R > 1 && base + NG < NI) issue_item(nxt, base + NG);
+  int idx_c;
+  ids_of(idx_c, cur);
+  i4 nxt;
+  issue_item(nxt, min(base + NG, last));
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(idx_c), "+v"(nxt) : : "memory");
 
   AccF acc;
   for (int r = 0; r < a.R; ++r) {
     const long item = base + (long)r * NG;
     if (item >= NI) break;
-    // ---- prefetch (issued BEFORE this item's gathers)
-    int idx_n = 0;
-    i4 nn = (i4){0, 0, 0, -1};
-    if (r + 1 < a.R && item + NG < NI && c < nxt.z - nxt.y) aload32(idx_n, a.col, (unsigned)(nxt.y + c) * 4u);
-    if (r + 2 < a.R && item + 2 * NG < NI) issue_item(nn, item + 2 * NG);
+    // ---- prefetch (issued BEFORE this item's gathers): ids of item r+1, record of item r+2 (clamped to the last item)
+    int idx_n;
+    i4 nn;
+    ids_of(idx_n, nxt);
+    issue_item(nn, min(item + 2 * NG, last));
     // ---- this item
     const int row = cur.x, beg = cur.y, end = cur.z, slot = cur.w;
     acc.init();
@@ -544,8 +555,7 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
     for (int cb = beg; cb < end; cb += L) {
       const int nidx = min(L, end - cb);
       if (cb != beg) {                                       // longer than one id chunk (rare): fetch + wait
-        idx = 0;
-        if (c < nidx) aload32(idx, a.col, (unsigned)(cb + c) * 4u);
+        aload32(idx, a.col, (unsigned)(cb + min(c, nidx - 1)) * 4u);
         await<0>(idx);
       }
       int j = 0;
@@ -564,7 +574,8 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
         *reinterpret_cast<f4a4*>(p + 3 * a.pstride) = acc.mn;
       }
     }
-    // Only if no lane group of the wave gathered anything have the prefetches possibly not landed: drain.
+    // The prefetches were issued before this item's gathers and VMEM returns in order, so once the wave has waited
+    // for any gather they have landed.  Only if no lane group of the wave gathered anything: drain.
     if (__builtin_amdgcn_ballot_w64(end > beg) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("" : "+v"(idx_n), "+v"(nn));                 // anchor: consumers cannot move above this point
     idx_c = idx_n; cur = nxt; nxt = nn;
@@ -787,7 +798,8 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
                     p->aggr[3] == PNA_AGG_STD && p->n_scaler == 1 && p->row_scale[0] == nullptr;
   const bool fast_ok = vec == 4 && !extra && std4 && p->col != nullptr && idx32 && p->x_rows < (1 << 24) &&
                        p->ldx * 4 < (1 << 24) && (int64_t)T * ts_in * 4 < (1 << 30) && p->work_items != nullptr &&
-                       p->n_work_items > 0 && p->n_work_items < (1 << 27) && t.reserved[1] == 0;
+                       p->n_work_items > 0 && p->n_work_items < (1 << 27) && p->n_edges > 0 && p->n_edges < (1LL << 30) &&
+                       t.reserved[1] == 0;
   int rc = 0;
   if (!fast_ok && U != 2 && U != 4 && U != 8) U = 4;       // the compiler-scheduled kernel is built for 2, 4, 8
   if (fast_ok) {
@@ -795,7 +807,7 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
     memset(&f, 0, sizeof(f));
     f.items = p->work_items; f.col = p->col; f.x = p->x; f.out = p->out; f.partials = p->partials;
     f.ldo = p->ldo; f.ts_out = ts_out; f.ldb = (unsigned)(p->ldx * 4); f.ts_in_b = (unsigned)(ts_in * 4);
-    f.n_items = p->n_work_items; f.F = p->F; f.L = k.L; f.G = k.G; f.R = k.R; f.T = T; f.tiles = tiles;
+    f.n_items = p->n_work_items; f.n_edges = (int)p->n_edges; f.F = p->F; f.L = k.L; f.G = k.G; f.R = k.R; f.T = T; f.tiles = tiles;
     f.pstride = k.pstride; f.block_stride = p->block_stride; f.nt = k.nt; f.dbg = k.dbg;
     const long fb = (p->n_work_items + rows_per_block - 1) / rows_per_block;
     dim3 fgrid((unsigned)fb, (unsigned)(tiles * T));

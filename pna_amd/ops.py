@@ -90,6 +90,7 @@ def segreduce(rowptr: torch.Tensor, col: Optional[torch.Tensor], x: torch.Tensor
         tn.update(tune)
     if items is not None and items.numel() > 0:
         a.work_items, a.n_work_items = _lib.dev_ptr(items, torch.int32, "work_items"), items.shape[0]
+        a.n_edges = 0 if col is None else col.numel()
     for k, v in tn.items():
         setattr(a.tune, k, int(v))
     rc = _lib.lib().pna_segreduce_fwd_f32(ctypes.byref(a), _lib.stream_ptr(dev))
