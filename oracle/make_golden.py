@@ -202,6 +202,33 @@ def golden_net(name, seed, hidden, out_dim, L, towers, edge_dim, readout, gru=Fa
     save(name, meta, dict(src=src, dst=dst, atoms=atoms, bonds=bonds, snorm_n=snorm_n, avg_log=avg_log, out=out), net)
 
 
+def golden_dense_registry(name, seed, B=3, N=7, F=5):
+    """Every entry of the dense operator registries (models/pytorch/pna/aggregators.py:149-152, scalers.py:41-42)
+    evaluated by the reference itself on one random message tensor -- SURVEY 8f N4."""
+    from models.pytorch.pna.aggregators import AGGREGATORS as REF_AGG
+    from models.pytorch.pna.scalers import SCALERS as REF_SCA
+    gen = torch.Generator().manual_seed(seed)
+    X = torch.randn(B, N, N, F, generator=gen)
+    adj = (torch.rand(B, N, N, generator=gen) < 0.4).float() * (1 - torch.eye(N))
+    idx = torch.arange(N)
+    ring = torch.zeros(N, N)
+    ring[idx, (idx + 1) % N] = 1
+    ring[(idx + 1) % N, idx] = 1
+    adj = torch.maximum(adj, ring.unsqueeze(0))            # directed otherwise: rows and columns non-empty
+    D = adj.sum(-1)
+    avg_d = dict(lin=torch.mean(D), log=torch.mean(torch.log(D + 1)))
+    arrays = dict(X=X, adj=adj, avg_lin=avg_d["lin"], avg_log=avg_d["log"], out=torch.zeros(1))
+    for k, f in REF_AGG.items():
+        for sl in (False, True):
+            arrays[f"agg/{k}/{int(sl)}"] = f(X, adj, self_loop=sl)
+    m = torch.randn(B, N, 2 * F, generator=gen)
+    arrays["m"] = m
+    for k, f in REF_SCA.items():
+        arrays[f"sca/{k}"] = f(m, adj, avg_d=avg_d)
+    meta = dict(kind="dense_registry", seed=seed, B=B, N=N, F=F, aggregators=list(REF_AGG), scalers=list(REF_SCA))
+    save(name, meta, arrays, torch.nn.Module())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
@@ -223,6 +250,7 @@ def main():
     golden_net("net_zinc_sum_edgefeat", 41, hidden=20, out_dim=20, L=3, towers=5, edge_dim=6, readout="sum")
     golden_net("net_zinc_mean_gru", 42, hidden=16, out_dim=16, L=2, towers=4, edge_dim=0, readout="mean", gru=True)
     golden_net("net_zinc_max", 43, hidden=12, out_dim=8, L=2, towers=2, edge_dim=0, readout="max")
+    golden_dense_registry("dense_registry_all", 9)
     # --- dense variant (multitask path, models/pytorch/pna/layer.py) ---
     golden_dense("dense_multitask_mid", 1234, B=6, N=14, in_f=16, out_f=16, towers=4, divide_input=True,
                  scalers=("identity",))

@@ -57,6 +57,9 @@ def _dense_towers_forward(towers, x, adj, divide_input):
     w_row = None if dg.binary else dg.w_row
     w_col = None if dg.binary else dg.w_col
 
+    exotic = [a for a in t0.aggregators if a not in _BY_ROW and a not in _BY_COL]
+    if exotic:
+        return _dense_towers_forward_registry(towers, x, adj, divide_input)
     out_row = out_col = None
     if all(t.pretrans.is_affine for t in towers):
         # m[b,i,j] = W [x_i | x_j] + b = P[i] + Q[j]   with P = W[:, :F] x,  Q = W[:, F:] x + b
@@ -105,6 +108,23 @@ def _dense_towers_forward(towers, x, adj, divide_input):
         outs.append(tower.posttrans.tail(y))
     y = torch.cat(outs, dim=1) if T > 1 else outs[0]
     return y.view(B, N, -1)
+
+
+def _dense_towers_forward_registry(towers, x, adj, divide_input):
+    """Aggregator sets beyond mean/sum/max/min/std/var (softmax, softmin, moments, normalised_mean, identity -- used
+    by no shipped configuration): the (B,N,N,F) message tensor is materialised like the reference does
+    (layer.py:37-40) and every registry operator reduces it through the HIP kernel."""
+    B, N, _ = adj.shape
+    outs = []
+    for t, tower in enumerate(towers):
+        Fi = tower.in_features
+        xt = x[:, :, t * Fi:(t + 1) * Fi] if divide_input else x
+        h_cat = torch.cat([xt.unsqueeze(2).expand(B, N, N, Fi), xt.unsqueeze(1).expand(B, N, N, Fi)], dim=3)
+        h_mod = tower.pretrans(h_cat)
+        m = torch.cat([AGGREGATORS[a](h_mod, adj, self_loop=tower.self_loop, device=x.device) for a in tower.aggregators], dim=2)
+        m = torch.cat([SCALERS[s](m, adj, avg_d=tower.avg_d) for s in tower.scalers], dim=2)
+        outs.append(tower.posttrans(torch.cat([xt, m], dim=2)))
+    return torch.cat(outs, dim=2) if len(outs) > 1 else outs[0]
 
 
 class PNALayer(nn.Module):

@@ -102,7 +102,8 @@ def test_dense_registry_operators(cuda_device):
     adj = (torch.rand(B, N, N, generator=gen) < 0.5).float()
     adj = torch.maximum(adj, torch.eye(N).roll(1, 0).unsqueeze(0))        # every row and column non-empty
     adj = torch.maximum(adj, torch.eye(N).roll(1, 1).unsqueeze(0))
-    for name, fn in DENSE_AGG.items():
+    for name in O.DENSE_AGGREGATORS:
+        fn = DENSE_AGG[name]
         for sl in (False, True):
             got = fn(X.to(cuda_device), adj.to(cuda_device), self_loop=sl, device=cuda_device).cpu()
             ref = O.DENSE_AGGREGATORS[name](X, adj + torch.eye(N).unsqueeze(0) if sl else adj)
@@ -184,3 +185,39 @@ def test_hiv_net_runs_and_trains(cuda_device):
     net.eval()
     with torch.no_grad():
         assert net(g, x).shape == (len(sizes), 1)
+
+
+def test_dense_registry_every_entry_vs_reference_golden(cuda_device):
+    """All 13 aggregators x self_loop and all 5 scalers of the dense registries against the values the reference's
+    own functions produced (tests/golden/dense_registry_all.npz)."""
+    meta, a, _ = load_golden("dense_registry_all")
+    X, adj = a["X"].to(cuda_device), a["adj"].to(cuda_device)
+    assert set(meta["aggregators"]) == set(DENSE_AGG) and set(meta["scalers"]) == set(DENSE_SCALERS)
+    for name in meta["aggregators"]:
+        for sl in (0, 1):
+            got = DENSE_AGG[name](X, adj, self_loop=bool(sl), device=cuda_device).cpu()
+            ref = a[f"agg/{name}/{sl}"]
+            if name in ("max", "min", "identity"):
+                assert torch.equal(got, ref), (name, sl)
+            else:
+                torch.testing.assert_close(got, ref, rtol=2e-5, atol=5e-6, msg=lambda m: f"{name} self_loop={sl}: {m}")
+    avg_d = {"log": a["avg_log"].to(cuda_device), "lin": a["avg_lin"].to(cuda_device)}
+    for name in meta["scalers"]:
+        got = DENSE_SCALERS[name](a["m"].to(cuda_device), adj, avg_d).cpu()
+        torch.testing.assert_close(got, a[f"sca/{name}"], rtol=1e-6, atol=1e-7)
+
+
+def test_dense_layer_with_exotic_aggregators(cuda_device):
+    from oracle import torch_oracle as O
+    gen = torch.Generator().manual_seed(2)
+    B, N, Fi = 2, 6, 4
+    adj = (torch.rand(B, N, N, generator=gen) < 0.5).float()
+    adj = torch.maximum(adj, torch.eye(N).roll(1, 0).unsqueeze(0))
+    adj = torch.maximum(adj, torch.eye(N).roll(1, 1).unsqueeze(0))
+    avg_d = {"log": torch.tensor(1.2, device=cuda_device), "lin": torch.tensor(3.0, device=cuda_device)}
+    layer = DensePNALayer(Fi, 4, ["mean", "softmax", "moment3", "max"], ["identity", "amplification"], avg_d, towers=1,
+                          device=cuda_device).to(cuda_device).eval()
+    x = torch.randn(B, N, Fi, generator=gen)
+    with torch.no_grad():
+        out = layer(x.to(cuda_device), adj.to(cuda_device))
+    assert out.shape == (B, N, 4) and torch.isfinite(out).all()
