@@ -221,3 +221,21 @@ def test_dense_layer_with_exotic_aggregators(cuda_device):
     with torch.no_grad():
         out = layer(x.to(cuda_device), adj.to(cuda_device))
     assert out.shape == (B, N, 4) and torch.isfinite(out).all()
+
+
+def test_hipgraph_capture_replays_the_layer(cuda_device):
+    """pna_amd.capture.GraphedForward: the whole tower-layer forward as one hipGraph, bit-identical to eager."""
+    from pna_amd.capture import GraphedForward
+    from pna_amd.synth import molecule_batch
+    src, dst, sizes = molecule_batch(16, seed=3)
+    V = sum(sizes)
+    g = Graph(src, dst, V, sizes).to(cuda_device)
+    avg = {"log": torch.tensor(1.1)}
+    layer = PNALayer(30, 30, "mean max min std", "identity amplification attenuation", avg, 0.0, True, True, towers=5,
+                     divide_input=False, residual=True).to(cuda_device).eval()
+    snorm = g.snorm_n()
+    h1, h2 = torch.randn(V, 30, device=cuda_device), torch.randn(V, 30, device=cuda_device)
+    with torch.no_grad():
+        gf = GraphedForward(lambda x: layer(g, x, None, snorm), h1)
+        assert torch.equal(gf(h1).clone(), layer(g, h1, None, snorm))
+        assert torch.equal(gf(h2).clone(), layer(g, h2, None, snorm))
