@@ -36,7 +36,8 @@ F = 75
 AGGREGATORS = "mean max min std"
 SCALERS = "identity amplification attenuation"
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md
-MFMA_F32_PEAK = 157.3e12   # FLOP/s
+MFMA_F32_PEAK = 157.3e12   # FLOP/s, f32-input MFMA (= the fp32 vector rate)
+MFMA_BF16_PEAK = 2.5e15    # FLOP/s, dense bf16 MFMA; the bf16x3 contraction spends 6 bf16 products per fp32 multiply
 
 
 def parse():
@@ -187,6 +188,23 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = E / (dt / args.steps)
 
+    # the same step with the contraction forced onto the exact f32-input MFMA (reported beside the headline number)
+    from pna_amd import ops as _ops
+    arith = "bf16x3" if (_ops.POSTTRANS_ARITH == "bf16x3" or (_ops.POSTTRANS_ARITH == "auto" and n_local >= _ops.X3_MIN_ROWS)) else "f32"
+    ms_per_step_f32 = ms_per_step
+    if arith != "f32":
+        keep = _ops.POSTTRANS_ARITH
+        _ops.POSTTRANS_ARITH = "f32"
+        for _ in range(2):
+            step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        ms_per_step_f32 = (time.perf_counter() - t1) / args.steps * 1e3
+        _ops.POSTTRANS_ARITH = keep
+
     # ---- per-kernel timing of the dominant kernels (HIP events, this rank) ------------------------------
     csr = g.csr
     with torch.no_grad():
@@ -196,6 +214,7 @@ def main():
         lin = layer.posttrans.fully_connected[0].linear
         amp, att = g.degree_scalers(float(avg_log))
         t_post = event_time_ms(lambda: PF.posttrans(agg, 4 * F, lin.weight, lin.bias, [None, amp, att]), args.kernel_iters)
+        t_post_f32 = event_time_ms(lambda: _ops.posttrans(agg, 4 * F, lin.weight, [None, amp, att], lin.bias, arith="f32"), args.kernel_iters)
         t_halo = event_time_ms(lambda: g.source_features(h), args.kernel_iters) if world > 1 else 0.0
     alg_read = e_local * (4 * F + 4) + 4 * (n_local + 1)
     alg_write = n_local * 16 * F
@@ -215,9 +234,18 @@ def main():
                 "edges_per_s_kernel_only": e_local / (t_seg * 1e-3),
                 "heavy_rows": hs.n_heavy, "heavy_segments": hs.n_seg}
     flops = 2.0 * n_local * (12 * F) * F
-    roofline_post = {"bound": "mfma", "kernel": "k_posttrans<3,false,5> (pna_posttrans_f32)", "achieved": flops / (t_post * 1e-3) / 1e12,
-                     "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s", "frac": flops / (t_post * 1e-3) / MFMA_F32_PEAK,
-                     "ms_per_launch": t_post}
+    if arith == "bf16x3":     # fp32-equivalent FLOP/s against the bf16 pipe's peak / 6 (six bf16 partial products per multiply)
+        roofline_post = {"bound": "mfma", "kernel": "k_posttrans_x3<3,false,5,2,8> (pna_posttrans_x3_f32)",
+                         "achieved": flops / (t_post * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK / 6 / 1e12, "unit": "TFLOP/s (fp32-equivalent)",
+                         "frac": flops / (t_post * 1e-3) / (MFMA_BF16_PEAK / 6), "ms_per_launch": t_post,
+                         "bf16_tflops_issued": 6 * flops / (t_post * 1e-3) / 1e12,
+                         "exact_f32_mfma_kernel": {"kernel": "k_posttrans<3,false,5> (pna_posttrans_f32)", "ms_per_launch": t_post_f32,
+                                                   "achieved": flops / (t_post_f32 * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12,
+                                                   "frac": flops / (t_post_f32 * 1e-3) / MFMA_F32_PEAK}}
+    else:
+        roofline_post = {"bound": "mfma", "kernel": "k_posttrans<3,false,5> (pna_posttrans_f32)", "achieved": flops / (t_post * 1e-3) / 1e12,
+                         "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s", "frac": flops / (t_post * 1e-3) / MFMA_F32_PEAK,
+                         "ms_per_launch": t_post}
 
     rec = {
         "metric": "PNA-layer fwd edges/sec (F=75, 4 aggr x 3 scalers)", "value": value, "unit": "edges/s",
@@ -228,9 +256,13 @@ def main():
                    "V": V, "E": E, "F": F, "aggregators": AGGREGATORS, "scalers": SCALERS,
                    "parallelism": f"dst-range shard x{world}, halo all-to-all" if world > 1 else "single GPU",
                    "x_row_pitch_floats": max(args.x_pitch, F),
+                   "posttrans_arith": ("bf16x3: fp32 in/out; each fp32 operand cut exactly into 3 bf16 terms, 6 partial products per multiply "
+                                       "on the bf16 MFMA pipe, fp32 accumulate; error vs float64 at the exact-f32 kernel's level "
+                                       "(tests/test_gpu_posttrans_x3.py)") if arith == "bf16x3" else "f32 (v_mfma_f32_16x16x4_f32)",
                    "max_in_degree": int(csr.max_degree), "halo_rows_rank0": getattr(g, "n_halo", 0)},
         "roofline": roofline, "roofline_posttrans": roofline_post,
-        "kernel_ms": {"segreduce": t_seg, "posttrans": t_post, "halo_all_to_all": t_halo},
+        "kernel_ms": {"segreduce": t_seg, "posttrans": t_post, "posttrans_exact_f32_mfma": t_post_f32, "halo_all_to_all": t_halo},
+        "ms_per_step_exact_f32_mfma": ms_per_step_f32, "value_exact_f32_mfma": E / (ms_per_step_f32 * 1e-3),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

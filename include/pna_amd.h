@@ -279,6 +279,57 @@ typedef struct pna_posttrans_args {
 
 int pna_posttrans_f32(const pna_posttrans_args* args, pna_stream_t stream);
 
+/* ---- the same contraction on the bf16 matrix pipe at fp32 accuracy ("bf16x3") ---------------------
+ *
+ * Same operation, arguments and epilogue as pna_posttrans_f32 (n_scaler <= 3).  Every fp32 operand is
+ * cut exactly into three bf16 terms (8+8+8 mantissa bits, by truncation) and each product is evaluated
+ * as its six partial products of weight >= 2^-16, accumulated in fp32 by v_mfma_f32_16x16x32_bf16; the
+ * dropped partial products are below 2^-23 of the product (the size of one fp32 rounding).  Inputs and
+ * outputs stay fp32; results agree with pna_posttrans_f32 to fp32 summation-order noise.  Non-finite
+ * inputs give NaN.  w_img / wh_img of the args are the images made by pna_posttrans_x3_pack_f32 (a
+ * different format from pna_posttrans_pack_f32's; sizes in BYTES from pna_posttrans_x3_packed_bytes).
+ */
+int64_t pna_posttrans_x3_packed_bytes(int32_t K, int32_t N, int32_t n_scaler, int32_t Kh, int64_t* wh_bytes);
+int pna_posttrans_x3_pack_f32(const float* w_ref, int64_t ldw_ref, int32_t N, int32_t K, int32_t n_scaler, int32_t Kh,
+                              void* w_img, void* wh_img /* nullable when Kh == 0 */, pna_stream_t stream);
+int pna_posttrans_x3_f32(const pna_posttrans_args* args, pna_stream_t stream);
+
+/* ---- fused PNASimpleLayer forward (inference) -----------------------------------------------------
+ *
+ * One launch for the whole of models/dgl/pna_layer.py:197-216 with aggregators "mean max min std":
+ *   a[v]  = [mean | max | min | std] over in-edges of x[col[e]]          (:168-187, :189-194)
+ *   y[v]  = residual[v] + relu((bias + sum_s row_scale[s][v] * (W_s . a[v])) * col_scale + col_shift)
+ * The (V, 4F) aggregate never reaches HBM: it is built per 32-row tile in LDS and contracted from there.
+ * w_img is the pna_posttrans_pack_f32 image of the Linear weight re-laid with each aggregator block
+ * zero-padded from F to B4 = round_up(F, 4) input columns (K = 4*B4 per scaler, Kh = 0).
+ * Rows with degree > heavy_threshold (0 = never) are reduced by the whole workgroup.
+ * Supported: 4 <= F <= 80, N <= 80, n_scaler <= 3.  Same numerics as the two-kernel path except for the
+ * summation order over hub rows' edges and over k (tolerance-level, not bit-level, agreement).
+ */
+typedef struct pna_fused_simple_args {
+  const int32_t* rowptr; /* [V+1] CSR by destination */
+  const int32_t* col;    /* [E] source row of x per edge */
+  const float* x;        /* (x_rows, ldx) source features */
+  int64_t ldx;
+  int32_t V;
+  int32_t F;
+  int32_t N;
+  int32_t n_scaler;
+  const float* row_scale[PNA_MAX_SCALER]; /* each [V] or NULL = identity */
+  const float* w_img;
+  const float* bias;      /* nullable [N] */
+  const float* col_scale; /* nullable [N] */
+  const float* col_shift; /* nullable [N] (with col_scale) */
+  const float* residual;  /* nullable (V, ld_res) */
+  int64_t ld_res;
+  float* y;               /* (V, ldy) */
+  int64_t ldy;
+  int32_t relu;
+  int32_t heavy_threshold;
+} pna_fused_simple_args;
+
+int pna_fused_simple_f32(const pna_fused_simple_args* args, pna_stream_t stream);
+
 const char* pna_last_error(void);
 int pna_abi_version(void);
 

@@ -84,6 +84,17 @@ class PnaPosttransArgs(ctypes.Structure):
     ]
 
 
+class PnaFusedSimpleArgs(ctypes.Structure):
+    _fields_ = [
+        ("rowptr", ctypes.c_void_p), ("col", ctypes.c_void_p), ("x", ctypes.c_void_p), ("ldx", ctypes.c_int64),
+        ("V", ctypes.c_int32), ("F", ctypes.c_int32), ("N", ctypes.c_int32), ("n_scaler", ctypes.c_int32),
+        ("row_scale", ctypes.c_void_p * PNA_MAX_SCALER),
+        ("w_img", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("col_scale", ctypes.c_void_p),
+        ("col_shift", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("ld_res", ctypes.c_int64),
+        ("y", ctypes.c_void_p), ("ldy", ctypes.c_int64), ("relu", ctypes.c_int32), ("heavy_threshold", ctypes.c_int32),
+    ]
+
+
 _lib = None
 
 
@@ -109,6 +120,17 @@ def lib():
         L.pna_degree_scalers_f32.restype = ctypes.c_int
         L.pna_posttrans_f32.argtypes = [ctypes.POINTER(PnaPosttransArgs), ctypes.c_void_p]
         L.pna_posttrans_f32.restype = ctypes.c_int
+        L.pna_posttrans_x3_f32.argtypes = [ctypes.POINTER(PnaPosttransArgs), ctypes.c_void_p]
+        L.pna_posttrans_x3_f32.restype = ctypes.c_int
+        L.pna_posttrans_x3_packed_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                    ctypes.POINTER(ctypes.c_int64)]
+        L.pna_posttrans_x3_packed_bytes.restype = ctypes.c_int64
+        L.pna_posttrans_x3_pack_f32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                                ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_void_p]
+        L.pna_posttrans_x3_pack_f32.restype = ctypes.c_int
+        L.pna_fused_simple_f32.argtypes = [ctypes.POINTER(PnaFusedSimpleArgs), ctypes.c_void_p]
+        L.pna_fused_simple_f32.restype = ctypes.c_int
         L.pna_posttrans_packed_floats.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                   ctypes.POINTER(ctypes.c_int64)]
         L.pna_posttrans_packed_floats.restype = ctypes.c_int64

@@ -1,0 +1,445 @@
+// pna_posttrans_x3.hip -- the posttrans contraction of pna_posttrans.hip on the bf16 matrix pipe, at fp32 accuracy.
+// Implements pna_posttrans_x3_{packed_bytes,pack_f32,f32} of include/pna_amd.h.
+//
+//   y[v] = epilogue( bias + Wh . h[v] + sum_s scale_s[v] * (W_s . a[v]) )        (models/dgl/pna_layer.py:65-68,:206)
+//
+// The f32-input MFMA runs at the fp32 vector rate (157 TF/s): the contraction, not HBM, bounded the layer.  The
+// bf16 pipe is 16x faster per instruction.  Every fp32 operand is cut EXACTLY into three bf16 terms by truncation,
+//   x = x0 + x1 + x2,   x0 = top 16 bits of x,  x1 = top 16 bits of (x - x0),  x2 = x - x0 - x1   (8+8+8 mantissa bits)
+// and the product a*b is evaluated as the six partial products of weight >= 2^-16,
+//   a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0),
+// each exact in fp32 (8 x 8 mantissa bits), accumulated in fp32 by v_mfma_f32_16x16x32_bf16.  The three dropped
+// products (a1 b2, a2 b1, a2 b2) are below 2^-23 |a b|: the same order as ONE fp32 rounding of the product, far below
+// the fp32 summation-order noise of a K = 900 contraction (tests/test_gpu_posttrans_x3.py measures both paths against
+// float64).  6 instructions x 16 cycles per K = 32 vs 8 x 32 cycles on the f32 MFMA: 2.7x less matrix-pipe time.
+// Non-finite inputs give NaN (x - x0 is NaN for x = Inf); finite inputs never overflow (truncation, not rounding).
+//
+// Tiling: a workgroup = 8 wavefronts; each wavefront owns RT row tiles of 16 rows x (NT x 16) columns x P panels
+// (P = S scalers [+ the h panel]); K is consumed 32 at a time.  The weight is pre-split and pre-packed
+// (pna_posttrans_x3_pack_f32) into the exact LDS image of every chunk, [term][panel][lane group][80 cols][8 k] bf16,
+// so that (i) the chunk is copied global -> LDS by global_load_lds_dwordx4 (no staging registers, no ds_write),
+// double buffered, one barrier per chunk, and (ii) a B fragment is one conflict-free ds_read_b128.  The A fragment
+// (lane (i, g): floats [k0+8g, k0+8g+8) of row i) is loaded one chunk ahead and split in registers while the other
+// wavefront of the SIMD keeps the matrix pipe busy; every B fragment feeds RT row tiles.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <type_traits>
+
+#include "pna_amd.h"
+#include "pna_internal.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef short bf8 __attribute__((ext_vector_type(8)));       // 8 bf16 = one MFMA A/B fragment
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) f4u { f4 v; };
+
+constexpr int kKC = 32;                       // k values per chunk
+constexpr int kMaxNT = 5;
+constexpr int kNW = kMaxNT * 16;              // 80 output columns per workgroup
+constexpr int kPanelB = 4 * kNW * 8 * 2;      // bytes of one (term, panel) image: [4 lane groups][80][8] bf16 = 5120
+constexpr int kPanelV = kPanelB / 16;         // ... in 16-byte pieces = 320 = 5 wavefronts' worth
+
+struct XArgs {
+  const float* a; const void* w_img; const float* h; const void* wh_img; const float* bias;
+  const float* row_scale[PNA_MAX_SCALER];
+  const float* row_post; const float* col_scale; const float* col_shift; const float* residual;
+  float* y;
+  long lda, ldh, ldy, ld_res;
+  int M, K, N, Kh, relu, grid_x;
+};
+
+__device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float bfloat(unsigned u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ float top16(float x) { return bfloat(fbits(x) & 0xFFFF0000u); }
+// upper halves of (even, odd) -> one dword {odd.hi16, even.hi16}
+__device__ __forceinline__ unsigned pack_hi(float even, float odd) { return __builtin_amdgcn_perm(fbits(odd), fbits(even), 0x07060302u); }
+
+// 8 floats -> the three bf16 fragments
+__device__ __forceinline__ void split8(const f4 lo, const f4 hi, bf8& t0, bf8& t1, bf8& t2) {
+  const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  u4 p0, p1, p2;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float xe = x[2 * j], xo = x[2 * j + 1];
+    const float re = xe - top16(xe), ro = xo - top16(xo);
+    const float se = re - top16(re), so = ro - top16(ro);
+    p0[j] = pack_hi(xe, xo);
+    p1[j] = pack_hi(re, ro);
+    p2[j] = pack_hi(se, so);
+  }
+  t0 = __builtin_bit_cast(bf8, p0); t1 = __builtin_bit_cast(bf8, p1); t2 = __builtin_bit_cast(bf8, p2);
+}
+
+// ---- weight packing ------------------------------------------------------------------------------------------------
+// w_img[ny][c][term][s][g][n][e]  = term(w_ref[ny*80 + n][Kh + s*K + c*32 + kperm(g, e)])   (0 outside K / N)
+// wh_img[ny][c][term][g][n][e]    = term(w_ref[ny*80 + n][c*32 + kperm(g, e)])              (0 outside Kh / N)
+// kperm(g, e) = 4g + e for e < 4, 16 + 4g + (e - 4) otherwise: element e of lane group g.  A and B agree on it, and it
+// makes each of the two A loads of a chunk read 64 contiguous bytes per row (lane groups 0..3 x 16 B).
+__global__ void k_pack_x3(const float* w_ref, long ldw, int N, int K, int S, int Kh, unsigned short* w_img, unsigned short* wh_img) {
+  const int nca = (K + kKC - 1) / kKC, nch = (Kh + kKC - 1) / kKC, nty = (N + kNW - 1) / kNW;
+  const long per = 4L * kNW * 8;
+  const long total_w = (long)nty * nca * 3 * S * per, total_h = (long)nty * nch * 3 * per;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total_w + total_h; i += (long)gridDim.x * blockDim.x) {
+    const bool is_h = i >= total_w;
+    long r = is_h ? i - total_w : i;
+    const int e = r % 8; r /= 8;
+    const int n = r % kNW; r /= kNW;
+    const int g = r % 4; r /= 4;
+    int s = 0;
+    if (!is_h) { s = r % S; r /= S; }
+    const int term = r % 3; r /= 3;
+    const int nc = is_h ? nch : nca;
+    const int c = r % nc; r /= nc;
+    const int ny = (int)r;
+    const int col = ny * kNW + n, k = c * kKC + 8 * g + e;
+    const int kmax = is_h ? Kh : K;
+    float w = 0.f;
+    if (col < N && k < kmax) w = w_ref[(long)col * ldw + (is_h ? 0 : Kh + (long)s * K) + k];
+    const float r1 = w - top16(w), r2 = r1 - top16(r1);
+    const float t = term == 0 ? w : term == 1 ? r1 : r2;
+    (is_h ? wh_img + (i - total_w) : w_img + i)[0] = (unsigned short)(fbits(t) >> 16);
+  }
+}
+
+template <int S, bool HAS_H, int NT, int RT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
+  constexpr int kThreads = WAVES * 64;
+  constexpr int kChunkV = 3 * S * kPanelV;     // 16-byte pieces of an aggregate chunk image (the h chunk is 3 * kPanelV)
+  constexpr int kTileRows = WAVES * 16 * RT;   // rows per workgroup tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 buffers x kChunkV x 16 B | column constants
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int n0 = blockIdx.y * kNW;
+  const int ntiles = (g.M + kTileRows - 1) / kTileRows;
+
+  // One accumulator set per scaler block (and one for the h block): the per-row scalers are applied in the epilogue,
+  // so the A operand is split ONCE per chunk -- the kernel is bound by instruction issue (one instruction per 4 cycles
+  // per SIMD, shared by MFMA and VALU), and re-scaling + re-splitting A per scaler tripled its VALU count.
+  constexpr int P = S + (HAS_H ? 1 : 0);
+  f4 acc[RT][P][NT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[r][p][n] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  const int nca = (g.K + kKC - 1) / kKC;
+  const int nch = HAS_H ? (g.Kh + kKC - 1) / kKC : 0;
+  const int nc = nca + nch;
+  const unsigned char* img_a = reinterpret_cast<const unsigned char*>(g.w_img) + (size_t)blockIdx.y * nca * kChunkV * 16;
+  const unsigned char* img_h = reinterpret_cast<const unsigned char*>(HAS_H ? g.wh_img : g.w_img) + (size_t)blockIdx.y * nch * 3 * kPanelV * 16;
+
+  // chunk image -> LDS buffer, asynchronously; every wavefront copies whole 1 KB pieces (the piece counts are
+  // multiples of 64), destination = wave-uniform base + lane * 16
+  constexpr int NI = (kChunkV + kThreads - 1) / kThreads;   // global_load_lds instructions per wavefront per chunk
+  auto stage_piece = [&](int c, int buf, int i) {
+    const unsigned char* src = img_a + (size_t)c * kChunkV * 16;
+    int pieces = kChunkV;
+    if constexpr (HAS_H) {
+      if (c >= nca) { src = img_h + (size_t)(c - nca) * 3 * kPanelV * 16; pieces = 3 * kPanelV; }
+    }
+    unsigned char* dst = lds + (size_t)buf * kChunkV * 16;
+    const int w0 = (i * WAVES + wave) * 64;              // first piece of this wavefront (wave-uniform)
+    if (w0 < pieces)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(w0 + lane) * 16),
+                                       (__attribute__((address_space(3))) void*)(dst + (size_t)w0 * 16), 16, 0, 0);
+  };
+  auto stage = [&](int c, int buf) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) stage_piece(c, buf, i);
+  };
+
+  // A operand of (tile t, chunk c), row tile r: floats [k, k+4) and [k+16, k+20) of the lane's row, k = 32c + 4 lg, as two
+  // clamped 16-byte windows ([kk, kk+4), kk = min(k, kmax-4); the launcher guarantees kmax >= 4), fixed up after the load.
+  auto a_src = [&](int c, const float*& src, long& ld, int& kmax, int& k) {
+    src = g.a; ld = g.lda; kmax = g.K; k = c * kKC + 8 * lg;
+    if constexpr (HAS_H) {
+      if (c >= nca) { src = g.h; ld = g.ldh; kmax = g.Kh; k = (c - nca) * kKC + 8 * lg; }
+    }
+  };
+  auto fix4 = [&](int k, int kmax, f4 t) -> f4 {        // window [kk,kk+4) -> elements [k,k+4), 0 beyond kmax
+    const int d = k - max(0, min(k, kmax - 4));
+    f4 v;
+    v.x = d == 0 ? t.x : d == 1 ? t.y : d == 2 ? t.z : t.w;
+    v.y = d == 0 ? t.y : d == 1 ? t.z : t.w;
+    v.z = d == 0 ? t.z : t.w;
+    v.w = t.w;
+    v.x = (k < kmax && d <= 3) ? v.x : 0.f;
+    v.y = (k + 1 < kmax && d <= 2) ? v.y : 0.f;
+    v.z = (k + 2 < kmax && d <= 1) ? v.z : 0.f;
+    v.w = (k + 3 < kmax && d == 0) ? v.w : 0.f;
+    return v;
+  };
+  f4 nxt[RT][2];                               // A of the next chunk (in flight)
+  bf8 A[3][RT];                                // the three bf16 terms of the chunk being multiplied
+  // Issued by hand, one piece at a time from inside the MFMA stream (hipcc would hoist plain loads into one burst at
+  // the top of the interval, and a burst of scattered-row loads from all wavefronts stalls them at the TA).  An
+  // asm-loaded register is written on EVERY path (the caller passes a valid tile even when there is no next one) and
+  // read only through the "+v" of the wait in take().
+  auto load_a_piece = [&](int t, int c, int r, int w) {
+    const float* src; long ld; int kmax, k;
+    a_src(c, src, ld, kmax, k);
+    const int row = min((t * WAVES + wave) * (16 * RT) + 16 * r + li, g.M - 1);
+    const int kk = max(0, min(k + 4 * w, kmax - 4));
+    const float* ptr = src + (size_t)row * ld + kk;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nxt[r][w]) : "v"(ptr) : "memory");
+  };
+  auto load_a = [&](int t, int c) {
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+      for (int w = 0; w < 2; ++w) load_a_piece(t, c, r, w);
+  };
+  auto take = [&](int c) {                     // next -> current (after the wait): fix the windows, split
+    const float* src; long ld; int kmax, k;
+    a_src(c, src, ld, kmax, k);
+    const bool tail = c * kKC + kKC > (c < nca ? g.K : nca * kKC + g.Kh);   // wave-uniform: only a row's last chunk needs fixing
+#pragma unroll
+    for (int r = 0; r < RT; ++r) asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt[r][0]), "+v"(nxt[r][1]) : : "memory");
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      if (tail) split8(fix4(k, kmax, nxt[r][0]), fix4(k + 4, kmax, nxt[r][1]), A[0][r], A[1][r], A[2][r]);
+      else split8(nxt[r][0], nxt[r][1], A[0][r], A[1][r], A[2][r]);
+    }
+  };
+
+  // Epilogue, from the MFMA's C/D layout (col = lane & 15, row = (lane >> 4) * 4 + reg): the scalers of a lane's four
+  // adjacent rows come as one 16-byte load each, the column constants from LDS; every load is unconditional (clamped
+  // row / column) and issued before its first use, only the store is predicated.  (Transposing the tile through LDS
+  // to store 16 bytes per lane was measured: no faster -- the epilogue is three dependent memory round trips, not
+  // instruction count -- and 16-byte accesses to rows of N = 75 floats are unaligned for 3 rows in 4, which is slower.)
+  float* const colc = reinterpret_cast<float*>(lds + (size_t)2 * kChunkV * 16);            // [3][80]: bias | scale | shift
+  for (int i = tid; i < kNW; i += kThreads) {
+    const int col = n0 + i;
+    colc[i] = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+    colc[kNW + i] = (g.col_scale && col < g.N) ? g.col_scale[col] : 1.f;
+    colc[2 * kNW + i] = (g.col_shift && col < g.N) ? g.col_shift[col] : 0.f;
+  }
+  auto scalers_cd = [&](int rb, f4 (&scv)[S]) {  // the lane's 4 adjacent rows: one 16-byte load per scaler
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      scv[s] = (f4){1.f, 1.f, 1.f, 1.f};
+      if (g.row_scale[s]) {
+        if (rb + 3 < g.M) scv[s] = reinterpret_cast<const f4u*>(g.row_scale[s] + rb)->v;
+        else
+          for (int r = 0; r < 4; ++r) scv[s][r] = g.row_scale[s][min(rb + r, g.M - 1)];
+      }
+    }
+  };
+  auto finish = [&](float v, int row, float cb, float cs, float ct) -> float {
+    v = v + cb;
+    if (g.row_post) v = v * g.row_post[row];                           // graph-norm (pna_layer.py:71-72)
+    if (g.col_scale) v = v * cs + ct;                                  // eval-mode BatchNorm folded to an affine map
+    if (g.relu) v = v > 0.f ? v : (v != v ? v : 0.f);                  // ReLU (keeps NaN)
+    return v;
+  };
+  auto epilogue = [&](int t) {
+    const int row0 = (t * WAVES + wave) * (16 * RT);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      f4 scv[S];
+      scalers_cd(row0 + 16 * rt + 4 * lg, scv);
+      float res[NT][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = min(row0 + 16 * rt + lg * 4 + r, g.M - 1);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          res[n][r] = g.residual ? g.residual[(size_t)row * g.ld_res + min(n0 + n * 16 + li, g.N - 1)] : 0.f;
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int cl = n * 16 + li, col = n0 + cl;
+        const float cb = colc[cl], cs = colc[kNW + cl], ct = colc[2 * kNW + cl];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row0 + 16 * rt + lg * 4 + r;
+          float v = HAS_H ? acc[rt][P - 1][n][r] : 0.f;
+#pragma unroll
+          for (int s = 0; s < S; ++s) v = v + scv[s][r] * acc[rt][s][n][r];
+          v = finish(v, min(row, g.M - 1), cb, cs, ct);
+          if (g.residual) v = res[n][r] + v;                               // h_in + h (pna_layer.py:212-213)
+          if (row < g.M && col < g.N) g.y[(size_t)row * g.ldy + col] = v;
+#pragma unroll
+          for (int p = 0; p < P; ++p) acc[rt][p][n][r] = 0.f;
+        }
+      }
+    }
+  };
+  // Persistent workgroup: tiles t = blockIdx.x, blockIdx.x + gridDim.x, ...; the (tile, chunk) pairs form ONE software
+  // pipeline, so the first chunk of the next tile is already in flight while this tile's epilogue runs.
+  int t = blockIdx.x, c = 0, buf = 0;
+  if (t >= ntiles) return;
+  stage(0, 0);
+  load_a(t, 0);
+  take(0);                                     // (waits vmcnt(0): chunk 0 of the image has landed too)
+  __syncthreads();
+  while (true) {
+    int tn = t, cn = c + 1;
+    if (cn == nc) { tn = t + gridDim.x; cn = 0; }
+    const bool more = tn < ntiles;
+    const int ta = more ? tn : t, ca = more ? cn : c;   // A prefetch target (a harmless re-load when there is no next chunk)
+    const bool is_h = HAS_H && c >= nca;
+    const unsigned baddr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(buf * kChunkV + lg * kNW + li) * 16u;   // LDS byte address of this lane's fragment column
+    // The chunk's S*NT (panel, column tile) groups form one software pipeline: while the 6*RT MFMAs of group g run,
+    // the three B fragments of group g+1 are read from LDS and one piece of the NEXT chunk's weight image is sent on
+    // its way to LDS -- spread over the groups, because a burst of VMEM issue from all wavefronts at once stalls
+    // every one of them at the TA.
+    // B fragment (term, panel p, column tile n): piece ((term*np + p)*4 + lg)*80 + n*16 + li;
+    // MFMAs ordered smallest partial products first, row tiles alternating (no MFMA waits for its predecessor).
+    auto run = [&](auto npanel_c, int p0, unsigned ba0) {
+      constexpr int NPN = decltype(npanel_c)::value;   // panels in this chunk's image; they accumulate into acc[.][p0 + p]
+      constexpr int NG = NPN * NT;
+      bf8 B[2][3];
+      // B fragments are read by hand (inline asm + counted lgkmcnt): hipcc sinks its own ds_reads next to their use
+      // and waits lgkmcnt(0), exposing one LDS round trip per group.  LDS returns in order, so with the three reads
+      // of group g+1 issued behind those of group g, `lgkmcnt(3)` means group g has landed.
+      auto load_b = [&](unsigned ba, int gi, int slot) {
+        const int p = gi / NT, n = gi % NT;
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(B[slot][tm]) : "v"(ba), "n"((((tm * NPN + p) * 4) * kNW + n * 16) * 16));
+      };
+      load_b(ba0, 0, 0);
+      constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+      for (int gi = 0; gi < NG; ++gi) {
+        const int p = gi / NT, n = gi % NT;
+        if (gi + 1 < NG) {
+          load_b(ba0, gi + 1, (gi + 1) & 1);
+          asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(B[gi & 1][0]), "+v"(B[gi & 1][1]), "+v"(B[gi & 1][2]));
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(B[gi & 1][0]), "+v"(B[gi & 1][1]), "+v"(B[gi & 1][2]));
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * RT; ++j)
+          if (gi == 0) load_a_piece(ta, ca, j >> 1, j & 1);   // HBM latency: first
+        if (more) {                                                 // the L2-resident weight image: spread over the rest
+#pragma unroll
+          for (int i = 0; i < NI; ++i)
+            if ((NG > 2 * RT ? 2 * RT + (i * (NG - 2 * RT)) / NI : NG - 1) == gi) stage_piece(cn, buf ^ 1, i);
+        }
+#pragma unroll
+        for (int pp = 0; pp < 6; ++pp)
+#pragma unroll
+          for (int r = 0; r < RT; ++r)
+            acc[r][p0 + p][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]][r], B[gi & 1][TB[pp]], acc[r][p0 + p][n], 0, 0, 0);
+      }
+    };
+    if (!is_h) {
+      run(std::integral_constant<int, S>{}, 0, baddr);
+    } else if (HAS_H) {
+      run(std::integral_constant<int, 1>{}, P - 1, baddr);
+    }
+    if (c == nc - 1) {
+      __builtin_amdgcn_sched_barrier(0);         // keep the epilogue's loads out of the MFMA stream (register pressure)
+      epilogue(t);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!more) break;
+    take(cn);                                          // waits vmcnt(0): this wavefront's share of the next chunk is in LDS
+    __syncthreads();                                   // ... everyone's is, and everyone is done reading this chunk
+    buf ^= 1; t = tn; c = cn;
+  }
+}
+
+template <int S, bool HAS_H, int NT, int RT, int WAVES>
+int launch_v(const XArgs& g, hipStream_t st) {
+  const size_t lds = (size_t)2 * 3 * S * kPanelB + (size_t)(3 * kNW) * sizeof(float);
+  if (hipFuncSetAttribute((const void*)k_posttrans_x3<S, HAS_H, NT, RT, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return -1;
+  const int ntiles = (g.M + WAVES * 16 * RT - 1) / (WAVES * 16 * RT);
+  const dim3 grid((unsigned)(ntiles < g.grid_x ? ntiles : g.grid_x), (unsigned)((g.N + kNW - 1) / kNW));
+  hipLaunchKernelGGL((k_posttrans_x3<S, HAS_H, NT, RT, WAVES>), grid, dim3(WAVES * 64), lds, st, g);
+  return 0;
+}
+
+template <int S, bool HAS_H, int NT>
+int launch_k(const XArgs& g, hipStream_t st) {
+  // two row tiles per wavefront while the accumulators fit (RT * P * NT * 4 registers), else one
+  constexpr int RT = (S + (HAS_H ? 1 : 0)) * NT > 15 ? 1 : 2;
+  return launch_v<S, HAS_H, NT, RT, 8>(g, st);
+}
+
+template <int S, bool HAS_H>
+int launch_nt(const XArgs& g, int nt, hipStream_t st) {
+  if (nt <= 1) return launch_k<S, HAS_H, 1>(g, st);
+  if (nt <= 3) return launch_k<S, HAS_H, 3>(g, st);
+  return launch_k<S, HAS_H, 5>(g, st);
+}
+
+template <int S>
+int launch_s(const XArgs& g, bool has_h, int nt, hipStream_t st) {
+  return has_h ? launch_nt<S, true>(g, nt, st) : launch_nt<S, false>(g, nt, st);
+}
+
+}  // namespace
+
+extern "C" int64_t pna_posttrans_x3_packed_bytes(int32_t K, int32_t N, int32_t n_scaler, int32_t Kh, int64_t* wh_bytes) {
+  const int64_t nca = (K + kKC - 1) / kKC, nch = (Kh + kKC - 1) / kKC, nty = (N + kNW - 1) / kNW;
+  if (wh_bytes) *wh_bytes = nty * nch * 3 * kPanelB;
+  return nty * nca * 3 * n_scaler * kPanelB;
+}
+
+extern "C" int pna_posttrans_x3_pack_f32(const float* w_ref, int64_t ldw, int32_t N, int32_t K, int32_t n_scaler, int32_t Kh,
+                                         void* w_img, void* wh_img, pna_stream_t stream) {
+  if (!w_ref || !w_img || N <= 0 || K <= 0 || n_scaler < 1 || n_scaler > 3 || Kh < 0 || (Kh > 0 && !wh_img) ||
+      ldw < (int64_t)Kh + (int64_t)n_scaler * K)
+    return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3_pack_f32: bad arguments (n_scaler must be 1..3)");
+  int64_t nh = 0;
+  const int64_t nw = pna_posttrans_x3_packed_bytes(K, N, n_scaler, Kh, &nh);
+  const int64_t elems = (nw + nh) / 2;
+  const int blocks = (int)((elems + 255) / 256 > 4096 ? 4096 : (elems + 255) / 256);
+  hipLaunchKernelGGL(k_pack_x3, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ref, (long)ldw, N, K, n_scaler, Kh,
+                     (unsigned short*)w_img, (unsigned short*)wh_img);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
+  return PNA_OK;
+}
+
+extern "C" int pna_posttrans_x3_f32(const pna_posttrans_args* p, pna_stream_t stream) {
+  if (!p) return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3_f32: null args");
+  if (p->M < 0 || p->K <= 0 || p->N <= 0) return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3_f32: bad M/K/N");
+  if (p->M == 0) return PNA_OK;
+  if (!p->a || !p->w_img || !p->y) return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3_f32: a/w_img/y must be non-null");
+  if (p->n_scaler < 1 || p->n_scaler > 3) return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3_f32: n_scaler must be 1..3");
+  if (p->lda < p->K || p->ldy < p->N) return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3_f32: leading dimensions too small");
+  if (p->K < 4 || (p->h != nullptr && p->Kh > 0 && p->Kh < 4))
+    return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3_f32: K and Kh must be >= 4 (pad the operand and the weight with zero columns)");
+  const bool has_h = p->h != nullptr && p->Kh > 0;
+  if (has_h && (!p->wh_img || p->ldh < p->Kh)) return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3_f32: h given without wh_img / ldh too small");
+  if (p->residual && p->ld_res < p->N) return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3_f32: ld_res too small");
+  if ((p->col_scale == nullptr) != (p->col_shift == nullptr))
+    return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3_f32: col_scale and col_shift come together");
+  XArgs g;
+  memset(&g, 0, sizeof(g));
+  g.a = p->a; g.w_img = p->w_img; g.h = has_h ? p->h : nullptr; g.wh_img = has_h ? p->wh_img : nullptr; g.bias = p->bias;
+  for (int s = 0; s < p->n_scaler; ++s) g.row_scale[s] = p->row_scale[s];
+  g.row_post = p->row_post; g.col_scale = p->col_scale; g.col_shift = p->col_shift; g.residual = p->residual;
+  g.y = p->y; g.lda = p->lda; g.ldh = p->ldh; g.ldy = p->ldy; g.ld_res = p->ld_res;
+  g.M = p->M; g.K = p->K; g.N = p->N; g.Kh = has_h ? p->Kh : 0; g.relu = p->relu;
+  {   // one persistent workgroup per CU (and per column tile)
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      return pna_set_error(PNA_E_NODEVICE, "pna_posttrans_x3_f32: cannot query the device");
+    const int ny = (p->N + kNW - 1) / kNW;
+    g.grid_x = (cus + ny - 1) / ny;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int nt = p->N >= kNW ? kMaxNT : (p->N + 15) / 16;
+  int rc;
+  switch (p->n_scaler) {
+    case 1: rc = launch_s<1>(g, has_h, nt, st); break;
+    case 2: rc = launch_s<2>(g, has_h, nt, st); break;
+    default: rc = launch_s<3>(g, has_h, nt, st); break;
+  }
+  if (rc != 0) return pna_set_error(PNA_E_LAUNCH, "pna_posttrans_x3_f32: could not reserve LDS");
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
+  return PNA_OK;
+}

@@ -7,12 +7,20 @@
 Both require GPU tensors; there is no CPU path.
 """
 import ctypes
+import os
 from typing import Optional, Sequence
 
 import torch
 
 from . import _lib
 from .graph import HeavySchedule
+
+# Arithmetic of the posttrans contraction: "f32" = v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain), "bf16x3" = fp32
+# operands cut exactly into three bf16 terms, six partial products on the bf16 matrix pipe (fp32-level accuracy, see
+# pna_posttrans_x3.hip), "auto" = bf16x3 where it is implemented (<= 3 scalers) and the problem fills its 256-row
+# persistent tiles (>= X3_MIN_ROWS rows), f32 otherwise.
+POSTTRANS_ARITH = os.environ.get("PNA_AMD_POSTTRANS", "auto")
+X3_MIN_ROWS = 16384
 
 _TUNE = {}   # process-wide tuning overrides (set by tools/sweep.py and bench.py), see set_tuning()
 
@@ -125,10 +133,34 @@ def pack_posttrans_weight(weight: torch.Tensor, K: int, n_scaler: int, Kh: int):
     return w_img, wh_img
 
 
+def pack_posttrans_weight_x3(weight: torch.Tensor, K: int, n_scaler: int, Kh: int):
+    """(w_img, wh_img) bf16x3 tile images (pna_posttrans_x3_pack_f32); cached like pack_posttrans_weight."""
+    key = (weight._version, tuple(weight.shape), weight.stride(0), K, n_scaler, Kh)
+    hit = getattr(weight, "_pna_amd_pack_x3", None)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    L = _lib.lib()
+    N = weight.shape[0]
+    nh = ctypes.c_int64(0)
+    nw = L.pna_posttrans_x3_packed_bytes(K, N, n_scaler, Kh, ctypes.byref(nh))
+    w_img = torch.empty(nw // 4, dtype=torch.float32, device=weight.device)
+    wh_img = torch.empty(max(nh.value // 4, 1), dtype=torch.float32, device=weight.device) if Kh else None
+    rc = L.pna_posttrans_x3_pack_f32(_lib.dev_ptr(weight, torch.float32, "weight"), _ld(weight), N, K, n_scaler, Kh,
+                                     _lib.dev_ptr(w_img, torch.float32, "w_img"), _lib.dev_ptr(wh_img, torch.float32, "wh_img"),
+                                     _lib.stream_ptr(weight.device))
+    _lib.check(rc, "pna_posttrans_x3_pack_f32")
+    try:
+        weight._pna_amd_pack_x3 = (key, w_img, wh_img)
+    except AttributeError:
+        pass
+    return w_img, wh_img
+
+
 def posttrans(a_mat: torch.Tensor, K: int, weight: torch.Tensor, row_scales: Sequence[Optional[torch.Tensor]],
               bias: Optional[torch.Tensor] = None, h: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
               row_post: Optional[torch.Tensor] = None, col_scale: Optional[torch.Tensor] = None,
-              col_shift: Optional[torch.Tensor] = None, relu: bool = False, residual: Optional[torch.Tensor] = None):
+              col_shift: Optional[torch.Tensor] = None, relu: bool = False, residual: Optional[torch.Tensor] = None,
+              arith: Optional[str] = None):
     """y = residual + act(((bias + h@Wh^T + sum_s row_scales[s][:,None] * (a[:, :K] @ W_s^T)) * row_post[:,None]) *
     col_scale + col_shift)                                                                      (see pna_amd.h).
 
@@ -139,7 +171,13 @@ def posttrans(a_mat: torch.Tensor, K: int, weight: torch.Tensor, row_scales: Seq
     if weight.shape[1] != Kh + S * K:
         raise ValueError(f"weight has {weight.shape[1]} input columns, expected Kh + n_scaler*K = {Kh + S * K}")
     dev = a_mat.device
-    w_img, wh_img = pack_posttrans_weight(weight, K, S, Kh)
+    arith = arith or POSTTRANS_ARITH
+    if arith not in ("f32", "bf16x3", "auto"):
+        raise ValueError(f"unknown posttrans arithmetic {arith!r} (f32 | bf16x3 | auto)")
+    if arith == "bf16x3" and S > 3:
+        raise ValueError("the bf16x3 posttrans kernel supports at most 3 scalers")
+    x3 = arith == "bf16x3" or (arith == "auto" and S <= 3 and M >= X3_MIN_ROWS)
+    w_img, wh_img = (pack_posttrans_weight_x3 if x3 else pack_posttrans_weight)(weight, K, S, Kh)
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=dev)
     g = _lib.PnaPosttransArgs()
@@ -162,6 +200,65 @@ def posttrans(a_mat: torch.Tensor, K: int, weight: torch.Tensor, row_scales: Seq
     if residual is not None:
         g.residual, g.ld_res = _lib.dev_ptr(residual, torch.float32, "residual"), _ld(residual)
     g.y, g.ldy = _lib.dev_ptr(out, torch.float32, "y"), _ld(out)
-    rc = _lib.lib().pna_posttrans_f32(ctypes.byref(g), _lib.stream_ptr(dev))
-    _lib.check(rc, "pna_posttrans_f32")
+    fn = "pna_posttrans_x3_f32" if x3 else "pna_posttrans_f32"
+    rc = getattr(_lib.lib(), fn)(ctypes.byref(g), _lib.stream_ptr(dev))
+    _lib.check(rc, fn)
+    return out
+
+
+def pack_fused_weight(weight: torch.Tensor, F: int, n_scaler: int):
+    """Packed image of a PNASimpleLayer posttrans weight (N, S*4*F) for pna_fused_simple_f32: every aggregator block
+    zero-padded from F to round_up(F, 4) input columns.  Cached on the weight object per version."""
+    key = (weight._version, tuple(weight.shape), F, n_scaler)
+    hit = getattr(weight, "_pna_amd_fpack", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    N, B4 = weight.shape[0], (F + 3) // 4 * 4
+    wp = torch.nn.functional.pad(weight.detach().reshape(N, n_scaler * 4, F), (0, B4 - F)).reshape(N, n_scaler * 4 * B4)
+    wp = wp.contiguous()
+    L = _lib.lib()
+    nh = ctypes.c_int64(0)
+    nw = L.pna_posttrans_packed_floats(4 * B4, N, n_scaler, 0, ctypes.byref(nh))
+    w_img = torch.empty(nw, dtype=torch.float32, device=weight.device)
+    rc = L.pna_posttrans_pack_f32(_lib.dev_ptr(wp, torch.float32, "weight"), _ld(wp), N, 4 * B4, n_scaler, 0,
+                                  _lib.dev_ptr(w_img, torch.float32, "w_img"), None, _lib.stream_ptr(weight.device))
+    _lib.check(rc, "pna_posttrans_pack_f32")
+    try:
+        weight._pna_amd_fpack = (key, w_img)
+    except AttributeError:
+        pass
+    return w_img
+
+
+def fused_simple(rowptr: torch.Tensor, col: torch.Tensor, x: torch.Tensor, F: int, weight: torch.Tensor,
+                 row_scales: Sequence[Optional[torch.Tensor]], bias: Optional[torch.Tensor] = None,
+                 col_scale: Optional[torch.Tensor] = None, col_shift: Optional[torch.Tensor] = None, relu: bool = False,
+                 residual: Optional[torch.Tensor] = None, heavy_threshold: int = 0, out: Optional[torch.Tensor] = None):
+    """PNASimpleLayer forward ("mean max min std") in one launch (pna_fused_simple_f32, see pna_amd.h)."""
+    V, S, N = rowptr.numel() - 1, len(row_scales), weight.shape[0]
+    if weight.shape[1] != S * 4 * F:
+        raise ValueError(f"weight has {weight.shape[1]} input columns, expected n_scaler*4*F = {S * 4 * F}")
+    dev = x.device
+    w_img = pack_fused_weight(weight, F, S)
+    if out is None:
+        out = torch.empty(V, N, dtype=torch.float32, device=dev)
+    g = _lib.PnaFusedSimpleArgs()
+    g.rowptr, g.col = _lib.dev_ptr(rowptr, torch.int32, "rowptr"), _lib.dev_ptr(col, torch.int32, "col")
+    g.x, g.ldx = _lib.dev_ptr(x, torch.float32, "x"), _ld(x)
+    g.V, g.F, g.N, g.n_scaler = V, F, N, S
+    for i, rs in enumerate(row_scales):
+        if rs is not None:
+            if rs.numel() != V:
+                raise ValueError("row scale must have one entry per destination row")
+            g.row_scale[i] = _lib.dev_ptr(rs, torch.float32, "row_scale").value
+    g.w_img = _lib.dev_ptr(w_img, torch.float32, "w_img")
+    g.bias = _lib.dev_ptr(bias, torch.float32, "bias")
+    g.col_scale = _lib.dev_ptr(col_scale, torch.float32, "col_scale")
+    g.col_shift = _lib.dev_ptr(col_shift, torch.float32, "col_shift")
+    if residual is not None:
+        g.residual, g.ld_res = _lib.dev_ptr(residual, torch.float32, "residual"), _ld(residual)
+    g.y, g.ldy = _lib.dev_ptr(out, torch.float32, "y"), _ld(out)
+    g.relu, g.heavy_threshold = (1 if relu else 0), heavy_threshold
+    rc = _lib.lib().pna_fused_simple_f32(ctypes.byref(g), _lib.stream_ptr(dev))
+    _lib.check(rc, "pna_fused_simple_f32")
     return out

@@ -115,6 +115,10 @@ def test_ctypes_struct_layout_matches_header_field_order():
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = [re.sub(r"\[.*\]", "", f.strip().split()[-1].lstrip("*")) for f in body.split(";") if f.strip()]
     assert fields == [n for n, _ in _lib.PnaPosttransArgs._fields_]
+    body = re.search(r"typedef struct pna_fused_simple_args \{(.*?)\} pna_fused_simple_args;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = [re.sub(r"\[.*\]", "", f.strip().split()[-1].lstrip("*")) for f in body.split(";") if f.strip()]
+    assert fields == [n for n, _ in _lib.PnaFusedSimpleArgs._fields_]
 
 
 @pytest.mark.parametrize("name", golden_names("dgl_tower"))
