@@ -231,9 +231,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
       }
     }
   };
-  auto finish = [&](float v, int row, float cb, float cs, float ct) -> float {
+  auto finish = [&](float v, float rp, float cb, float cs, float ct) -> float {
     v = v + cb;
-    if (g.row_post) v = v * g.row_post[row];                           // graph-norm (pna_layer.py:71-72)
+    if (g.row_post) v = v * rp;                                        // graph-norm (pna_layer.py:71-72)
     if (g.col_scale) v = v * cs + ct;                                  // eval-mode BatchNorm folded to an affine map
     if (g.relu) v = v > 0.f ? v : (v != v ? v : 0.f);                  // ReLU (keeps NaN)
     return v;
@@ -244,6 +244,13 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
     for (int rt = 0; rt < RT; ++rt) {
       f4 scv[S];
       scalers_cd(row0 + 16 * rt + 4 * lg, scv);
+      f4 rpv = (f4){1.f, 1.f, 1.f, 1.f};       // graph-norm factors of the lane's 4 rows: one load, not one per element
+      if (g.row_post) {
+        const int rb = row0 + 16 * rt + 4 * lg;
+        if (rb + 3 < g.M) rpv = reinterpret_cast<const f4u*>(g.row_post + rb)->v;
+        else
+          for (int r = 0; r < 4; ++r) rpv[r] = g.row_post[min(rb + r, g.M - 1)];
+      }
       float res[NT][4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
           float v = HAS_H ? acc[rt][P - 1][n][r] : 0.f;
 #pragma unroll
           for (int s = 0; s < S; ++s) v = v + scv[s][r] * acc[rt][s][n][r];
-          v = finish(v, min(row, g.M - 1), cb, cs, ct);
+          v = finish(v, rpv[r], cb, cs, ct);
           if (g.residual) v = res[n][r] + v;                               // h_in + h (pna_layer.py:212-213)
           if (row < g.M && col < g.N) g.y[(size_t)row * g.ldy + col] = v;
 #pragma unroll

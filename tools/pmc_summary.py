@@ -22,9 +22,11 @@ agg = collections.defaultdict(list)
 for r in rows:
     k = r["Kernel_Name"]
     if "k_segreduce" in k:
-        name = "segreduce_calib" if int(r["Grid_Size"]) < 2_000_000 else "segreduce_c3"
+        name = "segreduce_calib" if int(r["Grid_Size"]) < 4_000_000 else "segreduce_c3"
+    elif "k_posttrans_x3" in k:
+        name = "posttrans_bf16x3_c3"
     elif "k_posttrans" in k:
-        name = "posttrans_c3"
+        name = "posttrans_f32_c3"
     elif "k_heavy_finalize" in k:
         name = "heavy_finalize_c3"
     else:

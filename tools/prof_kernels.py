@@ -49,7 +49,9 @@ b = torch.zeros(F, device=dev)
 with torch.no_grad():
     for _ in range(n):
         agg = PF.aggregate(g, x, F, aggs)
-    for _ in range(n):
-        y = PF.posttrans(agg, 4 * F, W, b, [None, amp, att])
+    from pna_amd import ops
+    for arith in ("bf16x3", "f32"):           # both contraction kernels: the bf16x3 default and the exact f32-MFMA one
+        for _ in range(n):
+            y = ops.posttrans(agg, 4 * F, W, [None, amp, att], b, arith=arith)
 torch.cuda.synchronize()
 print("ok", float(y.abs().mean()))

@@ -55,7 +55,8 @@ print("ACCURACY", "PASS" if ok else "FAIL", flush=True)
 
 if len(sys.argv) > 1 and sys.argv[1] == "time":
     M, K, N, S = 1_000_000, 300, 75, 3
-    a = torch.randn(M, K, device=dev)
+    pitch = int(os.environ.get("A_PITCH", K))
+    a = torch.randn(M, pitch, device=dev)[:, :K]
     W = torch.randn(N, S * K, device=dev) / 30
     b = torch.randn(N, device=dev)
     scales = [None, torch.rand(M, device=dev), torch.rand(M, device=dev)]
@@ -65,10 +66,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "time":
         fn = lambda: ops.posttrans(a, K, W, scales, b, out=y, relu=True, residual=res, arith=arith)  # noqa: E731
         for _ in range(3):
             fn()
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        for _ in range(20):
-            fn()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t) / 20 * 1e3
+        ms = 1e9
+        for _ in range(5):                       # best of 5 batches of 20 launches
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+            ms = min(ms, (time.perf_counter() - t) / 20 * 1e3)
         print(f"{arith}: {ms:.3f} ms  ({2 * M * K * N * S / ms / 1e9:.1f} TF/s fp32-equivalent)", flush=True)
