@@ -235,7 +235,7 @@ def main():
                 "heavy_rows": hs.n_heavy, "heavy_segments": hs.n_seg}
     flops = 2.0 * n_local * (12 * F) * F
     if arith == "bf16x3":     # fp32-equivalent FLOP/s against the bf16 pipe's peak / 6 (six bf16 partial products per multiply)
-        roofline_post = {"bound": "mfma", "kernel": "k_posttrans_x3<3,false,5,2,8> (pna_posttrans_x3_f32)",
+        roofline_post = {"bound": "mfma", "kernel": "k_posttrans_x3<3,false,5,1,12> (pna_posttrans_x3_f32)",
                          "achieved": flops / (t_post * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK / 6 / 1e12, "unit": "TFLOP/s (fp32-equivalent)",
                          "frac": flops / (t_post * 1e-3) / (MFMA_BF16_PEAK / 6), "ms_per_launch": t_post,
                          "bf16_tflops_issued": 6 * flops / (t_post * 1e-3) / 1e12,

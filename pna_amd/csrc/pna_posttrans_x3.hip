@@ -14,13 +14,15 @@
 // float64).  6 instructions x 16 cycles per K = 32 vs 8 x 32 cycles on the f32 MFMA: 2.7x less matrix-pipe time.
 // Non-finite inputs give NaN (x - x0 is NaN for x = Inf); finite inputs never overflow (truncation, not rounding).
 //
-// Tiling: a workgroup = 8 wavefronts; each wavefront owns RT row tiles of 16 rows x (NT x 16) columns x P panels
-// (P = S scalers [+ the h panel]); K is consumed 32 at a time.  The weight is pre-split and pre-packed
-// (pna_posttrans_x3_pack_f32) into the exact LDS image of every chunk, [term][panel][lane group][80 cols][8 k] bf16,
-// so that (i) the chunk is copied global -> LDS by global_load_lds_dwordx4 (no staging registers, no ds_write),
-// double buffered, one barrier per chunk, and (ii) a B fragment is one conflict-free ds_read_b128.  The A fragment
-// (lane (i, g): floats [k0+8g, k0+8g+8) of row i) is loaded one chunk ahead and split in registers while the other
-// wavefront of the SIMD keeps the matrix pipe busy; every B fragment feeds RT row tiles.
+// Tiling: persistent workgroups (one per CU) of WAVES wavefronts; each wavefront owns RT row tiles of 16 rows x (NT x 16)
+// columns x P panels (P = S scalers [+ the h panel]; 12 wavefronts x 1 row tile by default); K is consumed 32 at a time.
+// The weight is pre-split and pre-packed (pna_posttrans_x3_pack_f32) into the exact LDS image of every chunk,
+// [term][panel][lane group][80 cols][8 k] bf16, so that (i) the chunk is copied global -> LDS by
+// global_load_lds_dwordx4 (no staging registers, no ds_write), double buffered, one barrier per chunk, and (ii) a B
+// fragment is one conflict-free ds_read_b128.  The A fragment (lane (i, g): floats [k0+8g, k0+8g+8) of row i) is
+// loaded one chunk ahead and split in registers once per chunk.  The kernel is bound by instruction issue (one
+// instruction per 4 cycles per SIMD, MFMA and VALU together) and by its synchronized non-MFMA phases (epilogue, split,
+// barrier skew), not by the matrix pipe: see DESIGN.md 4.2b for the phase-timer breakdown.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -368,9 +370,12 @@ int launch_v(const XArgs& g, hipStream_t st) {
 
 template <int S, bool HAS_H, int NT>
 int launch_k(const XArgs& g, hipStream_t st) {
-  // two row tiles per wavefront while the accumulators fit (RT * P * NT * 4 registers), else one
-  constexpr int RT = (S + (HAS_H ? 1 : 0)) * NT > 15 ? 1 : 2;
-  return launch_v<S, HAS_H, NT, RT, 8>(g, st);
+  // One row tile per wavefront, 12 wavefronts (3 per SIMD, 170 registers each) while the P * NT accumulator tiles fit
+  // that budget, else 8 (256 registers).  Measured on C3 (S=3, NT=5): 0.775 ms, against 0.82 for 2 row tiles x 8
+  // wavefronts (half the LDS fragment reads, but only 2 wavefronts per SIMD to cover each other's stalls), 0.87 for
+  // 1 x 8 and 1.19 for 1 x 16 (128 registers: spills).
+  constexpr int WAVES = (S + (HAS_H ? 1 : 0)) * NT > 15 ? 8 : 12;
+  return launch_v<S, HAS_H, NT, 1, WAVES>(g, st);
 }
 
 template <int S, bool HAS_H>
