@@ -42,7 +42,8 @@ enum {
   PNA_AGG_MAX = 2,  /* dgl/aggregators.py:10-11  NaN-propagating, like torch.max           */
   PNA_AGG_MIN = 3,  /* dgl/aggregators.py:14-15                                            */
   PNA_AGG_STD = 4,  /* dgl/aggregators.py:18-19  sqrt(relu(E[x^2]-E[x]^2) + 1e-5)          */
-  PNA_AGG_VAR = 5   /* dgl/aggregators.py:22-26  relu(E[x^2]-E[x]^2)                       */
+  PNA_AGG_VAR = 5,  /* dgl/aggregators.py:22-26  relu(E[x^2]-E[x]^2)                       */
+  PNA_AGG_VAR_RAW = 6 /* pytorch_geometric/aggregators.py:25-28  E[x^2]-E[x]^2, NOT clamped (forward only) */
 };
 #define PNA_MAX_AGGR 8
 #define PNA_MAX_SCALER 8

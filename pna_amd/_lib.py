@@ -16,7 +16,7 @@ PNA_ABI_VERSION = 3
 PNA_MAX_AGGR = 8
 PNA_MAX_SCALER = 8
 
-AGG_CODES = {"mean": 0, "sum": 1, "max": 2, "min": 3, "std": 4, "var": 5}
+AGG_CODES = {"mean": 0, "sum": 1, "max": 2, "min": 3, "std": 4, "var": 5, "var_raw": 6}
 
 
 class PnaTuning(ctypes.Structure):

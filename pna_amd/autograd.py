@@ -25,6 +25,8 @@ class AggregateFn(torch.autograd.Function):
             raise NotImplementedError("pna_amd: backward through weighted (non 0/1 adjacency) aggregation is not implemented")
         if len(set(aggregators)) != len(aggregators):
             raise NotImplementedError("pna_amd: backward needs distinct aggregators")
+        if "var_raw" in aggregators:
+            raise NotImplementedError("pna_amd: backward through the unclamped PyG `var` aggregator is not implemented")
         csr = graph.csr
         col = None if edge_resident else (csr.col if col_override is None else col_override)
         aggs = list(aggregators)

@@ -238,7 +238,7 @@ __device__ __forceinline__ void walk(const KArgs& a, Acc<VEC, EXTRA>& acc, int r
 template <int VEC, bool EXTRA>
 __device__ __forceinline__ void finalize_store(const KArgs& a, const Acc<VEC, EXTRA>& acc, int row, int deg,
                                                long offi, long offo) {
-  float mean[VEC], var[VEC], sd[VEC], mx[VEC], mn[VEC];
+  float mean[VEC], var[VEC], vraw[VEC], sd[VEC], mx[VEC], mn[VEC];
   const bool empty = deg <= 0;
   const float D = (EXTRA && a.ew) ? acc.wsum : (float)deg;
   // one IEEE division per row; mean = s * (1/D) is within 1 ulp of the reference's s / D (exact for
@@ -249,6 +249,7 @@ __device__ __forceinline__ void finalize_store(const KArgs& a, const Acc<VEC, EX
     mean[k] = acc.s[k] * invD;
     const float msq = acc.q[k] * invD;
     const float t = msq - mean[k] * mean[k];
+    vraw[k] = t;
     var[k] = (t < 0.f) ? 0.f : t;                         // relu (keeps NaN)
     sd[k] = sqrtf(var[k] + 1e-5f);
     // the fast fold's v_max/v_min ignore NaN; q != q <=> the row holds a NaN message (torch propagates it)
@@ -270,6 +271,7 @@ __device__ __forceinline__ void finalize_store(const KArgs& a, const Acc<VEC, EX
           case PNA_AGG_MAX: v = mx[k]; break;
           case PNA_AGG_MIN: v = mn[k]; break;
           case PNA_AGG_STD: v = sd[k]; break;
+          case PNA_AGG_VAR_RAW: v = vraw[k]; break;
           default: v = var[k]; break;
         }
         o[k] = empty ? 0.f : v * sc;
@@ -729,7 +731,7 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
   if (p->n_aggr <= 0 || p->n_aggr > PNA_MAX_AGGR || p->n_scaler <= 0 || p->n_scaler > PNA_MAX_SCALER)
     return pna_set_error(PNA_E_INVALID, "pna_segreduce_fwd_f32: n_aggr/n_scaler out of range");
   for (int i = 0; i < p->n_aggr; ++i)
-    if (p->aggr[i] < PNA_AGG_MEAN || p->aggr[i] > PNA_AGG_VAR)
+    if (p->aggr[i] < PNA_AGG_MEAN || p->aggr[i] > PNA_AGG_VAR_RAW)
       return pna_set_error(PNA_E_INVALID, "pna_segreduce_fwd_f32: unknown aggregator code");
   const int T = p->n_tower > 1 ? p->n_tower : 1;
   const int64_t ts_in = T > 1 ? p->tower_stride_in : 0, ts_out = T > 1 ? p->tower_stride_out : 0;
