@@ -331,6 +331,21 @@ typedef struct pna_fused_simple_args {
 
 int pna_fused_simple_f32(const pna_fused_simple_args* args, pna_stream_t stream);
 
+/* ---- batching + destination-sorted CSR on the device ----------------------------------
+ *
+ * Replaces dgl.batch (realworld_benchmark/data/molecules.py:153-164: offset + concatenate the member graphs' edge
+ * lists) and the in-edge CSR DGL builds inside update_all (models/dgl/pna_layer.py:64,:202).
+ *   global ids:  dst[k] + node_offset[edge_graph[k]]  (same for src; both NULL = ids are already global)
+ *   rowptr[V+1], col[E] (source per CSR edge), eid[E] (original edge per CSR edge), row[E] (destination per CSR edge)
+ * grouped by destination and STABLE inside a group (the original edge order: DGL's mailbox order).  One radix sort
+ * over the bits the node count needs; workspace from pna_collate_workspace_bytes (-1 if a size leaves int32).
+ */
+int64_t pna_collate_workspace_bytes(int64_t n_edges, int32_t n_nodes);
+int pna_collate_csr_i32(const int32_t* src, const int32_t* dst, int64_t n_edges, int32_t n_nodes,
+                        const int32_t* edge_graph /* nullable [E] */, const int32_t* node_offset /* nullable [n_graphs] */,
+                        int32_t* rowptr, int32_t* col, int32_t* eid, int32_t* row,
+                        void* workspace, int64_t workspace_bytes, pna_stream_t stream);
+
 const char* pna_last_error(void);
 int pna_abi_version(void);
 

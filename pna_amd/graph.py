@@ -40,20 +40,50 @@ class HeavySchedule(NamedTuple):
     seg_heavy: Optional[torch.Tensor]     # int32 [n_seg]
 
 
-def build_csr(src, dst, num_nodes):
+def build_csr(src, dst, num_nodes, edge_graph=None, node_offset=None):
     """In-edges grouped by destination; inside a group the original edge order is kept (this is the
-    mailbox order DGL's degree-bucketed update_all presents to reduce_func)."""
+    mailbox order DGL's degree-bucketed update_all presents to reduce_func).  On the GPU this is
+    pna_collate_csr_i32 (one radix sort over the bits num_nodes needs), which can also apply
+    the member-graph offsets of a batch (edge_graph[k] = graph of edge k, node_offset[g] = first node of
+    graph g); on the CPU (tests, host-side preparation) the same result from torch sort / bincount."""
     if src.numel() >= 2 ** 31 or num_nodes >= 2 ** 31:
         raise ValueError("graph too large for int32 indices")
+    if dst.is_cuda:
+        return _build_csr_device(src, dst, num_nodes, edge_graph, node_offset)
     dst = dst.long()
+    src = src.long()
+    if edge_graph is not None:
+        off = node_offset.long()[edge_graph.long()]
+        src, dst = src + off, dst + off
     order = torch.sort(dst, stable=True).indices
     deg = torch.bincount(dst, minlength=num_nodes)
     rowptr = torch.zeros(num_nodes + 1, dtype=torch.int32, device=dst.device)
     rowptr[1:] = torch.cumsum(deg, 0).to(torch.int32)
-    col = src.long()[order].to(torch.int32)
+    col = src[order].to(torch.int32)
     row = dst[order].to(torch.int32)
     max_degree = int(deg.max().item()) if num_nodes > 0 and src.numel() > 0 else 0
     return CSR(rowptr, col, order, row, max_degree)
+
+
+def _build_csr_device(src, dst, num_nodes, edge_graph, node_offset):
+    dev = dst.device
+    E = int(src.numel())
+    i32 = lambda t: None if t is None else t.to(device=dev, dtype=torch.int32).contiguous()   # noqa: E731
+    src32, dst32, eg32, no32 = i32(src), i32(dst), i32(edge_graph), i32(node_offset)
+    rowptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(E, dtype=torch.int32, device=dev)
+    eid = torch.empty(E, dtype=torch.int32, device=dev)
+    row = torch.empty(E, dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    nbytes = L.pna_collate_workspace_bytes(E, num_nodes)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+    ptr = lambda t: None if t is None or t.numel() == 0 else ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    rc = L.pna_collate_csr_i32(ptr(src32), ptr(dst32), E, num_nodes, ptr(eg32), ptr(no32), ptr(rowptr), ptr(col), ptr(eid),
+                               ptr(row), ptr(ws), nbytes, _lib.stream_ptr(dev))
+    _lib.check(rc, "pna_collate_csr_i32")
+    ws.record_stream(torch.cuda.current_stream(dev))
+    max_degree = int((rowptr[1:] - rowptr[:-1]).max().item()) if num_nodes > 0 and E > 0 else 0
+    return CSR(rowptr, col, eid.long(), row, max_degree)
 
 
 def build_heavy_schedule(rowptr, max_degree, threshold=None, seg_len=None):
@@ -136,6 +166,27 @@ class Graph:
             sizes += g.batch_num_nodes
             offs += g.num_nodes
         return Graph(torch.cat(srcs), torch.cat(dsts), offs, sizes)
+
+    @staticmethod
+    def collate(srcs, dsts, num_nodes_list, device=None):
+        """dgl.batch of edge lists with LOCAL node ids, on the device: one concatenation, then the member-graph
+        offsets are applied inside the CSR build (pna_collate_csr_i32) -- data/molecules.py:153-164 without the
+        per-graph host work.  Returns the batched Graph (global ids in .src/.dst, CSR already built)."""
+        sizes = [int(n) for n in num_nodes_list]
+        src = torch.cat([torch.as_tensor(s) for s in srcs]).to(device) if device is not None else torch.cat([torch.as_tensor(s) for s in srcs])
+        dst = torch.cat([torch.as_tensor(d) for d in dsts]).to(src.device)
+        dev = src.device
+        counts = torch.tensor([int(torch.as_tensor(s).numel()) for s in srcs], device=dev)
+        node_offset = torch.zeros(len(sizes), dtype=torch.long, device=dev)
+        if len(sizes) > 1:
+            node_offset[1:] = torch.cumsum(torch.tensor(sizes[:-1], device=dev), 0)
+        edge_graph = torch.repeat_interleave(torch.arange(len(sizes), device=dev), counts)
+        V = sum(sizes)
+        csr = build_csr(src, dst, V, edge_graph, node_offset)
+        off = node_offset[edge_graph]
+        g = Graph(src.long() + off, dst.long() + off, V, sizes)
+        g._csr = csr
+        return g
 
     def source_features(self, h):
         """Feature table the gather kernel indexes with the CSR's source ids.  Identity for a whole graph;

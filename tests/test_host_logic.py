@@ -239,3 +239,18 @@ def _net_params(meta, a):
                 residual=True, aggregators=meta["aggregators"], scalers=meta["scalers"], avg_d={"log": a["avg_log"]},
                 towers=meta["towers"], divide_input_first=False, divide_input_last=True, edge_feat=meta["edge_dim"] > 0,
                 edge_dim=meta["edge_dim"], pretrans_layers=1, posttrans_layers=1, gru=meta["gru"], device="cpu")
+
+
+def test_collate_applies_member_graph_offsets_like_batch():
+    """Graph.collate (local ids + offsets inside the CSR build) == Graph.batch (offsets applied per graph on the host)."""
+    gen = torch.Generator().manual_seed(0)
+    sizes = [5, 1, 7, 3]
+    srcs = [torch.randint(0, n, (2 * n,), generator=gen) for n in sizes]
+    dsts = [torch.randint(0, n, (2 * n,), generator=gen) for n in sizes]
+    a = Graph.collate(srcs, dsts, sizes)
+    b = Graph.batch([Graph(s, d, n) for s, d, n in zip(srcs, dsts, sizes)])
+    assert a.num_nodes == b.num_nodes and a.batch_num_nodes == b.batch_num_nodes
+    assert torch.equal(a.src, b.src) and torch.equal(a.dst, b.dst)
+    for x, y in zip(a.csr[:4], b.csr[:4]):
+        assert torch.equal(x.long(), y.long())
+    assert a.csr.max_degree == b.csr.max_degree
