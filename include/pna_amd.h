@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PNA_ABI_VERSION 3
+#define PNA_ABI_VERSION 4 /* 4: + pna_posttrans_x3_*, pna_fused_simple_f32, pna_collate_*, PNA_AGG_VAR_RAW */
 
 #define PNA_OK 0
 #define PNA_E_INVALID (-1)   /* bad argument (null pointer, unsupported size, unknown code) */
