@@ -9,6 +9,7 @@ No CPU or eager fallback for the forward; gradients of the degree scalers themse
 (they depend on the graph only).
 """
 import ctypes
+import os
 
 import torch
 
@@ -72,6 +73,9 @@ class AggregateFn(torch.autograd.Function):
         csr = graph.csr
         dev = x.device
         need_x, need_d, need_e = ctx.needs
+        if ctx.col is not None and edge_term is None and ctx.col is csr.col and os.environ.get("PNA_AMD_BWD", "pull") == "pull":
+            gx, gd = _backward_pull(graph, x, dst_term, ident, amx, amn, gagg, aggs, all_aggs, T, F, need_x, need_d)
+            return (None, gx, gd, None, None, None, None, None, None, None, None)
         b = _lib.PnaSegreduceBwdArgs()
         b.rowptr = _lib.dev_ptr(csr.rowptr, torch.int32, "rowptr")
         b.col = _lib.dev_ptr(ctx.col, torch.int32, "col")
@@ -122,6 +126,89 @@ class AggregateFn(torch.autograd.Function):
         return (None, gx, gd, ge, None, None, None, None, None, None, None)
 
 
+def _column_sums(t):
+    """t.sum(0) for a tall (M, N) tensor.  torch's reduction over the long outer dimension of a (1e6, 75) tensor takes
+    15 ms on this stack (rocBLAS gemv: 10 ms, ones @ t: 1.5 ms); folding 64 rows into one (M/64, 64*N) row first gives the
+    reduce kernel a wide inner dimension: 0.07 ms."""
+    M, N = t.shape
+    t = t.contiguous()
+    main = (M // 64) * 64
+    out = t[:main].view(-1, 64 * N).sum(0).view(64, N).sum(0) if main else torch.zeros(N, dtype=t.dtype, device=t.device)
+    return out + t[main:].sum(0) if main < M else out
+
+
+def _backward_pull(graph, x, dst_term, ident, amx, amn, gagg, aggs, all_aggs, T, F, need_x, need_d):
+    """Gradient of the aggregation w.r.t. the source table / destination term WITHOUT one atomic per edge and feature
+    (the scatter kernel: 750 M atomics = 11.4 ms on the roofline workload).  With messages m_k = x[u_k] + dst_term[v]:
+
+        dL/dm_k = base[v] + cvar[v] (m_k - mean[v]) + [k = argmax] G_max[v] + [k = argmin] G_min[v]
+                = R1[v] + R2[v] x[u_k] + (max / min terms),     R2 = cvar,  R1 = base + cvar (dst_term - mean)
+
+    so  grad_x[u] = sum_{out-edges (u,v)} R1[v]  +  x[u] * sum_{out-edges} R2[v]  +  (max / min terms): the two sums are a
+    PULL over the TRANSPOSED graph -- the forward segment-reduce kernel ("sum", 2T towers) on the (V, 2TF) table [R1|R2]
+    -- and the max / min terms are one sparse scatter of V*F values each.  grad_dst[v] = D base + G_max + G_min (the
+    variance term sums to zero over a row).  Formulas as in pna_segreduce_bwd.hip."""
+    from . import functional as PF
+    from .graph import Graph
+    csr = graph.csr
+    V, TF = ident.shape[0], T * F
+    A, A2 = len(aggs), len(all_aggs)
+    iv = ident.view(V, T, A2, F)
+    G = gagg.view(V, T, A, F)
+    D = (csr.rowptr[1:] - csr.rowptr[:-1]).to(torch.float32).view(V, 1, 1)
+    has = D > 0
+    invD = torch.where(has, 1.0 / D.clamp(min=1), torch.zeros_like(D))
+    base = torch.zeros(V, T, F, dtype=torch.float32, device=x.device)
+    if "mean" in aggs:
+        base = base + G[:, :, aggs.index("mean")] * invD
+    if "sum" in aggs:
+        base = base + G[:, :, aggs.index("sum")]
+    cvar = None
+    if any(a in _STAT_AGGS for a in aggs):
+        sd = iv[:, :, all_aggs.index("std")]
+        v = iv[:, :, all_aggs.index("var")] if "var" in all_aggs else sd * sd - 1e-5      # relu'(raw var): 0 at and below 0
+        gs = torch.zeros_like(sd)
+        if "var" in aggs:
+            gs = gs + G[:, :, aggs.index("var")]
+        if "std" in aggs:
+            gs = gs + G[:, :, aggs.index("std")] / (2.0 * sd)
+        cvar = torch.where((v > 0) & has, gs * (2.0 * invD), torch.zeros_like(gs))
+    gx = gd = None
+    if need_x:
+        R1 = base
+        if cvar is not None:
+            mean = iv[:, :, all_aggs.index("mean")]
+            R1 = base + cvar * ((dst_term.view(V, T, F) - mean) if dst_term is not None else -mean)
+        table = torch.cat([R1.reshape(V, TF)] + ([cvar.reshape(V, TF)] if cvar is not None else []), dim=1)
+        gT = getattr(graph, "_pna_amd_transposed", None)
+        if gT is None or gT.num_nodes != x.shape[0]:
+            gT = Graph(csr.row.long(), csr.col.long(), x.shape[0])        # edge (v -> u): pulls row v of the table into u
+            graph._pna_amd_transposed = gT
+        S = PF.aggregate(gT, table, F, ["sum"], n_tower=table.shape[1] // F)
+        gx = S[:, :TF]
+        if cvar is not None:
+            gx = gx + x[:, :TF] * S[:, TF:]
+        gx = gx.contiguous()
+        cols = torch.arange(TF, device=x.device)
+        for name, arg in (("max", amx), ("min", amn)):
+            if name in aggs:
+                valid = arg >= 0
+                tgt = csr.col.long()[arg.clamp(min=0).long()] * TF + cols                     # flat element of grad_x
+                vals = torch.where(valid, G[:, :, aggs.index(name)].reshape(V, TF), torch.zeros((), device=x.device))
+                gx.view(-1).index_add_(0, tgt.view(-1), vals.reshape(-1))
+        if x.shape[1] != TF:
+            full = torch.zeros_like(x)
+            full[:, :TF] = gx
+            gx = full
+    if need_d:
+        gd = D * base
+        for name in ("max", "min"):
+            if name in aggs:
+                gd = gd + torch.where(has, G[:, :, aggs.index(name)], torch.zeros((), device=x.device))
+        gd = gd.reshape(V, TF)
+    return gx, gd
+
+
 class PosttransFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, agg, K, weight, bias, row_scales, h_self):
@@ -139,19 +226,23 @@ class PosttransFn(torch.autograd.Function):
         S = len(scales)
         Kh = 0 if h_self is None else h_self.shape[1]
         a = agg[:, :K]
-        gys = [gy if rs is None else gy * rs.unsqueeze(1) for rs in scales]         # scale_s (.) gy
+        # G = [scale_0 (.) gy | scale_1 (.) gy | ...]  (M, S*N): one operand for both big products, so that each is ONE
+        # library GEMM (three (N x M)(M x K) products with M = 1e6 ran at 20 TF/s; the fused (S*N x M)(M x K) one tiles better)
+        G = gy if S == 1 and scales[0] is None else torch.cat([gy if rs is None else gy * rs.unsqueeze(1) for rs in scales], dim=1)
+        N = gy.shape[1]
         g_agg = g_w = g_b = g_h = None
         if ctx.needs_input_grad[0]:
-            g_agg = torch.cat(gys, dim=1) @ torch.cat([weight[:, Kh + s * K:Kh + (s + 1) * K] for s in range(S)], dim=0)
+            g_agg = G @ torch.cat([weight[:, Kh + s * K:Kh + (s + 1) * K] for s in range(S)], dim=0)
             if agg.shape[1] != K:
                 full = torch.zeros_like(agg)
                 full[:, :K] = g_agg
                 g_agg = full
         if ctx.needs_input_grad[2]:
-            parts = ([gy.t() @ h_self] if Kh else []) + [g.t() @ a for g in gys]
+            gw = G.t() @ a                                                         # (S*N, K): block s = (scale_s gy)^T a
+            parts = ([gy.t() @ h_self] if Kh else []) + [gw[s * N:(s + 1) * N] for s in range(S)]
             g_w = torch.cat(parts, dim=1)
         if ctx.has_bias and ctx.needs_input_grad[3]:
-            g_b = gy.sum(0)
+            g_b = _column_sums(gy)
         if Kh and ctx.needs_input_grad[5]:
             g_h = gy @ weight[:, :Kh]
         return g_agg, None, g_w, g_b, None, g_h

@@ -75,6 +75,36 @@ def test_aggregate_backward(cuda_device, aggs, T, F, terms, hub):
         torch.testing.assert_close(etg.grad.cpu().double(), eto.grad[eid.cpu()], rtol=2e-4, atol=2e-4 * scale)
 
 
+@pytest.mark.parametrize("mode", ["pull", "scatter"])
+@pytest.mark.parametrize("aggs,T,F,hub", [(["mean", "max", "min", "std"], 1, 75, 0), (["sum", "var", "min"], 3, 6, 500),
+                                          (["max"], 1, 4, 0), (["mean", "std", "var", "sum", "max", "min"], 2, 20, 300)])
+def test_aggregate_backward_dst_term_only_both_paths(cuda_device, monkeypatch, mode, aggs, T, F, hub):
+    """Messages x[src] + dst_term[dst] (no per-edge term): the default backward is the atomic-free PULL over the
+    transposed graph (autograd._backward_pull); PNA_AMD_BWD=scatter forces the re-gather/atomic kernel.  Both must
+    match float64 autograd through the oracle, including rows without in-edges and hub rows."""
+    monkeypatch.setenv("PNA_AMD_BWD", mode)
+    V, E = 300, 3000
+    src, dst = _graph(F + T, V, E, hub)
+    g = Graph(src, dst, V).to(cuda_device)
+    gen = torch.Generator().manual_seed(F * 3 + T)
+    x = torch.randn(V, T * F, generator=gen, dtype=torch.float64)
+    dt = torch.randn(V, T * F, generator=gen, dtype=torch.float64)
+    avg_log = torch.tensor(1.6)
+    scalers = ["identity", "amplification", "attenuation"]
+    xo, dto = x.clone().requires_grad_(True), dt.clone().requires_grad_(True)
+    ref = _oracle_aggregate(xo, dto, None, src, dst, V, aggs, scalers, avg_log, T, F)
+    R = torch.randn(ref.shape, generator=gen, dtype=torch.float64)
+    (ref * R).sum().backward()
+    xg = x.float().to(cuda_device).requires_grad_(True)
+    dtg = dt.float().to(cuda_device).requires_grad_(True)
+    amp, att = g.degree_scalers(float(avg_log))
+    out = PF.aggregate(g, xg, F, aggs, n_tower=T, dst_term=dtg, row_scales=[None, amp, att])
+    (out * R.float().to(cuda_device)).sum().backward()
+    scale = 1 + ref.detach().abs().max().item()
+    torch.testing.assert_close(xg.grad.cpu().double(), xo.grad, rtol=2e-4, atol=2e-4 * scale)
+    torch.testing.assert_close(dtg.grad.cpu().double(), dto.grad, rtol=2e-4, atol=2e-4 * scale)
+
+
 def test_aggregate_backward_edge_resident(cuda_device):
     V, E, F = 150, 1800, 12
     src, dst = _graph(3, V, E, 300)
