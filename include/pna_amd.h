@@ -220,6 +220,20 @@ typedef struct pna_segreduce_bwd_args {
 int pna_segreduce_bwd_f32(const pna_segreduce_bwd_args* args, pna_stream_t stream);
 
 /*
+ * Pull formulation of the same backward for messages WITHOUT a per-edge term (m_k = x[col_k] + dst_term[v]):
+ *     dL/dm_k = R1[v] + R2[v] * x[col_k] + [k = argmax] G_max[v] + [k = argmin] G_min[v]
+ *     R2 = (G_var + G_std / (2 std)) [var > 0] (2/D),   R1 = G_mean/D + G_sum + R2 * (dst_term[v] - mean[v])
+ * so grad_x[u] = sum_{out-edges (u,v)} R1[v] + x[u] * sum_{out-edges} R2[v] + the max/min terms: the two sums are
+ * pna_segreduce_fwd_f32 ("sum", 2 * n_tower towers) over the TRANSPOSED graph on the table written by
+ * pna_segreduce_bwd_rowprep_f32 -- table[v] = [R1 (n_tower*F) | R2 (n_tower*F, only if std/var is among aggr[])] --
+ * and pna_segreduce_bwd_argscatter_f32 adds the max/min terms with V*n_tower*F atomics each (instead of one atomic
+ * per edge and feature).  rowprep also writes grad_dst[v] = D*(G_mean/D + G_sum) + G_max + G_min when grad_dst != NULL
+ * (the variance term sums to zero over a row).  Same args struct; fields the formulation does not need are ignored.
+ */
+int pna_segreduce_bwd_rowprep_f32(const pna_segreduce_bwd_args* args, float* table, int64_t ld_table, pna_stream_t stream);
+int pna_segreduce_bwd_argscatter_f32(const pna_segreduce_bwd_args* args, pna_stream_t stream);
+
+/*
  * Per-row degree scalers of the DGL variant -- models/dgl/scalers.py:12-19 evaluated with the
  * reference's exact fp32 rounding sequence (np.log in float64, rounded to fp32, then
  * Tensor.__rtruediv__ = reciprocal()*scalar for amplification and a true division for attenuation):

@@ -113,6 +113,10 @@ def lib():
         L.pna_segreduce_fwd_f32.restype = ctypes.c_int
         L.pna_segreduce_bwd_f32.argtypes = [ctypes.POINTER(PnaSegreduceBwdArgs), ctypes.c_void_p]
         L.pna_segreduce_bwd_f32.restype = ctypes.c_int
+        L.pna_segreduce_bwd_rowprep_f32.argtypes = [ctypes.POINTER(PnaSegreduceBwdArgs), ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+        L.pna_segreduce_bwd_rowprep_f32.restype = ctypes.c_int
+        L.pna_segreduce_bwd_argscatter_f32.argtypes = [ctypes.POINTER(PnaSegreduceBwdArgs), ctypes.c_void_p]
+        L.pna_segreduce_bwd_argscatter_f32.restype = ctypes.c_int
         L.pna_segreduce_partials_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
         L.pna_segreduce_partials_bytes.restype = ctypes.c_int64
         L.pna_degree_scalers_f32.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p,

@@ -141,71 +141,64 @@ def _backward_pull(graph, x, dst_term, ident, amx, amn, gagg, aggs, all_aggs, T,
     """Gradient of the aggregation w.r.t. the source table / destination term WITHOUT one atomic per edge and feature
     (the scatter kernel: 750 M atomics = 11.4 ms on the roofline workload).  With messages m_k = x[u_k] + dst_term[v]:
 
-        dL/dm_k = base[v] + cvar[v] (m_k - mean[v]) + [k = argmax] G_max[v] + [k = argmin] G_min[v]
-                = R1[v] + R2[v] x[u_k] + (max / min terms),     R2 = cvar,  R1 = base + cvar (dst_term - mean)
+        dL/dm_k = R1[v] + R2[v] x[u_k] + [k = argmax] G_max[v] + [k = argmin] G_min[v]      (see include/pna_amd.h)
 
-    so  grad_x[u] = sum_{out-edges (u,v)} R1[v]  +  x[u] * sum_{out-edges} R2[v]  +  (max / min terms): the two sums are a
-    PULL over the TRANSPOSED graph -- the forward segment-reduce kernel ("sum", 2T towers) on the (V, 2TF) table [R1|R2]
-    -- and the max / min terms are one sparse scatter of V*F values each.  grad_dst[v] = D base + G_max + G_min (the
-    variance term sums to zero over a row).  Formulas as in pna_segreduce_bwd.hip."""
+    so  grad_x[u] = sum_{out-edges (u,v)} R1[v]  +  x[u] * sum_{out-edges} R2[v]  +  (max / min terms):
+    pna_segreduce_bwd_rowprep_f32 writes the (V, 2TF) table [R1|R2] (and grad_dst), the two sums are a PULL over the
+    TRANSPOSED graph with the forward kernel ("sum", 2T towers), pna_segreduce_bwd_argscatter_f32 adds the max / min
+    terms with V*T*F atomics each."""
     from . import functional as PF
     from .graph import Graph
     csr = graph.csr
+    dev = x.device
     V, TF = ident.shape[0], T * F
     A, A2 = len(aggs), len(all_aggs)
-    iv = ident.view(V, T, A2, F)
-    G = gagg.view(V, T, A, F)
-    D = (csr.rowptr[1:] - csr.rowptr[:-1]).to(torch.float32).view(V, 1, 1)
-    has = D > 0
-    invD = torch.where(has, 1.0 / D.clamp(min=1), torch.zeros_like(D))
-    base = torch.zeros(V, T, F, dtype=torch.float32, device=x.device)
-    if "mean" in aggs:
-        base = base + G[:, :, aggs.index("mean")] * invD
-    if "sum" in aggs:
-        base = base + G[:, :, aggs.index("sum")]
-    cvar = None
-    if any(a in _STAT_AGGS for a in aggs):
-        sd = iv[:, :, all_aggs.index("std")]
-        v = iv[:, :, all_aggs.index("var")] if "var" in all_aggs else sd * sd - 1e-5      # relu'(raw var): 0 at and below 0
-        gs = torch.zeros_like(sd)
-        if "var" in aggs:
-            gs = gs + G[:, :, aggs.index("var")]
-        if "std" in aggs:
-            gs = gs + G[:, :, aggs.index("std")] / (2.0 * sd)
-        cvar = torch.where((v > 0) & has, gs * (2.0 * invD), torch.zeros_like(gs))
-    gx = gd = None
+    has_var = any(a in _STAT_AGGS for a in aggs)
+    b = _lib.PnaSegreduceBwdArgs()
+    b.rowptr = _lib.dev_ptr(csr.rowptr, torch.int32, "rowptr")
+    b.col = _lib.dev_ptr(csr.col, torch.int32, "col")
+    b.V, b.F = V, F
+    if dst_term is not None:
+        b.dst_term, b.ld_dst = _lib.dev_ptr(dst_term, torch.float32, "dst_term"), dst_term.stride(0)
+    b.n_tower, b.n_aggr, b.tower_stride_in = T, A, F
+    for i, name in enumerate(aggs):
+        b.aggr[i] = _lib.AGG_CODES[name]
+    b.gagg, b.ld_g, b.tower_stride_g = _lib.dev_ptr(gagg, torch.float32, "gagg"), gagg.stride(0), A * F
+    if has_var:
+        base = ident.data_ptr()
+        b.mean = ctypes.c_void_p(base + 4 * all_aggs.index("mean") * F)
+        b.stdv = ctypes.c_void_p(base + 4 * all_aggs.index("std") * F)
+        if "var" in all_aggs:
+            b.var = ctypes.c_void_p(base + 4 * all_aggs.index("var") * F)
+        b.ld_stat, b.tower_stride_stat = ident.stride(0), A2 * F
+    if amx is not None:
+        b.argmax, b.argmin, b.ld_arg = (_lib.dev_ptr(amx, torch.int32, "argmax"), _lib.dev_ptr(amn, torch.int32, "argmin"),
+                                        amx.stride(0))
+    gd = None
+    if need_d:
+        gd = torch.empty(V, TF, dtype=torch.float32, device=dev)
+        b.grad_dst, b.ld_gd = _lib.dev_ptr(gd, torch.float32, "grad_dst"), gd.stride(0)
+    table = torch.empty(V, TF * (2 if has_var else 1), dtype=torch.float32, device=dev)
+    rc = _lib.lib().pna_segreduce_bwd_rowprep_f32(ctypes.byref(b), _lib.dev_ptr(table, torch.float32, "table"), table.stride(0),
+                                                  _lib.stream_ptr(dev))
+    _lib.check(rc, "pna_segreduce_bwd_rowprep_f32")
+    gx = None
     if need_x:
-        R1 = base
-        if cvar is not None:
-            mean = iv[:, :, all_aggs.index("mean")]
-            R1 = base + cvar * ((dst_term.view(V, T, F) - mean) if dst_term is not None else -mean)
-        table = torch.cat([R1.reshape(V, TF)] + ([cvar.reshape(V, TF)] if cvar is not None else []), dim=1)
         gT = getattr(graph, "_pna_amd_transposed", None)
         if gT is None or gT.num_nodes != x.shape[0]:
             gT = Graph(csr.row.long(), csr.col.long(), x.shape[0])        # edge (v -> u): pulls row v of the table into u
             graph._pna_amd_transposed = gT
         S = PF.aggregate(gT, table, F, ["sum"], n_tower=table.shape[1] // F)
-        gx = S[:, :TF]
-        if cvar is not None:
-            gx = gx + x[:, :TF] * S[:, TF:]
+        gx = (S[:, :TF] + x[:, :TF] * S[:, TF:]) if has_var else S
         gx = gx.contiguous()
-        cols = torch.arange(TF, device=x.device)
-        for name, arg in (("max", amx), ("min", amn)):
-            if name in aggs:
-                valid = arg >= 0
-                tgt = csr.col.long()[arg.clamp(min=0).long()] * TF + cols                     # flat element of grad_x
-                vals = torch.where(valid, G[:, :, aggs.index(name)].reshape(V, TF), torch.zeros((), device=x.device))
-                gx.view(-1).index_add_(0, tgt.view(-1), vals.reshape(-1))
+        if amx is not None:
+            b.grad_x, b.ld_gx = _lib.dev_ptr(gx, torch.float32, "grad_x"), gx.stride(0)
+            rc = _lib.lib().pna_segreduce_bwd_argscatter_f32(ctypes.byref(b), _lib.stream_ptr(dev))
+            _lib.check(rc, "pna_segreduce_bwd_argscatter_f32")
         if x.shape[1] != TF:
             full = torch.zeros_like(x)
             full[:, :TF] = gx
             gx = full
-    if need_d:
-        gd = D * base
-        for name in ("max", "min"):
-            if name in aggs:
-                gd = gd + torch.where(has, G[:, :, aggs.index(name)], torch.zeros((), device=x.device))
-        gd = gd.reshape(V, TF)
     return gx, gd
 
 

@@ -230,6 +230,97 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_bwd(const BArgs a) {
   }
 }
 
+
+// ---- pull formulation (messages without a per-edge term) -------------------------------------------------------------
+// dL/dm_k = R1[v] + R2[v] * x[u_k] + max/min terms, R2 = cvar, R1 = base + cvar * (dst_term - mean): one thread per
+// (row, tower*F + f).  table[v] = [R1 (T*F) | R2 (T*F, only when std/var is present)]; grad_dst[v] = D*base + G_max + G_min.
+struct PArgs {
+  const int32_t* rowptr; const int32_t* col;
+  const float* g[6]; const float* mean; const float* stdv; const float* var; const float* dst_term;
+  const int32_t* argmax; const int32_t* argmin;
+  float* table; float* grad_dst; float* grad_x;
+  long ld_g, ld_stat, ld_dst, ld_table, ld_gd, ld_arg, ld_gx, ts_in, ts_g, ts_stat;
+  int V, F, T, has_var;
+};
+
+__global__ __launch_bounds__(kBlock) void k_bwd_rowprep(const PArgs a) {
+  const int TF = a.T * a.F;
+  const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= (long)a.V * TF) return;
+  const int v = (int)(i / TF), c = (int)(i - (long)v * TF);
+  const int t = c / a.F, f = c - t * a.F;
+  const float D = (float)(a.rowptr[v + 1] - a.rowptr[v]);
+  const size_t og = (size_t)v * a.ld_g + (size_t)t * a.ts_g + f;
+  float base = 0.f;
+  if (D > 0.f) {
+    if (a.g[PNA_AGG_MEAN]) base = a.g[PNA_AGG_MEAN][og] / D;
+    if (a.g[PNA_AGG_SUM]) base = base + a.g[PNA_AGG_SUM][og];
+  }
+  float r1 = base;
+  if (a.has_var) {
+    float cvar = 0.f;
+    const size_t os = (size_t)v * a.ld_stat + (size_t)t * a.ts_stat + f;
+    if (D > 0.f) {
+      const float sd = a.stdv ? a.stdv[os] : 1.f;
+      const float vr = a.var ? a.var[os] : sd * sd - 1e-5f;              // relu'(raw var): 0 at and below 0
+      float gs = a.g[PNA_AGG_VAR] ? a.g[PNA_AGG_VAR][og] : 0.f;
+      if (a.g[PNA_AGG_STD]) gs = gs + a.g[PNA_AGG_STD][og] / (2.f * sd);
+      cvar = vr > 0.f ? gs * (2.f / D) : 0.f;
+      const float dt = a.dst_term ? a.dst_term[(size_t)v * a.ld_dst + (size_t)t * a.ts_in + f] : 0.f;
+      r1 = base + cvar * (dt - a.mean[os]);
+    }
+    a.table[(size_t)v * a.ld_table + TF + c] = cvar;
+  }
+  a.table[(size_t)v * a.ld_table + c] = r1;
+  if (a.grad_dst) {
+    float gd = D * base;
+    if (D > 0.f) {
+      if (a.g[PNA_AGG_MAX]) gd = gd + a.g[PNA_AGG_MAX][og];
+      if (a.g[PNA_AGG_MIN]) gd = gd + a.g[PNA_AGG_MIN][og];
+    }
+    a.grad_dst[(size_t)v * a.ld_gd + c] = gd;
+  }
+}
+
+// grad_x[col[arg[v,c]]][c] += G[v,c] for max and min: V*T*F atomics each instead of E*T*F
+__global__ __launch_bounds__(kBlock) void k_bwd_argscatter(const PArgs a) {
+  const int TF = a.T * a.F;
+  const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= (long)a.V * TF) return;
+  const int v = (int)(i / TF), c = (int)(i - (long)v * TF);
+  const int t = c / a.F, f = c - t * a.F;
+  const size_t og = (size_t)v * a.ld_g + (size_t)t * a.ts_g + f;
+  const size_t oa = (size_t)v * a.ld_arg + (size_t)t * a.ts_in + f;
+  if (a.g[PNA_AGG_MAX]) {
+    const int e = a.argmax[oa];
+    if (e >= 0) unsafeAtomicAdd(a.grad_x + (size_t)a.col[e] * a.ld_gx + c, a.g[PNA_AGG_MAX][og]);
+  }
+  if (a.g[PNA_AGG_MIN]) {
+    const int e = a.argmin[oa];
+    if (e >= 0) unsafeAtomicAdd(a.grad_x + (size_t)a.col[e] * a.ld_gx + c, a.g[PNA_AGG_MIN][og]);
+  }
+}
+
+int fill_pull_args(const pna_segreduce_bwd_args* p, PArgs& k, const char* who) {
+  memset(&k, 0, sizeof(k));
+  if (!p) return pna_set_error(PNA_E_INVALID, "null args");
+  if (p->V < 0 || p->F <= 0 || !p->rowptr || !p->gagg || p->n_aggr <= 0 || p->n_aggr > PNA_MAX_AGGR) return pna_set_error(PNA_E_INVALID, who);
+  const int T = p->n_tower > 1 ? p->n_tower : 1;
+  for (int i = 0; i < p->n_aggr; ++i) {
+    const int code = p->aggr[i];
+    if (code < PNA_AGG_MEAN || code > PNA_AGG_VAR || k.g[code]) return pna_set_error(PNA_E_INVALID, who);
+    k.g[code] = p->gagg + (int64_t)i * p->F;
+  }
+  k.has_var = k.g[PNA_AGG_STD] || k.g[PNA_AGG_VAR];
+  if (k.has_var && (!p->mean || !(p->stdv || p->var) || (k.g[PNA_AGG_STD] && !p->stdv))) return pna_set_error(PNA_E_INVALID, who);
+  k.rowptr = p->rowptr; k.col = p->col; k.mean = p->mean; k.stdv = p->stdv; k.var = p->var; k.dst_term = p->dst_term;
+  k.argmax = p->argmax; k.argmin = p->argmin; k.grad_dst = p->grad_dst; k.grad_x = p->grad_x;
+  k.ld_g = p->ld_g; k.ld_stat = p->ld_stat; k.ld_dst = p->ld_dst; k.ld_gd = p->ld_gd; k.ld_arg = p->ld_arg; k.ld_gx = p->ld_gx;
+  k.ts_in = T > 1 ? p->tower_stride_in : 0; k.ts_g = T > 1 ? p->tower_stride_g : 0; k.ts_stat = T > 1 ? p->tower_stride_stat : 0;
+  k.V = p->V; k.F = p->F; k.T = T;
+  return PNA_OK;
+}
+
 }  // namespace
 
 extern "C" int pna_segreduce_bwd_f32(const pna_segreduce_bwd_args* p, pna_stream_t stream) {
@@ -278,6 +369,36 @@ extern "C" int pna_segreduce_bwd_f32(const pna_segreduce_bwd_args* p, pna_stream
   dim3 grid((unsigned)(light_blocks + k.n_heavy_blocks), (unsigned)(tiles * T));
   if (vec == 4) hipLaunchKernelGGL((k_segreduce_bwd<4>), grid, dim3(kBlock), 0, (hipStream_t)stream, k);
   else hipLaunchKernelGGL((k_segreduce_bwd<1>), grid, dim3(kBlock), 0, (hipStream_t)stream, k);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
+  return PNA_OK;
+}
+
+extern "C" int pna_segreduce_bwd_rowprep_f32(const pna_segreduce_bwd_args* p, float* table, int64_t ld_table, pna_stream_t stream) {
+  PArgs k;
+  int rc = fill_pull_args(p, k, "pna_segreduce_bwd_rowprep_f32: bad arguments");
+  if (rc != PNA_OK) return rc;
+  if (p->V == 0) return PNA_OK;
+  const long TF = (long)k.T * k.F;
+  if (!table || ld_table < TF * (k.has_var ? 2 : 1)) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_rowprep_f32: table too narrow");
+  if (p->edge_term) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_rowprep_f32: the pull formulation has no per-edge term");
+  k.table = table; k.ld_table = ld_table;
+  const long n = (long)k.V * TF;
+  hipLaunchKernelGGL(k_bwd_rowprep, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, k);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
+  return PNA_OK;
+}
+
+extern "C" int pna_segreduce_bwd_argscatter_f32(const pna_segreduce_bwd_args* p, pna_stream_t stream) {
+  PArgs k;
+  int rc = fill_pull_args(p, k, "pna_segreduce_bwd_argscatter_f32: bad arguments");
+  if (rc != PNA_OK) return rc;
+  if (p->V == 0 || (!k.g[PNA_AGG_MAX] && !k.g[PNA_AGG_MIN])) return PNA_OK;
+  if (!p->col || !p->grad_x || (k.g[PNA_AGG_MAX] && !p->argmax) || (k.g[PNA_AGG_MIN] && !p->argmin))
+    return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_argscatter_f32: col / grad_x / argmax / argmin missing");
+  const long n = (long)k.V * k.T * k.F;
+  hipLaunchKernelGGL(k_bwd_argscatter, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, k);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
   return PNA_OK;
