@@ -148,8 +148,13 @@ def main():
     h_all = torch.randn(V, F, generator=torch.Generator().manual_seed(1234)) if world == 1 else None
     # node features live in a 16-byte aligned row pitch (80 floats for F=75), the layout a multi-layer net keeps
     # its activations in; the kernels accept any pitch (--x-pitch 75 = dense rows, ~3 % slower gather)
-    h_buf = torch.zeros(hi - lo, max(args.x_pitch, F), device=dev)
-    h = h_buf[:, :F]
+    if world > 1:
+        # multi-GPU: the features live in the shard's resident [local | halo] table, so the halo exchange of the
+        # timed step receives the peers' rows in place (no concatenation pass)
+        h = g.alloc_features(F, pitch=max(args.x_pitch, F), device=dev)
+    else:
+        h_buf = torch.zeros(hi - lo, max(args.x_pitch, F), device=dev)
+        h = h_buf[:, :F]
     if world == 1:
         h.copy_(h_all)
     else:

@@ -64,6 +64,16 @@ def _worker(rank, world, port, V, E, F):
         xg = x.clone().requires_grad_(True)
         (xg[src] * w).sum().backward()
         torch.testing.assert_close(x_local.grad, xg.grad[lo:hi], rtol=1e-5, atol=1e-5)
+        # 5. resident extended table (inference path): features written into alloc_features() are exchanged in place,
+        #    with a row pitch wider than F; the same gather identity must hold and the local rows stay untouched
+        h_res = g.alloc_features(F, pitch=F + 3)
+        h_res.copy_(x[lo:hi])
+        with torch.no_grad():
+            ext2 = g.source_features(h_res)
+        assert ext2.shape == (g.num_nodes + g.n_halo, F) and ext2.stride(0) == F + 3
+        assert ext2.untyped_storage().data_ptr() == h_res.untyped_storage().data_ptr()       # no concatenation happened
+        assert torch.equal(ext2[g.src], x[src[mine]])
+        assert torch.equal(ext2[: g.num_nodes], x[lo:hi])
         dist.barrier()
     finally:
         dist.destroy_process_group()
