@@ -101,6 +101,32 @@ with torch.no_grad():
 out["molhiv_simple_layer"] = dict(graphs=2048, V=V, E=E, hidden=80, eager_ms=eager, hipgraph_ms=graphed,
                                   edges_per_s_hipgraph=E / graphed * 1e3, cpu_oracle_ms=cpu, max_abs_err_vs_oracle=err)
 
+# ---- the whole MolHIV net of the reference's README (PNASimpleLayer x 4, hidden 80, mean readout), same batch ----
+from pna_amd.nets import PNANetHIV  # noqa: E402
+net = PNANetHIV(dict(hidden_dim=80, out_dim=80, in_feat_dropout=0.0, dropout=0.3, L=4, readout="mean", batch_norm=True,
+                     residual=True, aggregators=AGG, scalers=SCA, avg_d=avg, posttrans_layers=1, device=dev)).to(dev)
+gen = torch.Generator().manual_seed(0)
+atoms = torch.stack([torch.randint(0, d, (V,), generator=gen) for d in (119, 4, 12, 12, 10, 6, 6, 2, 2)], dim=1).to(dev)
+labels = torch.randint(0, 2, (len(sizes),), generator=gen)
+net.eval()
+with torch.no_grad():
+    net_eager = gpu_ms(lambda: net(g, atoms))
+opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+net.train()
+
+
+def train_step():
+    opt.zero_grad()
+    loss = net.loss(net(g, atoms), labels)
+    loss.backward()
+    opt.step()
+
+
+net_train = gpu_ms(train_step, iters=20)
+out["molhiv_net_4_layers"] = dict(graphs=2048, V=V, E=E, hidden=80, L=4, inference_eager_ms=net_eager,
+                                  graphs_per_s_inference=2048 / net_eager * 1e3, train_step_ms=net_train,
+                                  graphs_per_s_training=2048 / net_train * 1e3)
+
 # ---- configs[0]: multitask dense layer, B=128 graphs of N=50 nodes, hidden 16, 4 towers ----
 gen = torch.Generator().manual_seed(1234)
 B, N = 128, 50
