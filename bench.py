@@ -118,11 +118,19 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PNA_BENCH_ONE_DEVICE=1 PNA_BENCH_BACKEND=gloo: smoke-test the N > 1 code path on a box with ONE GPU (all ranks on
+    # cuda:0, exchange staged through the host; timings are meaningless) -- tools/gpu_check.sh does this with N=2
+    one_dev = os.environ.get("PNA_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("PNA_BENCH_BACKEND", "nccl")
+    local_dev = 0 if one_dev else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from pna_amd import Graph
     from pna_amd.dgl.pna_layer import PNASimpleLayer
