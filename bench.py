@@ -232,13 +232,15 @@ def main():
     alg_read = e_local * (4 * F + 4) + 4 * (n_local + 1)
     alg_write = n_local * 16 * F
     alg_bytes = alg_read + alg_write
-    traffic = None
+    traffic = traffic_post = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")      # PMC-derived HBM bytes per launch, if collected
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("pna_segreduce_c3", {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get("pna_segreduce_c3", {}).get("hbm_bytes_per_launch")
+            traffic_post = tj.get("pna_posttrans_x3_c3" if arith == "bf16x3" else "pna_posttrans_f32_c3", {}).get("hbm_bytes_per_launch")
         except Exception:
-            traffic = None
+            traffic = traffic_post = None
     roofline = {"bound": "hbm", "kernel": "k_segreduce_fast<4> + k_heavy_finalize (pna_segreduce_fwd_f32)",
                 "achieved": alg_bytes / (t_seg * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": alg_bytes / (t_seg * 1e-3) / HBM_PEAK, "traffic": traffic,
@@ -250,7 +252,7 @@ def main():
     if arith == "bf16x3":     # fp32-equivalent FLOP/s against the bf16 pipe's peak / 6 (six bf16 partial products per multiply)
         roofline_post = {"bound": "mfma", "kernel": "k_posttrans_x3<3,false,5,1,12> (pna_posttrans_x3_f32)",
                          "achieved": flops / (t_post * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK / 6 / 1e12, "unit": "TFLOP/s (fp32-equivalent)",
-                         "frac": flops / (t_post * 1e-3) / (MFMA_BF16_PEAK / 6), "ms_per_launch": t_post,
+                         "frac": flops / (t_post * 1e-3) / (MFMA_BF16_PEAK / 6), "ms_per_launch": t_post, "traffic": traffic_post,
                          "bf16_tflops_issued": 6 * flops / (t_post * 1e-3) / 1e12,
                          "exact_f32_mfma_kernel": {"kernel": "k_posttrans<3,false,5> (pna_posttrans_f32)", "ms_per_launch": t_post_f32,
                                                    "achieved": flops / (t_post_f32 * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12,
@@ -258,7 +260,7 @@ def main():
     else:
         roofline_post = {"bound": "mfma", "kernel": "k_posttrans<3,false,5> (pna_posttrans_f32)", "achieved": flops / (t_post * 1e-3) / 1e12,
                          "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s", "frac": flops / (t_post * 1e-3) / MFMA_F32_PEAK,
-                         "ms_per_launch": t_post}
+                         "ms_per_launch": t_post, "traffic": traffic_post}
 
     rec = {
         "metric": "PNA-layer fwd edges/sec (F=75, 4 aggr x 3 scalers)", "value": value, "unit": "edges/s",

@@ -51,7 +51,14 @@ if "segreduce_calib" in out and "FETCH_SIZE" in out["segreduce_calib"]:
     summary["pna_segreduce_c3"] = {"fabric_read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                                    "hbm_bytes_per_launch": rd + wr,
                                    "algorithmic_bytes_per_launch": 10_000_000 * (4 * F + 4) + 4 * 1_000_001 + 1_000_000 * 16 * F}
-    json.dump({"pna_segreduce_c3": summary["pna_segreduce_c3"], "calibration": summary["calibration"]},
-              open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
+    traffic = {"pna_segreduce_c3": summary["pna_segreduce_c3"], "calibration": summary["calibration"]}
+    for key, name in (("posttrans_bf16x3_c3", "pna_posttrans_x3_c3"), ("posttrans_f32_c3", "pna_posttrans_f32_c3")):
+        k = out.get(key, {})
+        if "FETCH_SIZE" in k and "WRITE_SIZE" in k:      # same byte scale: the contraction's A loads are 16-byte gathers too
+            summary[name] = {"fabric_read_bytes_per_launch": k["FETCH_SIZE"] * scale, "write_bytes_per_launch": k["WRITE_SIZE"] * 1024,
+                             "hbm_bytes_per_launch": k["FETCH_SIZE"] * scale + k["WRITE_SIZE"] * 1024,
+                             "algorithmic_bytes_per_launch": 1_000_000 * (4 * F * 4 + F * 4) + 2 * 1_000_000 * 4}
+            traffic[name] = summary[name]
+    json.dump(traffic, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
 json.dump(summary, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summary.get("pna_segreduce_c3"), indent=1), json.dumps(summary.get("calibration"), indent=1))
