@@ -5,6 +5,6 @@ lukecavabarrett/pna: hand-written HIP kernels behind the reference's own layer A
     from pna_amd.pytorch.pna.layer import PNALayer                     # <- models/pytorch/pna/layer.py
     from pna_amd import Graph                                          # <- the DGLGraph the layers consume
 """
-from .graph import Graph  # noqa: F401
+from .graph import Graph, avg_d_from_adjacency, avg_d_from_degrees  # noqa: F401
 
 __version__ = "0.1.0"

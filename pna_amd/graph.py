@@ -277,3 +277,28 @@ class Graph:
             sizes = torch.tensor(self.batch_num_nodes, dtype=torch.float32, device=self.device)
             self._snorm_n = torch.repeat_interleave((1.0 / sizes).sqrt(), sizes.long()).unsqueeze(1)
         return self._snorm_n
+
+
+def avg_d_from_degrees(D):
+    """The `avg_d` dictionary the sparse nets are configured with: statistics of the in-degrees D of ALL training-set
+    nodes -- realworld_benchmark/main_molecules.py:368-372, main_HIV.py:240-244.  `D`: a float/int tensor of in-degrees,
+    a Graph, or an iterable of Graphs (their degrees are concatenated, like the reference's `torch.cat`).
+    Returns 0-dim fp32 tensors: lin = mean(D), exp = mean(exp(1/D) - 1), log = mean(log(D + 1))."""
+    if isinstance(D, Graph):
+        D = D.in_degrees()
+    elif not torch.is_tensor(D):
+        D = torch.cat([g.in_degrees() for g in D])
+    D = D.to(torch.float32)
+    return dict(lin=torch.mean(D), exp=torch.mean(torch.exp(torch.div(1, D)) - 1), log=torch.mean(torch.log(D + 1)))
+
+
+def avg_d_from_adjacency(adjs):
+    """The dense variant's `avg_d`: the mean over batches of per-batch means of the row sums D = adj.sum(-1) --
+    multitask_benchmark/util/train.py:90-94.  `adjs`: an iterable of (B, N, N) adjacency tensors (or one tensor)."""
+    if torch.is_tensor(adjs):
+        adjs = [adjs]
+    dlist = [torch.sum(A, dim=-1) for A in adjs]
+    n = len(dlist)
+    return dict(lin=sum(torch.mean(D) for D in dlist) / n,
+                exp=sum(torch.mean(torch.exp(torch.div(1, D)) - 1) for D in dlist) / n,
+                log=sum(torch.mean(torch.log(D + 1)) for D in dlist) / n)

@@ -254,3 +254,24 @@ def test_collate_applies_member_graph_offsets_like_batch():
     for x, y in zip(a.csr[:4], b.csr[:4]):
         assert torch.equal(x.long(), y.long())
     assert a.csr.max_degree == b.csr.max_degree
+
+
+def test_avg_d_producers_match_the_reference_formulas():
+    """avg_d of the sparse nets (main_molecules.py:368-372) and of the dense benchmark
+    (util/train.py:90-94: mean over batches of per-batch means)."""
+    import math
+    from pna_amd import avg_d_from_adjacency, avg_d_from_degrees
+    g1 = Graph(torch.tensor([0, 1, 2, 2]), torch.tensor([1, 2, 0, 1]), 3)          # in-degrees 1, 2, 1
+    g2 = Graph(torch.tensor([0, 1]), torch.tensor([1, 0]), 2)                        # in-degrees 1, 1
+    a = avg_d_from_degrees([g1, g2])
+    D = [1, 2, 1, 1, 1]
+    assert a["lin"].item() == pytest.approx(sum(D) / 5)
+    assert a["log"].item() == pytest.approx(sum(math.log(d + 1) for d in D) / 5, rel=1e-6)
+    assert a["exp"].item() == pytest.approx(sum(math.exp(1 / d) - 1 for d in D) / 5, rel=1e-6)
+    assert a["log"].dtype == torch.float32 and a["log"].dim() == 0
+    assert avg_d_from_degrees(g1)["lin"].item() == pytest.approx(4 / 3)
+    adj1 = torch.tensor([[[0., 1.], [1., 0.]]])                                      # D = 1, 1
+    adj2 = torch.tensor([[[0., 1., 1.], [1., 0., 0.], [1., 0., 0.]]])                # D = 2, 1, 1
+    b = avg_d_from_adjacency([adj1, adj2])
+    assert b["lin"].item() == pytest.approx((1.0 + 4 / 3) / 2)
+    assert b["log"].item() == pytest.approx((math.log(2) + (math.log(3) + 2 * math.log(2)) / 3) / 2, rel=1e-6)
