@@ -62,3 +62,40 @@ def test_full_size_properties(cuda_device, c3):
     r = ops.segreduce(c.rowptr, col_rev, xd, F, AGGS, heavy=g.heavy_schedule(), workspace=g.workspace, items=g.work_items())
     assert torch.equal(r[:, F:3 * F], a[:, F:3 * F])
     torch.testing.assert_close(r[:, :F], a[:, :F], rtol=1e-4, atol=1e-5)
+
+
+def test_full_size_contraction_bf16x3_properties(cuda_device, c3):
+    """The posttrans contraction at the roofline size (1M x 900 -> 75), where the layers use the bf16x3 kernel:
+    sampled rows against float64, agreement with the exact f32-MFMA kernel on every row, determinism, and row
+    permutation equivariance (a row's result does not depend on which tile / wavefront / lane computes it)."""
+    from pna_amd import ops
+    g, x = c3
+    xd = x.to(cuda_device)
+    agg = PF.aggregate(g, xd, F, AGGS)
+    gen = torch.Generator().manual_seed(7)
+    W = (torch.randn(F, 12 * F, generator=gen) / (12 * F) ** 0.5).to(cuda_device)
+    b = torch.randn(F, generator=gen).to(cuda_device)
+    amp, att = g.degree_scalers(2.2488)
+    scales = [None, amp, att]
+    assert V >= ops.X3_MIN_ROWS
+    y = ops.posttrans(agg, 4 * F, W, scales, b, arith="bf16x3")
+    # determinism
+    assert torch.equal(y, ops.posttrans(agg, 4 * F, W, scales, b, arith="bf16x3"))
+    # every row against the exact-fp32 kernel: differences are fp32 summation-order noise relative to the output scale
+    y32 = ops.posttrans(agg, 4 * F, W, scales, b, arith="f32")
+    assert (y - y32).abs().max().item() <= 2e-5 * y32.abs().max().item()
+    # 4096 sampled rows against float64, error relative to the mass sum |a_k w_k|
+    idx = torch.randint(0, V, (4096,), generator=gen).to(cuda_device)
+    a64 = agg[idx].double()
+    ref = b.double()[None, :].repeat(idx.numel(), 1)
+    mass = b.abs().double()[None, :].repeat(idx.numel(), 1)
+    for s, sc in enumerate(scales):
+        f = torch.ones(idx.numel(), dtype=torch.float64, device=cuda_device) if sc is None else sc[idx].double()
+        Ws = W[:, s * 4 * F:(s + 1) * 4 * F].double()
+        ref = ref + f[:, None] * (a64 @ Ws.t())
+        mass = mass + f.abs()[:, None] * (a64.abs() @ Ws.abs().t())
+    assert ((y[idx].double() - ref).abs() / mass).max().item() <= 5e-7
+    # row permutation equivariance, bit for bit
+    perm = torch.randperm(V, generator=gen).to(cuda_device)
+    yp = ops.posttrans(agg[perm].contiguous(), 4 * F, W, [None, amp[perm].contiguous(), att[perm].contiguous()], b, arith="bf16x3")
+    assert torch.equal(yp, y[perm])
