@@ -16,6 +16,13 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
+    # a fresh checkout has no libpna_amd.so (built artefacts stay out of git): build it when hipcc is here, keep a
+    # current prebuilt copy otherwise (the GPU box receives the built file with the snapshot)
+    try:
+        from pna_amd import build as _build
+        _build.build(verbose=False)
+    except Exception as ex:            # the tests that need the library fail with their own message
+        print(f"[conftest] libpna_amd.so not (re)built: {ex}", file=sys.stderr)
 
 
 def load_golden(name):
