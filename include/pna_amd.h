@@ -13,7 +13,9 @@
  *   - stream-ordered and asynchronous: nothing here synchronises the device;
  *   - re-entrant: no global mutable state except the per-thread last-error string;
  *   - return value 0 = success, negative = error (see PNA_E_*); pna_last_error() gives the text;
- *   - all arithmetic is fp32; indices are int32; row strides (ld*) are in floats.
+ *   - all data is fp32 and all arithmetic is fp32 (pna_posttrans_x3_f32 evaluates each fp32 product as six exact
+ *     bf16 partial products accumulated in fp32 -- fp32-level accuracy, see there); indices are int32; row strides
+ *     (ld*) are in floats.
  */
 #ifndef PNA_AMD_H
 #define PNA_AMD_H
