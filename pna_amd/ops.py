@@ -171,11 +171,14 @@ def posttrans(a_mat: torch.Tensor, K: int, weight: torch.Tensor, row_scales: Seq
     if weight.shape[1] != Kh + S * K:
         raise ValueError(f"weight has {weight.shape[1]} input columns, expected Kh + n_scaler*K = {Kh + S * K}")
     dev = a_mat.device
+    explicit = arith is not None
     arith = arith or POSTTRANS_ARITH
     if arith not in ("f32", "bf16x3", "auto"):
         raise ValueError(f"unknown posttrans arithmetic {arith!r} (f32 | bf16x3 | auto)")
     if arith == "bf16x3" and S > 3:
-        raise ValueError("the bf16x3 posttrans kernel supports at most 3 scalers")
+        if explicit:
+            raise ValueError("the bf16x3 posttrans kernel supports at most 3 scalers")
+        arith = "f32"                              # the process-wide preference falls back where bf16x3 is not implemented
     x3 = arith == "bf16x3" or (arith == "auto" and S <= 3 and M >= X3_MIN_ROWS)
     w_img, wh_img = (pack_posttrans_weight_x3 if x3 else pack_posttrans_weight)(weight, K, S, Kh)
     if out is None:
