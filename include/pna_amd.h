@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define PNA_ABI_VERSION 4 /* 4: + pna_posttrans_x3_*, pna_fused_simple_f32, pna_collate_*, PNA_AGG_VAR_RAW */
+#define PNA_ABI_VERSION 5 /* 5: pna_posttrans_args.pipeline; the hand-scheduled gather takes dst_term; + pna_pack_rows_f32.
+                             4: + pna_posttrans_x3_*, pna_fused_simple_f32, pna_collate_*, PNA_AGG_VAR_RAW */
 
 #define PNA_OK 0
 #define PNA_E_INVALID (-1)   /* bad argument (null pointer, unsupported size, unknown code) */
@@ -59,7 +60,8 @@ typedef struct pna_tuning {
   int32_t vec;             /* features per lane: 4 (dwordx4 gathers) or 1; 0 = auto                   */
   int32_t nt_store;        /* 1 = non-temporal output stores; 0 = auto(1); -1 = plain stores          */
   int32_t prefetch;        /* 1 = fetch the next row's source ids one row ahead; 0 = auto(1); -1 = off */
-  int32_t reserved[2];     /* [0]: debug bits for bench experiments (bit0 = skip output stores);
+  int32_t reserved[2];     /* [0]: ignored by the shipped library (bench-experiment knobs that exist only in the
+                                   separate -DPNA_AMD_EXPERIMENTS build of tools/build_experiments.sh);
                               [1]: 1 = force the compiler-scheduled kernel instead of the hand-scheduled one */
 } pna_tuning;
 
@@ -84,6 +86,10 @@ typedef struct pna_tuning {
  *   (row_scale[s] == NULL means the identity scaler).  Scaler-major / aggregator-minor is the
  *   reference's concatenation order (pna_layer.py:48-49).
  * Rows with no in-edges get 0 in every block (DGL's zero initialiser; undefined in the reference).
+ * Arithmetic: fp32, no FMA contraction, sums in CSR edge order (hub rows: per 128-edge segment, then over segments).
+ * One deliberate departure from the reference's formula: mean = s * (1/D) with ONE IEEE division per row instead of
+ * s / D per feature -- within 1 ulp of s / D (exact when D is a power of two), far inside the summation-order noise
+ * the 1e-5 parity bar allows for mean / std; max, min and the degree scalers are bit-exact.
  * edge_weight (nullable, [E]): mean/sum/std/var use sum_k w_k m_k and D = sum_k w_k; max/min use
  *   only edges with w_k > 0.
  * argmax/argmin (nullable, (V, ld_arg) int32): CSR edge position k of the first max / min, -1 for
@@ -142,8 +148,9 @@ typedef struct pna_segreduce_args {
   const int32_t* seg_heavy;  /* [n_seg] index into heavy_rows of the row each segment belongs to   */
   float* partials;           /* workspace, pna_segreduce_partials_bytes(n_seg, F, n_tower) bytes   */
 
-  /* Optional work list for the hand-scheduled kernel (used when the call is the plain 4-aggregator gather
-   * mean|max|min|std with the identity scaler): n_work_items records {row, beg, end, slot} (int32 x 4).  slot < 0:
+  /* Optional work list for the hand-scheduled kernel (used when the call is the 4-aggregator gather
+   * mean|max|min|std with the identity scaler, messages x[col[k]] or x[col[k]] + dst_term[v] -- i.e. what
+   * PNASimpleLayer and the PNATower layers without edge features issue): n_work_items records {row, beg, end, slot} (int32 x 4).  slot < 0:
    * the record is a whole row [beg,end) = [rowptr[row], rowptr[row+1]) whose result is finalised and stored;
    * slot >= 0: the record is heavy segment number `slot` (its partials go to partials[slot]; the segments of a
    * heavy row must be the ones heavy_segptr describes).  Every row must be covered exactly once, either by one
@@ -292,6 +299,10 @@ typedef struct pna_posttrans_args {
   int64_t ld_res;
   float* y;            /* (M, ldy), N columns */
   int64_t ldy;
+  int32_t pipeline;    /* pna_posttrans_x3_f32 only: 0 = library default; 2 = two weight buffers in LDS, one barrier at every
+                          chunk boundary; 3 = three weight buffers, one barrier in the middle of every chunk (wavefronts
+                          cross chunk boundaries unsynchronised).  Same arithmetic, bit-identical results. */
+  int32_t _pad_p;
 } pna_posttrans_args;
 
 int pna_posttrans_f32(const pna_posttrans_args* args, pna_stream_t stream);
@@ -302,8 +313,15 @@ int pna_posttrans_f32(const pna_posttrans_args* args, pna_stream_t stream);
  * cut exactly into three bf16 terms (8+8+8 mantissa bits, by truncation) and each product is evaluated
  * as its six partial products of weight >= 2^-16, accumulated in fp32 by v_mfma_f32_16x16x32_bf16; the
  * dropped partial products are below 2^-23 of the product (the size of one fp32 rounding).  Inputs and
- * outputs stay fp32; results agree with pna_posttrans_f32 to fp32 summation-order noise.  Non-finite
- * inputs give NaN.  w_img / wh_img of the args are the images made by pna_posttrans_x3_pack_f32 (a
+ * outputs stay fp32; results agree with pna_posttrans_f32 to fp32 summation-order noise.
+ * Non-finite operands: NaN propagates; a +-Inf in `a` / `h` / the weight keeps its row's results +-Inf / NaN exactly as
+ * in pna_posttrans_f32 when the other operand's three bf16 terms are all non-zero (any generic fp32 value), and gives
+ * NaN instead of +-Inf where the other operand is exactly bf16-representable (its residual terms are 0: Inf * 0) --
+ * non-finite wherever the fp32 contraction is non-finite, never finite garbage (before the ReLU of the epilogue,
+ * which maps -Inf to 0 but keeps NaN).  Subnormal bf16 terms (operands below 2^-126, residual terms of operands below
+ * ~2^-110) may be flushed by the matrix pipe: an absolute error of at most 2^-126 * |other operand| per product.
+ * tests/test_gpu_posttrans_x3.py pins all of this (mixed 1e-20..1e20 magnitudes, cancellation between scaler blocks,
+ * K = 900 equal-sign sums, subnormals, single infinities).  w_img / wh_img of the args are the images made by pna_posttrans_x3_pack_f32 (a
  * different format from pna_posttrans_pack_f32's; sizes in BYTES from pna_posttrans_x3_packed_bytes).
  */
 int64_t pna_posttrans_x3_packed_bytes(int32_t K, int32_t N, int32_t n_scaler, int32_t Kh, int64_t* wh_bytes);

@@ -12,7 +12,9 @@
 // products (a1 b2, a2 b1, a2 b2) are below 2^-23 |a b|: the same order as ONE fp32 rounding of the product, far below
 // the fp32 summation-order noise of a K = 900 contraction (tests/test_gpu_posttrans_x3.py measures both paths against
 // float64).  6 instructions x 16 cycles per K = 32 vs 8 x 32 cycles on the f32 MFMA: 2.7x less matrix-pipe time.
-// Non-finite inputs give NaN (x - x0 is NaN for x = Inf); finite inputs never overflow (truncation, not rounding).
+// +-Inf operands (`a`, `h`, and weights at pack time) stay infinities (split8_inf) and NaN propagates, so the Inf/NaN
+// pattern of the result is the fp32 contraction's (except Inf * Inf at the same k, which gives NaN); finite inputs never overflow (truncation, not rounding).  bf16-subnormal terms (|x| < 2^-126, and the residual terms of
+// |x| < ~2^-110) may be flushed by the matrix pipe: an ABSOLUTE error of at most 2^-126 |w| per product, see the tests.
 //
 // Tiling: persistent workgroups (one per CU) of WAVES wavefronts; each wavefront owns RT row tiles of 16 rows x (NT x 16)
 // columns x P panels (P = S scalers [+ the h panel]; 12 wavefronts x 1 row tile by default); K is consumed 32 at a time.
@@ -40,6 +42,7 @@ struct __attribute__((packed, aligned(4))) f4u { f4 v; };
 
 constexpr int kKC = 32;                       // k values per chunk
 constexpr int kMaxNT = 5;
+constexpr int kDefaultNBuf = 3;              // weight buffers of the default pipeline (pna_posttrans_args.pipeline = 0)
 constexpr int kNW = kMaxNT * 16;              // 80 output columns per workgroup
 constexpr int kPanelB = 4 * kNW * 8 * 2;      // bytes of one (term, panel) image: [4 lane groups][80][8] bf16 = 5120
 constexpr int kPanelV = kPanelB / 16;         // ... in 16-byte pieces = 320 = 5 wavefronts' worth
@@ -75,6 +78,37 @@ __device__ __forceinline__ void split8(const f4 lo, const f4 hi, bf8& t0, bf8& t
   t0 = __builtin_bit_cast(bf8, p0); t1 = __builtin_bit_cast(bf8, p1); t2 = __builtin_bit_cast(bf8, p2);
 }
 
+// The same for a fragment that holds +-Inf: x - top16(x) would be Inf - Inf = NaN and poison the whole row, and an Inf in
+// the top term would meet the other operand's residual terms, which are 0 for a bf16-representable value (Inf * 0 = NaN),
+// where the fp32 contraction gives +-Inf.  An infinite element is therefore carried by its LOWEST term alone (t0 = t1 = 0,
+// t2 = +-Inf): of the six partial products only a2*b0 sees it, and b0 = 0 only where the fp32 product Inf * w is NaN too
+// (w = 0).  NaN needs nothing: it propagates through the subtraction.
+__device__ __forceinline__ void split8_inf(const f4 lo, const f4 hi, bf8& t0, bf8& t1, bf8& t2) {
+  const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  u4 p0, p1, p2;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float xe = x[2 * j], xo = x[2 * j + 1];
+    const bool ie = __builtin_fabsf(xe) == INFINITY, io = __builtin_fabsf(xo) == INFINITY;
+    const float fe = ie ? 0.f : xe, fo = io ? 0.f : xo;
+    const float re = fe - top16(fe), ro = fo - top16(fo);
+    const float se = re - top16(re), so = ro - top16(ro);
+    p0[j] = pack_hi(fe, fo);
+    p1[j] = pack_hi(re, ro);
+    p2[j] = pack_hi(ie ? xe : se, io ? xo : so);
+  }
+  t0 = __builtin_bit_cast(bf8, p0); t1 = __builtin_bit_cast(bf8, p1); t2 = __builtin_bit_cast(bf8, p2);
+}
+// largest magnitude of the 8 floats (NaN operands are ignored by v_max3: they need no special path)
+__device__ __forceinline__ float absmax8(const f4 lo, const f4 hi) {
+  float m;
+  asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(m) : "v"(lo.x), "v"(lo.y), "v"(lo.z));
+  asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(m) : "v"(m), "v"(lo.w), "v"(hi.x));
+  asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(m) : "v"(m), "v"(hi.y), "v"(hi.z));
+  asm("v_max_f32 %0, %1, |%2|" : "=v"(m) : "v"(m), "v"(hi.w));
+  return m;
+}
+
 // ---- weight packing ------------------------------------------------------------------------------------------------
 // w_img[ny][c][term][s][g][n][e]  = term(w_ref[ny*80 + n][Kh + s*K + c*32 + kperm(g, e)])   (0 outside K / N)
 // wh_img[ny][c][term][g][n][e]    = term(w_ref[ny*80 + n][c*32 + kperm(g, e)])              (0 outside Kh / N)
@@ -100,20 +134,25 @@ __global__ void k_pack_x3(const float* w_ref, long ldw, int N, int K, int S, int
     const int kmax = is_h ? Kh : K;
     float w = 0.f;
     if (col < N && k < kmax) w = w_ref[(long)col * ldw + (is_h ? 0 : Kh + (long)s * K) + k];
-    const float r1 = w - top16(w), r2 = r1 - top16(r1);
-    const float t = term == 0 ? w : term == 1 ? r1 : r2;
+    const bool winf = __builtin_fabsf(w) == INFINITY;           // an infinite weight is carried by its lowest term alone (see split8_inf)
+    const float wf = winf ? 0.f : w;
+    const float r1 = wf - top16(wf), r2 = winf ? w : r1 - top16(r1);
+    const float t = term == 0 ? wf : term == 1 ? r1 : r2;
     (is_h ? wh_img + (i - total_w) : w_img + i)[0] = (unsigned short)(fbits(t) >> 16);
   }
 }
 
-template <int S, bool HAS_H, int NT, int RT, int WAVES>
+// GEN: the generic epilogue (any M; rows and columns predicated per element) -- used only for the < 16 rows a matrix has
+// beyond a multiple of 16; otherwise the straight-line one, with wavefront tiles entirely past M skipped.  (Both in one
+// kernel made the compiler drain vmcnt at the top of every chunk: its scoreboard merges the two paths conservatively.)
+template <int S, bool HAS_H, int NT, int RT, int WAVES, int NBUF, bool GEN>
 __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
   constexpr int kThreads = WAVES * 64;
   constexpr int kChunkV = 3 * S * kPanelV;     // 16-byte pieces of an aggregate chunk image (the h chunk is 3 * kPanelV)
   constexpr int kTileRows = WAVES * 16 * RT;   // rows per workgroup tile
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 buffers x kChunkV x 16 B | column constants
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, in an SGPR
   const int li = lane & 15, lg = lane >> 4;
   const int n0 = blockIdx.y * kNW;
   const int ntiles = (g.M + kTileRows - 1) / kTileRows;
@@ -146,10 +185,16 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
       if (c >= nca) { src = img_h + (size_t)(c - nca) * 3 * kPanelV * 16; pieces = 3 * kPanelV; }
     }
     unsigned char* dst = lds + (size_t)buf * kChunkV * 16;
-    const int w0 = (i * WAVES + wave) * 64;              // first piece of this wavefront (wave-uniform)
-    if (w0 < pieces)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(w0 + lane) * 16),
-                                       (__attribute__((address_space(3))) void*)(dst + (size_t)w0 * 16), 16, 0, 0);
+    int w0 = (i * WAVES + wave) * 64;                    // first piece of this wavefront (wave-uniform)
+    if constexpr (NBUF == 3) {
+      // the 3-buffer pipeline waits with COUNTED vmcnt: every wavefront issues exactly NI copies per chunk; a slot past
+      // the image re-copies an earlier piece (same bytes to the same LDS address: harmless)
+      if (w0 >= pieces) w0 = w0 % pieces;
+    } else {
+      if (w0 >= pieces) return;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(w0 + lane) * 16),
+                                     (__attribute__((address_space(3))) void*)(dst + (size_t)w0 * 16), 16, 0, 0);
   };
   auto stage = [&](int c, int buf) {
 #pragma unroll
@@ -197,16 +242,25 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
 #pragma unroll
       for (int w = 0; w < 2; ++w) load_a_piece(t, c, r, w);
   };
-  auto take = [&](int c) {                     // next -> current (after the wait): fix the windows, split
+  auto take = [&](int c, bool keep_ni = false) {   // next -> current (after the wait): fix the windows, split
     const float* src; long ld; int kmax, k;
     a_src(c, src, ld, kmax, k);
     const bool tail = c * kKC + kKC > (c < nca ? g.K : nca * kKC + g.Kh);   // wave-uniform: only a row's last chunk needs fixing
+    // keep_ni (3-buffer pipeline): the NI weight copies issued AFTER these A loads may stay in flight (VMEM returns in order).
+    // The waits carry NO register operands and sit in their own branches; the registers are tied by ONE anchor after the
+    // merge.  (Two "+v" waits in two branches made the compiler copy nxt into fresh registers at the top of one branch --
+    // BEFORE that branch's wait, i.e. while the loads were still in flight: stale A fragments on short K.)
+    if (keep_ni) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
 #pragma unroll
-    for (int r = 0; r < RT; ++r) asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt[r][0]), "+v"(nxt[r][1]) : : "memory");
+    for (int r = 0; r < RT; ++r) asm volatile("" : "+v"(nxt[r][0]), "+v"(nxt[r][1]) : : "memory");
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
-      if (tail) split8(fix4(k, kmax, nxt[r][0]), fix4(k + 4, kmax, nxt[r][1]), A[0][r], A[1][r], A[2][r]);
-      else split8(nxt[r][0], nxt[r][1], A[0][r], A[1][r], A[2][r]);
+      f4 lo4 = nxt[r][0], hi4 = nxt[r][1];
+      if (tail) { lo4 = fix4(k, kmax, lo4); hi4 = fix4(k + 4, kmax, hi4); }
+      // +-Inf anywhere in the wavefront's fragment (5 VALU to find out): the slower split that keeps it an infinity
+      if (__builtin_amdgcn_ballot_w64(absmax8(lo4, hi4) == INFINITY) != 0) split8_inf(lo4, hi4, A[0][r], A[1][r], A[2][r]);
+      else split8(lo4, hi4, A[0][r], A[1][r], A[2][r]);
     }
   };
 
@@ -215,7 +269,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
   // row / column) and issued before its first use, only the store is predicated.  (Transposing the tile through LDS
   // to store 16 bytes per lane was measured: no faster -- the epilogue is three dependent memory round trips, not
   // instruction count -- and 16-byte accesses to rows of N = 75 floats are unaligned for 3 rows in 4, which is slower.)
-  float* const colc = reinterpret_cast<float*>(lds + (size_t)2 * kChunkV * 16);            // [3][80]: bias | scale | shift
+  float* const colc = reinterpret_cast<float*>(lds + (size_t)NBUF * kChunkV * 16);         // [3][80]: bias | scale | shift
   for (int i = tid; i < kNW; i += kThreads) {
     const int col = n0 + i;
     colc[i] = (g.bias && col < g.N) ? g.bias[col] : 0.f;
@@ -280,114 +334,313 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
       }
     }
   };
-  // Persistent workgroup: tiles t = blockIdx.x, blockIdx.x + gridDim.x, ...; the (tile, chunk) pairs form ONE software
-  // pipeline, so the first chunk of the next tile is already in flight while this tile's epilogue runs.
-  int t = blockIdx.x, c = 0, buf = 0;
-  if (t >= ntiles) return;
-  stage(0, 0);
-  load_a(t, 0);
-  take(0);                                     // (waits vmcnt(0): chunk 0 of the image has landed too)
-  __syncthreads();
-  while (true) {
-    int tn = t, cn = c + 1;
-    if (cn == nc) { tn = t + gridDim.x; cn = 0; }
-    const bool more = tn < ntiles;
-    const int ta = more ? tn : t, ca = more ? cn : c;   // A prefetch target (a harmless re-load when there is no next chunk)
-    const bool is_h = HAS_H && c >= nca;
-    const unsigned baddr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(buf * kChunkV + lg * kNW + li) * 16u;   // LDS byte address of this lane's fragment column
-    // The chunk's S*NT (panel, column tile) groups form one software pipeline: while the 6*RT MFMAs of group g run,
-    // the three B fragments of group g+1 are read from LDS and one piece of the NEXT chunk's weight image is sent on
-    // its way to LDS -- spread over the groups, because a burst of VMEM issue from all wavefronts at once stalls
-    // every one of them at the TA.
-    // B fragment (term, panel p, column tile n): piece ((term*np + p)*4 + lg)*80 + n*16 + li;
-    // MFMAs ordered smallest partial products first, row tiles alternating (no MFMA waits for its predecessor).
-    auto run = [&](auto npanel_c, int p0, unsigned ba0) {
-      constexpr int NPN = decltype(npanel_c)::value;   // panels in this chunk's image; they accumulate into acc[.][p0 + p]
-      constexpr int NG = NPN * NT;
-      bf8 B[2][3];
-      // B fragments are read by hand (inline asm + counted lgkmcnt): hipcc sinks its own ds_reads next to their use
-      // and waits lgkmcnt(0), exposing one LDS round trip per group.  LDS returns in order, so with the three reads
-      // of group g+1 issued behind those of group g, `lgkmcnt(3)` means group g has landed.
-      auto load_b = [&](unsigned ba, int gi, int slot) {
-        const int p = gi / NT, n = gi % NT;
+  // The same epilogue for a wavefront whose 16*RT rows all exist (every tile but the matrix's last): straight-line.
+  // The generic epilogue above is ~1100 instructions per row tile (a uniform branch per optional operand per element,
+  // 64-bit address arithmetic per element, row/column predicates around every store) and the kernel is bound by
+  // instruction issue while all wavefronts sit in it together -- it cost 15 k of the 74 k cycles of a tile period.
+  // Here absent operands are neutral constants (x*1, +0 are exact), ReLU is `v < lo ? 0 : v` with lo = 0 or -inf (keeps
+  // NaN like the generic form), every load is issued before the first use, rows need no predicate and only a column
+  // tile that crosses N predicates its stores.
+  auto zero_acc = [&]() {
 #pragma unroll
-        for (int tm = 0; tm < 3; ++tm)
-          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(B[slot][tm]) : "v"(ba), "n"((((tm * NPN + p) * 4) * kNW + n * 16) * 16));
-      };
-      load_b(ba0, 0, 0);
-      constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
+    for (int r = 0; r < RT; ++r)
 #pragma unroll
-      for (int gi = 0; gi < NG; ++gi) {
-        const int p = gi / NT, n = gi % NT;
-        if (gi + 1 < NG) {
-          load_b(ba0, gi + 1, (gi + 1) & 1);
-          asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(B[gi & 1][0]), "+v"(B[gi & 1][1]), "+v"(B[gi & 1][2]));
-        } else {
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(B[gi & 1][0]), "+v"(B[gi & 1][1]), "+v"(B[gi & 1][2]));
-        }
+      for (int p = 0; p < P; ++p)
 #pragma unroll
-        for (int j = 0; j < 2 * RT; ++j)
-          if (gi == 0) load_a_piece(ta, ca, j >> 1, j & 1);   // HBM latency: first
-        if (more) {                                                 // the L2-resident weight image: spread over the rest
+        for (int n = 0; n < NT; ++n) acc[r][p][n] = (f4){0.f, 0.f, 0.f, 0.f};
+  };
+  auto epilogue_full = [&](int t) {
+    // Addresses are (wave-uniform 64-bit base in SGPRs) + (32-bit lane offset): one VALU per address instead of a
+    // 64-bit multiply-add chain, and nothing loop-invariant for the compiler to hoist into the MFMA loop's registers
+    // (the lane ids go through an empty asm so that values derived from them are rebuilt here).
+    int li_ = li, lg_ = lg;
+    asm volatile("" : "+v"(li_), "+v"(lg_));
+    const int row0 = (t * WAVES + wave) * (16 * RT);
+    const float lo = g.relu ? 0.f : -INFINITY;
+    const f4 ones = (f4){1.f, 1.f, 1.f, 1.f};
+    const unsigned ldyb = (unsigned)g.ldy * 4u, ldrb = (unsigned)g.ld_res * 4u;       // (launcher: pitches < 2^24 floats)
 #pragma unroll
-          for (int i = 0; i < NI; ++i)
-            if ((NG > 2 * RT ? 2 * RT + (i * (NG - 2 * RT)) / NI : NG - 1) == gi) stage_piece(cn, buf ^ 1, i);
-        }
+    for (int rt = 0; rt < RT; ++rt) {
+      const unsigned rl = 16u * rt + 4u * (unsigned)lg_;                              // first of the lane's 4 rows, tile-local
+      f4 scv[S];
 #pragma unroll
-        for (int pp = 0; pp < 6; ++pp)
-#pragma unroll
-          for (int r = 0; r < RT; ++r)
-            acc[r][p0 + p][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]][r], B[gi & 1][TB[pp]], acc[r][p0 + p][n], 0, 0, 0);
+      for (int s = 0; s < S; ++s) {
+        scv[s] = ones;
+        if (g.row_scale[s])
+          scv[s] = reinterpret_cast<const f4u*>(reinterpret_cast<const char*>(g.row_scale[s] + row0) + rl * 4u)->v;
       }
-    };
-    if (!is_h) {
-      run(std::integral_constant<int, S>{}, 0, baddr);
-    } else if (HAS_H) {
-      run(std::integral_constant<int, 1>{}, P - 1, baddr);
+      f4 rpv = ones;
+      if (g.row_post) rpv = reinterpret_cast<const f4u*>(reinterpret_cast<const char*>(g.row_post + row0) + rl * 4u)->v;
+      float res[NT][4];
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) res[n][r] = 0.f;
+      if (g.residual) {
+        const char* rbase = reinterpret_cast<const char*>(g.residual + (size_t)row0 * g.ld_res);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const unsigned cc = (unsigned)min(n0 + n * 16 + li_, g.N - 1);
+          const unsigned vo = rl * ldrb + cc * 4u;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) res[n][r] = *reinterpret_cast<const float*>(rbase + (size_t)r * ldrb + vo);
+        }
+      }
+      // Every load above is waited for HERE, once, ahead of the first (predicated) store: otherwise the compiler
+      // sinks the wait into the first predicated block and has to repeat it -- as vmcnt(0), which then also waits for
+      // the stores issued meanwhile -- at every control-flow merge that follows.
+#pragma unroll
+      for (int s = 0; s < S; ++s) asm volatile("" : "+v"(scv[s]));
+      asm volatile("" : "+v"(rpv));
+#pragma unroll
+      for (int n = 0; n < NT; ++n) asm volatile("" : "+v"(res[n][0]), "+v"(res[n][1]), "+v"(res[n][2]), "+v"(res[n][3]));
+      char* const ybase = reinterpret_cast<char*>(g.y + (size_t)row0 * g.ldy);
+      const unsigned yo = rl * ldyb + (unsigned)(n0 + li_) * 4u;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int cl = n * 16 + li_;
+        const float cb = colc[cl], cs = colc[kNW + cl], ct = colc[2 * kNW + cl];
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = HAS_H ? __builtin_fmaf(scv[0][r], acc[rt][0][n][r], acc[rt][P - 1][n][r]) : scv[0][r] * acc[rt][0][n][r];
+#pragma unroll
+          for (int s = 1; s < S; ++s) x = __builtin_fmaf(scv[s][r], acc[rt][s][n][r], x);
+          x = (x + cb) * rpv[r];
+          x = __builtin_fmaf(x, cs, ct);
+          x = x < lo ? 0.f : x;
+          v[r] = res[n][r] + x;
+#pragma unroll
+          for (int p = 0; p < P; ++p) acc[rt][p][n][r] = 0.f;
+        }
+        if (n0 + (n + 1) * 16 <= g.N) {                 // wave-uniform: the whole column tile exists
+#pragma unroll
+          for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(ybase + (size_t)r * ldyb + (yo + n * 64u)) = v[r];
+        } else if (n0 + cl < g.N) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(ybase + (size_t)r * ldyb + (yo + n * 64u)) = v[r];
+        }
+      }
     }
-    if (c == nc - 1) {
-      __builtin_amdgcn_sched_barrier(0);         // keep the epilogue's loads out of the MFMA stream (register pressure)
-      epilogue(t);
-      __builtin_amdgcn_sched_barrier(0);
+  };
+  if constexpr (NBUF == 2) {
+    // Persistent workgroup: tiles t = blockIdx.x, blockIdx.x + gridDim.x, ...; the (tile, chunk) pairs form ONE software
+    // pipeline, so the first chunk of the next tile is already in flight while this tile's epilogue runs.
+    int t = blockIdx.x, c = 0, buf = 0;
+    if (t >= ntiles) return;
+    stage(0, 0);
+    load_a(t, 0);
+    take(0);                                     // (waits vmcnt(0): chunk 0 of the image has landed too)
+    __syncthreads();
+    while (true) {
+      int tn = t, cn = c + 1;
+      if (cn == nc) { tn = t + gridDim.x; cn = 0; }
+      const bool more = tn < ntiles;
+      const int ta = more ? tn : t, ca = more ? cn : c;   // A prefetch target (a harmless re-load when there is no next chunk)
+      const bool is_h = HAS_H && c >= nca;
+      const unsigned baddr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(buf * kChunkV + lg * kNW + li) * 16u;   // LDS byte address of this lane's fragment column
+      // The chunk's S*NT (panel, column tile) groups form one software pipeline: while the 6*RT MFMAs of group g run,
+      // the three B fragments of group g+1 are read from LDS and one piece of the NEXT chunk's weight image is sent on
+      // its way to LDS -- spread over the groups, because a burst of VMEM issue from all wavefronts at once stalls
+      // every one of them at the TA.
+      // B fragment (term, panel p, column tile n): piece ((term*np + p)*4 + lg)*80 + n*16 + li;
+      // MFMAs ordered smallest partial products first, row tiles alternating (no MFMA waits for its predecessor).
+      auto run = [&](auto npanel_c, int p0, unsigned ba0) {
+        constexpr int NPN = decltype(npanel_c)::value;   // panels in this chunk's image; they accumulate into acc[.][p0 + p]
+        constexpr int NG = NPN * NT;
+        bf8 B[2][3];
+        // B fragments are read by hand (inline asm + counted lgkmcnt): hipcc sinks its own ds_reads next to their use
+        // and waits lgkmcnt(0), exposing one LDS round trip per group.  LDS returns in order, so with the three reads
+        // of group g+1 issued behind those of group g, `lgkmcnt(3)` means group g has landed.
+        auto load_b = [&](unsigned ba, int gi, int slot) {
+          const int p = gi / NT, n = gi % NT;
+  #pragma unroll
+          for (int tm = 0; tm < 3; ++tm)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(B[slot][tm]) : "v"(ba), "n"((((tm * NPN + p) * 4) * kNW + n * 16) * 16));
+        };
+        load_b(ba0, 0, 0);
+        constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
+  #pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+          const int p = gi / NT, n = gi % NT;
+          if (gi + 1 < NG) {
+            load_b(ba0, gi + 1, (gi + 1) & 1);
+            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(B[gi & 1][0]), "+v"(B[gi & 1][1]), "+v"(B[gi & 1][2]));
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(B[gi & 1][0]), "+v"(B[gi & 1][1]), "+v"(B[gi & 1][2]));
+          }
+  #pragma unroll
+          for (int j = 0; j < 2 * RT; ++j)
+            if (gi == 0) load_a_piece(ta, ca, j >> 1, j & 1);   // HBM latency: first
+          if (more) {                                                 // the L2-resident weight image: spread over the rest
+  #pragma unroll
+            for (int i = 0; i < NI; ++i)
+              if ((NG > 2 * RT ? 2 * RT + (i * (NG - 2 * RT)) / NI : NG - 1) == gi) stage_piece(cn, buf ^ 1, i);
+          }
+  #pragma unroll
+          for (int pp = 0; pp < 6; ++pp)
+  #pragma unroll
+            for (int r = 0; r < RT; ++r)
+              acc[r][p0 + p][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]][r], B[gi & 1][TB[pp]], acc[r][p0 + p][n], 0, 0, 0);
+        }
+      };
+      if (!is_h) {
+        run(std::integral_constant<int, S>{}, 0, baddr);
+      } else if (HAS_H) {
+        run(std::integral_constant<int, 1>{}, P - 1, baddr);
+      }
+      if (c == nc - 1) {
+        __builtin_amdgcn_sched_barrier(0);         // keep the epilogue's loads out of the MFMA stream (register pressure)
+        if constexpr (GEN) epilogue(t);
+        else if ((t * WAVES + wave) * (16 * RT) < g.M) epilogue_full(t);          // (launcher: M is a multiple of 16 * RT)
+        else zero_acc();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (!more) break;
+      take(cn);                                          // waits vmcnt(0): this wavefront's share of the next chunk is in LDS
+      __syncthreads();                                   // ... everyone's is, and everyone is done reading this chunk
+      buf ^= 1; t = tn; c = cn;
     }
-    if (!more) break;
-    take(cn);                                          // waits vmcnt(0): this wavefront's share of the next chunk is in LDS
-    __syncthreads();                                   // ... everyone's is, and everyone is done reading this chunk
-    buf ^= 1; t = tn; c = cn;
+  } else {
+    // ---- 3 weight buffers, ONE barrier per chunk placed in the MIDDLE of the chunk's MFMA stream -------------------------
+    // With the barrier at the chunk boundary every wavefront drains its loads, splits its next A fragment and waits for the
+    // slowest of the 12 at the same moment -- the matrix pipe idles through all of it, ten times per tile.  Here step k
+    // (tile, chunk) reads buffer k % 3; barrier B_k sits between group H and H+1 of step k.  At B_k every wavefront has
+    // finished step k-1, so buffer (k+2) % 3 = (k-1) % 3 is free: the copies of step k+2's image are issued AFTER B_k and
+    // waited for (counted vmcnt, they are older than the A loads of the following step) BEFORE B_{k+1}; step k+2 starts
+    // after B_{k+1}.  At a chunk boundary a wavefront only waits for ITS OWN next A fragment and splits it while the other
+    // wavefronts of its SIMD keep the matrix pipe busy: wavefronts are synchronised mid-chunk only.
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nsteps = my_tiles * nc;
+    int t = blockIdx.x, c = 0, buf = 0;
+    if (t >= ntiles) return;
+    stage(0, 0);
+    if (nsteps > 1) stage(nc > 1 ? 1 : 0, 1);
+    load_a(t, 0);
+    take(0);                                   // vmcnt(0): both images and the first A fragment have landed
+    __syncthreads();
+    for (int k = 0; k < nsteps; ++k) {
+      int tn = t, cn = c + 1;
+      if (cn == nc) { tn = t + gridDim.x; cn = 0; }
+      const bool more1 = k + 1 < nsteps, more2 = k + 2 < nsteps;
+      const int ta = more1 ? tn : t, ca = more1 ? cn : c;   // A prefetch target (a harmless re-load on the last step)
+      int c2 = cn + 1;
+      if (c2 >= nc) c2 -= nc;                              // chunk of step k+2
+      const int buf2 = buf == 0 ? 2 : buf - 1;             // (k + 2) % 3
+      const bool is_h = HAS_H && c >= nca;
+      const unsigned baddr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(buf * kChunkV + lg * kNW + li) * 16u;
+      auto run3 = [&](auto npanel_c, int p0, unsigned ba0) {
+        constexpr int NPN = decltype(npanel_c)::value;
+        constexpr int NG = NPN * NT;
+        constexpr int H = (NG - 1) / 2;                    // the barrier follows the B prefetch of group H
+        bf8 B[2][3];
+        auto load_b = [&](unsigned ba, int gi, int slot) {
+          const int p = gi / NT, n = gi % NT;
+#pragma unroll
+          for (int tm = 0; tm < 3; ++tm)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(B[slot][tm]) : "v"(ba), "n"((((tm * NPN + p) * 4) * kNW + n * 16) * 16));
+        };
+        load_b(ba0, 0, 0);
+        constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+          const int p = gi / NT, n = gi % NT;
+          if (gi + 1 < NG) {
+            load_b(ba0, gi + 1, (gi + 1) & 1);
+            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(B[gi & 1][0]), "+v"(B[gi & 1][1]), "+v"(B[gi & 1][2]));
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(B[gi & 1][0]), "+v"(B[gi & 1][1]), "+v"(B[gi & 1][2]));
+          }
+#pragma unroll
+          for (int j = 0; j < 2 * RT; ++j)
+            if (gi == 0) load_a_piece(ta, ca, j >> 1, j & 1);
+          if (gi == H) {
+            // everything older than the 2*RT A loads just issued has landed: this wavefront's copies of step k+1's image
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"(2 * RT) : "memory");
+          }
+          if (more2) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+              if (gi >= H && (NG - 1 > H ? H + 1 + (i * (NG - 1 - H)) / NI : H) == gi) stage_piece(c2, buf2, i);
+          }
+#pragma unroll
+          for (int pp = 0; pp < 6; ++pp)
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+              acc[r][p0 + p][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]][r], B[gi & 1][TB[pp]], acc[r][p0 + p][n], 0, 0, 0);
+        }
+      };
+      if (!is_h) {
+        run3(std::integral_constant<int, S>{}, 0, baddr);
+      } else if (HAS_H) {
+        run3(std::integral_constant<int, 1>{}, P - 1, baddr);
+      }
+      // next A fragment first (its wait leaves this step's NI weight copies in flight), then the epilogue: the other way
+      // round the counted wait would also sit out the epilogue's stores
+      if (more1) take(cn, more2);
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (c == nc - 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (GEN) epilogue(t);
+        else if ((t * WAVES + wave) * (16 * RT) < g.M) epilogue_full(t);        // (launcher: M is a multiple of 16 * RT)
+        else zero_acc();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      t = tn; c = cn; buf = buf == 2 ? 0 : buf + 1;
+    }
   }
 }
 
-template <int S, bool HAS_H, int NT, int RT, int WAVES>
+template <int S, bool HAS_H, int NT, int RT, int WAVES, int NBUF, bool GEN>
 int launch_v(const XArgs& g, hipStream_t st) {
-  const size_t lds = (size_t)2 * 3 * S * kPanelB + (size_t)(3 * kNW) * sizeof(float);
-  if (hipFuncSetAttribute((const void*)k_posttrans_x3<S, HAS_H, NT, RT, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  const size_t lds = (size_t)NBUF * 3 * S * kPanelB + (size_t)(3 * kNW) * sizeof(float);
+  if (hipFuncSetAttribute((const void*)k_posttrans_x3<S, HAS_H, NT, RT, WAVES, NBUF, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return -1;
   const int ntiles = (g.M + WAVES * 16 * RT - 1) / (WAVES * 16 * RT);
   const dim3 grid((unsigned)(ntiles < g.grid_x ? ntiles : g.grid_x), (unsigned)((g.N + kNW - 1) / kNW));
-  hipLaunchKernelGGL((k_posttrans_x3<S, HAS_H, NT, RT, WAVES>), grid, dim3(WAVES * 64), lds, st, g);
+  hipLaunchKernelGGL((k_posttrans_x3<S, HAS_H, NT, RT, WAVES, NBUF, GEN>), grid, dim3(WAVES * 64), lds, st, g);
   return 0;
 }
 
 template <int S, bool HAS_H, int NT>
-int launch_k(const XArgs& g, hipStream_t st) {
+int launch_k(const XArgs& g, int nbuf, hipStream_t st) {
   // One row tile per wavefront, 12 wavefronts (3 per SIMD, 170 registers each) while the P * NT accumulator tiles fit
   // that budget, else 8 (256 registers).  Measured on C3 (S=3, NT=5): 0.775 ms, against 0.82 for 2 row tiles x 8
   // wavefronts (half the LDS fragment reads, but only 2 wavefronts per SIMD to cover each other's stalls), 0.87 for
   // 1 x 8 and 1.19 for 1 x 16 (128 registers: spills).
   constexpr int WAVES = (S + (HAS_H ? 1 : 0)) * NT > 15 ? 8 : 12;
-  return launch_v<S, HAS_H, NT, 1, WAVES>(g, st);
+  // rows [0, M16): the straight-line epilogue; the M % 16 rows beyond: a second launch with the generic one
+  const int M16 = g.M - g.M % 16;
+  if (M16 > 0) {
+    XArgs m = g;
+    m.M = M16;
+    const int rc = nbuf == 3 ? launch_v<S, HAS_H, NT, 1, WAVES, 3, false>(m, st) : launch_v<S, HAS_H, NT, 1, WAVES, 2, false>(m, st);
+    if (rc != 0) return rc;
+  }
+  if (g.M > M16) {
+    XArgs r = g;
+    r.M = g.M - M16;
+    r.a = g.a + (size_t)M16 * g.lda;
+    if (g.h) r.h = g.h + (size_t)M16 * g.ldh;
+    for (int s = 0; s < S; ++s) if (g.row_scale[s]) r.row_scale[s] = g.row_scale[s] + M16;
+    if (g.row_post) r.row_post = g.row_post + M16;
+    if (g.residual) r.residual = g.residual + (size_t)M16 * g.ld_res;
+    r.y = g.y + (size_t)M16 * g.ldy;
+    return launch_v<S, HAS_H, NT, 1, WAVES, 2, true>(r, st);
+  }
+  return 0;
 }
 
 template <int S, bool HAS_H>
-int launch_nt(const XArgs& g, int nt, hipStream_t st) {
-  if (nt <= 1) return launch_k<S, HAS_H, 1>(g, st);
-  if (nt <= 3) return launch_k<S, HAS_H, 3>(g, st);
-  return launch_k<S, HAS_H, 5>(g, st);
+int launch_nt(const XArgs& g, int nt, int nbuf, hipStream_t st) {
+  if (nt <= 1) return launch_k<S, HAS_H, 1>(g, nbuf, st);
+  if (nt <= 3) return launch_k<S, HAS_H, 3>(g, nbuf, st);
+  return launch_k<S, HAS_H, 5>(g, nbuf, st);
 }
 
 template <int S>
-int launch_s(const XArgs& g, bool has_h, int nt, hipStream_t st) {
-  return has_h ? launch_nt<S, true>(g, nt, st) : launch_nt<S, false>(g, nt, st);
+int launch_s(const XArgs& g, bool has_h, int nt, int nbuf, hipStream_t st) {
+  return has_h ? launch_nt<S, true>(g, nt, nbuf, st) : launch_nt<S, false>(g, nt, nbuf, st);
 }
 
 }  // namespace
@@ -445,10 +698,13 @@ extern "C" int pna_posttrans_x3_f32(const pna_posttrans_args* p, pna_stream_t st
   hipStream_t st = (hipStream_t)stream;
   const int nt = p->N >= kNW ? kMaxNT : (p->N + 15) / 16;
   int rc;
+  if (p->pipeline != 0 && p->pipeline != 2 && p->pipeline != 3)
+    return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3_f32: pipeline must be 0 (default), 2 or 3");
+  const int nbuf = p->pipeline ? p->pipeline : kDefaultNBuf;
   switch (p->n_scaler) {
-    case 1: rc = launch_s<1>(g, has_h, nt, st); break;
-    case 2: rc = launch_s<2>(g, has_h, nt, st); break;
-    default: rc = launch_s<3>(g, has_h, nt, st); break;
+    case 1: rc = launch_s<1>(g, has_h, nt, nbuf, st); break;
+    case 2: rc = launch_s<2>(g, has_h, nt, nbuf, st); break;
+    default: rc = launch_s<3>(g, has_h, nt, nbuf, st); break;
   }
   if (rc != 0) return pna_set_error(PNA_E_LAUNCH, "pna_posttrans_x3_f32: could not reserve LDS");
   hipError_t e = hipGetLastError();

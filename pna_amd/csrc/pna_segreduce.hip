@@ -39,6 +39,17 @@ constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr int kNQ = 7;   // partial quantities per heavy segment: s, q, mx, mn, amx, amn, wsum
 
+// Bench-experiment knobs (tune.reserved[0]: bit0 = skip the output stores, bits 8.. = KB of dummy dynamic LDS per block to
+// cap the blocks per CU) exist only in the separate experiments build (-DPNA_AMD_EXPERIMENTS, tools/build_experiments.sh);
+// the shipped library ignores tune.reserved[0].
+#ifdef PNA_AMD_EXPERIMENTS
+#define PNA_STORES_ON(a, probe) (!(((a).dbg & 1) && (probe) != 12345.678f))
+#define PNA_DBG_WORD(t) ((t).reserved[0])
+#else
+#define PNA_STORES_ON(a, probe) true
+#define PNA_DBG_WORD(t) 0
+#endif
+
 struct KArgs {
   const int32_t* rowptr; const int32_t* col;
   const float* x; const float* dst_term; const float* edge_term; const float* ew;
@@ -364,7 +375,7 @@ __global__ __launch_bounds__(kBlock) void k_segreduce(const KArgs a) {
     if (!(thr > 0 && deg > thr)) {                           // heavy rows are done by the segment blocks
       acc.init();
       walk<VEC, U, EXTRA, IDX32>(a, acc, row, beg_c, end_c, c, grp_lane0, offi, idx_c, pf);
-      if (lane_ok && !((a.dbg & 1) && acc.s[0] != 12345.678f)) finalize_store<VEC, EXTRA>(a, acc, row, deg, offi, offo);
+      if (lane_ok && PNA_STORES_ON(a, acc.s[0])) finalize_store<VEC, EXTRA>(a, acc, row, deg, offi, offo);
     }
     idx_c = idx_n; beg_c = beg_n; end_c = end_n; beg_n = beg_nn; end_n = end_nn;
   }
@@ -425,15 +436,16 @@ struct AccF {   // fast-path accumulators of one lane: 4 features
   }
 };
 
-template <int I, int U> struct Drain {   // wait for gather I of U (U-1-I younger ones may stay in flight), fold it
-  static __device__ __forceinline__ void run(AccF& acc, f4 (&v)[U], int nvalid, bool partial) {
+template <int I, int U, bool DST> struct Drain {   // wait for gather I of U (U-1-I younger ones may stay in flight), fold it
+  static __device__ __forceinline__ void run(AccF& acc, f4 (&v)[U], int nvalid, bool partial, const f4 dt) {
     await<U - 1 - I>(v[I]);
-    if (partial) acc.fold_masked(v[I], I < nvalid); else acc.fold(v[I]);
-    Drain<I + 1, U>::run(acc, v, nvalid, partial);
+    const f4 m = DST ? v[I] + dt : v[I];                     // message = x[src] (+ dst_term[row]), as k_segreduce forms it
+    if (partial) acc.fold_masked(m, I < nvalid); else acc.fold(m);
+    Drain<I + 1, U, DST>::run(acc, v, nvalid, partial, dt);
   }
 };
-template <int U> struct Drain<U, U> {
-  static __device__ __forceinline__ void run(AccF&, f4 (&)[U], int, bool) {}
+template <int U, bool DST> struct Drain<U, U, DST> {
+  static __device__ __forceinline__ void run(AccF&, f4 (&)[U], int, bool, const f4) {}
 };
 
 // Slim argument block of the hand-scheduled kernel.  Everything the row loop touches fits in ~40 SGPRs; the full
@@ -445,8 +457,10 @@ struct FArgs {
   const int32_t* items;   // [n_items][4] = {row, beg, end, slot}: slot < 0 -> whole row (finalise + store),
                           //                 slot >= 0 -> heavy segment: raw partials to partials[slot]
   const int32_t* col; const float* x; float* out; float* partials;
+  const float* dst;       // per-destination additive term (the h_dst half of a factorised pretrans), DST kernels only
   long ldo, ts_out;
   unsigned ldb, ts_in_b;  // x row pitch / tower stride in bytes
+  unsigned ldd_b;         // dst_term row pitch in bytes
   int n_items, n_edges, F, L, G, R, T, tiles, pstride, block_stride, nt, dbg;
 };
 
@@ -481,21 +495,23 @@ __device__ __forceinline__ void fast_finalize_store(const FArgs& a, const AccF& 
 }
 
 // U gathers of one row issued back to back from the ids held by the group's lanes, then folded in order.
-template <int U, bool PARTIAL>
+template <int U, bool PARTIAL, bool DST>
 __device__ __forceinline__ void fast_batch(const float* x, AccF& acc, int idx, int src_lane0, unsigned ldb,
-                                           unsigned offb, int nvalid) {
+                                           unsigned offb, int nvalid, const f4 dt) {
   int id[U];
   f4 v[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) id[u] = __shfl(idx, src_lane0 + (PARTIAL ? min(u, nvalid - 1) : u));
 #pragma unroll
   for (int u = 0; u < U; ++u) aload128(v[u], x, __umul24((unsigned)id[u], ldb) + offb);
-  Drain<0, U>::run(acc, v, nvalid, PARTIAL);
+  Drain<0, U, DST>::run(acc, v, nvalid, PARTIAL, dt);
 }
 
 // The prefetch invariants: the first L source ids of item r+1 and the record of item r+2 are requested BEFORE
 // item r's gathers; VMEM returns in order, so once the wave has waited for any gather of item r they have landed.
-template <int U>
+// DST: message = x[src] + dst_term[row] (the tower layers: models/dgl/pna_layer.py:35-40 with the 1-layer pretrans
+// factorised to node level).  The row's term is one more dwordx4 per lane, fetched one item ahead like the source ids.
+template <int U, bool DST>
 __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -531,15 +547,23 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
     aload32(dst, a.col, min(pos, e_last) * 4u);
   };
 
+  const unsigned ldd_b = a.ldd_b;
+  auto dst_of = [&](f4& dst, const i4 rec) {                 // lane c <- dst_term[row][its 4 features] (row < V always)
+    aload128(dst, a.dst, __umul24((unsigned)rec.x, ldd_b) + offb);
+  };
+
   // prologue: record of item 0 -> its first ids and the record of item 1
   i4 cur;
   issue_item(cur, base);
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur) : : "memory");
   int idx_c;
   ids_of(idx_c, cur);
+  f4 dt_c = (f4){0.f, 0.f, 0.f, 0.f};
+  if constexpr (DST) dst_of(dt_c, cur);
   i4 nxt;
   issue_item(nxt, min(base + NG, last));
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(idx_c), "+v"(nxt) : : "memory");
+  if constexpr (DST) asm volatile("s_waitcnt vmcnt(0)" : "+v"(idx_c), "+v"(nxt), "+v"(dt_c) : : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" : "+v"(idx_c), "+v"(nxt) : : "memory");
 
   AccF acc;
   for (int r = 0; r < a.R; ++r) {
@@ -548,7 +572,9 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
     // ---- prefetch (issued BEFORE this item's gathers): ids of item r+1, record of item r+2 (clamped to the last item)
     int idx_n;
     i4 nn;
+    f4 dt_n = (f4){0.f, 0.f, 0.f, 0.f};
     ids_of(idx_n, nxt);
+    if constexpr (DST) dst_of(dt_n, nxt);
     issue_item(nn, min(item + 2 * NG, last));
     // ---- this item
     const int row = cur.x, beg = cur.y, end = cur.z, slot = cur.w;
@@ -561,10 +587,10 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
         await<0>(idx);
       }
       int j = 0;
-      for (; j + U <= nidx; j += U) fast_batch<U, false>(a.x, acc, idx, grp_lane0 + j, ldb, offb, U);
-      if (j < nidx) fast_batch<U, true>(a.x, acc, idx, grp_lane0 + j, ldb, offb, nidx - j);
+      for (; j + U <= nidx; j += U) fast_batch<U, false, DST>(a.x, acc, idx, grp_lane0 + j, ldb, offb, U, dt_c);
+      if (j < nidx) fast_batch<U, true, DST>(a.x, acc, idx, grp_lane0 + j, ldb, offb, nidx - j, dt_c);
     }
-    if (lane_ok && !((a.dbg & 1) && acc.s.x != 12345.678f)) {
+    if (lane_ok && PNA_STORES_ON(a, acc.s.x)) {
       if (slot < 0) {
         fast_finalize_store(a, acc, row, end - beg, offo);
       } else {                                               // heavy segment: raw (s, q, max, min) to the workspace
@@ -580,6 +606,7 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
     // for any gather they have landed.  Only if no lane group of the wave gathered anything: drain.
     if (__builtin_amdgcn_ballot_w64(end > beg) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("" : "+v"(idx_n), "+v"(nn));                 // anchor: consumers cannot move above this point
+    if constexpr (DST) { asm volatile("" : "+v"(dt_n)); dt_c = dt_n; }
     idx_c = idx_n; cur = nxt; nxt = nn;
   }
 }
@@ -783,7 +810,7 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
   k.R = t.rows_per_group > 0 ? t.rows_per_group : 4;
   k.nt = t.nt_store >= 0 ? 1 : 0;
   k.pf = t.prefetch >= 0 ? 1 : 0;
-  k.dbg = t.reserved[0];   // bit0: skip the output stores (bench experiments only; results are then undefined)
+  k.dbg = PNA_DBG_WORD(t);   // experiments build only (see PNA_STORES_ON)
   k.pstride = (p->F + 3) / 4 * 4;
   const int NG = kWaves * k.G;
   k.n_heavy_blocks = heavy ? (k.n_seg + NG - 1) / NG : 0;
@@ -791,6 +818,7 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
   const long light_blocks = (p->V + rows_per_block - 1) / rows_per_block;
   if (light_blocks + k.n_heavy_blocks > 0x7fffffffL) return pna_set_error(PNA_E_INVALID, "pna_segreduce_fwd_f32: grid too large");
   const bool extra = p->dst_term || p->edge_term || p->edge_weight || p->argmax || p->argmin;
+  const bool extra_fast = p->edge_term || p->edge_weight || p->argmax || p->argmin;   // what the hand-scheduled kernel lacks
   dim3 grid((unsigned)(light_blocks + k.n_heavy_blocks), (unsigned)(tiles * T));
   hipStream_t st = (hipStream_t)stream;
   // 32-bit gather offsets when the whole feature table is addressable with them
@@ -798,9 +826,11 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
   // hand-scheduled kernel for the configuration the layers issue (see k_segreduce_fast / FArgs)
   const bool std4 = p->n_aggr == 4 && p->aggr[0] == PNA_AGG_MEAN && p->aggr[1] == PNA_AGG_MAX && p->aggr[2] == PNA_AGG_MIN &&
                     p->aggr[3] == PNA_AGG_STD && p->n_scaler == 1 && p->row_scale[0] == nullptr;
-  const bool fast_ok = vec == 4 && !extra && std4 && p->col != nullptr && idx32 && p->x_rows < (1 << 24) &&
+  const bool fast_ok = vec == 4 && !extra_fast && std4 && p->col != nullptr && idx32 && p->x_rows < (1 << 24) &&
                        p->ldx * 4 < (1 << 24) && (int64_t)T * ts_in * 4 < (1 << 30) && p->work_items != nullptr &&
                        p->n_work_items > 0 && p->n_work_items < (1 << 27) && p->n_edges > 0 && p->n_edges < (1LL << 30) &&
+                       (!p->dst_term || (p->V < (1 << 24) && p->ld_dst * 4 < (1 << 24) &&
+                                         (double)p->V * (double)p->ld_dst * 4.0 < 4294967296.0)) &&
                        t.reserved[1] == 0;
   int rc = 0;
   if (!fast_ok && U != 2 && U != 4 && U != 8) U = 4;       // the compiler-scheduled kernel is built for 2, 4, 8
@@ -811,15 +841,28 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
     f.ldo = p->ldo; f.ts_out = ts_out; f.ldb = (unsigned)(p->ldx * 4); f.ts_in_b = (unsigned)(ts_in * 4);
     f.n_items = p->n_work_items; f.n_edges = (int)p->n_edges; f.F = p->F; f.L = k.L; f.G = k.G; f.R = k.R; f.T = T; f.tiles = tiles;
     f.pstride = k.pstride; f.block_stride = p->block_stride; f.nt = k.nt; f.dbg = k.dbg;
+    f.dst = p->dst_term; f.ldd_b = (unsigned)(p->ld_dst * 4);
     const long fb = (p->n_work_items + rows_per_block - 1) / rows_per_block;
     dim3 fgrid((unsigned)fb, (unsigned)(tiles * T));
-    switch (U) {
-      case 2: hipLaunchKernelGGL((k_segreduce_fast<2>), fgrid, dim3(kBlock), 0, st, f); break;
-      case 3: hipLaunchKernelGGL((k_segreduce_fast<3>), fgrid, dim3(kBlock), 0, st, f); break;
-      case 4: hipLaunchKernelGGL((k_segreduce_fast<4>), fgrid, dim3(kBlock), 0, st, f); break;
-      case 5: hipLaunchKernelGGL((k_segreduce_fast<5>), fgrid, dim3(kBlock), 0, st, f); break;
-      case 6: hipLaunchKernelGGL((k_segreduce_fast<6>), fgrid, dim3(kBlock), 0, st, f); break;
-      default: hipLaunchKernelGGL((k_segreduce_fast<8>), fgrid, dim3(kBlock), 0, st, f); break;
+    const unsigned dyn_lds = (unsigned)(k.dbg >> 8) * 1024u;   // 0 in the shipped build
+    if (p->dst_term) {
+      switch (U) {
+        case 2: hipLaunchKernelGGL((k_segreduce_fast<2, true>), fgrid, dim3(kBlock), dyn_lds, st, f); break;
+        case 3: hipLaunchKernelGGL((k_segreduce_fast<3, true>), fgrid, dim3(kBlock), dyn_lds, st, f); break;
+        case 4: hipLaunchKernelGGL((k_segreduce_fast<4, true>), fgrid, dim3(kBlock), dyn_lds, st, f); break;
+        case 5: hipLaunchKernelGGL((k_segreduce_fast<5, true>), fgrid, dim3(kBlock), dyn_lds, st, f); break;
+        case 6: hipLaunchKernelGGL((k_segreduce_fast<6, true>), fgrid, dim3(kBlock), dyn_lds, st, f); break;
+        default: hipLaunchKernelGGL((k_segreduce_fast<8, true>), fgrid, dim3(kBlock), dyn_lds, st, f); break;
+      }
+    } else {
+      switch (U) {
+        case 2: hipLaunchKernelGGL((k_segreduce_fast<2, false>), fgrid, dim3(kBlock), dyn_lds, st, f); break;
+        case 3: hipLaunchKernelGGL((k_segreduce_fast<3, false>), fgrid, dim3(kBlock), dyn_lds, st, f); break;
+        case 4: hipLaunchKernelGGL((k_segreduce_fast<4, false>), fgrid, dim3(kBlock), dyn_lds, st, f); break;
+        case 5: hipLaunchKernelGGL((k_segreduce_fast<5, false>), fgrid, dim3(kBlock), dyn_lds, st, f); break;
+        case 6: hipLaunchKernelGGL((k_segreduce_fast<6, false>), fgrid, dim3(kBlock), dyn_lds, st, f); break;
+        default: hipLaunchKernelGGL((k_segreduce_fast<8, false>), fgrid, dim3(kBlock), dyn_lds, st, f); break;
+      }
     }
   } else {
     rc = launch_any(k, vec, U, extra, idx32, grid, st);
@@ -829,6 +872,9 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
   if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
   if (heavy) {
     dim3 g2((unsigned)((k.n_heavy + kWaves - 1) / kWaves), (unsigned)(tiles * T));
+    // the hand-scheduled kernel writes (s, q, max, min) partials with NaN-dropping max/min: finish them with the
+    // plain finalize (NaN restored from q), also when a dst_term was added to the messages
+    const bool extra = !fast_ok && (p->dst_term || p->edge_term || p->edge_weight || p->argmax || p->argmin);
     if (vec == 4) {
       if (extra) hipLaunchKernelGGL((k_heavy_finalize<4, true>), g2, dim3(kBlock), 0, st, k);
       else hipLaunchKernelGGL((k_heavy_finalize<4, false>), g2, dim3(kBlock), 0, st, k);

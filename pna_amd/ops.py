@@ -160,7 +160,7 @@ def posttrans(a_mat: torch.Tensor, K: int, weight: torch.Tensor, row_scales: Seq
               bias: Optional[torch.Tensor] = None, h: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
               row_post: Optional[torch.Tensor] = None, col_scale: Optional[torch.Tensor] = None,
               col_shift: Optional[torch.Tensor] = None, relu: bool = False, residual: Optional[torch.Tensor] = None,
-              arith: Optional[str] = None):
+              arith: Optional[str] = None, pipeline: int = 0):
     """y = residual + act(((bias + h@Wh^T + sum_s row_scales[s][:,None] * (a[:, :K] @ W_s^T)) * row_post[:,None]) *
     col_scale + col_shift)                                                                      (see pna_amd.h).
 
@@ -203,6 +203,7 @@ def posttrans(a_mat: torch.Tensor, K: int, weight: torch.Tensor, row_scales: Seq
     if residual is not None:
         g.residual, g.ld_res = _lib.dev_ptr(residual, torch.float32, "residual"), _ld(residual)
     g.y, g.ldy = _lib.dev_ptr(out, torch.float32, "y"), _ld(out)
+    g.pipeline = int(pipeline) if x3 else 0      # bf16x3 only: 0 = default, 2 / 3 = weight buffers in LDS (include/pna_amd.h)
     fn = "pna_posttrans_x3_f32" if x3 else "pna_posttrans_f32"
     rc = getattr(_lib.lib(), fn)(ctypes.byref(g), _lib.stream_ptr(dev))
     _lib.check(rc, fn)
