@@ -51,6 +51,12 @@ def parse():
     p.add_argument("--cpu-sample-rows", type=int, default=250_000)
     p.add_argument("--x-pitch", type=int, default=80, help="row pitch (floats) of the resident feature matrix")
     p.add_argument("--kernel-iters", type=int, default=20, help="launches used for the per-kernel HIP-event timing")
+    p.add_argument("--workload", choices=("c3", "c5"), default="c3",
+                   help="c3 = BASELINE.json configs[2] (1M nodes / 10M edges per GPU, F=75: the configuration the metric is quoted on); "
+                        "c5 = configs[4] (2M nodes / 20M edges per GPU, F=128: V=16M E=160M over 8 GPUs)")
+    p.add_argument("--balance", choices=("nodes", "edges"), default="nodes", help="N > 1: destination ranges of equal node or in-edge counts")
+    p.add_argument("--no-cold", action="store_true", help="skip the cold-cache leg (3 rotating copies of the inputs)")
+    p.add_argument("--check-rows", type=int, default=96, help="rows re-computed on the host after the timed loop")
     return p.parse_args()
 
 
@@ -110,8 +116,56 @@ def cpu_baseline(src, dst, V, h, layer_sd, avg_log, sample_rows):
                       f"reduce_func + torch CPU Linear/BN/ReLU"}
 
 
+def sampled_check(g, h_ext, y, layer_sd, avg_log, n_rows, lo=0):
+    """Rows of the timed step's OUTPUT against the oracle, after the timed loop: the C restatement of reduce_func on the
+    sampled rows' in-edges (oracle/pna_oracle.c), then Linear / BatchNorm / ReLU / residual in float64.  Proves the timed
+    kernels did the work; the full-size bit-level properties live in tests/test_gpu_fullsize.py."""
+    import numpy as np
+    from oracle import c_oracle
+    csr = g.csr
+    V = g.num_nodes
+    deg = (csr.rowptr[1:] - csr.rowptr[:-1]).long()
+    gen = torch.Generator().manual_seed(7)
+    rows = torch.randint(0, V, (n_rows,), generator=gen)
+    rows[0] = int(torch.argmax(deg))                                   # a hub row (heavy-segment path)
+    rows[1] = int(torch.argmin(deg))
+    rows = torch.unique(rows).to(csr.rowptr.device)
+    beg, end = csr.rowptr[rows].long(), csr.rowptr[rows + 1].long()
+    cnt = end - beg
+    rp = torch.zeros(rows.numel() + 1, dtype=torch.int64, device=rows.device)
+    rp[1:] = torch.cumsum(cnt, 0)
+    pos = torch.arange(int(rp[-1]), device=rows.device) - torch.repeat_interleave(rp[:-1], cnt) + torch.repeat_interleave(beg, cnt)
+    srcs = csr.col[pos].long()
+    uniq, inv = torch.unique(srcs, return_inverse=True)
+    Fw = y.shape[1]
+    x_sub = h_ext[uniq][:, :F_of(layer_sd)].float().cpu().numpy()
+    amp, att = c_oracle.degree_scalers(rp.cpu().numpy().astype(np.int32), float(avg_log))
+    agg = c_oracle.segreduce(rp.cpu().numpy().astype(np.int32), inv.cpu().numpy().astype(np.int32), x_sub, x_sub.shape[1],
+                             AGGREGATORS.split(), [None, amp, att])
+    sd = {k: v.double().cpu() for k, v in layer_sd.items()}
+    z = torch.from_numpy(agg).double() @ sd["posttrans.fully_connected.0.linear.weight"].t() + sd["posttrans.fully_connected.0.linear.bias"]
+    z = (z - sd["batchnorm_h.running_mean"]) / torch.sqrt(sd["batchnorm_h.running_var"] + 1e-5) * sd["batchnorm_h.weight"] + sd["batchnorm_h.bias"]
+    ref = h_ext[rows][:, :Fw].double().cpu() + torch.relu(z)
+    got = y[rows].double().cpu()
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    return {"rows": int(rows.numel()), "edges": int(rp[-1]), "max_abs_err": err, "max_abs_ref": scale, "rel_to_max": err / max(scale, 1e-30),
+            "ok": bool(err <= 1e-4 * max(scale, 1.0)), "tolerance": "1e-4 x max|y| (fp32 layer vs float64 contraction of the fp32 oracle aggregate)"}
+
+
+def F_of(layer_sd):
+    return layer_sd["posttrans.fully_connected.0.linear.weight"].shape[1] // 12
+
+
 def main():
     args = parse()
+    global F
+    if args.workload == "c5":
+        F = 128
+        if args.nodes_per_gpu == V_PER_GPU and args.edges_per_gpu == E_PER_GPU:
+            args.nodes_per_gpu, args.edges_per_gpu = 2_000_000, 20_000_000
+        if args.x_pitch == 80:
+            args.x_pitch = 128
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -143,7 +197,7 @@ def main():
     deg = torch.bincount(dst, minlength=V)
     avg_log = torch.log(deg.double() + 1).mean().float()            # avg_d['log'] of this graph (main_HIV.py:240-244)
     if world > 1:
-        g = shard_graph(src, dst, V)
+        g = shard_graph(src, dst, V, balance=args.balance)
         lo, hi = g.lo, g.hi
     else:
         g = Graph(src, dst, V)
@@ -163,7 +217,8 @@ def main():
     if world > 1:
         # multi-GPU: the features live in the shard's resident [local | halo] table, so the halo exchange of the
         # timed step receives the peers' rows in place (no concatenation pass)
-        h = g.alloc_features(F, pitch=max(args.x_pitch, F), device=dev)
+        # (dense rows, pitch F: exactly F floats per halo row cross xGMI; the 16-byte aligned pitch would ship 6.7 % padding)
+        h = g.alloc_features(F, pitch=F if args.x_pitch == 80 else max(args.x_pitch, F), device=dev)
     else:
         h_buf = torch.zeros(hi - lo, max(args.x_pitch, F), device=dev)
         h = h_buf[:, :F]
@@ -205,6 +260,42 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = E / (dt / args.steps)
 
+    # ---- the timed kernels did the work: sampled rows of one more step's output against the oracle --------------------
+    check = None
+    if rank == 0 or world > 1:
+        try:
+            with torch.no_grad():
+                y_chk = layer(g, h)
+                h_ext_chk = g.source_features(h)
+            check = sampled_check(g, h_ext_chk, y_chk, layer_sd, avg_log, args.check_rows)
+        except Exception as ex:                                     # reported, never silently dropped
+            check = {"ok": False, "error": repr(ex)}
+        if not check.get("ok"):
+            print(f"[bench] rank {rank}: sampled parity check FAILED: {check}", file=sys.stderr, flush=True)
+
+    # ---- cold-cache leg: 3 rotating copies of the feature table and of the graph's index arrays, so that no
+    # step finds its 300 MB of features / 40 MB of source ids in the 256 MiB Infinity Cache from the previous step --------
+    ms_per_step_cold = None
+    if world == 1 and not args.no_cold:
+        copies = []
+        for i in range(3):
+            gi = Graph(src, dst, V)
+            gi._csr = type(csr0 := g.csr)(csr0.rowptr.clone(), csr0.col.clone(), csr0.eid, csr0.row, csr0.max_degree)
+            gi.degree_scalers(float(avg_log)); gi.heavy_schedule(); gi.work_items()
+            hb = torch.zeros(hi - lo, max(args.x_pitch, F), device=dev)
+            hb[:, :F].copy_(h)
+            copies.append((gi, hb[:, :F]))
+        with torch.no_grad():
+            for i in range(3):
+                layer(*copies[i])
+            sync()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                layer(*copies[i % 3])
+            sync()
+        ms_per_step_cold = (time.perf_counter() - t1) / args.steps * 1e3
+        del copies
+
     # the same step with the contraction forced onto the exact f32-input MFMA (reported beside the headline number)
     from pna_amd import ops as _ops
     arith = "bf16x3" if (_ops.POSTTRANS_ARITH == "bf16x3" or (_ops.POSTTRANS_ARITH == "auto" and n_local >= _ops.X3_MIN_ROWS)) else "f32"
@@ -225,7 +316,7 @@ def main():
     # ---- per-kernel timing of the dominant kernels (HIP events, this rank) ------------------------------
     csr = g.csr
     with torch.no_grad():
-        x_ext = g.source_features(h)
+        x_ext = g.source_features(h)                                   # (synchronous form: the halo has landed)
         t_seg = event_time_ms(lambda: PF.aggregate(g, x_ext, F, AGGREGATORS.split()), args.kernel_iters)
         agg = PF.aggregate(g, x_ext, F, AGGREGATORS.split())
         lin = layer.posttrans.fully_connected[0].linear
@@ -236,27 +327,32 @@ def main():
     alg_read = e_local * (4 * F + 4) + 4 * (n_local + 1)
     alg_write = n_local * 16 * F
     alg_bytes = alg_read + alg_write
-    traffic = traffic_post = None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")      # PMC-derived HBM bytes per launch, if collected
-    if os.path.exists(tpath):
+    # `traffic` is NOT measured in this run (PMC counters need their own rocprofv3 passes): it is the committed result of
+    # the passes named in traffic_source, for the C3 shape at N=1 only
+    traffic = traffic_post = traffic_source = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath) and args.workload == "c3" and world == 1 and args.nodes_per_gpu == V_PER_GPU and args.edges_per_gpu == E_PER_GPU:
         try:
             tj = json.load(open(tpath))
             traffic = tj.get("pna_segreduce_c3", {}).get("hbm_bytes_per_launch")
             traffic_post = tj.get("pna_posttrans_x3_c3" if arith == "bf16x3" else "pna_posttrans_f32_c3", {}).get("hbm_bytes_per_launch")
+            traffic_source = ("profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/prof_kernels.py, "
+                              + tj.get("collected", "round 1") + "; NOT measured in this run")
         except Exception:
-            traffic = traffic_post = None
+            traffic = traffic_post = traffic_source = None
     roofline = {"bound": "hbm", "kernel": "k_segreduce_fast<4> + k_heavy_finalize (pna_segreduce_fwd_f32)",
                 "achieved": alg_bytes / (t_seg * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": alg_bytes / (t_seg * 1e-3) / HBM_PEAK, "traffic": traffic,
+                "frac": alg_bytes / (t_seg * 1e-3) / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source,
                 "ms_per_launch": t_seg, "algorithmic_bytes_per_launch": alg_bytes,
                 "read_only_frac": alg_read / (t_seg * 1e-3) / HBM_PEAK,
                 "edges_per_s_kernel_only": e_local / (t_seg * 1e-3),
                 "heavy_rows": hs.n_heavy, "heavy_segments": hs.n_seg}
     flops = 2.0 * n_local * (12 * F) * F
     if arith == "bf16x3":     # fp32-equivalent FLOP/s against the bf16 pipe's peak / 6 (six bf16 partial products per multiply)
-        roofline_post = {"bound": "mfma", "kernel": "k_posttrans_x3<3,false,5,1,12> (pna_posttrans_x3_f32)",
+        roofline_post = {"bound": "mfma", "kernel": "k_posttrans_x3<S=3,NT=5,RT=1,12 wavefronts, 3 weight buffers> (pna_posttrans_x3_f32)",
                          "achieved": flops / (t_post * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK / 6 / 1e12, "unit": "TFLOP/s (fp32-equivalent)",
                          "frac": flops / (t_post * 1e-3) / (MFMA_BF16_PEAK / 6), "ms_per_launch": t_post, "traffic": traffic_post,
+                         "traffic_source": traffic_source,
                          "bf16_tflops_issued": 6 * flops / (t_post * 1e-3) / 1e12,
                          "exact_f32_mfma_kernel": {"kernel": "k_posttrans<3,false,5> (pna_posttrans_f32)", "ms_per_launch": t_post_f32,
                                                    "achieved": flops / (t_post_f32 * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12,
@@ -266,20 +362,31 @@ def main():
                          "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s", "frac": flops / (t_post * 1e-3) / MFMA_F32_PEAK,
                          "ms_per_launch": t_post, "traffic": traffic_post}
 
+    # the LAYER against its own compulsory traffic: gathers + ids + rowptr, residual read, y written -- no 4F aggregate
+    layer_bytes = e_local * (4 * F + 4) + 4 * (n_local + 1) + n_local * 4 * F * 2
+    roofline_layer = {"bound": "hbm", "kernel": "whole PNASimpleLayer step (segreduce + posttrans)", "algorithmic_bytes_per_step": layer_bytes,
+                      "achieved": layer_bytes / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                      "frac": layer_bytes / (ms_per_step * 1e-3) / HBM_PEAK,
+                      "note": "E(4F+4) + 4(V+1) + 2*V*4F: what a layer that never materialised the 4F aggregate would have to move"}
+    wl = ("BASELINE.json configs[2]: synthetic power-law graph |V|=1M |E|=10M per GPU, F=75, " if args.workload == "c3" else
+          "BASELINE.json configs[4]: synthetic power-law graph |V|=2M |E|=20M per GPU (16M / 160M over 8 GPUs), F=128, ")
     rec = {
-        "metric": "PNA-layer fwd edges/sec (F=75, 4 aggr x 3 scalers)", "value": value, "unit": "edges/s",
+        "metric": f"PNA-layer fwd edges/sec (F={F}, 4 aggr x 3 scalers)", "value": value, "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[2]: synthetic power-law graph |V|=1M |E|=10M per GPU, F=75, "
-                               "single PNA (simple) layer fwd: 4 aggregators x 3 scalers + posttrans Linear(900->75) + BN + ReLU + residual",
+        "config": {"workload": wl + f"single PNA (simple) layer fwd: 4 aggregators x 3 scalers + posttrans Linear({12 * F}->{F}) + BN + ReLU + residual",
                    "V": V, "E": E, "F": F, "aggregators": AGGREGATORS, "scalers": SCALERS,
                    "parallelism": f"dst-range shard x{world}, halo all-to-all" if world > 1 else "single GPU",
                    "x_row_pitch_floats": max(args.x_pitch, F),
                    "posttrans_arith": ("bf16x3: fp32 in/out; each fp32 operand cut exactly into 3 bf16 terms, 6 partial products per multiply "
                                        "on the bf16 MFMA pipe, fp32 accumulate; error vs float64 at the exact-f32 kernel's level "
                                        "(tests/test_gpu_posttrans_x3.py)") if arith == "bf16x3" else "f32 (v_mfma_f32_16x16x4_f32)",
-                   "max_in_degree": int(csr.max_degree), "halo_rows_rank0": getattr(g, "n_halo", 0)},
-        "roofline": roofline, "roofline_posttrans": roofline_post,
+                   "max_in_degree": int(csr.max_degree), "halo_rows_rank0": getattr(g, "n_halo", 0),
+                   "interior_rows_rank0": int(g.interior_mask().sum().item()) if world > 1 else None,
+                   "local_rows_rank0": n_local, "local_edges_rank0": e_local, "partition_balance": args.balance if world > 1 else None},
+        "roofline": roofline, "roofline_posttrans": roofline_post, "roofline_layer": roofline_layer,
+        "ms_per_step_cold": ms_per_step_cold, "value_cold": (E / (ms_per_step_cold * 1e-3)) if ms_per_step_cold else None,
+        "parity_check": check,
         "kernel_ms": {"segreduce": t_seg, "posttrans": t_post, "posttrans_exact_f32_mfma": t_post_f32, "halo_all_to_all": t_halo,
                       "csr_build_once_per_graph": csr_build_ms},
         "ms_per_step_exact_f32_mfma": ms_per_step_f32, "value_exact_f32_mfma": E / (ms_per_step_f32 * 1e-3),
@@ -290,6 +397,12 @@ def main():
         except Exception as ex:                                     # the baseline must never sink the GPU number
             rec["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": f"failed: {ex!r}"}
+    rpath = os.path.join(ROOT, "profiles", "cpu_reference_source.json")
+    if rank == 0 and world == 1 and os.path.exists(rpath):
+        try:      # the reference's OWN source (DGL stand-in) cannot travel to the GPU box: timed once in the build container, recorded
+            rec["cpu_baseline_reference_source"] = json.load(open(rpath))
+        except Exception:
+            pass
     if rank == 0:
         print(json.dumps(rec), flush=True)
     if world > 1:

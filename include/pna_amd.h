@@ -62,7 +62,9 @@ typedef struct pna_tuning {
   int32_t prefetch;        /* 1 = fetch the next row's source ids one row ahead; 0 = auto(1); -1 = off */
   int32_t reserved[2];     /* [0]: ignored by the shipped library (bench-experiment knobs that exist only in the
                                    separate -DPNA_AMD_EXPERIMENTS build of tools/build_experiments.sh);
-                              [1]: 1 = force the compiler-scheduled kernel instead of the hand-scheduled one */
+                              [1]: 1 = force the compiler-scheduled kernel instead of the hand-scheduled one;
+                                   2 = REQUIRE the hand-scheduled kernel (PNA_E_INVALID if the call does not qualify):
+                                   a work list that covers only part of the rows is only honoured by that kernel */
 } pna_tuning;
 
 /*
@@ -379,6 +381,15 @@ int pna_collate_csr_i32(const int32_t* src, const int32_t* dst, int64_t n_edges,
                         const int32_t* edge_graph /* nullable [E] */, const int32_t* node_offset /* nullable [n_graphs] */,
                         int32_t* rowptr, int32_t* col, int32_t* eid, int32_t* row,
                         void* workspace, int64_t workspace_bytes, pna_stream_t stream);
+
+/* ---- halo packing for the destination-sharded multi-GPU path (the reference has no distributed code) ------
+ *
+ *   out[i, 0:F] = x[idx[i], 0:F]      i in [0, n)
+ * One launch packs the feature rows every peer asked for (idx = the peers' request lists, concatenated in peer order) into
+ * the contiguous send buffer of the per-layer all-to-all; pna_amd/shard.py is the caller.  Rows need 4-byte alignment only.
+ */
+int pna_pack_rows_f32(const float* x, int64_t ldx, const int32_t* idx, int64_t n, int32_t F, float* out, int64_t ldo,
+                      pna_stream_t stream);
 
 const char* pna_last_error(void);
 int pna_abi_version(void);

@@ -140,6 +140,9 @@ def lib():
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
         L.pna_collate_csr_i32.restype = ctypes.c_int
+        L.pna_pack_rows_f32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                        ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+        L.pna_pack_rows_f32.restype = ctypes.c_int
         L.pna_fused_simple_f32.argtypes = [ctypes.POINTER(PnaFusedSimpleArgs), ctypes.c_void_p]
         L.pna_fused_simple_f32.restype = ctypes.c_int
         L.pna_posttrans_packed_floats.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,

@@ -222,41 +222,44 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
     v.w = (k + 3 < kmax && d == 0) ? v.w : 0.f;
     return v;
   };
-  f4 nxt[RT][2];                               // A of the next chunk (in flight)
+  f4 nxt[2][RT][2];                            // A fragments in flight: one set (2-buffer pipeline) or two (3-buffer: 2 chunks ahead)
   bf8 A[3][RT];                                // the three bf16 terms of the chunk being multiplied
-  // Issued by hand, one piece at a time from inside the MFMA stream (hipcc would hoist plain loads into one burst at
-  // the top of the interval, and a burst of scattered-row loads from all wavefronts stalls them at the TA).  An
-  // asm-loaded register is written on EVERY path (the caller passes a valid tile even when there is no next one) and
-  // read only through the "+v" of the wait in take().
-  auto load_a_piece = [&](int t, int c, int r, int w) {
+  // Issued by hand (hipcc would hoist plain loads into one burst at the top of the interval, and a burst of scattered-row
+  // loads from all wavefronts stalls them at the TA).  Rules for a register written by an asm load: it is written on EVERY
+  // path (the caller passes a valid tile even when there is no next one), no control flow lies between the load and the
+  // wait that covers it (a register with two reaching definitions may be copied by the compiler at the merge, i.e. while
+  // the load is still in flight), and it is read only after the "+v" anchor that follows the wait in take().
+  typedef f4 aset_t[RT][2];
+  auto load_a_piece = [&](aset_t& dst, int t, int c, int r, int w) {
     const float* src; long ld; int kmax, k;
     a_src(c, src, ld, kmax, k);
     const int row = min((t * WAVES + wave) * (16 * RT) + 16 * r + li, g.M - 1);
     const int kk = max(0, min(k + 4 * w, kmax - 4));
     const float* ptr = src + (size_t)row * ld + kk;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nxt[r][w]) : "v"(ptr) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[r][w]) : "v"(ptr) : "memory");
   };
-  auto load_a = [&](int t, int c) {
+  auto load_a = [&](aset_t& dst, int t, int c) {
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
-      for (int w = 0; w < 2; ++w) load_a_piece(t, c, r, w);
+      for (int w = 0; w < 2; ++w) load_a_piece(dst, t, c, r, w);
   };
-  auto take = [&](int c, bool keep_ni = false) {   // next -> current (after the wait): fix the windows, split
+  // next -> current: fix the windows, split.  wait: 0 = vmcnt(0) first, 1 = vmcnt(NI) first (the NI weight copies issued AFTER
+  // these A loads may stay in flight: VMEM returns in order), 2 = none (an earlier counted wait already covered the loads).
+  // The waits carry NO register operands; the registers are tied by ONE anchor after them.  (Two "+v" waits in two branches
+  // made the compiler copy the fragment into fresh registers at the top of one branch -- BEFORE that branch's wait, while the
+  // loads were still in flight: stale A fragments on short K.)
+  auto take = [&](aset_t& cur, int c, int wait) {
     const float* src; long ld; int kmax, k;
     a_src(c, src, ld, kmax, k);
     const bool tail = c * kKC + kKC > (c < nca ? g.K : nca * kKC + g.Kh);   // wave-uniform: only a row's last chunk needs fixing
-    // keep_ni (3-buffer pipeline): the NI weight copies issued AFTER these A loads may stay in flight (VMEM returns in order).
-    // The waits carry NO register operands and sit in their own branches; the registers are tied by ONE anchor after the
-    // merge.  (Two "+v" waits in two branches made the compiler copy nxt into fresh registers at the top of one branch --
-    // BEFORE that branch's wait, i.e. while the loads were still in flight: stale A fragments on short K.)
-    if (keep_ni) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NI) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    if (wait == 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NI) : "memory");
+    else if (wait == 0) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
 #pragma unroll
-    for (int r = 0; r < RT; ++r) asm volatile("" : "+v"(nxt[r][0]), "+v"(nxt[r][1]) : : "memory");
+    for (int r = 0; r < RT; ++r) asm volatile("" : "+v"(cur[r][0]), "+v"(cur[r][1]) : : "memory");
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
-      f4 lo4 = nxt[r][0], hi4 = nxt[r][1];
+      f4 lo4 = cur[r][0], hi4 = cur[r][1];
       if (tail) { lo4 = fix4(k, kmax, lo4); hi4 = fix4(k + 4, kmax, hi4); }
       // +-Inf anywhere in the wavefront's fragment (5 VALU to find out): the slower split that keeps it an infinity
       if (__builtin_amdgcn_ballot_w64(absmax8(lo4, hi4) == INFINITY) != 0) split8_inf(lo4, hi4, A[0][r], A[1][r], A[2][r]);
@@ -429,8 +432,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
     int t = blockIdx.x, c = 0, buf = 0;
     if (t >= ntiles) return;
     stage(0, 0);
-    load_a(t, 0);
-    take(0);                                     // (waits vmcnt(0): chunk 0 of the image has landed too)
+    load_a(nxt[0], t, 0);
+    take(nxt[0], 0, 0);                           // (waits vmcnt(0): chunk 0 of the image has landed too)
     __syncthreads();
     while (true) {
       int tn = t, cn = c + 1;
@@ -469,10 +472,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
           } else {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(B[gi & 1][0]), "+v"(B[gi & 1][1]), "+v"(B[gi & 1][2]));
           }
-  #pragma unroll
-          for (int j = 0; j < 2 * RT; ++j)
-            if (gi == 0) load_a_piece(ta, ca, j >> 1, j & 1);   // HBM latency: first
-          if (more) {                                                 // the L2-resident weight image: spread over the rest
+            if (more) {                                                 // the L2-resident weight image: spread over the rest
   #pragma unroll
             for (int i = 0; i < NI; ++i)
               if ((NG > 2 * RT ? 2 * RT + (i * (NG - 2 * RT)) / NI : NG - 1) == gi) stage_piece(cn, buf ^ 1, i);
@@ -484,6 +484,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
               acc[r][p0 + p][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]][r], B[gi & 1][TB[pp]], acc[r][p0 + p][n], 0, 0, 0);
         }
       };
+      load_a(nxt[0], ta, ca);                            // HBM latency: first (and outside the is_h branches, see load_a_piece)
       if (!is_h) {
         run(std::integral_constant<int, S>{}, 0, baddr);
       } else if (HAS_H) {
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
         __builtin_amdgcn_sched_barrier(0);
       }
       if (!more) break;
-      take(cn);                                          // waits vmcnt(0): this wavefront's share of the next chunk is in LDS
+      take(nxt[0], cn, 0);                               // waits vmcnt(0): this wavefront's share of the next chunk is in LDS
       __syncthreads();                                   // ... everyone's is, and everyone is done reading this chunk
       buf ^= 1; t = tn; c = cn;
     }
@@ -510,25 +511,38 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
     // waited for (counted vmcnt, they are older than the A loads of the following step) BEFORE B_{k+1}; step k+2 starts
     // after B_{k+1}.  At a chunk boundary a wavefront only waits for ITS OWN next A fragment and splits it while the other
     // wavefronts of its SIMD keep the matrix pipe busy: wavefronts are synchronised mid-chunk only.
+    // The A fragment is fetched TWO chunks ahead into two alternating register sets: the loads of step k+2 are issued at
+    // the top of step k (into the set that held step k's fragment), so the counted wait before B_k -- which lets only
+    // those youngest 2*RT loads stay in flight -- has already covered step k+1's fragment (issued a whole chunk earlier):
+    // a wavefront never waits for HBM at a chunk boundary, and the latency it tolerates is 1.5 chunk times.
     const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int nsteps = my_tiles * nc;
     int t = blockIdx.x, c = 0, buf = 0;
     if (t >= ntiles) return;
     stage(0, 0);
     if (nsteps > 1) stage(nc > 1 ? 1 : 0, 1);
-    load_a(t, 0);
-    take(0);                                   // vmcnt(0): both images and the first A fragment have landed
+    load_a(nxt[0], t, 0);
+    take(nxt[0], 0, 0);                         // vmcnt(0): both images and the first A fragment have landed
+    {
+      int t1 = t, c1 = 1;
+      if (c1 == nc) { t1 = t + gridDim.x; c1 = 0; }
+      const bool m1 = nsteps > 1;
+      load_a(nxt[1], m1 ? t1 : t, m1 ? c1 : 0);   // step 1's fragment (a harmless re-load when there is no step 1)
+    }
     __syncthreads();
-    for (int k = 0; k < nsteps; ++k) {
+    auto step = [&](auto par_c, int k) {
+      constexpr int PAR = decltype(par_c)::value;
+      aset_t& mine = nxt[PAR];           // free now (held step k's fragment): receives step k+2's
+      aset_t& other = nxt[PAR ^ 1];      // holds step k+1's
       int tn = t, cn = c + 1;
       if (cn == nc) { tn = t + gridDim.x; cn = 0; }
+      int t2 = tn, c2 = cn + 1;
+      if (c2 == nc) { t2 = tn + gridDim.x; c2 = 0; }       // (tile, chunk) of step k+2
       const bool more1 = k + 1 < nsteps, more2 = k + 2 < nsteps;
-      const int ta = more1 ? tn : t, ca = more1 ? cn : c;   // A prefetch target (a harmless re-load on the last step)
-      int c2 = cn + 1;
-      if (c2 >= nc) c2 -= nc;                              // chunk of step k+2
       const int buf2 = buf == 0 ? 2 : buf - 1;             // (k + 2) % 3
       const bool is_h = HAS_H && c >= nca;
       const unsigned baddr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(buf * kChunkV + lg * kNW + li) * 16u;
+      load_a(mine, more2 ? t2 : t, more2 ? c2 : c);       // (a harmless re-load of this step's fragment near the end)
       auto run3 = [&](auto npanel_c, int p0, unsigned ba0) {
         constexpr int NPN = decltype(npanel_c)::value;
         constexpr int NG = NPN * NT;
@@ -551,11 +565,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
           } else {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(B[gi & 1][0]), "+v"(B[gi & 1][1]), "+v"(B[gi & 1][2]));
           }
-#pragma unroll
-          for (int j = 0; j < 2 * RT; ++j)
-            if (gi == 0) load_a_piece(ta, ca, j >> 1, j & 1);
           if (gi == H) {
-            // everything older than the 2*RT A loads just issued has landed: this wavefront's copies of step k+1's image
+            // everything older than the 2*RT A loads issued at the top of this step has landed: this wavefront's copies
+            // of step k+1's image AND step k+1's A fragment
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"(2 * RT) : "memory");
           }
           if (more2) {
@@ -575,10 +587,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
       } else if (HAS_H) {
         run3(std::integral_constant<int, 1>{}, P - 1, baddr);
       }
-      // next A fragment first (its wait leaves this step's NI weight copies in flight), then the epilogue: the other way
-      // round the counted wait would also sit out the epilogue's stores
-      if (more1) take(cn, more2);
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // the next fragment first, then the epilogue (the fragment landed before this step's barrier: no wait here)
+      if (more1) take(other, cn, 2);
       if (c == nc - 1) {
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (GEN) epilogue(t);
@@ -587,7 +597,12 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
         __builtin_amdgcn_sched_barrier(0);
       }
       t = tn; c = cn; buf = buf == 2 ? 0 : buf + 1;
+    };
+    for (int k = 0; k < nsteps; k += 2) {
+      step(std::integral_constant<int, 0>{}, k);
+      if (k + 1 < nsteps) step(std::integral_constant<int, 1>{}, k + 1);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the re-loads of the last steps
   }
 }
 
@@ -602,45 +617,51 @@ int launch_v(const XArgs& g, hipStream_t st) {
   return 0;
 }
 
-template <int S, bool HAS_H, int NT>
-int launch_k(const XArgs& g, int nbuf, hipStream_t st) {
-  // One row tile per wavefront, 12 wavefronts (3 per SIMD, 170 registers each) while the P * NT accumulator tiles fit
-  // that budget, else 8 (256 registers).  Measured on C3 (S=3, NT=5): 0.775 ms, against 0.82 for 2 row tiles x 8
-  // wavefronts (half the LDS fragment reads, but only 2 wavefronts per SIMD to cover each other's stalls), 0.87 for
-  // 1 x 8 and 1.19 for 1 x 16 (128 registers: spills).
-  constexpr int WAVES = (S + (HAS_H ? 1 : 0)) * NT > 15 ? 8 : 12;
-  // rows [0, M16): the straight-line epilogue; the M % 16 rows beyond: a second launch with the generic one
-  const int M16 = g.M - g.M % 16;
-  if (M16 > 0) {
+template <int S, bool HAS_H, int NT, int RT, int WAVES>
+int launch_split(const XArgs& g, int nbuf, hipStream_t st) {
+  // rows [0, Mf): wavefront tiles of 16 * RT whole rows, the straight-line epilogue; the rows beyond: a second launch with the
+  // generic one
+  const int Mf = g.M - g.M % (16 * RT);
+  if (Mf > 0) {
     XArgs m = g;
-    m.M = M16;
-    const int rc = nbuf == 3 ? launch_v<S, HAS_H, NT, 1, WAVES, 3, false>(m, st) : launch_v<S, HAS_H, NT, 1, WAVES, 2, false>(m, st);
+    m.M = Mf;
+    const int rc = nbuf == 3 ? launch_v<S, HAS_H, NT, RT, WAVES, 3, false>(m, st) : launch_v<S, HAS_H, NT, RT, WAVES, 2, false>(m, st);
     if (rc != 0) return rc;
   }
-  if (g.M > M16) {
+  if (g.M > Mf) {
     XArgs r = g;
-    r.M = g.M - M16;
-    r.a = g.a + (size_t)M16 * g.lda;
-    if (g.h) r.h = g.h + (size_t)M16 * g.ldh;
-    for (int s = 0; s < S; ++s) if (g.row_scale[s]) r.row_scale[s] = g.row_scale[s] + M16;
-    if (g.row_post) r.row_post = g.row_post + M16;
-    if (g.residual) r.residual = g.residual + (size_t)M16 * g.ld_res;
-    r.y = g.y + (size_t)M16 * g.ldy;
-    return launch_v<S, HAS_H, NT, 1, WAVES, 2, true>(r, st);
+    r.M = g.M - Mf;
+    r.a = g.a + (size_t)Mf * g.lda;
+    if (g.h) r.h = g.h + (size_t)Mf * g.ldh;
+    for (int s = 0; s < S; ++s) if (g.row_scale[s]) r.row_scale[s] = g.row_scale[s] + Mf;
+    if (g.row_post) r.row_post = g.row_post + Mf;
+    if (g.residual) r.residual = g.residual + (size_t)Mf * g.ld_res;
+    r.y = g.y + (size_t)Mf * g.ldy;
+    constexpr int WT = (S + (HAS_H ? 1 : 0)) * NT > 15 ? 8 : 12;
+    return launch_v<S, HAS_H, NT, 1, WT, 2, true>(r, st);
   }
   return 0;
 }
 
+template <int S, bool HAS_H, int NT>
+int launch_k(const XArgs& g, int nbuf, int shape, hipStream_t st) {
+  // One row tile per wavefront, 12 wavefronts (3 per SIMD, <= 168 registers each) while the P * NT accumulator tiles fit
+  // that budget, else 8 (256 registers).  
+  constexpr int WAVES = (S + (HAS_H ? 1 : 0)) * NT > 15 ? 8 : 12;
+  (void)shape;   // 8 wavefronts x 2 row tiles was measured in round 1 (slower) and spills with the 3-buffer pipeline: not built
+  return launch_split<S, HAS_H, NT, 1, WAVES>(g, nbuf, st);
+}
+
 template <int S, bool HAS_H>
-int launch_nt(const XArgs& g, int nt, int nbuf, hipStream_t st) {
-  if (nt <= 1) return launch_k<S, HAS_H, 1>(g, nbuf, st);
-  if (nt <= 3) return launch_k<S, HAS_H, 3>(g, nbuf, st);
-  return launch_k<S, HAS_H, 5>(g, nbuf, st);
+int launch_nt(const XArgs& g, int nt, int nbuf, int shape, hipStream_t st) {
+  if (nt <= 1) return launch_k<S, HAS_H, 1>(g, nbuf, shape, st);
+  if (nt <= 3) return launch_k<S, HAS_H, 3>(g, nbuf, shape, st);
+  return launch_k<S, HAS_H, 5>(g, nbuf, shape, st);
 }
 
 template <int S>
-int launch_s(const XArgs& g, bool has_h, int nt, int nbuf, hipStream_t st) {
-  return has_h ? launch_nt<S, true>(g, nt, nbuf, st) : launch_nt<S, false>(g, nt, nbuf, st);
+int launch_s(const XArgs& g, bool has_h, int nt, int nbuf, int shape, hipStream_t st) {
+  return has_h ? launch_nt<S, true>(g, nt, nbuf, shape, st) : launch_nt<S, false>(g, nt, nbuf, shape, st);
 }
 
 }  // namespace
@@ -698,13 +719,14 @@ extern "C" int pna_posttrans_x3_f32(const pna_posttrans_args* p, pna_stream_t st
   hipStream_t st = (hipStream_t)stream;
   const int nt = p->N >= kNW ? kMaxNT : (p->N + 15) / 16;
   int rc;
-  if (p->pipeline != 0 && p->pipeline != 2 && p->pipeline != 3)
+  const int pl = p->pipeline, shape = 0;
+  if (pl != 0 && pl != 2 && pl != 3)
     return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3_f32: pipeline must be 0 (default), 2 or 3");
-  const int nbuf = p->pipeline ? p->pipeline : kDefaultNBuf;
+  const int nbuf = pl ? pl : kDefaultNBuf;
   switch (p->n_scaler) {
-    case 1: rc = launch_s<1>(g, has_h, nt, nbuf, st); break;
-    case 2: rc = launch_s<2>(g, has_h, nt, nbuf, st); break;
-    default: rc = launch_s<3>(g, has_h, nt, nbuf, st); break;
+    case 1: rc = launch_s<1>(g, has_h, nt, nbuf, shape, st); break;
+    case 2: rc = launch_s<2>(g, has_h, nt, nbuf, shape, st); break;
+    default: rc = launch_s<3>(g, has_h, nt, nbuf, shape, st); break;
   }
   if (rc != 0) return pna_set_error(PNA_E_LAUNCH, "pna_posttrans_x3_f32: could not reserve LDS");
   hipError_t e = hipGetLastError();

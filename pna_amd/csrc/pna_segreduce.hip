@@ -831,8 +831,10 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
                        p->n_work_items > 0 && p->n_work_items < (1 << 27) && p->n_edges > 0 && p->n_edges < (1LL << 30) &&
                        (!p->dst_term || (p->V < (1 << 24) && p->ld_dst * 4 < (1 << 24) &&
                                          (double)p->V * (double)p->ld_dst * 4.0 < 4294967296.0)) &&
-                       t.reserved[1] == 0;
+                       t.reserved[1] != 1;
   int rc = 0;
+  if (!fast_ok && t.reserved[1] == 2)
+    return pna_set_error(PNA_E_INVALID, "pna_segreduce_fwd_f32: the hand-scheduled kernel was required (tune.reserved[1] = 2) but this call does not qualify for it");
   if (!fast_ok && U != 2 && U != 4 && U != 8) U = 4;       // the compiler-scheduled kernel is built for 2, 4, 8
   if (fast_ok) {
     FArgs f;

@@ -146,8 +146,8 @@ def _towers_forward(towers, graph, h, e, snorm_n, divide_input):
             x_src = h @ Wa.reshape(T * Fi, Fi).t()
             x_dst = torch.addmm(b.reshape(-1), h, Wb.reshape(T * Fi, Fi).t())
         x_edge = e_csr @ We.reshape(T * Fi, ed).t() if t0.edge_features else None
-        x_src = graph.source_features(x_src)                  # multi-GPU: halo exchange of the PROJECTED rows
-        agg = PF.aggregate(graph, x_src, Fi, t0.aggregators, n_tower=T, dst_term=x_dst, edge_term=x_edge)
+        x_src = graph.source_features(x_src, defer=True)      # multi-GPU: halo exchange of the PROJECTED rows, overlapped
+        agg = PF.aggregate(graph, x_src, Fi, t0.aggregators, n_tower=T, dst_term=x_dst, edge_term=x_edge)   # (waits for it)
     else:
         # general pretrans (MLP with hidden layers): per-edge messages are materialised in CSR order
         src, dst = csr.col.long(), csr.row.long()
@@ -255,7 +255,8 @@ class PNASimpleLayer(nn.Module):
     def forward(self, g, h):
         graph = as_graph(g)
         h_in = h
-        agg = PF.aggregate(graph, graph.source_features(h), self.in_dim, self.aggregators)   # (V, A*F), identity only
+        # (V, A*F), identity scaler only; on a sharded graph the halo exchange overlaps the rows that do not need it
+        agg = PF.aggregate(graph, graph.source_features(h, defer=True), self.in_dim, self.aggregators)
         lin = self.posttrans.fully_connected[0].linear
         scales = _row_scales(graph, self.scalers, self.avg_d, h.device)
         K = len(self.aggregators) * self.in_dim

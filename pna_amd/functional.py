@@ -27,11 +27,37 @@ def aggregate(graph, x, F, aggregators, *, n_tower=1, dst_term=None, edge_term=N
     """
     x, dst_term, edge_term = _unit_stride(x), _unit_stride(dst_term), _unit_stride(edge_term)
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, dst_term, edge_term)):
+        graph.finish_exchange()
         from .autograd import AggregateFn
         return AggregateFn.apply(graph, x, dst_term, edge_term, F, tuple(aggregators), n_tower, tuple(row_scales),
                                  edge_resident, edge_weight, col_override)
     csr = graph.csr
     col = None if edge_resident else (csr.col if col_override is None else col_override)
+    if getattr(graph, "_pending", None) is not None:
+        # a sharded graph whose halo exchange is still in flight (HaloGraph.source_features(defer=True)): the rows that only
+        # read local sources go first, on the hand-scheduled kernel (the only one that honours a partial work list)
+        done = None
+        if (col is csr.col and edge_term is None and edge_weight is None and tuple(aggregators) == ("mean", "max", "min", "std")
+                and all(r is None for r in row_scales)):
+            _, items_in, items_bd = graph.split_work_lists()
+            A = len(aggregators)
+            out = torch.empty(csr.rowptr.numel() - 1, n_tower * A * F, dtype=torch.float32, device=x.device)
+            try:
+                if items_in.shape[0]:
+                    ops.segreduce(csr.rowptr, col, x, F, aggregators, row_scales, n_tower=n_tower, tower_stride_in=F,
+                                  dst_term=dst_term, out=out, items=items_in, tune=dict(generic=2))
+                graph.finish_exchange()
+                if items_bd.shape[0]:
+                    ops.segreduce(csr.rowptr, col, x, F, aggregators, row_scales, n_tower=n_tower, tower_stride_in=F,
+                                  dst_term=dst_term, out=out, heavy=graph.heavy_schedule(), workspace=graph.workspace,
+                                  items=items_bd, tune=dict(generic=2))
+                done = out
+            except RuntimeError as ex:                       # the call does not qualify for that kernel: one ordinary launch
+                if "hand-scheduled kernel was required" not in str(ex):
+                    raise
+        graph.finish_exchange()
+        if done is not None:
+            return done
     return ops.segreduce(csr.rowptr, col, x, F, aggregators, row_scales,
                          n_tower=n_tower, tower_stride_in=F, dst_term=dst_term, edge_term=edge_term,
                          edge_weight=edge_weight, heavy=graph.heavy_schedule(), workspace=graph.workspace,

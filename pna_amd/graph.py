@@ -188,10 +188,14 @@ class Graph:
         g._csr = csr
         return g
 
-    def source_features(self, h):
+    def source_features(self, h, defer=False):
         """Feature table the gather kernel indexes with the CSR's source ids.  Identity for a whole graph;
-        pna_amd.shard.HaloGraph overrides it with the halo all-to-all ([local rows | halo rows])."""
+        pna_amd.shard.HaloGraph overrides it with the halo all-to-all ([local rows | halo rows]); `defer` lets that
+        exchange overlap the aggregation of the rows that do not need it."""
         return h
+
+    def finish_exchange(self):
+        """Nothing to wait for on a whole graph (see HaloGraph)."""
 
     # -- cached index structures ---------------------------------------------------------------
     @property
@@ -206,6 +210,18 @@ class Graph:
             c = self.csr
             self._heavy[key] = build_heavy_schedule(c.rowptr, c.max_degree, *key)
         return self._heavy[key]
+
+    def work_items_subset(self, rows_mask, include_heavy, threshold=None, seg_len=None):
+        """The work list of work_items() restricted to the light rows selected by `rows_mask` (bool [V]), with or
+        without the heavy rows' segments: how the sharded layers split a launch into the rows that only read local sources
+        (aggregated while the halo exchange is in flight) and the rest.  Natural order.  Not cached."""
+        hs = self.heavy_schedule(threshold, seg_len)
+        full = self.work_items(threshold, seg_len)
+        n_seg = hs.n_seg if hs.n_heavy > 0 else 0
+        light = full[n_seg:]
+        keep = rows_mask.to(light.device)[light[:, 0].long()]
+        parts = ([full[:n_seg]] if include_heavy and n_seg else []) + [light[keep]]
+        return torch.cat(parts, dim=0).contiguous() if len(parts) > 1 else parts[0].contiguous()
 
     def work_items(self, threshold=None, seg_len=None, order="natural", window=96):
         """int32 (n, 4) work list {row, beg, end, slot} for the hand-scheduled kernel (include/pna_amd.h): first

@@ -266,3 +266,15 @@ def fused_simple(rowptr: torch.Tensor, col: torch.Tensor, x: torch.Tensor, F: in
     rc = _lib.lib().pna_fused_simple_f32(ctypes.byref(g), _lib.stream_ptr(dev))
     _lib.check(rc, "pna_fused_simple_f32")
     return out
+
+
+def pack_rows(x: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[i] = x[idx[i]] for fp32 rows of any 4-byte aligned pitch (pna_pack_rows_f32): the send-side packing of the halo
+    all-to-all (pna_amd/shard.py).  idx: int32 [n]."""
+    n, F = idx.numel(), x.shape[1]
+    if out is None:
+        out = torch.empty(n, F, dtype=torch.float32, device=x.device)
+    rc = _lib.lib().pna_pack_rows_f32(_lib.dev_ptr(x, torch.float32, "x"), _ld(x), _lib.dev_ptr(idx, torch.int32, "idx"), n, F,
+                                      _lib.dev_ptr(out, torch.float32, "out"), _ld(out), _lib.stream_ptr(x.device))
+    _lib.check(rc, "pna_pack_rows_f32")
+    return out

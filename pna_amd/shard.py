@@ -10,10 +10,11 @@ CPU for the tests):
   * the only cross-GPU dependency is reading source rows owned by a peer.  Per peer the sorted,
     de-duplicated list of referenced rows (the halo) is computed once per graph; source ids are
     remapped to [local rows | halo rows of peer 0 | halo rows of peer 1 | ...];
-  * per layer: pack the rows each peer asked for (one index_select), ONE all_to_all_single with
+  * per layer: pack the rows each peer asked for (pna_pack_rows_f32), ONE all_to_all_single with
     per-peer split sizes (direct point-to-point transfers over xGMI -- every peer link is used
     concurrently; a ring would be bound by a single 153 GB/s link), then the ordinary fused
-    segment-reduce over the extended feature table.
+    segment-reduce over the extended feature table -- the rows that only read local sources are
+    aggregated WHILE the exchange is in flight (HaloGraph.split_work_lists, functional.aggregate).
 """
 from typing import List, Optional
 
@@ -23,18 +24,75 @@ import torch.distributed as dist
 from .graph import Graph
 
 
-def partition_bounds(num_nodes: int, world_size: int) -> List[int]:
-    """Contiguous destination ranges: rank r owns [bounds[r], bounds[r+1])."""
-    return [(num_nodes * r) // world_size for r in range(world_size + 1)]
+def partition_bounds(num_nodes: int, world_size: int, dst: Optional[torch.Tensor] = None, balance: str = "nodes") -> List[int]:
+    """Contiguous destination ranges: rank r owns [bounds[r], bounds[r+1]).  balance="nodes": equal node counts;
+    balance="edges": equal in-edge counts (each rank's gather work; needs the global `dst`) -- on a power-law graph the
+    node-balanced ranges differ by the hubs they happen to contain."""
+    if balance == "nodes" or dst is None:
+        return [(num_nodes * r) // world_size for r in range(world_size + 1)]
+    if balance != "edges":
+        raise ValueError(f"unknown balance {balance!r} (nodes | edges)")
+    deg = torch.bincount(dst.long(), minlength=num_nodes)
+    cum = torch.cumsum(deg, 0)
+    total = int(cum[-1].item()) if num_nodes else 0
+    targets = torch.tensor([(total * r) // world_size for r in range(1, world_size)], device=cum.device, dtype=cum.dtype)
+    cuts = torch.searchsorted(cum, targets, right=False) + 1 if world_size > 1 else targets
+    b = [0] + [int(v) for v in cuts.tolist()] + [num_nodes]
+    for i in range(1, len(b)):                       # monotone, inside [0, V]
+        b[i] = min(max(b[i], b[i - 1]), num_nodes)
+    return b
+
+
+def bfs_order(src: torch.Tensor, dst: torch.Tensor, num_nodes: int, start: Optional[int] = None) -> torch.Tensor:
+    """A locality-aware renumbering: perm[new_id] = old_id in breadth-first order from `start` (default: the node of largest
+    in-degree), unreached nodes appended in id order.  Neighbours get close ids, so contiguous destination ranges cut fewer
+    edges on graphs that HAVE locality (meshes, molecules batched in arbitrary order, citation graphs); on the locality-free
+    Chung-Lu benchmark graph it cannot help (tools/halo_dryrun.py reports both).  Level-synchronous, torch ops only."""
+    dev = src.device
+    order = torch.sort(src.long(), stable=True)
+    s_sorted, nbr = order.values, dst.long()[order.indices]
+    rp = torch.zeros(num_nodes + 1, dtype=torch.long, device=dev)
+    rp[1:] = torch.cumsum(torch.bincount(s_sorted, minlength=num_nodes), 0)
+    if start is None:
+        start = int(torch.argmax(torch.bincount(dst.long(), minlength=num_nodes)).item())
+    seen = torch.zeros(num_nodes, dtype=torch.bool, device=dev)
+    seen[start] = True
+    frontier = torch.tensor([start], device=dev)
+    out = [frontier]
+    while frontier.numel():
+        cnt = rp[frontier + 1] - rp[frontier]
+        if int(cnt.sum().item()) == 0:
+            break
+        base = torch.repeat_interleave(rp[frontier], cnt)
+        offs = torch.arange(int(cnt.sum().item()), device=dev) - torch.repeat_interleave(torch.cumsum(cnt, 0) - cnt, cnt)
+        cand = nbr[base + offs]
+        cand = cand[~seen[cand]]
+        if cand.numel() == 0:
+            break
+        # first occurrence order keeps the discovery order deterministic
+        uniq, inv = torch.unique(cand, return_inverse=True)
+        first = torch.full((uniq.numel(),), cand.numel(), dtype=torch.long, device=dev).scatter_reduce_(
+            0, inv, torch.arange(cand.numel(), device=dev), reduce="amin")
+        frontier = uniq[torch.argsort(first)]
+        seen[frontier] = True
+        out.append(frontier)
+    rest = torch.nonzero(~seen).flatten()
+    return torch.cat(out + [rest])
 
 
 class HaloGraph(Graph):
     """The local shard: a Graph whose destinations are this rank's nodes (renumbered from 0) and whose
     source ids index the extended table [local | halo].  `source_features(h_local)` performs the halo
-    exchange and returns that table; the layers call it before gathering."""
+    exchange and returns that table; the layers call it before gathering.
+
+    Overlap: destination rows whose in-edges ALL come from local sources ("interior" rows) do not depend on the
+    exchange.  With `source_features(h, defer=True)` the all-to-all is only STARTED (async); `functional.aggregate` then
+    launches the interior rows' work list, waits for the exchange and launches the rest ("boundary" rows and every hub row).
+    Every row is still reduced by one lane group in its original edge order: results are bit-identical to the unsharded
+    kernel whichever way the launch is split."""
 
     def __init__(self, src_ext, dst_local, n_local, n_halo, send_idx, send_splits, recv_splits, group, lo, hi,
-                 global_num_nodes, batch_num_nodes=None):
+                 global_num_nodes, batch_num_nodes=None, any_exchange=True):
         super().__init__(src_ext, dst_local, n_local, batch_num_nodes)
         self.n_halo = n_halo
         self.send_idx = send_idx                  # int64 [sum(send_splits)] local rows to pack, grouped by peer
@@ -43,19 +101,44 @@ class HaloGraph(Graph):
         self.group = group
         self.lo, self.hi = lo, hi
         self.global_num_nodes = global_num_nodes
+        self.any_exchange = any_exchange          # False only when NO rank of the group has a halo (decided collectively)
         self._ext = None                          # resident [local | halo] table of alloc_features()
+        self._send_idx32 = None
+        self._pending = None                      # the in-flight exchange started by source_features(defer=True)
+        self._split = None                        # (interior mask, interior items, boundary items)
 
     def to(self, device):
         g = HaloGraph(self.src.to(device), self.dst.to(device), self.num_nodes, self.n_halo, self.send_idx.to(device),
                       self.send_splits, self.recv_splits, self.group, self.lo, self.hi, self.global_num_nodes,
-                      self.batch_num_nodes)
+                      self.batch_num_nodes, self.any_exchange)
         return g
 
+    # -- row classes -----------------------------------------------------------------------------------
+    def interior_mask(self) -> torch.Tensor:
+        """bool [n_local]: rows that are not hubs and whose in-edges all have LOCAL sources (ids < n_local)."""
+        return self.split_work_lists()[0]
+
+    def split_work_lists(self):
+        """(interior mask, work list of the interior rows, work list of everything else incl. all hub segments)."""
+        if self._split is None:
+            c = self.csr
+            remote = (c.col.long() >= self.num_nodes).to(torch.int32)
+            per_row = torch.zeros(self.num_nodes, dtype=torch.int32, device=remote.device)
+            if remote.numel():
+                per_row.index_add_(0, c.row.long(), remote)
+            deg = (c.rowptr[1:] - c.rowptr[:-1])
+            hs = self.heavy_schedule()
+            interior = (per_row == 0) & (deg <= hs.threshold if hs.threshold > 0 else torch.ones_like(deg, dtype=torch.bool))
+            self._split = (interior, self.work_items_subset(interior, include_heavy=False),
+                           self.work_items_subset(~interior, include_heavy=True))
+        return self._split
+
+    # -- feature tables ---------------------------------------------------------------------------------
     def alloc_features(self, F: int, pitch: Optional[int] = None, device=None) -> torch.Tensor:
-        """A resident extended table [local | halo] of row pitch `pitch` floats; returns its LOCAL part (n_local, F), a
-        view.  Features kept there are exchanged in place by `source_features`: peers' rows land directly behind the
-        local ones (whole pitch-sized rows travel), so the step saves the concatenation of the packed halo with the
-        local rows -- 2x(local + halo) bytes of HBM traffic, more than the gather kernel itself moves at 8 GPUs."""
+        """A resident extended table [local | halo] of row pitch `pitch` floats (default F: dense rows, so that exactly F
+        floats per halo row cross xGMI); returns its LOCAL part (n_local, F), a view.  Features kept there are exchanged in
+        place by `source_features`: peers' rows land directly behind the local ones, so the step has no concatenation pass
+        (which would move 2 x (local + halo) bytes, more than the gather kernel itself at 8 GPUs)."""
         pitch = F if pitch is None else max(int(pitch), F)
         self._ext = torch.zeros(self.num_nodes + self.n_halo, pitch, dtype=torch.float32,
                                 device=self.device if device is None else device)
@@ -67,17 +150,42 @@ class HaloGraph(Graph):
                 and h_local.storage_offset() == e.storage_offset() and h_local.stride(0) == e.stride(0) and h_local.stride(1) == 1
                 and h_local.shape[0] == self.num_nodes and not (torch.is_grad_enabled() and h_local.requires_grad))
 
-    def source_features(self, h_local: torch.Tensor) -> torch.Tensor:
+    def _pack(self, e):
+        """Rows the peers asked for, grouped by peer: pna_pack_rows_f32 on the GPU (whole pitch-wide rows of the resident
+        table; pitch = F unless the caller chose otherwise), index_select on the CPU (gloo tests)."""
+        if e.is_cuda:
+            from . import ops
+            if self._send_idx32 is None or self._send_idx32.device != e.device:
+                self._send_idx32 = self.send_idx.to(device=e.device, dtype=torch.int32)
+            return ops.pack_rows(e[: self.num_nodes], self._send_idx32)
+        return e[: self.num_nodes].index_select(0, self.send_idx)
+
+    def finish_exchange(self):
+        """Wait for the exchange started by source_features(defer=True) (no-op otherwise)."""
+        if self._pending is not None:
+            work, keep = self._pending
+            work.wait()
+            self._pending = None
+
+    def source_features(self, h_local: torch.Tensor, defer: bool = False) -> torch.Tensor:
         """[h_local | halo rows] after one all-to-all; differentiable (the backward is the transposed
-        all-to-all followed by a scatter-add into the owners' rows)."""
+        all-to-all followed by a scatter-add into the owners' rows).  defer=True (inference on the resident table only):
+        return as soon as the exchange is STARTED; the caller must hand the result to functional.aggregate, which overlaps
+        the interior rows with it, or call finish_exchange() before touching the halo part."""
         if h_local.shape[0] != self.num_nodes:
             raise ValueError(f"expected {self.num_nodes} local rows, got {h_local.shape[0]}")
-        if self.n_halo == 0 and sum(self.send_splits) == 0:
+        self.finish_exchange()
+        if not self.any_exchange:                 # no rank has a halo: nobody enters the collective
             return h_local
         if self._resident(h_local):               # inference on features living in the resident table: no pack-side
             e = self._ext                         # concatenation, the halo is received in place
-            send = e[: self.num_nodes].index_select(0, self.send_idx)
-            dist.all_to_all_single(e[self.num_nodes:], send, self.recv_splits, self.send_splits, group=self.group)
+            send = self._pack(e)
+            recv = e[self.num_nodes:]
+            if defer:
+                work = dist.all_to_all_single(recv, send, self.recv_splits, self.send_splits, group=self.group, async_op=True)
+                self._pending = (work, send)      # `send` must outlive the transfer
+            else:
+                dist.all_to_all_single(recv, send, self.recv_splits, self.send_splits, group=self.group)
             return e[:, : h_local.shape[1]]
         return _HaloExchange.apply(h_local, self)
 
@@ -104,13 +212,15 @@ class _HaloExchange(torch.autograd.Function):
 
 
 def shard_graph(src: torch.Tensor, dst: torch.Tensor, num_nodes: int, rank: Optional[int] = None,
-                world_size: Optional[int] = None, group=None) -> HaloGraph:
+                world_size: Optional[int] = None, group=None, balance: str = "nodes") -> HaloGraph:
     """Build this rank's shard from the GLOBAL edge list (every rank passes the same src/dst, e.g. a
-    deterministic generator or a replicated file).  Collective: every rank of `group` must call it."""
+    deterministic generator or a replicated file).  Collective: every rank of `group` must call it.
+    balance: "nodes" (equal node counts) or "edges" (equal in-edge counts), see partition_bounds.  For a locality-aware
+    numbering renumber the graph with bfs_order() first."""
     rank = dist.get_rank(group) if rank is None else rank
     world_size = dist.get_world_size(group) if world_size is None else world_size
     dev = src.device
-    bounds = partition_bounds(num_nodes, world_size)
+    bounds = partition_bounds(num_nodes, world_size, dst, balance)
     lo, hi = bounds[rank], bounds[rank + 1]
     n_local = hi - lo
     mine = (dst >= lo) & (dst < hi)
@@ -141,4 +251,10 @@ def shard_graph(src: torch.Tensor, dst: torch.Tensor, num_nodes: int, rank: Opti
     want = torch.cat(recv_lists) if n_halo else s.new_empty(0)
     send_idx = s.new_empty(sum(send_splits))
     dist.all_to_all_single(send_idx, want, send_splits, recv_splits, group=group)
-    return HaloGraph(src_ext, d, n_local, n_halo, send_idx, send_splits, recv_splits, group, lo, hi, num_nodes)
+    # Does ANY rank exchange anything?  Decided once, collectively: every rank then either always enters the per-layer
+    # collective (possibly with empty splits) or never does -- a rank skipping it on its own would hang gloo and
+    # desynchronise NCCL's collective sequence.
+    tot = torch.tensor([n_halo + sum(send_splits)], dtype=torch.long, device=dev)
+    dist.all_reduce(tot, group=group)
+    return HaloGraph(src_ext, d, n_local, n_halo, send_idx, send_splits, recv_splits, group, lo, hi, num_nodes,
+                     any_exchange=bool(int(tot.item()) > 0))

@@ -60,6 +60,33 @@ def _worker(rank, world, port, V, E, F):
         assert torch.equal(got_s, want_s)
         assert torch.equal(got_r, want_s)
         torch.testing.assert_close(got_t, want_t, rtol=1e-6, atol=1e-6)      # projected rows: library GEMM on a different row count
+        # (c) the overlap path: (b) started the exchange asynchronously and aggregated the interior rows (only local sources)
+        #     while it was in flight, then the boundary rows + hub segments -- two launches of the hand-scheduled kernel
+        #     over disjoint work lists.  Same bits as the one-launch unsharded kernel, whatever the interior fraction.
+        interior, items_in, items_bd = gs.split_work_lists()
+        assert gs._pending is None and items_in.shape[0] + items_bd.shape[0] >= gs.num_nodes
+        # a graph WITH locality (mostly the ring v <-> v+1): almost every row is interior
+        src2, dst2 = powerlaw_graph(V, 2 * V + 600, seed=12, device=dev)
+        gs2, g2 = shard_graph(src2, dst2, V, balance="edges"), Graph(src2, dst2, V)
+        lo2, hi2 = gs2.lo, gs2.hi
+        hr2 = gs2.alloc_features(F)                                          # dense pitch: exactly F floats per halo row travel
+        hr2.copy_(h[lo2:hi2])
+        with torch.no_grad():
+            got2 = simple(gs2, hr2)
+            want2 = simple(g2, h)[lo2:hi2]
+            agg_split = __import__("pna_amd.functional", fromlist=["aggregate"]).aggregate(
+                gs2, gs2.source_features(hr2, defer=True), F, ["mean", "max", "min", "std"])
+            agg_whole = __import__("pna_amd.functional", fromlist=["aggregate"]).aggregate(
+                gs2, gs2.source_features(hr2), F, ["mean", "max", "min", "std"])
+        in2 = gs2.interior_mask()
+        assert int(in2.sum()) > 0.8 * gs2.num_nodes and int((~in2).sum()) > 0
+        assert torch.equal(got2, want2) and torch.equal(agg_split, agg_whole)
+        # the HIP pack kernel = index_select
+        from pna_amd import ops
+        idx = torch.randint(0, V, (5000,), device=dev, dtype=torch.int32)
+        for width, pitch in ((F, F), (75, 80), (3, 7), (128, 128)):
+            tab = torch.randn(V, pitch, device=dev)[:, :width]
+            assert torch.equal(ops.pack_rows(tab, idx), tab[idx.long()])
         dist.barrier()
     finally:
         dist.destroy_process_group()

@@ -74,9 +74,100 @@ def _worker(rank, world, port, V, E, F):
         assert ext2.untyped_storage().data_ptr() == h_res.untyped_storage().data_ptr()       # no concatenation happened
         assert torch.equal(ext2[g.src], x[src[mine]])
         assert torch.equal(ext2[: g.num_nodes], x[lo:hi])
+        # 6. deferred exchange (the overlap path): started asynchronously, finished explicitly, same table
+        h_res.copy_(x[lo:hi])
+        g._ext[g.num_nodes:].zero_()
+        with torch.no_grad():
+            ext3 = g.source_features(h_res, defer=True)
+        assert g._pending is not None
+        g.finish_exchange()
+        assert g._pending is None and torch.equal(ext3[g.src], x[src[mine]])
+        # 7. row classes: every row is in exactly one work list; interior rows only have local sources; hub rows are boundary
+        interior, items_in, items_bd = g.split_work_lists()
+        hs = g.heavy_schedule()
+        rows_in = items_in[:, 0].long()
+        rows_bd_light = items_bd[items_bd[:, 3] < 0][:, 0].long()
+        seg_rows = items_bd[items_bd[:, 3] >= 0][:, 0].long()
+        covered = torch.cat([rows_in, rows_bd_light, torch.unique(seg_rows)])
+        assert covered.numel() == g.num_nodes and torch.equal(torch.sort(covered).values, torch.arange(g.num_nodes))
+        assert bool(interior[rows_in].all()) and not bool(interior[rows_bd_light].any())
+        for r in rows_in.tolist()[:50]:
+            e0, e1 = int(cl.rowptr[r]), int(cl.rowptr[r + 1])
+            assert bool((cl.col[e0:e1].long() < g.num_nodes).all())
+        halo_rows = torch.unique(cl.row.long()[cl.col.long() >= g.num_nodes])
+        assert not bool(interior[halo_rows].any())
+        if hs.n_heavy:
+            assert not bool(interior[hs.heavy_rows.long()].any())
+        # 8. edge-balanced partition: same identities, bounds monotone, edge counts within one max-degree of each other
+        g2 = shard_graph(src, dst, V, balance="edges")
+        b2 = partition_bounds(V, world, dst, "edges")
+        assert b2[0] == 0 and b2[-1] == V and all(b2[i] <= b2[i + 1] for i in range(world))
+        deg_all = torch.bincount(dst, minlength=V)
+        per = [int(deg_all[b2[i]:b2[i + 1]].sum()) for i in range(world)]
+        assert max(per) - min(per) <= 2 * int(deg_all.max()) + 1
+        mine2 = (dst >= b2[rank]) & (dst < b2[rank + 1])
+        xl2 = x[b2[rank]:b2[rank + 1]].clone()
+        with torch.no_grad():
+            ext4 = g2.source_features(xl2)
+        assert torch.equal(ext4[g2.src], x[src[mine2]])
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def _worker_no_halo(rank, world, port):
+    """A graph whose edges never cross the partition: NO rank has a halo, so nobody enters the per-layer collective -- and
+    a graph where only ONE rank has a halo: every rank must enter it (the other with empty splits), or gloo hangs."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pna_amd.shard import shard_graph
+        V, F = 40, 3
+        x = torch.randn(V, F, generator=torch.Generator().manual_seed(0))
+        lo, hi = (V * rank) // world, (V * (rank + 1)) // world
+        # (a) block-diagonal: ring inside each half
+        a = torch.arange(V)
+        half = V // world
+        src = a
+        dst = (a // half) * half + (a % half + 1) % half
+        g = shard_graph(src, dst, V)
+        assert g.n_halo == 0 and not g.any_exchange
+        with torch.no_grad():
+            assert torch.equal(g.source_features(x[lo:hi].clone()), x[lo:hi])
+        # (b) one extra edge 0 -> V-1: only the LAST rank needs a halo row, only rank 0 sends one
+        src2, dst2 = torch.cat([src, torch.tensor([0])]), torch.cat([dst, torch.tensor([V - 1])])
+        g2 = shard_graph(src2, dst2, V)
+        assert g2.any_exchange and g2.n_halo == (1 if rank == world - 1 else 0)
+        with torch.no_grad():
+            ext = g2.source_features(x[lo:hi].clone())
+        mine = (dst2 >= lo) & (dst2 < hi)
+        assert torch.equal(ext[g2.src], x[src2[mine]])
+        xl = x[lo:hi].clone().requires_grad_(True)
+        g2.source_features(xl).sum().backward()                         # the backward collective is entered by everyone too
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_without_halo_do_not_desynchronise_the_collective():
+    mp.spawn(_worker_no_halo, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def test_bfs_order_is_a_permutation_and_restores_locality():
+    """A path graph with shuffled ids has no locality under contiguous ranges; its BFS order is the path again."""
+    sys.path.insert(0, ROOT)
+    from pna_amd.shard import bfs_order
+    V = 2000
+    perm = torch.randperm(V, generator=torch.Generator().manual_seed(1))
+    a = torch.arange(V - 1)
+    src, dst = torch.cat([perm[a], perm[a + 1]]), torch.cat([perm[a + 1], perm[a]])
+    order = bfs_order(src, dst, V, start=int(perm[0]))
+    assert torch.equal(torch.sort(order).values, torch.arange(V))
+    new_id = torch.empty(V, dtype=torch.long)
+    new_id[order] = torch.arange(V)
+    cut = lambda s_, d_: int(((s_ // (V // 8)) != (d_ // (V // 8))).sum())     # edges crossing 8 contiguous ranges  # noqa: E731
+    assert cut(new_id[src], new_id[dst]) == 2 * 7 and cut(src, dst) > 1000
 
 
 @pytest.mark.parametrize("world", [2, 3])

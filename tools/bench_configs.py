@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Timing of the parity-test configurations of BASELINE.json (configs[0], [1], [3]) on one MI355X: eager launches
 vs hipGraph replay, next to the oracle's CPU restatement on this box's host cores.  These are not bench.py
-lines (bench.py reports configs[2]); the numbers go to profiles/r01_configs.json.
+lines (bench.py reports configs[2]); the numbers go to profiles/r0N_configs.json.
 
     python tools/bench_configs.py > gpurun_out/configs.json
 """
@@ -77,7 +77,7 @@ with torch.no_grad():
     cpu = cpu_ms(lambda: O.dgl_layer_forward(sd, src, dst, V, h, None, snorm.cpu(), AGG.split(), SCA.split(), avg["log"], 5,
                                              False, True, True, True, False))
 out["zinc_tower_layer"] = dict(graphs=128, V=V, E=E, hidden=75, towers=5, eager_ms=eager, hipgraph_ms=graphed,
-                               edges_per_s_hipgraph=E / graphed * 1e3, cpu_oracle_ms=cpu, max_abs_err_vs_oracle=err)
+                               edges_per_s_hipgraph=E / graphed * 1e3, cpu_oracle_ms=cpu, max_abs_err_vs_oracle=err, max_rel_err_vs_oracle=err / ref.abs().max().item())
 
 # ---- configs[3]: MolHIV-shaped batch, PNASimpleLayer hidden 80, 2048 graphs ----
 src, dst, sizes = molecule_batch(2048, mean_nodes=25.5, sd_nodes=12, lo=6, hi=222, seed=41, lognormal=True)
@@ -99,7 +99,7 @@ with torch.no_grad():
     err = (gf(hd).cpu() - ref).abs().max().item()
     cpu = cpu_ms(lambda: O.simple_layer_forward(sd, src, dst, V, h, AGG.split(), SCA.split(), avg["log"]))
 out["molhiv_simple_layer"] = dict(graphs=2048, V=V, E=E, hidden=80, eager_ms=eager, hipgraph_ms=graphed,
-                                  edges_per_s_hipgraph=E / graphed * 1e3, cpu_oracle_ms=cpu, max_abs_err_vs_oracle=err)
+                                  edges_per_s_hipgraph=E / graphed * 1e3, cpu_oracle_ms=cpu, max_abs_err_vs_oracle=err, max_rel_err_vs_oracle=err / ref.abs().max().item())
 
 # ---- the whole MolHIV net of the reference's README (PNASimpleLayer x 4, hidden 80, mean readout), same batch ----
 from pna_amd.nets import PNANetHIV  # noqa: E402
@@ -155,5 +155,31 @@ with torch.no_grad():
     cpu = cpu_ms(lambda: O.dense_layer_forward(sd, x, adj, AGG.split(), ["identity"], avg_d, 4, True))
 E = int(adj.sum().item())
 out["multitask_dense_layer"] = dict(B=B, N=N, hidden=16, towers=4, directed_edges=E, eager_ms=eager,
-                                    edges_per_s_eager=E / eager * 1e3, cpu_oracle_ms=cpu, max_abs_err_vs_oracle=err)
+                                    edges_per_s_eager=E / eager * 1e3, cpu_oracle_ms=cpu, max_abs_err_vs_oracle=err, max_rel_err_vs_oracle=err / ref.abs().max().item())
+
+# ---- the TOWER variant at roofline scale (T = 1, pretrans Linear(150 -> 75) factorised to node level,
+# message = W_a h_src + (W_b h_dst + b)): its aggregation runs on the hand-scheduled kernel since round 2 ----
+from pna_amd import functional as PF  # noqa: E402
+from pna_amd.synth import powerlaw_graph  # noqa: E402
+Vc, Ec, Fc = 1_000_000, 10_000_000, 75
+s3, d3 = powerlaw_graph(Vc, Ec, seed=1234, device=dev)
+g3 = Graph(s3, d3, Vc)
+avg3 = {"log": torch.log(g3.in_degrees().double() + 1).mean().float().cpu()}
+h3 = torch.randn(Vc, Fc, device=dev, generator=torch.Generator(device=dev).manual_seed(1234))
+sn3 = torch.ones(Vc, 1, device=dev)
+tower = PNALayer(Fc, Fc, AGG, SCA, avg3, 0.0, True, True, towers=1, divide_input=False, residual=True).eval()
+randomise(tower)
+tower = tower.to(dev)
+simple = PNASimpleLayer(Fc, Fc, AGG, SCA, avg3, 0.0, True, True).eval()
+randomise(simple)
+simple = simple.to(dev)
+xs = torch.randn(Vc, 80, device=dev)[:, :Fc]
+xd3 = torch.randn(Vc, 80, device=dev)[:, :Fc]
+with torch.no_grad():
+    t_tower = gpu_ms(lambda: tower(g3, h3, None, sn3), iters=20)
+    t_simple = gpu_ms(lambda: simple(g3, h3), iters=20)
+    t_agg_tower = gpu_ms(lambda: PF.aggregate(g3, xs, Fc, AGG.split(), dst_term=xd3), iters=20)
+    t_agg_simple = gpu_ms(lambda: PF.aggregate(g3, xs, Fc, AGG.split()), iters=20)
+out["c3_tower_layer"] = dict(V=Vc, E=Ec, F=Fc, towers=1, layer_ms=t_tower, simple_layer_ms=t_simple, aggregate_tower_ms=t_agg_tower,
+                             aggregate_simple_ms=t_agg_simple, edges_per_s_layer=Ec / t_tower * 1e3)
 print(json.dumps(out, indent=1))
