@@ -178,7 +178,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
   // chunk image -> LDS buffer, asynchronously; every wavefront copies whole 1 KB pieces (the piece counts are
   // multiples of 64), destination = wave-uniform base + lane * 16
   constexpr int NI = (kChunkV + kThreads - 1) / kThreads;   // global_load_lds instructions per wavefront per chunk
-  auto stage_piece = [&](int c, int buf, int i) {
+  auto stage_piece = [&](int c, int buf, int i) __attribute__((always_inline)) {
     const unsigned char* src = img_a + (size_t)c * kChunkV * 16;
     int pieces = kChunkV;
     if constexpr (HAS_H) {
@@ -196,20 +196,20 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(w0 + lane) * 16),
                                      (__attribute__((address_space(3))) void*)(dst + (size_t)w0 * 16), 16, 0, 0);
   };
-  auto stage = [&](int c, int buf) {
+  auto stage = [&](int c, int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) stage_piece(c, buf, i);
   };
 
   // A operand of (tile t, chunk c), row tile r: floats [k, k+4) and [k+16, k+20) of the lane's row, k = 32c + 4 lg, as two
   // clamped 16-byte windows ([kk, kk+4), kk = min(k, kmax-4); the launcher guarantees kmax >= 4), fixed up after the load.
-  auto a_src = [&](int c, const float*& src, long& ld, int& kmax, int& k) {
+  auto a_src = [&](int c, const float*& src, long& ld, int& kmax, int& k) __attribute__((always_inline)) {
     src = g.a; ld = g.lda; kmax = g.K; k = c * kKC + 8 * lg;
     if constexpr (HAS_H) {
       if (c >= nca) { src = g.h; ld = g.ldh; kmax = g.Kh; k = (c - nca) * kKC + 8 * lg; }
     }
   };
-  auto fix4 = [&](int k, int kmax, f4 t) -> f4 {        // window [kk,kk+4) -> elements [k,k+4), 0 beyond kmax
+  auto fix4 = [&](int k, int kmax, f4 t) -> f4 __attribute__((always_inline)) {        // window [kk,kk+4) -> elements [k,k+4), 0 beyond kmax
     const int d = k - max(0, min(k, kmax - 4));
     f4 v;
     v.x = d == 0 ? t.x : d == 1 ? t.y : d == 2 ? t.z : t.w;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
   // wait that covers it (a register with two reaching definitions may be copied by the compiler at the merge, i.e. while
   // the load is still in flight), and it is read only after the "+v" anchor that follows the wait in take().
   typedef f4 aset_t[RT][2];
-  auto load_a_piece = [&](aset_t& dst, int t, int c, int r, int w) {
+  auto load_a_piece = [&](aset_t& dst, int t, int c, int r, int w) __attribute__((always_inline)) {
     const float* src; long ld; int kmax, k;
     a_src(c, src, ld, kmax, k);
     const int row = min((t * WAVES + wave) * (16 * RT) + 16 * r + li, g.M - 1);
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
     const float* ptr = src + (size_t)row * ld + kk;
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[r][w]) : "v"(ptr) : "memory");
   };
-  auto load_a = [&](aset_t& dst, int t, int c) {
+  auto load_a = [&](aset_t& dst, int t, int c) __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
   // The waits carry NO register operands; the registers are tied by ONE anchor after them.  (Two "+v" waits in two branches
   // made the compiler copy the fragment into fresh registers at the top of one branch -- BEFORE that branch's wait, while the
   // loads were still in flight: stale A fragments on short K.)
-  auto take = [&](aset_t& cur, int c, int wait) {
+  auto take = [&](aset_t& cur, int c, int wait) __attribute__((always_inline)) {
     const float* src; long ld; int kmax, k;
     a_src(c, src, ld, kmax, k);
     const bool tail = c * kKC + kKC > (c < nca ? g.K : nca * kKC + g.Kh);   // wave-uniform: only a row's last chunk needs fixing
@@ -290,14 +290,14 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
       }
     }
   };
-  auto finish = [&](float v, float rp, float cb, float cs, float ct) -> float {
+  auto finish = [&](float v, float rp, float cb, float cs, float ct) -> float __attribute__((always_inline)) {
     v = v + cb;
     if (g.row_post) v = v * rp;                                        // graph-norm (pna_layer.py:71-72)
     if (g.col_scale) v = v * cs + ct;                                  // eval-mode BatchNorm folded to an affine map
     if (g.relu) v = v > 0.f ? v : (v != v ? v : 0.f);                  // ReLU (keeps NaN)
     return v;
   };
-  auto epilogue = [&](int t) {
+  auto epilogue = [&](int t) __attribute__((always_inline)) {
     const int row0 = (t * WAVES + wave) * (16 * RT);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
   // Here absent operands are neutral constants (x*1, +0 are exact), ReLU is `v < lo ? 0 : v` with lo = 0 or -inf (keeps
   // NaN like the generic form), every load is issued before the first use, rows need no predicate and only a column
   // tile that crosses N predicates its stores.
-  auto zero_acc = [&]() {
+  auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[r][p][n] = (f4){0.f, 0.f, 0.f, 0.f};
   };
-  auto epilogue_full = [&](int t) {
+  auto epilogue_full = [&](int t) __attribute__((always_inline)) {
     // Addresses are (wave-uniform 64-bit base in SGPRs) + (32-bit lane offset): one VALU per address instead of a
     // 64-bit multiply-add chain, and nothing loop-invariant for the compiler to hoist into the MFMA loop's registers
     // (the lane ids go through an empty asm so that values derived from them are rebuilt here).
@@ -448,14 +448,15 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
       // every one of them at the TA.
       // B fragment (term, panel p, column tile n): piece ((term*np + p)*4 + lg)*80 + n*16 + li;
       // MFMAs ordered smallest partial products first, row tiles alternating (no MFMA waits for its predecessor).
-      auto run = [&](auto npanel_c, int p0, unsigned ba0) {
+      auto run = [&](auto npanel_c, auto p0_c, unsigned ba0) __attribute__((always_inline)) {
+        constexpr int p0 = decltype(p0_c)::value;
         constexpr int NPN = decltype(npanel_c)::value;   // panels in this chunk's image; they accumulate into acc[.][p0 + p]
         constexpr int NG = NPN * NT;
         bf8 B[2][3];
         // B fragments are read by hand (inline asm + counted lgkmcnt): hipcc sinks its own ds_reads next to their use
         // and waits lgkmcnt(0), exposing one LDS round trip per group.  LDS returns in order, so with the three reads
         // of group g+1 issued behind those of group g, `lgkmcnt(3)` means group g has landed.
-        auto load_b = [&](unsigned ba, int gi, int slot) {
+        auto load_b = [&](unsigned ba, int gi, int slot) __attribute__((always_inline)) {
           const int p = gi / NT, n = gi % NT;
   #pragma unroll
           for (int tm = 0; tm < 3; ++tm)
@@ -486,9 +487,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
       };
       load_a(nxt[0], ta, ca);                            // HBM latency: first (and outside the is_h branches, see load_a_piece)
       if (!is_h) {
-        run(std::integral_constant<int, S>{}, 0, baddr);
+        run(std::integral_constant<int, S>{}, std::integral_constant<int, 0>{}, baddr);
       } else if (HAS_H) {
-        run(std::integral_constant<int, 1>{}, P - 1, baddr);
+        run(std::integral_constant<int, 1>{}, std::integral_constant<int, P - 1>{}, baddr);
       }
       if (c == nc - 1) {
         __builtin_amdgcn_sched_barrier(0);         // keep the epilogue's loads out of the MFMA stream (register pressure)
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
       load_a(nxt[1], m1 ? t1 : t, m1 ? c1 : 0);   // step 1's fragment (a harmless re-load when there is no step 1)
     }
     __syncthreads();
-    auto step = [&](auto par_c, int k) {
+    auto step = [&](auto par_c, int k) __attribute__((always_inline)) {
       constexpr int PAR = decltype(par_c)::value;
       aset_t& mine = nxt[PAR];           // free now (held step k's fragment): receives step k+2's
       aset_t& other = nxt[PAR ^ 1];      // holds step k+1's
@@ -543,12 +544,13 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
       const bool is_h = HAS_H && c >= nca;
       const unsigned baddr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(buf * kChunkV + lg * kNW + li) * 16u;
       load_a(mine, more2 ? t2 : t, more2 ? c2 : c);       // (a harmless re-load of this step's fragment near the end)
-      auto run3 = [&](auto npanel_c, int p0, unsigned ba0) {
+      auto run3 = [&](auto npanel_c, auto p0_c, unsigned ba0) __attribute__((always_inline)) {
+        constexpr int p0 = decltype(p0_c)::value;       // compile-time: a run-time panel index puts the accumulators in scratch
         constexpr int NPN = decltype(npanel_c)::value;
         constexpr int NG = NPN * NT;
         constexpr int H = (NG - 1) / 2;                    // the barrier follows the B prefetch of group H
         bf8 B[2][3];
-        auto load_b = [&](unsigned ba, int gi, int slot) {
+        auto load_b = [&](unsigned ba, int gi, int slot) __attribute__((always_inline)) {
           const int p = gi / NT, n = gi % NT;
 #pragma unroll
           for (int tm = 0; tm < 3; ++tm)
@@ -583,9 +585,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
         }
       };
       if (!is_h) {
-        run3(std::integral_constant<int, S>{}, 0, baddr);
+        run3(std::integral_constant<int, S>{}, std::integral_constant<int, 0>{}, baddr);
       } else if (HAS_H) {
-        run3(std::integral_constant<int, 1>{}, P - 1, baddr);
+        run3(std::integral_constant<int, 1>{}, std::integral_constant<int, P - 1>{}, baddr);
       }
       // the next fragment first, then the epilogue (the fragment landed before this step's barrier: no wait here)
       if (more1) take(other, cn, 2);

@@ -636,7 +636,7 @@ __global__ __launch_bounds__(kBlock) void k_heavy_finalize(const KArgs a) {
   Acc<VEC, EXTRA> acc;
   acc.init();
   auto merge = [&](const float (&ps)[VEC], const float (&pq)[VEC], const float (&pmx)[VEC], const float (&pmn)[VEC],
-                   const int (&pax)[VEC], const int (&pan)[VEC], float pw) {
+                   const int (&pax)[VEC], const int (&pan)[VEC], float pw) __attribute__((always_inline)) {
     if constexpr (EXTRA) acc.wsum = acc.wsum + pw;
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
@@ -684,9 +684,8 @@ __global__ __launch_bounds__(kBlock) void k_heavy_finalize(const KArgs a) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      if (sb + i * G >= s1) break;
-      merge(ps[i], pq[i], pmx[i], pmn[i], pax[i], pan[i], pw[i]);
+    for (int i = 0; i < PB; ++i) {                       // (no `break`: it kept the loop rolled and the partial arrays in scratch)
+      if (sb + i * G < s1) merge(ps[i], pq[i], pmx[i], pmn[i], pax[i], pan[i], pw[i]);
     }
   }
   // combine the lane groups' results into group 0, in group order

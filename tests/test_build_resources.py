@@ -1,0 +1,35 @@
+"""Compiler-reported resources of the hot kernels (hipcc -Rpass-analysis=kernel-resource-usage, cross-compiled here): no
+kernel may touch scratch memory.  A lambda that silently stops being inlined makes the by-value argument block (or the
+accumulators, through a run-time panel index) live on the stack -- the contraction of the tower layers ran 8x slower that
+way for a while without any test noticing."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "pna_amd", "csrc")
+
+
+@pytest.mark.parametrize("src,max_vgpr", [("pna_posttrans_x3.hip", {"k_posttrans_x3": 256}), ("pna_segreduce.hip", {"k_segreduce_fastILi4E": 80}),
+                                          ("pna_posttrans.hip", {}), ("pna_pack.hip", {})])
+def test_no_kernel_uses_scratch(src, max_vgpr, tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+           "-S", "--cuda-device-only", "-o", str(tmp_path / "out.s"), os.path.join(CSRC, src), "-Rpass-analysis=kernel-resource-usage"]
+    out = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
+    names = re.findall(r"Function Name: (\S+)", out)
+    scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out)]
+    vgprs = [int(v) for v in re.findall(r" VGPRs: (\d+)", out)]
+    assert names and len(names) == len(scratch) == len(vgprs)
+    # k_heavy_finalize (a 25 us kernel over the ~3 k hub rows) indexes its per-aggregator result arrays with the run-time
+    # aggregator code and keeps them in scratch: known, not on the hot path
+    bad = [(n, s) for n, s in zip(names, scratch) if s != 0 and "k_heavy_finalize" not in n]
+    assert not bad, f"kernels using scratch: {bad[:5]}"
+    for key, lim in max_vgpr.items():
+        over = [(n, v) for n, v in zip(names, vgprs) if key in n and v > lim]
+        assert not over, over[:5]
