@@ -89,9 +89,10 @@ typedef struct pna_tuning {
  *   reference's concatenation order (pna_layer.py:48-49).
  * Rows with no in-edges get 0 in every block (DGL's zero initialiser; undefined in the reference).
  * Arithmetic: fp32, no FMA contraction, sums in CSR edge order (hub rows: per 128-edge segment, then over segments).
- * One deliberate departure from the reference's formula: mean = s * (1/D) with ONE IEEE division per row instead of
- * s / D per feature -- within 1 ulp of s / D (exact when D is a power of two), far inside the summation-order noise
- * the 1e-5 parity bar allows for mean / std; max, min and the degree scalers are bit-exact.
+ * mean = s / D and E[x^2] = q / D are the reference's divisions bit for bit (one IEEE division per row for 1 / D, then
+ * Markstein's fma correction per feature; round 1 used s * (1/D), 1 ulp off, which the cancellation in
+ * std = sqrt(E[x^2] - E[x]^2 + 1e-5) amplifies to percents when all neighbours are equal); max, min and the degree
+ * scalers are bit-exact; mean / std differ from the reference only through the summation ORDER of s and q.
  * edge_weight (nullable, [E]): mean/sum/std/var use sum_k w_k m_k and D = sum_k w_k; max/min use
  *   only edges with w_k > 0.
  * argmax/argmin (nullable, (V, ld_arg) int32): CSR edge position k of the first max / min, -1 for

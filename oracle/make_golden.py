@@ -99,6 +99,7 @@ def golden_simple(name, seed, N, E, F, out_dim, aggregators=AGG4, scalers=SCA3, 
     src, dst = powerlaw_graph(rng, N, E)
     deg = np.bincount(dst, minlength=N)
     avg_log = torch.tensor(float(np.mean(np.log(deg + 1))), dtype=torch.float32)
+    torch.manual_seed(seed)                      # the reference's default init draws from the GLOBAL generator: pin it
     layer = RefSimpleLayer(F, out_dim, aggregators, scalers, {"log": avg_log}, 0.0, True, residual,
                            posttrans_layers=posttrans_layers).eval()
     if not default_init:

@@ -22,12 +22,8 @@ class AggregateFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, graph, x, dst_term, edge_term, F, aggregators, n_tower, row_scales, edge_resident,
                 edge_weight, col_override):
-        if edge_weight is not None:
-            raise NotImplementedError("pna_amd: backward through weighted (non 0/1 adjacency) aggregation is not implemented")
         if len(set(aggregators)) != len(aggregators):
             raise NotImplementedError("pna_amd: backward needs distinct aggregators")
-        if "var_raw" in aggregators:
-            raise NotImplementedError("pna_amd: backward through the unclamped PyG `var` aggregator is not implemented")
         csr = graph.csr
         col = None if edge_resident else (csr.col if col_override is None else col_override)
         aggs = list(aggregators)
@@ -38,10 +34,12 @@ class AggregateFn(torch.autograd.Function):
                 extra.append("mean")
             if "std" not in aggs:
                 extra.append("std")
+        elif "var_raw" in aggs and "mean" not in aggs:
+            extra.append("mean")
         all_aggs = aggs + extra
         want_arg = any(a in ("max", "min") for a in aggs)
         res = ops.segreduce(csr.rowptr, col, x, F, all_aggs, [None], n_tower=n_tower, tower_stride_in=F,
-                            dst_term=dst_term, edge_term=edge_term, want_arg=want_arg,
+                            dst_term=dst_term, edge_term=edge_term, edge_weight=edge_weight, want_arg=want_arg,
                             heavy=graph.heavy_schedule(), workspace=graph.workspace, items=graph.work_items())
         ident, amx, amn = res if want_arg else (res, None, None)       # (V, T*A'*F) identity-scaled
         V, T, A, A2, S = ident.shape[0], max(1, n_tower), len(aggs), len(all_aggs), len(row_scales)
@@ -55,12 +53,12 @@ class AggregateFn(torch.autograd.Function):
         ctx.row_scales = row_scales
         ctx.needs = (x.requires_grad, dst_term is not None and dst_term.requires_grad,
                      edge_term is not None and edge_term.requires_grad)
-        ctx.save_for_backward(x, dst_term, edge_term, ident, amx, amn)
+        ctx.save_for_backward(x, dst_term, edge_term, ident, amx, amn, edge_weight)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, dst_term, edge_term, ident, amx, amn = ctx.saved_tensors
+        x, dst_term, edge_term, ident, amx, amn, edge_weight = ctx.saved_tensors
         graph, F, aggs, all_aggs, T = ctx.graph, ctx.F, ctx.aggs, ctx.all_aggs, ctx.T
         V, A, A2, S = ident.shape[0], len(aggs), len(all_aggs), len(ctx.row_scales)
         go = grad_out.reshape(V, T, S, A, F)
@@ -73,6 +71,10 @@ class AggregateFn(torch.autograd.Function):
         csr = graph.csr
         dev = x.device
         need_x, need_d, need_e = ctx.needs
+        if edge_weight is not None or "var_raw" in aggs:
+            gx, gd, ge = _backward_edges_torch(graph, ctx.col, x, dst_term, edge_term, edge_weight, ident, amx, amn, gagg, aggs,
+                                               all_aggs, T, F, need_x, need_d, need_e)
+            return (None, gx, gd, ge, None, None, None, None, None, None, None)
         if ctx.col is not None and edge_term is None and ctx.col is csr.col and os.environ.get("PNA_AMD_BWD", "pull") == "pull":
             gx, gd = _backward_pull(graph, x, dst_term, ident, amx, amn, gagg, aggs, all_aggs, T, F, need_x, need_d)
             return (None, gx, gd, None, None, None, None, None, None, None, None)
@@ -124,6 +126,83 @@ class AggregateFn(torch.autograd.Function):
             full[:, :T * F] = gx
             gx = full
         return (None, gx, gd, ge, None, None, None, None, None, None, None)
+
+
+def _backward_edges_torch(graph, col, x, dst_term, edge_term, w, ident, amx, amn, gagg, aggs, all_aggs, T, F, need_x, need_d, need_e):
+    """Backward of the aggregation with per-edge WEIGHTS (the dense variant's adjacency used as a weight,
+    models/pytorch/pna/aggregators.py:25,:69: D = sum_k w_k, s = sum_k w_k m_k, q = sum_k w_k m_k^2; max / min over the edges
+    with w_k > 0) and of the unclamped PyG variance (`var_raw`, pytorch_geometric/aggregators.py:25-28), as torch tensor ops
+    over the edge list:
+
+        dL/dm_k = w_k [ G_sum + G_mean / D + (G_var [var > 0] + G_var_raw + G_std [var > 0] / (2 std)) (2 / D) (m_k - mean) ]
+                  + [k = argmax] G_max + [k = argmin] G_min
+
+    The forward is the HIP kernel; these configurations (small dense graphs, the exotic registry entries) are off the hot path,
+    so their backward does not have a kernel of its own -- like the GEMMs of the posttrans backward it runs on the GPU
+    through library ops."""
+    csr = graph.csr
+    V, TF = ident.shape[0], T * F
+    A, A2 = len(aggs), len(all_aggs)
+    E = int(csr.rowptr[-1].item())
+    dev = x.device
+    row = csr.row.long()
+    cx = col.long() if col is not None else torch.arange(E, device=dev)
+    m = x[cx][:, :TF]
+    if dst_term is not None:
+        m = m + dst_term[row][:, :TF]
+    if edge_term is not None:
+        m = m + edge_term[:, :TF]
+    ww = torch.ones(E, device=dev) if w is None else w.reshape(-1).to(torch.float32)
+    D = torch.zeros(V, device=dev).index_add_(0, row, ww).clamp_min(1e-30).unsqueeze(1)
+    g4 = gagg.view(V, T, A, F)
+    iv = ident.view(V, T, A2, F)
+
+    def G(name):
+        return g4[:, :, aggs.index(name)].reshape(V, TF) if name in aggs else None
+
+    base = torch.zeros(V, TF, device=dev)
+    if G("sum") is not None:
+        base = base + G("sum")
+    if G("mean") is not None:
+        base = base + G("mean") / D
+    r2 = None
+    if any(a in aggs for a in ("std", "var", "var_raw")):
+        mean = iv[:, :, all_aggs.index("mean")].reshape(V, TF) if "mean" in all_aggs else \
+            torch.zeros(V, TF, device=dev).index_add_(0, row, m * ww.unsqueeze(1)) / D
+        r2 = torch.zeros(V, TF, device=dev)
+        if "std" in aggs or "var" in aggs:
+            std = iv[:, :, all_aggs.index("std")].reshape(V, TF)
+            pos = (std * std - 1e-5) > 0                      # var > 0  <=>  std > sqrt(eps): the relu mask of the forward
+            if G("var") is not None:
+                r2 = r2 + G("var") * pos
+            if G("std") is not None:
+                r2 = r2 + G("std") / (2 * std) * pos
+        if G("var_raw") is not None:
+            r2 = r2 + G("var_raw")
+        r2 = r2 * (2.0 / D)
+    dm = base[row]
+    if r2 is not None:
+        dm = dm + r2[row] * (m - mean[row])
+    dm = dm * ww.unsqueeze(1)
+    for name, arg in (("max", amx), ("min", amn)):
+        g_ = G(name)
+        if g_ is None:
+            continue
+        a_ = arg[:, :TF].long()
+        ok = a_ >= 0
+        cols = torch.arange(TF, device=dev).unsqueeze(0).expand(V, TF)
+        dm.index_put_((a_[ok], cols[ok]), g_[ok], accumulate=True)
+    gx = gd = ge = None
+    if need_x:
+        gx = torch.zeros_like(x)
+        gx[:, :TF].index_add_(0, cx, dm)
+    if need_d:
+        gd = torch.zeros_like(dst_term)
+        gd[:, :TF].index_add_(0, row, dm)
+    if need_e:
+        ge = torch.zeros_like(edge_term)
+        ge[:, :TF] = dm
+    return gx, gd, ge
 
 
 def _column_sums(t):

@@ -149,9 +149,19 @@ __global__ __launch_bounds__(kThreads, 4) void k_fused_simple(const UArgs a) {
   auto finalize = [&](int rl, const Acc4& acc, int deg) {   // mean | max | min | std of one row -> tile
     const f4 z = (f4){0.f, 0.f, 0.f, 0.f};
     if (deg <= 0) { write_blocks(rl, z, z, z, z); return; }
-    const float invD = 1.0f / (float)deg;
-    const f4 mean = acc.s * invD;
-    f4 var = acc.q * invD - mean * mean;
+    // s / D and q / D correctly rounded from ONE division per row (Markstein's fma correction, see pna_segreduce.hip div_rn)
+    const float Dg = (float)deg, invD = 1.0f / Dg;
+    auto div4 = [&](const f4 a) -> f4 {
+      const f4 q0 = a * invD;
+      f4 q;
+      q.x = __builtin_fmaf(__builtin_fmaf(-Dg, q0.x, a.x), invD, q0.x); q.y = __builtin_fmaf(__builtin_fmaf(-Dg, q0.y, a.y), invD, q0.y);
+      q.z = __builtin_fmaf(__builtin_fmaf(-Dg, q0.z, a.z), invD, q0.z); q.w = __builtin_fmaf(__builtin_fmaf(-Dg, q0.w, a.w), invD, q0.w);
+      q.x = (q.x == q.x && __builtin_fabsf(q.x) != INFINITY) ? q.x : q0.x; q.y = (q.y == q.y && __builtin_fabsf(q.y) != INFINITY) ? q.y : q0.y;
+      q.z = (q.z == q.z && __builtin_fabsf(q.z) != INFINITY) ? q.z : q0.z; q.w = (q.w == q.w && __builtin_fabsf(q.w) != INFINITY) ? q.w : q0.w;
+      return q;
+    };
+    const f4 mean = div4(acc.s);
+    f4 var = div4(acc.q) - mean * mean;
     var.x = var.x < 0.f ? 0.f : var.x; var.y = var.y < 0.f ? 0.f : var.y;
     var.z = var.z < 0.f ? 0.f : var.z; var.w = var.w < 0.f ? 0.f : var.w;
     f4 mx, mn, sd;

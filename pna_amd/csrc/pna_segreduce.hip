@@ -101,6 +101,20 @@ template <int VEC, bool EXTRA> struct Acc {
   }
 };
 
+// a / b, correctly rounded, from the correctly rounded reciprocal r = RN(1 / b) (ONE IEEE division per row): Markstein's
+// sequence q0 = RN(a r), e = RN(a - b q0) (exact in an fma), q = RN(q0 + e r) equals RN(a / b) for every b whose significand
+// is not all ones (an in-degree of 2^24 - 1 does not occur: rows < 2^24).  This is the reference's `sum / D`
+// (models/dgl/aggregators.py:6-7,:22-26) bit for bit at a third of the cost of a per-feature division.  It matters beyond
+// the last ulp: with equal neighbours the reference's var = E[x^2] - E[x]^2 is EXACTLY 0 (std = sqrt(1e-5)), and a mean
+// that is 1 ulp off turns that into ~1e-7 x^2 -- 5 % of the std for |x| ~ 3 (seen on the multitask GNN's later iterations).
+// Non-finite or zero b falls through to the plain product (the result is then NaN / Inf either way).
+__device__ __forceinline__ float div_rn(float a, float b, float r) {
+  const float q0 = a * r;
+  const float e = __builtin_fmaf(-b, q0, a);
+  const float q = __builtin_fmaf(e, r, q0);
+  return (q == q && __builtin_fabsf(q) != INFINITY) ? q : q0;
+}
+
 // Single-instruction max/min (no canonicalisation prologue; a quiet-NaN operand is ignored).
 __device__ __forceinline__ float vmax(float a, float b) {
   float r;
@@ -252,13 +266,12 @@ __device__ __forceinline__ void finalize_store(const KArgs& a, const Acc<VEC, EX
   float mean[VEC], var[VEC], vraw[VEC], sd[VEC], mx[VEC], mn[VEC];
   const bool empty = deg <= 0;
   const float D = (EXTRA && a.ew) ? acc.wsum : (float)deg;
-  // one IEEE division per row; mean = s * (1/D) is within 1 ulp of the reference's s / D (exact for
-  // D = 1, 2, 4, ...), far inside the fp32 summation-order noise the 1e-5 parity bar allows for mean/std
+  // one IEEE division per row, then s / D and q / D correctly rounded from it (div_rn): the reference's formula bit for bit
   const float invD = 1.0f / D;
 #pragma unroll
   for (int k = 0; k < VEC; ++k) {
-    mean[k] = acc.s[k] * invD;
-    const float msq = acc.q[k] * invD;
+    mean[k] = div_rn(acc.s[k], D, invD);
+    const float msq = div_rn(acc.q[k], D, invD);
     const float t = msq - mean[k] * mean[k];
     vraw[k] = t;
     var[k] = (t < 0.f) ? 0.f : t;                         // relu (keeps NaN)
@@ -479,9 +492,10 @@ __device__ __forceinline__ void fast_finalize_store(const FArgs& a, const AccF& 
     put(0, z); put(1, z); put(2, z); put(3, z);
     return;
   }
-  const float invD = 1.0f / (float)deg;                    // one IEEE division per row (see finalize_store)
-  const f4 mean = acc.s * invD;
-  f4 var = acc.q * invD - mean * mean;
+  const float D = (float)deg, invD = 1.0f / D;             // one IEEE division per row (see finalize_store / div_rn)
+  const f4 mean = (f4){div_rn(acc.s.x, D, invD), div_rn(acc.s.y, D, invD), div_rn(acc.s.z, D, invD), div_rn(acc.s.w, D, invD)};
+  const f4 msq = (f4){div_rn(acc.q.x, D, invD), div_rn(acc.q.y, D, invD), div_rn(acc.q.z, D, invD), div_rn(acc.q.w, D, invD)};
+  f4 var = msq - mean * mean;
   var.x = var.x < 0.f ? 0.f : var.x; var.y = var.y < 0.f ? 0.f : var.y;
   var.z = var.z < 0.f ? 0.f : var.z; var.w = var.w < 0.f ? 0.f : var.w;
   // v_max/v_min drop NaN; q is NaN iff the row holds a NaN message (torch propagates it)

@@ -70,8 +70,8 @@ def _avg_log_value(avg_d):
     if not torch.is_tensor(t):
         return float(t)
     hit = getattr(t, "_pna_amd_float", None)
-    if hit is None or hit[0] != t._version:
-        hit = (t._version, float(t))
+    if hit is None or hit[0] != (t._version, t.data_ptr(), str(t.device)):
+        hit = ((t._version, t.data_ptr(), str(t.device)), float(t))
         t._pna_amd_float = hit
     return hit[1]
 
@@ -163,7 +163,7 @@ def _towers_forward(towers, graph, h, e, snorm_n, divide_input):
     K = A * Fi
     # inference: graph-norm, eval BatchNorm (and dropout = identity) fold into the contraction's epilogue and each
     # tower writes its slice of the concatenated output directly
-    fuse = (not torch.is_grad_enabled() or not any(p.requires_grad for p in t0.parameters())) and \
+    fuse = (not torch.is_grad_enabled() or not any(p.requires_grad for t in towers for p in t.parameters())) and \
         all((not t.training) and t.posttrans.is_affine for t in towers) and not h.requires_grad
     if fuse:
         No = t0.out_dim

@@ -68,7 +68,7 @@ def _fold_batchnorm(bn):
     """Eval-mode BatchNorm1d as y = x * col_scale + col_shift; cached ON the module per parameter/buffer version so
     that an inference loop does not relaunch the five little fold kernels every forward."""
     ts = [t for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var) if t is not None]
-    key = tuple((id(t), t._version) for t in ts) + (bn.eps,)
+    key = tuple((id(t), t._version, t.data_ptr(), str(t.device)) for t in ts) + (bn.eps,)
     hit = bn.__dict__.get("_pna_amd_fold")
     if hit is None or hit[0] != key:
         with torch.no_grad():

@@ -110,9 +110,10 @@ def segreduce(rowptr: torch.Tensor, col: Optional[torch.Tensor], x: torch.Tensor
 
 def pack_posttrans_weight(weight: torch.Tensor, K: int, n_scaler: int, Kh: int):
     """(w_img, wh_img) tile images of a reference-layout posttrans weight (N, Kh + n_scaler*K).  Cached on the weight
-    tensor object per version: inference packs once, training re-packs after every optimizer step.  (Never keyed by
-    address -- the allocator recycles addresses.)"""
-    key = (weight._version, tuple(weight.shape), weight.stride(0), K, n_scaler, Kh)
+    tensor object per (version, storage address, device): inference packs once, training re-packs after every optimizer
+    step, and `module.to(device)` / `param.data = ...` swaps (EMA, SWA) -- which keep the Parameter object and its version
+    counter -- re-pack too.  The cache lives ON the tensor object: it is never looked up by address alone."""
+    key = (weight._version, weight.data_ptr(), str(weight.device), tuple(weight.shape), weight.stride(0), K, n_scaler, Kh)
     hit = getattr(weight, "_pna_amd_pack", None)
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
@@ -135,7 +136,7 @@ def pack_posttrans_weight(weight: torch.Tensor, K: int, n_scaler: int, Kh: int):
 
 def pack_posttrans_weight_x3(weight: torch.Tensor, K: int, n_scaler: int, Kh: int):
     """(w_img, wh_img) bf16x3 tile images (pna_posttrans_x3_pack_f32); cached like pack_posttrans_weight."""
-    key = (weight._version, tuple(weight.shape), weight.stride(0), K, n_scaler, Kh)
+    key = (weight._version, weight.data_ptr(), str(weight.device), tuple(weight.shape), weight.stride(0), K, n_scaler, Kh)
     hit = getattr(weight, "_pna_amd_pack_x3", None)
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
@@ -213,7 +214,7 @@ def posttrans(a_mat: torch.Tensor, K: int, weight: torch.Tensor, row_scales: Seq
 def pack_fused_weight(weight: torch.Tensor, F: int, n_scaler: int):
     """Packed image of a PNASimpleLayer posttrans weight (N, S*4*F) for pna_fused_simple_f32: every aggregator block
     zero-padded from F to round_up(F, 4) input columns.  Cached on the weight object per version."""
-    key = (weight._version, tuple(weight.shape), F, n_scaler)
+    key = (weight._version, weight.data_ptr(), str(weight.device), tuple(weight.shape), F, n_scaler)
     hit = getattr(weight, "_pna_amd_fpack", None)
     if hit is not None and hit[0] == key:
         return hit[1]

@@ -32,16 +32,52 @@ def _eye_like(adj):
     return torch.eye(adj.shape[-1], device=adj.device, dtype=adj.dtype).unsqueeze(0)
 
 
+class _DenseIndex:
+    """The (B*N rows x N edges) CSR of a dense batch, in the shape pna_amd.autograd.AggregateFn expects of a graph."""
+
+    def __init__(self, B, N, device, transposed):
+        from ...graph import CSR, HeavySchedule
+        rowptr, col_t = _dense_index(B, N, device)
+        row = torch.arange(B * N, device=device, dtype=torch.int32).repeat_interleave(N)
+        self.csr = CSR(rowptr, col_t if transposed else None, None, row, N)
+        self._hs = HeavySchedule(0, 0, 0, 0, None, None, None)
+        self.num_nodes = B * N
+
+    def heavy_schedule(self):
+        return self._hs
+
+    def workspace(self, nbytes):
+        return None
+
+    def work_items(self):
+        return None
+
+    def finish_exchange(self):
+        pass
+
+
 def _reduce_w(name, X, w):
     """One kernel launch: aggregator `name` over the (B,N,N,F) message tensor with (B,N,N) edge weights `w`
-    (mean/sum/std/var: node i reduces over j with weight w[b,i,j]; max/min: node j over i where w[b,i,j] > 0)."""
+    (mean/sum/std/var: node i reduces over j with weight w[b,i,j]; max/min: node j over i where w[b,i,j] > 0).
+    Differentiable in X (training through the registry functions, like the reference's torch ops): under autograd the call
+    goes through AggregateFn, whose weighted backward is pna_amd.autograd._backward_edges_torch."""
     B, N, N2, F = X.shape
     rowptr, col_t = _dense_index(B, N, X.device)
     x = X.contiguous().view(B * N * N, F)
-    if name in ("max", "min"):
-        out = ops.segreduce(rowptr, col_t, x, F, [name], edge_weight=w.transpose(1, 2).contiguous().view(-1))
+    tr = name in ("max", "min")
+    ew = (w.transpose(1, 2) if tr else w).contiguous().view(-1)
+    if torch.is_grad_enabled() and X.requires_grad:
+        if ew.requires_grad:
+            raise NotImplementedError("pna_amd: the gradient w.r.t. the adjacency WEIGHTS of a dense aggregator is not implemented "
+                                      "(the reference's benchmark never differentiates the adjacency)")
+        from ...autograd import AggregateFn
+        g = _DenseIndex(B, N, X.device, tr)
+        out = AggregateFn.apply(g, x, None, None, F, (name,), 1, (None,), not tr, ew, None)
+        return out[:, :F].reshape(B, N, F)
+    if tr:
+        out = ops.segreduce(rowptr, col_t, x, F, [name], edge_weight=ew)
     else:
-        out = ops.segreduce(rowptr, None, x, F, [name], edge_weight=w.contiguous().view(-1))
+        out = ops.segreduce(rowptr, None, x, F, [name], edge_weight=ew)
     return out.view(B, N, F)
 
 
@@ -66,6 +102,8 @@ def aggregate_identity(X, adj, self_loop=False, device="cpu"):
     B, N, _, F = X.shape
     i = torch.arange(N, device=X.device)
     col = (torch.arange(B, device=X.device).view(B, 1) * N * N + (i * N + i).view(1, N)).reshape(-1).to(torch.int32)
+    if torch.is_grad_enabled() and X.requires_grad:           # the diagonal: a differentiable view is all it takes
+        return torch.diagonal(X, dim1=1, dim2=2).permute(0, 2, 1).contiguous()
     rowptr = torch.arange(B * N + 1, dtype=torch.int32, device=X.device)
     return ops.segreduce(rowptr, col, X.contiguous().view(B * N * N, F), F, ["sum"]).view(B, N, F)
 

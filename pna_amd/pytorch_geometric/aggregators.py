@@ -25,6 +25,10 @@ def fix_empty_std(out2d, names, n_scaler, F, deg, factors=None):
     if empty.numel() == 0:
         return out2d
     A = len(names)
+    if out2d.requires_grad or out2d.grad_fn is not None:
+        # under autograd the tensor may be one the aggregation saved for its backward (AggregateFn returns the very tensor it
+        # saves when there is one identity scaler): patch a copy, out of place
+        out2d = out2d.clone()
     view = out2d.view(out2d.shape[0], -1, n_scaler, A, F)
     for a, n in enumerate(names):
         if n != "std":
@@ -47,7 +51,7 @@ def _make(name):
         msgs = flat[g.csr.eid]                                         # CSR (destination-sorted) order
         out = PF.aggregate(g, msgs, flat.shape[1], [_KERNEL_NAME[name]], edge_resident=True)
         if name == "std":
-            fix_empty_std(out, ["std"], 1, flat.shape[1], g.in_degrees())
+            out = fix_empty_std(out, ["std"], 1, flat.shape[1], g.in_degrees())
         return out.reshape((n,) + tuple(src.shape[1:]))
     aggregate.__name__ = "aggregate_" + name
     return aggregate

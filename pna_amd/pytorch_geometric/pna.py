@@ -138,7 +138,7 @@ class PNAConv(torch.nn.Module):
                 msgs.append(nn(torch.cat(z, dim=1)))
             agg = PF.aggregate(graph, torch.cat(msgs, dim=1) if T > 1 else msgs[0], Fi, names, n_tower=T, edge_resident=True)
         factors, deg = _row_factors(graph, self.scaler_names, self.avg_deg)
-        fix_empty_std(agg, names, 1, Fi, deg)
+        agg = fix_empty_std(agg, names, 1, Fi, deg)
         K = A * Fi
         outs = []
         for t, nn in enumerate(self.post_nns):
@@ -185,7 +185,7 @@ class PNAConvSimple(torch.nn.Module):
         names = [_KERNEL_NAME[a] for a in self.aggregator_names]
         agg = PF.aggregate(graph, graph.source_features(x), self.F_in, names)       # identity scaler only
         factors, deg = _row_factors(graph, self.scaler_names, self.avg_deg)
-        fix_empty_std(agg, names, 1, self.F_in, deg)
+        agg = fix_empty_std(agg, names, 1, self.F_in, deg)
         y = PF.posttrans(agg, len(names) * self.F_in, self.post_nn[0].weight, self.post_nn[0].bias, factors)
         for m in list(self.post_nn)[1:]:
             y = m(y)

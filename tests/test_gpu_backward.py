@@ -175,3 +175,122 @@ def test_layers_train_step(cuda_device):
             opt.step()
             losses.append(loss.item())
         assert losses[-1] < losses[0], losses
+
+
+def _dense_ref(name, X, adj, self_loop=False):
+    """The reference's dense aggregators (models/pytorch/pna/aggregators.py:17-146) restated in float64 torch for autograd."""
+    N = adj.shape[-1]
+    a = adj + torch.eye(N, dtype=adj.dtype).unsqueeze(0) if self_loop else adj
+    D = a.sum(-1, keepdim=True)
+    if name == "sum":
+        return (X * a.unsqueeze(-1)).sum(2)
+    if name == "mean":
+        return (X * a.unsqueeze(-1)).sum(2) / D
+    if name in ("var", "std"):
+        mean = (X * a.unsqueeze(-1)).sum(2) / D
+        var = torch.relu((X * X * a.unsqueeze(-1)).sum(2) / D - mean * mean)
+        return var if name == "var" else torch.sqrt(var + 1e-5)
+    if name in ("max", "min"):
+        big = float("-inf") if name == "max" else float("inf")
+        M = torch.where(a.unsqueeze(-1) > 0, X, torch.tensor(big, dtype=X.dtype))
+        return M.max(1)[0] if name == "max" else M.min(1)[0]
+    if name == "softmax":
+        e = torch.exp(X)
+        return (e * X * a.unsqueeze(-1)).sum(2) / (e * a.unsqueeze(-1)).sum(2)
+    if name == "normalised_mean":
+        r = a.sum(-1) ** -0.5
+        return (X * (r.unsqueeze(-1) * a * r.unsqueeze(-2)).unsqueeze(-1)).sum(2)
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["sum", "mean", "var", "std", "max", "min", "softmax", "normalised_mean"])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_dense_registry_is_differentiable(cuda_device, name, weighted):
+    """the dense AGGREGATORS used to return a detached tensor (no gradient to the messages).  Gradients w.r.t. X
+    against float64 autograd through the reference's formulas, with 0/1 and with real-valued adjacency WEIGHTS (the dense
+    variant uses adj as a weight in mean / sum / std / var, aggregators.py:25,:69 -- the weighted backward was a
+    NotImplementedError in round 1)."""
+    from pna_amd.pytorch.pna.aggregators import AGGREGATORS
+    gen = torch.Generator().manual_seed(5)
+    B, N, F = 3, 9, 6
+    adj = (torch.rand(B, N, N, generator=gen) < 0.5).double()
+    adj = torch.maximum(adj, torch.eye(N).roll(1, 0).unsqueeze(0).double())       # every row has a neighbour
+    adj = torch.maximum(adj, torch.eye(N).roll(1, 1).unsqueeze(0).double())       # ... and every column
+    if weighted:
+        adj = adj * (torch.rand(B, N, N, generator=gen).double() + 0.5)
+    X = torch.randn(B, N, N, F, generator=gen, dtype=torch.float64)
+    R = torch.randn(B, N, F, generator=gen, dtype=torch.float64)
+    Xr = X.clone().requires_grad_(True)
+    (_dense_ref(name, Xr, adj) * R).sum().backward()
+    Xg = X.float().to(cuda_device).requires_grad_(True)
+    out = AGGREGATORS[name](Xg, adj.float().to(cuda_device), device=cuda_device)
+    assert out.requires_grad
+    (out * R.float().to(cuda_device)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu().double(), _dense_ref(name, X, adj), rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(Xg.grad.cpu().double(), Xr.grad, rtol=2e-4, atol=2e-5)
+
+
+def test_weighted_sparse_aggregate_backward(cuda_device):
+    """functional.aggregate with edge weights under autograd (x, dst_term and edge_term gradients) against float64."""
+    V, E, F, T = 60, 500, 5, 2
+    src, dst = _graph(3, V, E)
+    g = Graph(src, dst, V).to(cuda_device)
+    c = g.csr
+    gen = torch.Generator().manual_seed(9)
+    x, dt = torch.randn(V, T * F, generator=gen, dtype=torch.float64), torch.randn(V, T * F, generator=gen, dtype=torch.float64)
+    et = torch.randn(E, T * F, generator=gen, dtype=torch.float64)                   # CSR order
+    w = torch.rand(E, generator=gen, dtype=torch.float64) + 0.25
+    aggs = ["mean", "sum", "std", "var", "max", "min"]
+    row, col = c.row.long().cpu(), c.col.long().cpu()
+    xo, dto, eto = (t.clone().requires_grad_(True) for t in (x, dt, et))
+    m = xo[col] + dto[row] + eto
+    D = torch.zeros(V, dtype=torch.float64).index_add_(0, row, w).unsqueeze(1)
+    s = torch.zeros(V, T * F, dtype=torch.float64).index_add_(0, row, m * w.unsqueeze(1))
+    q = torch.zeros(V, T * F, dtype=torch.float64).index_add_(0, row, m * m * w.unsqueeze(1))
+    mean = s / D
+    var = torch.relu(q / D - mean * mean)
+    mx = torch.full((V, T * F), float("-inf"), dtype=torch.float64).scatter_reduce(0, row.unsqueeze(1).expand(-1, T * F), m, "amax")
+    mn = torch.full((V, T * F), float("inf"), dtype=torch.float64).scatter_reduce(0, row.unsqueeze(1).expand(-1, T * F), m, "amin")
+    blocks = dict(mean=mean, sum=s, std=torch.sqrt(var + 1e-5), var=var, max=mx, min=mn)
+    has = (D > 0).expand(-1, T * F)
+    ref = torch.cat([torch.cat([torch.where(has[:, t * F:(t + 1) * F], blocks[a][:, t * F:(t + 1) * F], torch.zeros(()).double())
+                                for a in aggs], 1) for t in range(T)], 1)
+    R = torch.randn(ref.shape, generator=gen, dtype=torch.float64)
+    (ref * R).sum().backward()
+    xg, dg, eg = (t.float().to(cuda_device).requires_grad_(True) for t in (x, dt, et))
+    out = PF.aggregate(g, xg, F, aggs, n_tower=T, dst_term=dg, edge_term=eg, edge_weight=w.float().to(cuda_device))
+    (out * R.float().to(cuda_device)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu().double(), ref.detach(), rtol=3e-5, atol=3e-5)
+    for got, want in ((xg.grad, xo.grad), (dg.grad, dto.grad), (eg.grad, eto.grad)):
+        torch.testing.assert_close(got.cpu().double(), want, rtol=3e-4, atol=3e-5)
+
+
+@pytest.mark.parametrize("conv", ["simple", "towers"])
+def test_pyg_layers_train_with_isolated_nodes_and_var(cuda_device, conv):
+    """(i) a node without in-edges + the default mean/min/max/std set used to raise 'modified by an inplace
+    operation' in backward (fix_empty_std patched a tensor AggregateFn had saved); (ii) the 'var' aggregator (unclamped,
+    kernel code var_raw) had no backward.  Gradients against float64 autograd through the oracle's restatement."""
+    from pna_amd.pytorch_geometric import PNAConv, PNAConvSimple
+    gen = torch.Generator().manual_seed(2)
+    V, E, F = 40, 160, 8
+    src = torch.randint(0, V, (E,), generator=gen)
+    dst = torch.randint(0, V - 3, (E,), generator=gen)                              # the last 3 nodes are isolated
+    ei = torch.stack([src, dst])
+    deg = torch.bincount(torch.bincount(dst, minlength=V))
+    aggs, scal = ["mean", "min", "max", "std", "var"], ["identity", "amplification", "attenuation"]
+    torch.manual_seed(0)
+    layer = (PNAConvSimple(F, F, aggs, scal, deg) if conv == "simple" else PNAConv(F, F, aggs, scal, deg, towers=2, divide_input=False))
+    layer = layer.to(cuda_device).train()
+    x = torch.randn(V, F, generator=gen).to(cuda_device).requires_grad_(True)
+    y = layer(x, ei.to(cuda_device))
+    y.square().sum().backward()                                                     # must not raise
+    assert torch.isfinite(x.grad).all() and x.grad.abs().sum() > 0
+    g1 = x.grad.clone()
+    # numerical check of the input gradient along a random direction (fp32 central difference through the same layer)
+    d = g1 / g1.norm()                  # along the gradient: the directional derivative is |g|, far above the fp32 noise of f
+    eps = 1e-2
+    with torch.no_grad():
+        f = lambda z: layer(z, ei.to(cuda_device)).double().square().sum().item()   # noqa: E731
+        num = (f(x.detach() + eps * d) - f(x.detach() - eps * d)) / (2 * eps)
+    ana = (g1.double() * d.double()).sum().item()
+    assert abs(num - ana) <= 3e-2 * abs(ana), (num, ana)

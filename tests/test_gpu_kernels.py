@@ -261,3 +261,34 @@ def test_hand_scheduled_kernel_with_dst_term_equals_template(cuda_device, T, F, 
         r64 = c_oracle.segreduce(rp, col, xc, F, aggs, acc_double=True, **kwo)
         msgs = xc[col][:, t * F:(t + 1) * F] + dc[np.repeat(np.arange(V), np.diff(rp))][:, t * F:(t + 1) * F]
         _check_blocks(got[:, t * A * F:(t + 1) * A * F], r32, r64, aggs, 1, F, f"tower {t}", _mass(rp, msgs))
+
+
+@pytest.mark.parametrize("F", [4, 16, 75, 128])
+def test_light_rows_are_bit_exact_in_every_block(cuda_device, F):
+    """Rows that one lane group walks alone (in-degree <= the hub threshold) are summed in CSR edge order, exactly like the C
+    restatement of the reference's reduce_func, and mean = s / D, E[x^2] = q / D are correctly rounded divisions (div_rn): so
+    not only max / min but mean, sum, var and std are BIT-identical to the oracle there -- including rows of equal neighbours,
+    where the reference's variance is exactly 0 and std exactly sqrt(1e-5) (the case a reciprocal-multiply mean gets wrong by
+    percents).  Hub rows differ only through the association of their 128-edge segments."""
+    rng = np.random.default_rng(F)
+    V, E = 3000, 30000
+    src, dst = _rand_graph(rng, V, E, hub=2000)
+    g = Graph(src, dst, V).to(cuda_device)
+    c = g.csr
+    x = torch.randn(V, F, generator=torch.Generator().manual_seed(F)) * 3.0
+    x[::7] = x[0]                                            # many equal source rows: exact-zero variances
+    aggs = ["mean", "max", "min", "std", "sum", "var"]
+    got = ops.segreduce(c.rowptr, c.col, x.to(cuda_device), F, aggs, heavy=g.heavy_schedule(), workspace=g.workspace,
+                        items=g.work_items()).cpu().numpy()
+    got4 = ops.segreduce(c.rowptr, c.col, x.to(cuda_device), F, aggs[:4], heavy=g.heavy_schedule(), workspace=g.workspace,
+                         items=g.work_items()).cpu().numpy()                    # the hand-scheduled kernel (mean|max|min|std)
+    rp, col = c.rowptr.cpu().numpy(), c.col.cpu().numpy()
+    ref = c_oracle.segreduce(rp, col, x.numpy(), F, aggs)
+    light = np.diff(rp) <= g.heavy_schedule().threshold
+    assert light.sum() > 2900 and (~light).sum() >= 1
+    assert np.array_equal(got[light], ref[light])
+    assert np.array_equal(got4[light], ref[light][:, :4 * F])
+    deg = np.diff(rp)
+    eq = np.array([d > 1 and len(set(col[rp[v]:rp[v + 1]] % 7)) == 1 and (col[rp[v]] % 7 == 0) for v, d in enumerate(deg)])
+    if eq.any():
+        assert np.all(got[eq][:, 3 * F:4 * F] == np.float32(np.sqrt(np.float32(1e-5))))
