@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define PNA_ABI_VERSION 5 /* 5: pna_posttrans_args.pipeline; the hand-scheduled gather takes dst_term; + pna_pack_rows_f32.
+#define PNA_ABI_VERSION 6 /* 6: pna_posttrans_args: act_slope (LeakyReLU), n_tower + tower strides.
+                             5: pna_posttrans_args.pipeline; the hand-scheduled gather takes dst_term; + pna_pack_rows_f32.
                              4: + pna_posttrans_x3_*, pna_fused_simple_f32, pna_collate_*, PNA_AGG_VAR_RAW */
 
 #define PNA_OK 0
@@ -292,7 +293,7 @@ typedef struct pna_posttrans_args {
   const float* h;      /* nullable (M, ldh): the node's own features (tower variant) */
   int64_t ldh;
   int32_t Kh;
-  int32_t relu;        /* 1 = ReLU after the affine column map */
+  int32_t relu;        /* activation after the affine column map: 0 = none, 1 = ReLU, 2 = LeakyReLU (act_slope) */
   const float* wh_img; /* packed self weight (when h != NULL) */
   const float* bias;   /* nullable [N] */
   const float* row_post;  /* nullable [M]: graph-norm factor snorm_n */
@@ -305,7 +306,21 @@ typedef struct pna_posttrans_args {
   int32_t pipeline;    /* pna_posttrans_x3_f32 only: 0 = library default; 2 = two weight buffers in LDS, one barrier at every
                           chunk boundary; 3 = three weight buffers, one barrier in the middle of every chunk (wavefronts
                           cross chunk boundaries unsynchronised).  Same arithmetic, bit-identical results. */
-  int32_t _pad_p;
+  float act_slope;     /* relu == 2: LeakyReLU, act(v) = v < 0 ? act_slope * v : v (the FCLayer 'LeakyReLU' of the tower layers'
+                          mixing network, models/layers.py:157, slope 0.01); ignored for relu == 0 / 1 */
+  /* Towers (models/dgl/pna_layer.py:133-139 runs the towers' posttrans one after the other): n_tower > 1 evaluates n_tower
+   * independent contractions of the same shape in ONE call.  Tower t reads a + t*tower_stride_a and h + t*tower_stride_h
+   * (0 = all towers share h), the images w_img + t*tower_stride_w / wh_img + t*tower_stride_wh (floats for pna_posttrans_f32,
+   * BYTES for pna_posttrans_x3_f32: t-th image of a buffer of n_tower images packed one after the other), bias / col_scale /
+   * col_shift + t*N, and writes y + t*tower_stride_y (column slices of one row-major matrix).  row_scale / row_post are shared;
+   * residual must be NULL.  n_tower <= 1: one contraction, strides ignored. */
+  int32_t n_tower;
+  int32_t _pad_t;
+  int64_t tower_stride_a;
+  int64_t tower_stride_h;
+  int64_t tower_stride_w;
+  int64_t tower_stride_wh;
+  int64_t tower_stride_y;
 } pna_posttrans_args;
 
 int pna_posttrans_f32(const pna_posttrans_args* args, pna_stream_t stream);

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to the HI
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpna_amd.so")
 
-PNA_ABI_VERSION = 5
+PNA_ABI_VERSION = 6
 PNA_MAX_AGGR = 8
 PNA_MAX_SCALER = 8
 
@@ -81,7 +81,10 @@ class PnaPosttransArgs(ctypes.Structure):
         ("row_post", ctypes.c_void_p), ("col_scale", ctypes.c_void_p), ("col_shift", ctypes.c_void_p),
         ("residual", ctypes.c_void_p), ("ld_res", ctypes.c_int64),
         ("y", ctypes.c_void_p), ("ldy", ctypes.c_int64),
-        ("pipeline", ctypes.c_int32), ("_pad_p", ctypes.c_int32),
+        ("pipeline", ctypes.c_int32), ("act_slope", ctypes.c_float),
+        ("n_tower", ctypes.c_int32), ("_pad_t", ctypes.c_int32),
+        ("tower_stride_a", ctypes.c_int64), ("tower_stride_h", ctypes.c_int64), ("tower_stride_w", ctypes.c_int64),
+        ("tower_stride_wh", ctypes.c_int64), ("tower_stride_y", ctypes.c_int64),
     ]
 
 

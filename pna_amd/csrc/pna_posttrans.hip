@@ -47,7 +47,9 @@ struct GArgs {
   const float* row_post; const float* col_scale; const float* col_shift; const float* residual;
   float* y;
   long lda, ldh, ldy, ld_res;
+  long ts_a, ts_h, ts_w, ts_wh, ts_y;          // tower strides (blockIdx.z = tower), floats
   int M, K, N, Kh, relu;
+  float slope;
 };
 
 // ---- weight packing ------------------------------------------------------------------------------
@@ -82,7 +84,17 @@ __global__ void k_pack(const float* w_ref, long ldw, int N, int K, int S, int Kh
 // NT = number of live 16-column tiles (compile time: a run-time guard around every MFMA costs a scalar branch
 // per MFMA and breaks the ds_read / MFMA interleave).
 template <int S, bool HAS_H, int NT>
-__global__ __launch_bounds__(kBlock, (S + (HAS_H ? 1 : 0)) * NT <= 15 ? 4 : 2) void k_posttrans(const GArgs g) {
+__global__ __launch_bounds__(kBlock, (S + (HAS_H ? 1 : 0)) * NT <= 15 ? 4 : 2) void k_posttrans(const GArgs g0) {
+  // blockIdx.z = tower: the same contraction on the tower's slices (models/dgl/pna_layer.py:133-139 in one launch)
+  GArgs g = g0;
+  {
+    const long tw = blockIdx.z;
+    g.a += tw * g0.ts_a; g.w_img += tw * g0.ts_w; g.y += tw * g0.ts_y;
+    if (g0.h) g.h += tw * g0.ts_h;
+    if (g0.wh_img) g.wh_img += tw * g0.ts_wh;
+    if (g0.bias) g.bias += tw * g0.N;
+    if (g0.col_scale) { g.col_scale += tw * g0.N; g.col_shift += tw * g0.N; }
+  }
   constexpr int P = S + (HAS_H ? 1 : 0);       // panels resident in LDS per buffer
   constexpr int SV = (S * kPanel / 4 + kBlock - 1) / kBlock;     // dwordx4 per thread to stage S panels
   extern __shared__ float lds[];               // 2 buffers x P panels x 16 x 84 floats
@@ -264,7 +276,7 @@ __global__ __launch_bounds__(kBlock, (S + (HAS_H ? 1 : 0)) * NT <= 15 ? 4 : 2) v
       for (int s = 0; s < S; ++s) v = v + sc[s][r] * acc[s][n][r];
       if (g.row_post) v = v * rp[r];                                   // graph-norm (pna_layer.py:71-72)
       if (g.col_scale) v = v * cs + ct;                                // eval-mode BatchNorm folded to an affine map
-      if (g.relu) v = v > 0.f ? v : (v != v ? v : 0.f);                // ReLU (keeps NaN)
+      if (g.relu) v = v > 0.f ? v : (v != v ? v : (g.relu == 2 ? g.slope * v : 0.f));   // ReLU / LeakyReLU (keep NaN)
       if (g.residual) v = g.residual[(size_t)row * g.ld_res + col] + v;  // h_in + h (pna_layer.py:212-213)
       g.y[(size_t)row * g.ldy + col] = v;
     }
@@ -336,7 +348,15 @@ extern "C" int pna_posttrans_f32(const pna_posttrans_args* p, pna_stream_t strea
   g.row_post = p->row_post; g.col_scale = p->col_scale; g.col_shift = p->col_shift; g.residual = p->residual;
   g.y = p->y; g.lda = p->lda; g.ldh = p->ldh; g.ldy = p->ldy; g.ld_res = p->ld_res;
   g.M = p->M; g.K = p->K; g.N = p->N; g.Kh = has_h ? p->Kh : 0; g.relu = p->relu;
-  dim3 grid((unsigned)((p->M + 63) / 64), (unsigned)((p->N + kNW - 1) / kNW));
+  if (p->relu < 0 || p->relu > 2) return pna_set_error(PNA_E_INVALID, "pna_posttrans_f32: relu must be 0, 1 or 2");
+  g.slope = p->relu == 2 ? p->act_slope : 0.f;
+  const int T = p->n_tower > 1 ? p->n_tower : 1;
+  if (T > 1) {
+    if (p->residual) return pna_set_error(PNA_E_INVALID, "pna_posttrans_f32: residual is not supported with n_tower > 1");
+    if (T > 65535) return pna_set_error(PNA_E_INVALID, "pna_posttrans_f32: too many towers");
+    g.ts_a = p->tower_stride_a; g.ts_h = p->tower_stride_h; g.ts_w = p->tower_stride_w; g.ts_wh = p->tower_stride_wh; g.ts_y = p->tower_stride_y;
+  }
+  dim3 grid((unsigned)((p->M + 63) / 64), (unsigned)((p->N + kNW - 1) / kNW), (unsigned)T);
   hipStream_t st = (hipStream_t)stream;
   // live 16-column tiles per workgroup (all column tiles of the grid use the same instantiation; columns >= N
   // are zero in the packed image and masked at the store)

@@ -27,6 +27,7 @@
 // barrier skew), not by the matrix pipe: see DESIGN.md 4.2b for the phase-timer breakdown.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 
@@ -54,6 +55,8 @@ struct XArgs {
   float* y;
   long lda, ldh, ldy, ld_res;
   int M, K, N, Kh, relu, grid_x;
+  float slope;                 // LeakyReLU slope (relu == 2), 0 for ReLU
+  unsigned long long* dbg;     // experiments build only: per-wavefront phase timers (null otherwise)
 };
 
 __device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(unsigned, x); }
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
     v = v + cb;
     if (g.row_post) v = v * rp;                                        // graph-norm (pna_layer.py:71-72)
     if (g.col_scale) v = v * cs + ct;                                  // eval-mode BatchNorm folded to an affine map
-    if (g.relu) v = v > 0.f ? v : (v != v ? v : 0.f);                  // ReLU (keeps NaN)
+    if (g.relu) v = v > 0.f ? v : (v != v ? v : (g.relu == 2 ? g.slope * v : 0.f));   // ReLU / LeakyReLU (keep NaN)
     return v;
   };
   auto epilogue = [&](int t) __attribute__((always_inline)) {
@@ -360,6 +363,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
     asm volatile("" : "+v"(li_), "+v"(lg_));
     const int row0 = (t * WAVES + wave) * (16 * RT);
     const float lo = g.relu ? 0.f : -INFINITY;
+    const bool leaky = g.relu == 2;
     const f4 ones = (f4){1.f, 1.f, 1.f, 1.f};
     const unsigned ldyb = (unsigned)g.ldy * 4u, ldrb = (unsigned)g.ld_res * 4u;       // (launcher: pitches < 2^24 floats)
 #pragma unroll
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
           for (int s = 1; s < S; ++s) x = __builtin_fmaf(scv[s][r], acc[rt][s][n][r], x);
           x = (x + cb) * rpv[r];
           x = __builtin_fmaf(x, cs, ct);
-          x = x < lo ? 0.f : x;
+          x = x < lo ? (leaky ? x * g.slope : 0.f) : x;  // ReLU / LeakyReLU / none (lo = -inf); NaN < lo is false: NaN is kept
           v[r] = res[n][r] + x;
 #pragma unroll
           for (int p = 0; p < P; ++p) acc[rt][p][n][r] = 0.f;
@@ -531,6 +535,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
       load_a(nxt[1], m1 ? t1 : t, m1 ? c1 : 0);   // step 1's fragment (a harmless re-load when there is no step 1)
     }
     __syncthreads();
+#ifdef PNA_AMD_EXPERIMENTS
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // phase timers, tools/x3_timers.py
+#endif
     auto step = [&](auto par_c, int k) __attribute__((always_inline)) {
       constexpr int PAR = decltype(par_c)::value;
       aset_t& mine = nxt[PAR];           // free now (held step k's fragment): receives step k+2's
@@ -544,6 +551,12 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
       const bool is_h = HAS_H && c >= nca;
       const unsigned baddr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(buf * kChunkV + lg * kNW + li) * 16u;
       load_a(mine, more2 ? t2 : t, more2 ? c2 : c);       // (a harmless re-load of this step's fragment near the end)
+#ifdef PNA_AMD_EXPERIMENTS
+      const unsigned long long tm0 = clock64();
+#endif
+#ifdef PNA_AMD_EXPERIMENTS
+      unsigned long long tm1 = 0, tm1b = 0, tm2 = 0;
+#endif
       auto run3 = [&](auto npanel_c, auto p0_c, unsigned ba0) __attribute__((always_inline)) {
         constexpr int p0 = decltype(p0_c)::value;       // compile-time: a run-time panel index puts the accumulators in scratch
         constexpr int NPN = decltype(npanel_c)::value;
@@ -570,7 +583,15 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
           if (gi == H) {
             // everything older than the 2*RT A loads issued at the top of this step has landed: this wavefront's copies
             // of step k+1's image AND step k+1's A fragment
+#ifdef PNA_AMD_EXPERIMENTS
+            tm1 = clock64();
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * RT) : "memory");
+            tm1b = clock64();
+            asm volatile("s_barrier" : : : "memory");
+            tm2 = clock64();
+#else
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"(2 * RT) : "memory");
+#endif
           }
           if (more2) {
 #pragma unroll
@@ -589,8 +610,14 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
       } else if (HAS_H) {
         run3(std::integral_constant<int, 1>{}, std::integral_constant<int, P - 1>{}, baddr);
       }
+#ifdef PNA_AMD_EXPERIMENTS
+      const unsigned long long tm3 = clock64();
+#endif
       // the next fragment first, then the epilogue (the fragment landed before this step's barrier: no wait here)
       if (more1) take(other, cn, 2);
+#ifdef PNA_AMD_EXPERIMENTS
+      const unsigned long long tm4 = clock64();
+#endif
       if (c == nc - 1) {
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (GEN) epilogue(t);
@@ -598,13 +625,30 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
         else zero_acc();
         __builtin_amdgcn_sched_barrier(0);
       }
+#ifdef PNA_AMD_EXPERIMENTS
+      if (g.dbg) {
+        const unsigned long long tm5 = clock64();
+        tacc[0] += tm1 - tm0; tacc[1] += tm1b - tm1; tacc[2] += tm2 - tm1b; tacc[3] += tm3 - tm2; tacc[4] += tm4 - tm3; tacc[5] += tm5 - tm4;
+        tacc[6] += 1;
+      }
+#endif
       t = tn; c = cn; buf = buf == 2 ? 0 : buf + 1;
     };
+#ifdef PNA_AMD_EXPERIMENTS
+    const unsigned long long tstart = clock64();
+#endif
     for (int k = 0; k < nsteps; k += 2) {
       step(std::integral_constant<int, 0>{}, k);
       if (k + 1 < nsteps) step(std::integral_constant<int, 1>{}, k + 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the re-loads of the last steps
+#ifdef PNA_AMD_EXPERIMENTS
+    if (g.dbg && lane == 0) {
+      tacc[7] = clock64() - tstart;
+      unsigned long long* o = g.dbg + ((size_t)blockIdx.x * WAVES + wave) * 8;
+      for (int i = 0; i < 8; ++i) o[i] = tacc[i];
+    }
+#endif
   }
 }
 
@@ -711,6 +755,13 @@ extern "C" int pna_posttrans_x3_f32(const pna_posttrans_args* p, pna_stream_t st
   g.row_post = p->row_post; g.col_scale = p->col_scale; g.col_shift = p->col_shift; g.residual = p->residual;
   g.y = p->y; g.lda = p->lda; g.ldh = p->ldh; g.ldy = p->ldy; g.ld_res = p->ld_res;
   g.M = p->M; g.K = p->K; g.N = p->N; g.Kh = has_h ? p->Kh : 0; g.relu = p->relu;
+  if (p->relu < 0 || p->relu > 2) return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3_f32: relu must be 0, 1 or 2");
+  g.slope = p->relu == 2 ? p->act_slope : 0.f;
+  const int T = p->n_tower > 1 ? p->n_tower : 1;
+  if (T > 1 && p->residual) return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3_f32: residual is not supported with n_tower > 1");
+#ifdef PNA_AMD_EXPERIMENTS
+  if (const char* e = getenv("PNA_X3_DBG_PTR")) g.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // device buffer: 8 counters per wavefront
+#endif
   {   // one persistent workgroup per CU (and per column tile)
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
@@ -725,10 +776,22 @@ extern "C" int pna_posttrans_x3_f32(const pna_posttrans_args* p, pna_stream_t st
   if (pl != 0 && pl != 2 && pl != 3)
     return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3_f32: pipeline must be 0 (default), 2 or 3");
   const int nbuf = pl ? pl : kDefaultNBuf;
-  switch (p->n_scaler) {
-    case 1: rc = launch_s<1>(g, has_h, nt, nbuf, shape, st); break;
-    case 2: rc = launch_s<2>(g, has_h, nt, nbuf, shape, st); break;
-    default: rc = launch_s<3>(g, has_h, nt, nbuf, shape, st); break;
+  rc = 0;
+  for (int t = 0; t < T && rc == 0; ++t) {           // towers: one persistent launch each (large M: launch cost is immaterial)
+    XArgs gt = g;
+    if (T > 1) {
+      gt.a = g.a + (size_t)t * p->tower_stride_a;
+      gt.w_img = (const unsigned char*)g.w_img + (size_t)t * p->tower_stride_w;
+      if (has_h) { gt.h = g.h + (size_t)t * p->tower_stride_h; gt.wh_img = (const unsigned char*)g.wh_img + (size_t)t * p->tower_stride_wh; }
+      if (g.bias) gt.bias = g.bias + (size_t)t * p->N;
+      if (g.col_scale) { gt.col_scale = g.col_scale + (size_t)t * p->N; gt.col_shift = g.col_shift + (size_t)t * p->N; }
+      gt.y = g.y + (size_t)t * p->tower_stride_y;
+    }
+    switch (p->n_scaler) {
+      case 1: rc = launch_s<1>(gt, has_h, nt, nbuf, shape, st); break;
+      case 2: rc = launch_s<2>(gt, has_h, nt, nbuf, shape, st); break;
+      default: rc = launch_s<3>(gt, has_h, nt, nbuf, shape, st); break;
+    }
   }
   if (rc != 0) return pna_set_error(PNA_E_LAUNCH, "pna_posttrans_x3_f32: could not reserve LDS");
   hipError_t e = hipGetLastError();

@@ -120,6 +120,25 @@ class PNATower(nn.Module):
         return _towers_forward([self], as_graph(g), h, e, snorm_n, divide_input=False)
 
 
+def _projection_cache(towers, Fi):
+    """([W_a ; W_b] (2*T*Fi, Fi), [0 ; b] (2*T*Fi)) of the towers' 1-layer pretrans, cached on the first tower per parameter
+    (version, address): one GEMM then gives the source-side rows W_a h (columns [0, T*Fi)) and the destination-side rows
+    W_b h + b (columns [T*Fi, 2*T*Fi)) of every tower."""
+    lins = [t.pretrans.fully_connected[0].linear for t in towers]
+    key = tuple((p._version, p.data_ptr(), str(p.device)) for l in lins for p in (l.weight, l.bias))
+    hit = towers[0].__dict__.get("_pna_amd_proj")
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            W = torch.stack([l.weight for l in lins])                                        # (T, Fi, 2Fi + ed)
+            T = len(lins)
+            Wcat = torch.cat([W[:, :, :Fi].reshape(T * Fi, Fi), W[:, :, Fi:2 * Fi].reshape(T * Fi, Fi)], dim=0).contiguous()
+            b = torch.stack([l.bias for l in lins]).reshape(-1)
+            bcat = torch.cat([torch.zeros_like(b), b]).contiguous()
+        hit = (key, Wcat, bcat)
+        towers[0].__dict__["_pna_amd_proj"] = hit
+    return hit[1], hit[2]
+
+
 def _towers_forward(towers, graph, h, e, snorm_n, divide_input):
     """Shared body of PNATower.forward / PNALayer.forward: all towers through one gather kernel."""
     t0 = towers[0]
@@ -142,6 +161,11 @@ def _towers_forward(towers, graph, h, e, snorm_n, divide_input):
             hv = h.reshape(V, T, Fi)
             x_src = torch.einsum("vti,tfi->vtf", hv, Wa).reshape(V, T * Fi)
             x_dst = (torch.einsum("vti,tfi->vtf", hv, Wb) + b).reshape(V, T * Fi)
+        elif not torch.is_grad_enabled() or not (h.requires_grad or W.requires_grad):
+            # inference: both projections of all towers as ONE GEMM against the cached [W_a ; W_b] (2*T*Fi x Fi) weight
+            Wcat, bcat = _projection_cache(towers, Fi)
+            x_cat = torch.addmm(bcat, h, Wcat.t())
+            x_src, x_dst = x_cat[:, :T * Fi], x_cat[:, T * Fi:]
         else:
             x_src = h @ Wa.reshape(T * Fi, Fi).t()
             x_dst = torch.addmm(b.reshape(-1), h, Wb.reshape(T * Fi, Fi).t())
@@ -165,6 +189,14 @@ def _towers_forward(towers, graph, h, e, snorm_n, divide_input):
     # tower writes its slice of the concatenated output directly
     fuse = (not torch.is_grad_enabled() or not any(p.requires_grad for t in towers for p in t.parameters())) and \
         all((not t.training) and t.posttrans.is_affine for t in towers) and not h.requires_grad
+    if fuse and (not divide_input or Fi >= 4) and all(t.graph_norm == t0.graph_norm and t.batch_norm == t0.batch_norm for t in towers):
+        # all towers' contractions in one call (one launch for the batches the exact-f32 kernel serves)
+        No = t0.out_dim
+        h_cat = torch.empty(V, T * No, dtype=torch.float32, device=h.device)
+        PF.posttrans_towers(agg, K, [t.posttrans.fully_connected[0].linear for t in towers], scales, h, not divide_input, h_cat,
+                            row_post=snorm_n if t0.graph_norm else None,
+                            bns=[t.batchnorm_h for t in towers] if t0.batch_norm else None)
+        return h_cat
     if fuse:
         No = t0.out_dim
         h_cat = torch.empty(V, T * No, dtype=torch.float32, device=h.device)
@@ -214,7 +246,13 @@ class PNALayer(nn.Module):
 
     def forward(self, g, h, e, snorm_n):
         h_cat = _towers_forward(list(self.towers), as_graph(g), h, e, snorm_n, self.divide_input)
-        h_out = self.mixing_network(h_cat)
+        mix = self.mixing_network
+        if (h_cat.shape[1] >= 4 and isinstance(mix.activation, nn.LeakyReLU) and mix.b_norm is None and (mix.dropout is None or not self.training)
+                and not (torch.is_grad_enabled() and (h_cat.requires_grad or any(p.requires_grad for p in mix.parameters())))):
+            # inference: Linear + LeakyReLU (+ residual) of the mixing network as one launch of the contraction kernel
+            return PF.linear_act(h_cat, mix.linear.weight, mix.linear.bias, leaky_slope=mix.activation.negative_slope,
+                                 residual=h if self.residual else None)
+        h_out = mix(h_cat)
         if self.residual:
             h_out = h + h_out
         return h_out

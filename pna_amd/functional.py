@@ -119,3 +119,41 @@ def posttrans(agg, K, weight, bias, row_scales, h_self=None, *, row_post=None, b
     w = weight if weight.stride(-1) == 1 else weight.contiguous()
     return ops.posttrans(agg, K, w, row_scales, bias, h_self, out=out, row_post=row_post, col_scale=col_scale,
                          col_shift=col_shift, relu=relu, residual=_unit_stride(residual))
+
+
+def _stack_cached(owner, tag, tensors):
+    """torch.stack(tensors) cached on `owner` per (version, address, device) of every tensor: the per-tower biases and folded
+    BatchNorm constants of a layer, which would otherwise cost a concatenation launch per forward."""
+    key = tuple((t._version, t.data_ptr(), str(t.device)) for t in tensors)
+    hit = owner.__dict__.get(tag)
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            hit = (key, torch.stack([t.detach() for t in tensors]).contiguous())
+        owner.__dict__[tag] = hit
+    return hit[1]
+
+
+def posttrans_towers(agg, K, towers_lin, row_scales, hs, h_shared, out, row_post=None, bns=None, relu=False):
+    """Inference-only: the first posttrans Linear of every tower (+ graph-norm / folded eval BatchNorm) in ONE call.
+    towers_lin: the nn.Linear of each tower; hs: the (V, Kh) shared input or the (V, T*Kh) divided one; bns: per-tower
+    BatchNorm1d modules (eval) or None."""
+    weights = [lin.weight for lin in towers_lin]
+    owner = towers_lin[0]
+    biases = _stack_cached(owner, "_pna_amd_bias_stack", [lin.bias for lin in towers_lin]) if towers_lin[0].bias is not None else None
+    cs = ct = None
+    if bns is not None:
+        folds = [_fold_batchnorm(bn) for bn in bns]
+        cs = _stack_cached(owner, "_pna_amd_cs_stack", [f[0] for f in folds])
+        ct = _stack_cached(owner, "_pna_amd_ct_stack", [f[1] for f in folds])
+    if row_post is not None:
+        row_post = row_post.reshape(-1).contiguous()
+    return ops.posttrans_towers(_unit_stride(agg), K, weights, row_scales, biases, _unit_stride(hs), h_shared, out, row_post=row_post,
+                                col_scale=cs, col_shift=ct, relu=relu)
+
+
+def linear_act(x, weight, bias, leaky_slope=None, relu=False, residual=None, out=None):
+    """act(x @ weight^T + bias) (+ residual) on the contraction kernels (inference): the tower layers' mixing network
+    (FCLayer(out, out, 'LeakyReLU') + residual, models/dgl/pna_layer.py:128,:141-144) as one launch."""
+    w = weight if weight.stride(-1) == 1 else weight.contiguous()
+    return ops.posttrans(_unit_stride(x), x.shape[1], w, [None], bias, out=out, relu=relu, leaky_slope=leaky_slope,
+                         residual=_unit_stride(residual))

@@ -161,7 +161,7 @@ def posttrans(a_mat: torch.Tensor, K: int, weight: torch.Tensor, row_scales: Seq
               bias: Optional[torch.Tensor] = None, h: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
               row_post: Optional[torch.Tensor] = None, col_scale: Optional[torch.Tensor] = None,
               col_shift: Optional[torch.Tensor] = None, relu: bool = False, residual: Optional[torch.Tensor] = None,
-              arith: Optional[str] = None, pipeline: int = 0):
+              arith: Optional[str] = None, pipeline: int = 0, leaky_slope: Optional[float] = None):
     """y = residual + act(((bias + h@Wh^T + sum_s row_scales[s][:,None] * (a[:, :K] @ W_s^T)) * row_post[:,None]) *
     col_scale + col_shift)                                                                      (see pna_amd.h).
 
@@ -200,7 +200,8 @@ def posttrans(a_mat: torch.Tensor, K: int, weight: torch.Tensor, row_scales: Seq
         g.row_post = _lib.dev_ptr(row_post, torch.float32, "row_post")
     g.col_scale = _lib.dev_ptr(col_scale, torch.float32, "col_scale")
     g.col_shift = _lib.dev_ptr(col_shift, torch.float32, "col_shift")
-    g.relu = 1 if relu else 0
+    g.relu = 2 if leaky_slope is not None else (1 if relu else 0)      # leaky_slope: LeakyReLU(v) = v < 0 ? slope * v : v
+    g.act_slope = float(leaky_slope) if leaky_slope is not None else 0.0
     if residual is not None:
         g.residual, g.ld_res = _lib.dev_ptr(residual, torch.float32, "residual"), _ld(residual)
     g.y, g.ldy = _lib.dev_ptr(out, torch.float32, "y"), _ld(out)
@@ -278,4 +279,58 @@ def pack_rows(x: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = 
     rc = _lib.lib().pna_pack_rows_f32(_lib.dev_ptr(x, torch.float32, "x"), _ld(x), _lib.dev_ptr(idx, torch.int32, "idx"), n, F,
                                       _lib.dev_ptr(out, torch.float32, "out"), _ld(out), _lib.stream_ptr(x.device))
     _lib.check(rc, "pna_pack_rows_f32")
+    return out
+
+
+def posttrans_towers(agg: torch.Tensor, K: int, weights: Sequence[torch.Tensor], row_scales: Sequence[Optional[torch.Tensor]],
+                     biases: Optional[torch.Tensor], h: Optional[torch.Tensor], h_shared: bool, out: torch.Tensor,
+                     row_post: Optional[torch.Tensor] = None, col_scale: Optional[torch.Tensor] = None,
+                     col_shift: Optional[torch.Tensor] = None, relu: bool = False, arith: Optional[str] = None):
+    """The posttrans contraction of ALL towers of a layer in one call (one launch on the exact-f32 kernel, which is what
+    small batches use): tower t maps agg[:, t*K:(t+1)*K] (and h[:, t*Kh:(t+1)*Kh], or the whole h when h_shared) through
+    weights[t] (N, Kh + S*K) into out[:, t*N:(t+1)*N].  biases / col_scale / col_shift: (T, N) contiguous or None.
+    models/dgl/pna_layer.py:133-139 loops over the towers in Python."""
+    T, S, N = len(weights), len(row_scales), weights[0].shape[0]
+    M = agg.shape[0]
+    Kh = 0 if h is None else (h.shape[1] if h_shared else h.shape[1] // T)
+    arith = arith or POSTTRANS_ARITH
+    if arith == "bf16x3" and S > 3:
+        arith = "f32"
+    x3 = arith == "bf16x3" or (arith == "auto" and S <= 3 and M >= X3_MIN_ROWS)
+    # one buffer holding the T packed images back to back, cached on the first weight per (version, address) of all of them
+    key = tuple((w._version, w.data_ptr(), str(w.device)) for w in weights) + (K, S, Kh, x3)
+    hit = getattr(weights[0], "_pna_amd_tower_pack", None)
+    if hit is None or hit[0] != key:
+        imgs = [(pack_posttrans_weight_x3 if x3 else pack_posttrans_weight)(w if w.stride(-1) == 1 else w.contiguous(), K, S, Kh)
+                for w in weights]
+        w_all = torch.cat([i[0].reshape(-1) for i in imgs])
+        wh_all = torch.cat([i[1].reshape(-1) for i in imgs]) if Kh else None
+        hit = (key, w_all, wh_all, imgs[0][0].numel(), imgs[0][1].numel() if Kh else 0)
+        try:
+            weights[0]._pna_amd_tower_pack = hit
+        except AttributeError:
+            pass
+    _, w_all, wh_all, w_stride, wh_stride = hit
+    g = _lib.PnaPosttransArgs()
+    g.a, g.lda, g.M, g.K, g.N, g.n_scaler = _lib.dev_ptr(agg, torch.float32, "a"), _ld(agg), M, K, N, S
+    for i, rs in enumerate(row_scales):
+        if rs is not None:
+            g.row_scale[i] = _lib.dev_ptr(rs, torch.float32, "row_scale").value
+    g.w_img = _lib.dev_ptr(w_all, torch.float32, "w_img")
+    if h is not None:
+        g.h, g.ldh, g.Kh = _lib.dev_ptr(h, torch.float32, "h"), _ld(h), Kh
+        g.wh_img = _lib.dev_ptr(wh_all, torch.float32, "wh_img")
+    g.bias = _lib.dev_ptr(biases, torch.float32, "bias")
+    if row_post is not None:
+        g.row_post = _lib.dev_ptr(row_post, torch.float32, "row_post")
+    g.col_scale = _lib.dev_ptr(col_scale, torch.float32, "col_scale")
+    g.col_shift = _lib.dev_ptr(col_shift, torch.float32, "col_shift")
+    g.relu = 1 if relu else 0
+    g.y, g.ldy = _lib.dev_ptr(out, torch.float32, "y"), _ld(out)
+    g.n_tower = T
+    g.tower_stride_a, g.tower_stride_h, g.tower_stride_y = K, (0 if h_shared else Kh), N
+    g.tower_stride_w, g.tower_stride_wh = (w_stride * 4, wh_stride * 4) if x3 else (w_stride, wh_stride)   # x3 images: bytes
+    fn = "pna_posttrans_x3_f32" if x3 else "pna_posttrans_f32"
+    rc = getattr(_lib.lib(), fn)(ctypes.byref(g), _lib.stream_ptr(agg.device))
+    _lib.check(rc, fn)
     return out

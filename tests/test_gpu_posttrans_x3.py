@@ -50,8 +50,7 @@ def test_bf16x3_posttrans_is_fp32_accurate(M, K, N, S, Kh, scale):
     # the two LDS pipelines of the kernel (2 buffers + barrier per chunk boundary / 3 buffers + mid-chunk barrier) do the
     # same arithmetic in the same order: bit-identical
     y2 = ops.posttrans(a, K, W, scales, b, h, arith="bf16x3", pipeline=2)
-    y3 = ops.posttrans(a, K, W, scales, b, h, arith="bf16x3", pipeline=3)
-    assert torch.equal(y2, y3)
+    assert torch.equal(y2, ops.posttrans(a, K, W, scales, b, h, arith="bf16x3", pipeline=3))
 
 
 def test_bf16x3_fused_tail_matches_f32_kernel():
@@ -312,3 +311,44 @@ def test_tower_layer_golden_through_bf16x3(cuda_device, monkeypatch, name):
     with torch.no_grad():
         out = layer(g, a["h"].to(cuda_device), e, a["snorm_n"].to(cuda_device)).cpu()
     torch.testing.assert_close(out, a["out"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("arith,M", [("f32", 700), ("bf16x3", 700), ("bf16x3", 20000)])
+def test_leaky_relu_epilogue_and_tower_batching(arith, M):
+    """ABI 6: (i) relu = 2 / act_slope = LeakyReLU (the mixing network of the tower layers, models/layers.py:157) against torch,
+    including -Inf (LeakyReLU(-Inf) = -Inf, ReLU(-Inf) = 0) and NaN inputs; (ii) n_tower contractions in one call = the same
+    contractions one by one, bit for bit, with per-tower h slices / shared h, biases and folded BatchNorm constants."""
+    from pna_amd import ops
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(M)
+    K, N = 48, 20
+    a = torch.randn(M, K, generator=gen).to(dev)
+    a[3, 5], a[9, 1] = float("-inf"), float("nan")
+    W = (torch.randn(N, K, generator=gen).abs() / 7).to(dev)                      # positive weights: row 3 is -Inf everywhere
+    b = torch.randn(N, generator=gen).to(dev)
+    res = torch.randn(M, N, generator=gen).to(dev)
+    y = ops.posttrans(a, K, W, [None], b, leaky_slope=0.01, residual=res, arith=arith)
+    ref = res + torch.nn.functional.leaky_relu(a @ W.t() + b, 0.01)
+    fin = torch.isfinite(ref)
+    assert torch.equal(torch.isnan(y), torch.isnan(ref)) and torch.equal(torch.isinf(y), torch.isinf(ref))
+    assert (y[fin] - ref[fin]).abs().max().item() <= 2e-5 * ref[fin].abs().max().item()
+    yr = ops.posttrans(a, K, W, [None], b, relu=True, arith=arith)
+    assert torch.equal(yr[3], torch.zeros(N, device=dev)) and torch.isnan(yr[9]).all()          # ReLU(-Inf) = +0, NaN kept
+    assert not torch.signbit(yr[3]).any()
+    # towers
+    T, S, Kh = 5, 3, 8
+    agg = torch.randn(M, T * K, generator=gen).to(dev)
+    scales = [None, (torch.rand(M, generator=gen) + 0.5).to(dev), (torch.rand(M, generator=gen) + 0.5).to(dev)]
+    Ws = [(torch.randn(N, Kh + S * K, generator=gen) / 12).to(dev) for _ in range(T)]
+    bs = torch.randn(T, N, generator=gen).to(dev)
+    cs, ct = (torch.rand(T, N, generator=gen) + 0.5).to(dev), torch.randn(T, N, generator=gen).to(dev)
+    rp = (torch.rand(M, generator=gen) + 0.5).to(dev)
+    for shared in (True, False):
+        h = torch.randn(M, Kh if shared else T * Kh, generator=gen).to(dev)
+        out = torch.full((M, T * N + 3), 5.0, device=dev)
+        ops.posttrans_towers(agg, K, Ws, scales, bs, h, shared, out[:, :T * N], row_post=rp, col_scale=cs, col_shift=ct, relu=True, arith=arith)
+        for t in range(T):
+            want = ops.posttrans(agg[:, t * K:(t + 1) * K], K, Ws[t], scales, bs[t], h if shared else h[:, t * Kh:(t + 1) * Kh],
+                                 row_post=rp, col_scale=cs[t], col_shift=ct[t], relu=True, arith=arith)
+            assert torch.equal(out[:, t * N:(t + 1) * N], want), (shared, t)
+        assert (out[:, T * N:] == 5.0).all()
