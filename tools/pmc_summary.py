@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Reduce rocprofv3 --pmc CSVs (gpurun_out/pmc_*/k_counter_collection.csv, produced over
-tools/prof_kernels.py) to profiles/<tag>_pmc_summary.json and profiles/hbm_traffic.json.
+"""Reduce rocprofv3 --pmc CSVs (gpurun_out/<prefix>*/k_counter_collection.csv, produced over
+tools/prof_kernels.py; `python tools/pmc_summary.py <tag> <prefix> "<when>"`) to profiles/<tag>_pmc_summary.json and profiles/hbm_traffic.json.
 
 HBM-side traffic per launch of the segment-reduce kernel = FETCH_SIZE * read_scale + WRITE_SIZE * 1024, with
 read_scale calibrated on the calibration launch of the same kernel (known fabric read volume, see
@@ -15,8 +15,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+prefix = sys.argv[2] if len(sys.argv) > 2 else "pmc_"          # gpurun_out/<prefix>*/ directories of the --pmc passes
+collected = sys.argv[3] if len(sys.argv) > 3 else tag
 rows = []
-for p in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_*", "*counter_collection.csv")):
+for p in glob.glob(os.path.join(ROOT, "gpurun_out", prefix + "*", "*counter_collection.csv")):
     rows += list(csv.DictReader(open(p)))
 agg = collections.defaultdict(list)
 for r in rows:
@@ -51,7 +53,7 @@ if "segreduce_calib" in out and "FETCH_SIZE" in out["segreduce_calib"]:
     summary["pna_segreduce_c3"] = {"fabric_read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                                    "hbm_bytes_per_launch": rd + wr,
                                    "algorithmic_bytes_per_launch": 10_000_000 * (4 * F + 4) + 4 * 1_000_001 + 1_000_000 * 16 * F}
-    traffic = {"pna_segreduce_c3": summary["pna_segreduce_c3"], "calibration": summary["calibration"]}
+    traffic = {"collected": collected, "pna_segreduce_c3": summary["pna_segreduce_c3"], "calibration": summary["calibration"]}
     for key, name in (("posttrans_bf16x3_c3", "pna_posttrans_x3_c3"), ("posttrans_f32_c3", "pna_posttrans_f32_c3")):
         k = out.get(key, {})
         if "FETCH_SIZE" in k and "WRITE_SIZE" in k:      # same byte scale: the contraction's A loads are 16-byte gathers too
