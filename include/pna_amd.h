@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define PNA_ABI_VERSION 6 /* 6: pna_posttrans_args: act_slope (LeakyReLU), n_tower + tower strides.
+#define PNA_ABI_VERSION 7 /* 7: + pna_small_*, pna_tower_post_*, pna_tower_layer_f32 (the molecule-batch tower layer).
+                             6: pna_posttrans_args: act_slope (LeakyReLU), n_tower + tower strides.
                              5: pna_posttrans_args.pipeline; the hand-scheduled gather takes dst_term; + pna_pack_rows_f32.
                              4: + pna_posttrans_x3_*, pna_fused_simple_f32, pna_collate_*, PNA_AGG_VAR_RAW */
 
@@ -382,6 +383,94 @@ typedef struct pna_fused_simple_args {
 } pna_fused_simple_args;
 
 int pna_fused_simple_f32(const pna_fused_simple_args* args, pna_stream_t stream);
+
+/* ---- the tower layer of molecule-sized batches: one call, two launches (BASELINE.json configs[1]) -------------------
+ *
+ * At ~3 k nodes / ~6 k edges per batch the layer is bound by launch and load LATENCY, so the work is cut by destination rows
+ * instead of by operator (pna_tower_fused.hip).  pna_tower_layer_f32 evaluates, in eval mode, all of
+ * models/dgl/pna_layer.py:133-148 (PNALayer.forward) with 1-layer pretrans / posttrans and no edge features:
+ *   launch 1   x_cat[v] = [ W_a,t h_t[v] | W_b,t h_t[v] + b_t ]_t          the pretrans Linear(2 Fi -> Fi) of every tower,
+ *                                                                          factorised to node level (:35-40)
+ *   launch 2   per 16 destination rows, never leaving the CU:
+ *              a_t[v]   = [mean | max | min | std] over in-edges (u -> v) of x_src,t[u] + x_dst,t[v]      (:42-56)
+ *              z_t[v]   = ((b_t + W_h,t h_t[v] + sum_s row_scale[s][v] (W_s,t a_t[v])) * row_post[v]) * col_scale + col_shift   (:65-74)
+ *              y[v]     = residual[v] + act(W_mix [z_0 .. z_T-1][v] + b_mix)                               (:141-147)
+ *   (mix_img == NULL: y = [z_0 .. z_T-1], the plain concatenation; PNATower on its own.)
+ * h_t = h[:, t*Fi .. (t+1)*Fi) when divide_input, else all of h (then Fin = Fi).  Exact fp32 products on
+ * v_mfma_f32_16x16x4_f32; the aggregation is the light-row arithmetic of pna_segreduce_fwd_f32 (edge order, s / D correctly
+ * rounded), for every row whatever its degree; results agree with the large-graph path to fp32 summation-order noise.
+ * Aggregators are fixed to mean|max|min|std, n_scaler <= 3.  Returns PNA_E_INVALID when one tower's 16-row tile does not fit
+ * the LDS (Fi > ~570): callers use the large-graph kernels then.
+ *
+ * Weight images (made once per weight update):
+ *   pna_small_pack_f32       a Linear weight (N, K) for pna_small_linear_f32: proj_img = pack of [W_a ; W_b] (2*T*Fi, Fin)
+ *                            (block-diagonal in Fin when divide_input), mix_img = pack of the mixing weight (No, T*Fo)
+ *   pna_tower_post_pack_f32  ONE tower's posttrans weight (Fo, Fi + n_scaler*4*Fi) in the reference's column order
+ *                            [h | scaler 0: mean max min std | scaler 1 ...] (:65); post_img = the T images one after the other,
+ *                            each pna_tower_post_packed_floats(Fi, Fo, n_scaler) floats
+ * pna_small_linear_f32 is launch 1 on its own: y = residual + act(x W^T + bias) for row counts where a library GEMM is
+ * launch-bound; any M, K <= 2500.
+ */
+int64_t pna_small_packed_floats(int32_t N, int32_t K);
+int pna_small_pack_f32(const float* w_ref, int64_t ldw_ref, int32_t N, int32_t K, float* img, pna_stream_t stream);
+
+typedef struct pna_small_linear_args {
+  const float* x;        /* (M, ldx), K columns used */
+  int64_t ldx;
+  int32_t M;
+  int32_t K;
+  int32_t N;
+  int32_t act;           /* 0 = none, 1 = ReLU, 2 = LeakyReLU(act_slope) */
+  const float* img;      /* pna_small_pack_f32 image of the (N, K) weight */
+  const float* bias;     /* nullable [N] */
+  float act_slope;
+  int32_t _pad;
+  const float* residual; /* nullable (M, ld_res): added after the activation */
+  int64_t ld_res;
+  float* y;              /* (M, ldy) */
+  int64_t ldy;
+} pna_small_linear_args;
+
+int pna_small_linear_f32(const pna_small_linear_args* args, pna_stream_t stream);
+
+int64_t pna_tower_post_packed_floats(int32_t Fi, int32_t Fo, int32_t n_scaler);
+int pna_tower_post_pack_f32(const float* w_ref, int64_t ldw_ref, int32_t Fi, int32_t Fo, int32_t n_scaler, float* img,
+                            pna_stream_t stream);
+
+typedef struct pna_tower_layer_args {
+  const int32_t* rowptr;  /* [V+1] CSR by destination */
+  const int32_t* col;     /* [E] source node per CSR edge */
+  int32_t V;
+  int32_t n_tower;        /* T */
+  int32_t Fi;             /* per-tower input width (= pretrans output width) */
+  int32_t Fo;             /* per-tower output width */
+  int32_t divide_input;   /* 0: every tower reads all of h (ldh >= Fi); 1: tower t reads columns [t*Fi, (t+1)*Fi) (ldh >= T*Fi) */
+  int32_t n_scaler;       /* 1..3 */
+  const float* h;         /* (V, ldh) node features */
+  int64_t ldh;
+  float* x_cat;           /* (V, ldx) workspace, 2*T*Fi columns: written by launch 1, read by launch 2 */
+  int64_t ldx;
+  const float* proj_img;  /* pna_small_pack_f32 image of [W_a ; W_b] (2*T*Fi, Fin) */
+  const float* proj_bias; /* [2*T*Fi] = [0 ; b], nullable */
+  const float* row_scale[PNA_MAX_SCALER]; /* each [V] or NULL = identity */
+  const float* post_img;  /* T pna_tower_post_pack_f32 images */
+  const float* post_bias; /* nullable [T*Fo] */
+  const float* row_post;  /* nullable [V]: graph-norm factor */
+  const float* col_scale; /* nullable [T*Fo]: eval BatchNorm scale of every tower, concatenated */
+  const float* col_shift; /* nullable [T*Fo] (with col_scale) */
+  const float* mix_img;   /* nullable: pna_small_pack_f32 image of the mixing weight (No, T*Fo) */
+  const float* mix_bias;  /* nullable [No] */
+  int32_t No;             /* mixing output width (ignored without mix_img: the output is T*Fo wide) */
+  int32_t mix_act;        /* 0 = none, 1 = ReLU, 2 = LeakyReLU(mix_slope) */
+  float mix_slope;
+  int32_t _pad;
+  const float* residual;  /* nullable (V, ld_res): added after the mixing activation */
+  int64_t ld_res;
+  float* y;               /* (V, ldy) */
+  int64_t ldy;
+} pna_tower_layer_args;
+
+int pna_tower_layer_f32(const pna_tower_layer_args* args, pna_stream_t stream);
 
 /* ---- batching + destination-sorted CSR on the device ----------------------------------
  *

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to the HI
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpna_amd.so")
 
-PNA_ABI_VERSION = 6
+PNA_ABI_VERSION = 7
 PNA_MAX_AGGR = 8
 PNA_MAX_SCALER = 8
 
@@ -99,6 +99,30 @@ class PnaFusedSimpleArgs(ctypes.Structure):
     ]
 
 
+class PnaSmallLinearArgs(ctypes.Structure):
+    _fields_ = [
+        ("x", ctypes.c_void_p), ("ldx", ctypes.c_int64), ("M", ctypes.c_int32), ("K", ctypes.c_int32), ("N", ctypes.c_int32),
+        ("act", ctypes.c_int32), ("img", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("act_slope", ctypes.c_float),
+        ("_pad", ctypes.c_int32), ("residual", ctypes.c_void_p), ("ld_res", ctypes.c_int64), ("y", ctypes.c_void_p),
+        ("ldy", ctypes.c_int64),
+    ]
+
+
+class PnaTowerLayerArgs(ctypes.Structure):
+    _fields_ = [
+        ("rowptr", ctypes.c_void_p), ("col", ctypes.c_void_p), ("V", ctypes.c_int32), ("n_tower", ctypes.c_int32),
+        ("Fi", ctypes.c_int32), ("Fo", ctypes.c_int32), ("divide_input", ctypes.c_int32), ("n_scaler", ctypes.c_int32),
+        ("h", ctypes.c_void_p), ("ldh", ctypes.c_int64), ("x_cat", ctypes.c_void_p), ("ldx", ctypes.c_int64),
+        ("proj_img", ctypes.c_void_p), ("proj_bias", ctypes.c_void_p),
+        ("row_scale", ctypes.c_void_p * PNA_MAX_SCALER),
+        ("post_img", ctypes.c_void_p), ("post_bias", ctypes.c_void_p), ("row_post", ctypes.c_void_p),
+        ("col_scale", ctypes.c_void_p), ("col_shift", ctypes.c_void_p),
+        ("mix_img", ctypes.c_void_p), ("mix_bias", ctypes.c_void_p), ("No", ctypes.c_int32), ("mix_act", ctypes.c_int32),
+        ("mix_slope", ctypes.c_float), ("_pad", ctypes.c_int32),
+        ("residual", ctypes.c_void_p), ("ld_res", ctypes.c_int64), ("y", ctypes.c_void_p), ("ldy", ctypes.c_int64),
+    ]
+
+
 _lib = None
 
 
@@ -154,6 +178,19 @@ def lib():
         L.pna_posttrans_pack_f32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                              ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.pna_posttrans_pack_f32.restype = ctypes.c_int
+        L.pna_small_packed_floats.argtypes = [ctypes.c_int32, ctypes.c_int32]
+        L.pna_small_packed_floats.restype = ctypes.c_int64
+        L.pna_small_pack_f32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+        L.pna_small_pack_f32.restype = ctypes.c_int
+        L.pna_small_linear_f32.argtypes = [ctypes.POINTER(PnaSmallLinearArgs), ctypes.c_void_p]
+        L.pna_small_linear_f32.restype = ctypes.c_int
+        L.pna_tower_post_packed_floats.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+        L.pna_tower_post_packed_floats.restype = ctypes.c_int64
+        L.pna_tower_post_pack_f32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                              ctypes.c_void_p, ctypes.c_void_p]
+        L.pna_tower_post_pack_f32.restype = ctypes.c_int
+        L.pna_tower_layer_f32.argtypes = [ctypes.POINTER(PnaTowerLayerArgs), ctypes.c_void_p]
+        L.pna_tower_layer_f32.restype = ctypes.c_int
         if L.pna_abi_version() != PNA_ABI_VERSION:
             raise RuntimeError(f"libpna_amd.so ABI {L.pna_abi_version()} != binding {PNA_ABI_VERSION}: rebuild")
         _lib = L

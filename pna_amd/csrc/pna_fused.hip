@@ -26,6 +26,7 @@
 
 #include "pna_amd.h"
 #include "pna_internal.h"
+#include "pna_rowstats.h"
 
 namespace {
 
@@ -49,8 +50,8 @@ struct UArgs {
   int V, F, N, heavy_threshold, relu, a_floats;
 };
 
-__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+using pna_dev::vmax;
+using pna_dev::vmin;
 
 struct Acc4 {
   f4 s, q, mx, mn;

@@ -42,11 +42,12 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(4))) f4u { f4 v; };
 
 constexpr int kKC = 32;                       // k values per chunk
-constexpr int kMaxNT = 5;
 constexpr int kDefaultNBuf = 3;              // weight buffers of the default pipeline (pna_posttrans_args.pipeline = 0)
-constexpr int kNW = kMaxNT * 16;              // 80 output columns per workgroup
-constexpr int kPanelB = 4 * kNW * 8 * 2;      // bytes of one (term, panel) image: [4 lane groups][80][8] bf16 = 5120
-constexpr int kPanelV = kPanelB / 16;         // ... in 16-byte pieces = 320 = 5 wavefronts' worth
+// Output columns per workgroup (template parameter NW): 80 (5 column tiles: N <= 80, or N > 128 in 80-column blocks) or 128
+// (8 tiles: 80 < N <= 128, e.g. BASELINE configs[4]'s F = 128 -- as two 80-column blocks it computed 10 tiles for 8 and read the
+// aggregate twice).  The packed image and everything below is laid out per NW.
+__host__ __device__ constexpr int nw_of(int N) { return (N > 80 && N <= 128) ? 128 : 80; }
+__host__ __device__ constexpr int panel_bytes(int NW) { return 4 * NW * 8 * 2; }   // one (term, panel) image: [4 lane groups][NW][8] bf16
 
 struct XArgs {
   const float* a; const void* w_img; const float* h; const void* wh_img; const float* bias;
@@ -117,6 +118,7 @@ __device__ __forceinline__ float absmax8(const f4 lo, const f4 hi) {
 // wh_img[ny][c][term][g][n][e]    = term(w_ref[ny*80 + n][c*32 + kperm(g, e)])              (0 outside Kh / N)
 // kperm(g, e) = 4g + e for e < 4, 16 + 4g + (e - 4) otherwise: element e of lane group g.  A and B agree on it, and it
 // makes each of the two A loads of a chunk read 64 contiguous bytes per row (lane groups 0..3 x 16 B).
+template <int kNW>
 __global__ void k_pack_x3(const float* w_ref, long ldw, int N, int K, int S, int Kh, unsigned short* w_img, unsigned short* wh_img) {
   const int nca = (K + kKC - 1) / kKC, nch = (Kh + kKC - 1) / kKC, nty = (N + kNW - 1) / kNW;
   const long per = 4L * kNW * 8;
@@ -148,8 +150,9 @@ __global__ void k_pack_x3(const float* w_ref, long ldw, int N, int K, int S, int
 // GEN: the generic epilogue (any M; rows and columns predicated per element) -- used only for the < 16 rows a matrix has
 // beyond a multiple of 16; otherwise the straight-line one, with wavefront tiles entirely past M skipped.  (Both in one
 // kernel made the compiler drain vmcnt at the top of every chunk: its scoreboard merges the two paths conservatively.)
-template <int S, bool HAS_H, int NT, int RT, int WAVES, int NBUF, bool GEN>
+template <int S, bool HAS_H, int kNW, int NT, int RT, int WAVES, int NBUF, bool GEN>
 __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
+  constexpr int kPanelB = panel_bytes(kNW), kPanelV = kPanelB / 16;
   constexpr int kThreads = WAVES * 64;
   constexpr int kChunkV = 3 * S * kPanelV;     // 16-byte pieces of an aggregate chunk image (the h chunk is 3 * kPanelV)
   constexpr int kTileRows = WAVES * 16 * RT;   // rows per workgroup tile
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
           const int p = gi / NT, n = gi % NT;
   #pragma unroll
           for (int tm = 0; tm < 3; ++tm)
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(B[slot][tm]) : "v"(ba), "n"((((tm * NPN + p) * 4) * kNW + n * 16) * 16));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(B[slot][tm]) : "v"(ba + (unsigned)(tm * NPN * 4 * kNW * 16)), "n"(((p * 4) * kNW + n * 16) * 16));
         };
         load_b(ba0, 0, 0);
         constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
@@ -567,7 +570,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
           const int p = gi / NT, n = gi % NT;
 #pragma unroll
           for (int tm = 0; tm < 3; ++tm)
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(B[slot][tm]) : "v"(ba), "n"((((tm * NPN + p) * 4) * kNW + n * 16) * 16));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(B[slot][tm]) : "v"(ba + (unsigned)(tm * NPN * 4 * kNW * 16)), "n"(((p * 4) * kNW + n * 16) * 16));
         };
         load_b(ba0, 0, 0);
         constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
@@ -652,18 +655,18 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
   }
 }
 
-template <int S, bool HAS_H, int NT, int RT, int WAVES, int NBUF, bool GEN>
+template <int S, bool HAS_H, int kNW, int NT, int RT, int WAVES, int NBUF, bool GEN>
 int launch_v(const XArgs& g, hipStream_t st) {
-  const size_t lds = (size_t)NBUF * 3 * S * kPanelB + (size_t)(3 * kNW) * sizeof(float);
-  if (hipFuncSetAttribute((const void*)k_posttrans_x3<S, HAS_H, NT, RT, WAVES, NBUF, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  const size_t lds = (size_t)NBUF * 3 * S * panel_bytes(kNW) + (size_t)(3 * kNW) * sizeof(float);
+  if (hipFuncSetAttribute((const void*)k_posttrans_x3<S, HAS_H, kNW, NT, RT, WAVES, NBUF, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return -1;
   const int ntiles = (g.M + WAVES * 16 * RT - 1) / (WAVES * 16 * RT);
   const dim3 grid((unsigned)(ntiles < g.grid_x ? ntiles : g.grid_x), (unsigned)((g.N + kNW - 1) / kNW));
-  hipLaunchKernelGGL((k_posttrans_x3<S, HAS_H, NT, RT, WAVES, NBUF, GEN>), grid, dim3(WAVES * 64), lds, st, g);
+  hipLaunchKernelGGL((k_posttrans_x3<S, HAS_H, kNW, NT, RT, WAVES, NBUF, GEN>), grid, dim3(WAVES * 64), lds, st, g);
   return 0;
 }
 
-template <int S, bool HAS_H, int NT, int RT, int WAVES>
+template <int S, bool HAS_H, int kNW, int NT, int RT, int WAVES>
 int launch_split(const XArgs& g, int nbuf, hipStream_t st) {
   // rows [0, Mf): wavefront tiles of 16 * RT whole rows, the straight-line epilogue; the rows beyond: a second launch with the
   // generic one
@@ -671,7 +674,9 @@ int launch_split(const XArgs& g, int nbuf, hipStream_t st) {
   if (Mf > 0) {
     XArgs m = g;
     m.M = Mf;
-    const int rc = nbuf == 3 ? launch_v<S, HAS_H, NT, RT, WAVES, 3, false>(m, st) : launch_v<S, HAS_H, NT, RT, WAVES, 2, false>(m, st);
+    int rc;
+    if constexpr (kNW == 80) rc = nbuf == 3 ? launch_v<S, HAS_H, kNW, NT, RT, WAVES, 3, false>(m, st) : launch_v<S, HAS_H, kNW, NT, RT, WAVES, 2, false>(m, st);
+    else rc = launch_v<S, HAS_H, kNW, NT, RT, WAVES, 2, false>(m, st);      // 128 columns: three 74 KB buffers do not fit the LDS
     if (rc != 0) return rc;
   }
   if (g.M > Mf) {
@@ -684,25 +689,26 @@ int launch_split(const XArgs& g, int nbuf, hipStream_t st) {
     if (g.residual) r.residual = g.residual + (size_t)Mf * g.ld_res;
     r.y = g.y + (size_t)Mf * g.ldy;
     constexpr int WT = (S + (HAS_H ? 1 : 0)) * NT > 15 ? 8 : 12;
-    return launch_v<S, HAS_H, NT, 1, WT, 2, true>(r, st);
+    return launch_v<S, HAS_H, kNW, NT, 1, WT, 2, true>(r, st);
   }
   return 0;
 }
 
-template <int S, bool HAS_H, int NT>
+template <int S, bool HAS_H, int kNW, int NT>
 int launch_k(const XArgs& g, int nbuf, int shape, hipStream_t st) {
   // One row tile per wavefront, 12 wavefronts (3 per SIMD, <= 168 registers each) while the P * NT accumulator tiles fit
   // that budget, else 8 (256 registers).  
   constexpr int WAVES = (S + (HAS_H ? 1 : 0)) * NT > 15 ? 8 : 12;
   (void)shape;   // 8 wavefronts x 2 row tiles was measured in round 1 (slower) and spills with the 3-buffer pipeline: not built
-  return launch_split<S, HAS_H, NT, 1, WAVES>(g, nbuf, st);
+  return launch_split<S, HAS_H, kNW, NT, 1, WAVES>(g, nbuf, st);
 }
 
 template <int S, bool HAS_H>
 int launch_nt(const XArgs& g, int nt, int nbuf, int shape, hipStream_t st) {
-  if (nt <= 1) return launch_k<S, HAS_H, 1>(g, nbuf, shape, st);
-  if (nt <= 3) return launch_k<S, HAS_H, 3>(g, nbuf, shape, st);
-  return launch_k<S, HAS_H, 5>(g, nbuf, shape, st);
+  if (nw_of(g.N) == 128) return launch_k<S, HAS_H, 128, 8>(g, nbuf, shape, st);      // 80 < N <= 128: one 8-tile block
+  if (nt <= 1) return launch_k<S, HAS_H, 80, 1>(g, nbuf, shape, st);
+  if (nt <= 3) return launch_k<S, HAS_H, 80, 3>(g, nbuf, shape, st);
+  return launch_k<S, HAS_H, 80, 5>(g, nbuf, shape, st);
 }
 
 template <int S>
@@ -713,9 +719,10 @@ int launch_s(const XArgs& g, bool has_h, int nt, int nbuf, int shape, hipStream_
 }  // namespace
 
 extern "C" int64_t pna_posttrans_x3_packed_bytes(int32_t K, int32_t N, int32_t n_scaler, int32_t Kh, int64_t* wh_bytes) {
+  const int kNW = nw_of(N);
   const int64_t nca = (K + kKC - 1) / kKC, nch = (Kh + kKC - 1) / kKC, nty = (N + kNW - 1) / kNW;
-  if (wh_bytes) *wh_bytes = nty * nch * 3 * kPanelB;
-  return nty * nca * 3 * n_scaler * kPanelB;
+  if (wh_bytes) *wh_bytes = nty * nch * 3 * panel_bytes(kNW);
+  return nty * nca * 3 * n_scaler * panel_bytes(kNW);
 }
 
 extern "C" int pna_posttrans_x3_pack_f32(const float* w_ref, int64_t ldw, int32_t N, int32_t K, int32_t n_scaler, int32_t Kh,
@@ -727,8 +734,12 @@ extern "C" int pna_posttrans_x3_pack_f32(const float* w_ref, int64_t ldw, int32_
   const int64_t nw = pna_posttrans_x3_packed_bytes(K, N, n_scaler, Kh, &nh);
   const int64_t elems = (nw + nh) / 2;
   const int blocks = (int)((elems + 255) / 256 > 4096 ? 4096 : (elems + 255) / 256);
-  hipLaunchKernelGGL(k_pack_x3, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ref, (long)ldw, N, K, n_scaler, Kh,
-                     (unsigned short*)w_img, (unsigned short*)wh_img);
+  if (nw_of(N) == 128)
+    hipLaunchKernelGGL(k_pack_x3<128>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ref, (long)ldw, N, K, n_scaler, Kh,
+                       (unsigned short*)w_img, (unsigned short*)wh_img);
+  else
+    hipLaunchKernelGGL(k_pack_x3<80>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ref, (long)ldw, N, K, n_scaler, Kh,
+                       (unsigned short*)w_img, (unsigned short*)wh_img);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
   return PNA_OK;
@@ -766,11 +777,12 @@ extern "C" int pna_posttrans_x3_f32(const pna_posttrans_args* p, pna_stream_t st
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
       return pna_set_error(PNA_E_NODEVICE, "pna_posttrans_x3_f32: cannot query the device");
+    const int kNW = nw_of(p->N);
     const int ny = (p->N + kNW - 1) / kNW;
     g.grid_x = (cus + ny - 1) / ny;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int nt = p->N >= kNW ? kMaxNT : (p->N + 15) / 16;
+  const int nt = p->N >= 80 ? 5 : (p->N + 15) / 16;      // (80-column blocks; launch_nt switches to one 128-column block itself)
   int rc;
   const int pl = p->pipeline, shape = 0;
   if (pl != 0 && pl != 2 && pl != 3)

@@ -27,6 +27,7 @@
 
 #include "pna_amd.h"
 #include "pna_internal.h"
+#include "pna_rowstats.h"
 
 namespace {
 
@@ -101,31 +102,9 @@ template <int VEC, bool EXTRA> struct Acc {
   }
 };
 
-// a / b, correctly rounded, from the correctly rounded reciprocal r = RN(1 / b) (ONE IEEE division per row): Markstein's
-// sequence q0 = RN(a r), e = RN(a - b q0) (exact in an fma), q = RN(q0 + e r) equals RN(a / b) for every b whose significand
-// is not all ones (an in-degree of 2^24 - 1 does not occur: rows < 2^24).  This is the reference's `sum / D`
-// (models/dgl/aggregators.py:6-7,:22-26) bit for bit at a third of the cost of a per-feature division.  It matters beyond
-// the last ulp: with equal neighbours the reference's var = E[x^2] - E[x]^2 is EXACTLY 0 (std = sqrt(1e-5)), and a mean
-// that is 1 ulp off turns that into ~1e-7 x^2 -- 5 % of the std for |x| ~ 3 (seen on the multitask GNN's later iterations).
-// Non-finite or zero b falls through to the plain product (the result is then NaN / Inf either way).
-__device__ __forceinline__ float div_rn(float a, float b, float r) {
-  const float q0 = a * r;
-  const float e = __builtin_fmaf(-b, q0, a);
-  const float q = __builtin_fmaf(e, r, q0);
-  return (q == q && __builtin_fabsf(q) != INFINITY) ? q : q0;
-}
-
-// Single-instruction max/min (no canonicalisation prologue; a quiet-NaN operand is ignored).
-__device__ __forceinline__ float vmax(float a, float b) {
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ float vmin(float a, float b) {
-  float r;
-  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
+using pna_dev::div_rn;   // (pna_rowstats.h: the correctly rounded s / D, single-instruction max / min)
+using pna_dev::vmax;
+using pna_dev::vmin;
 
 // One message m (already gathered) of CSR edge position e folded into the accumulators.
 template <int VEC, bool EXTRA>

@@ -252,8 +252,44 @@ class PNALayer(nn.Module):
                      edge_dim=edge_dim) for _ in range(towers))
         self.mixing_network = FCLayer(out_dim, out_dim, activation="LeakyReLU")
 
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop("_pna_amd_small", None)             # cached weight images follow the parameters' device / dtype
+        return super()._apply(fn, *args, **kwargs)
+
+    def _small_structure_ok(self):
+        """The structural conditions of the one-call path (they do not change after construction): 1-layer pretrans and
+        posttrans, no edge features, the four standard aggregators, <= 3 scalers, a mixing network without batch-norm."""
+        towers = list(self.towers)
+        t0, mix = towers[0], self.mixing_network
+        return (not self.edge_features and tuple(t0.aggregators) == ("mean", "max", "min", "std") and len(t0.scalers) <= 3
+                and all(len(t.pretrans.fully_connected) == 1 and len(t.posttrans.fully_connected) == 1
+                        and t.pretrans.fully_connected[0].activation is None and t.posttrans.fully_connected[0].activation is None
+                        and t.pretrans.fully_connected[0].b_norm is None and t.posttrans.fully_connected[0].b_norm is None
+                        and t.graph_norm == t0.graph_norm and t.batch_norm == t0.batch_norm for t in towers)
+                and mix.b_norm is None and (mix.activation is None or isinstance(mix.activation, (nn.LeakyReLU, nn.ReLU)))
+                and PF.small_tower_fits(len(towers), t0.in_dim, t0.out_dim, self.divide_input))
+
+    def _small_batch_path(self, graph, h):
+        """Whether this call is served by pna_tower_layer_f32 (one C call for the whole layer): inference on a whole
+        (unsharded) graph of molecule-batch size, with the structure _small_structure_ok() describes."""
+        if self.training or not h.is_cuda or h.dtype != torch.float32 or type(graph) is not Graph:
+            return False
+        ok = self.__dict__.get("_pna_amd_small_ok")
+        if ok is None:
+            ok = self.__dict__["_pna_amd_small_ok"] = self._small_structure_ok()
+        if not ok or not 0 < h.shape[0] <= PF.SMALL_TOWER_ROWS * (8 if self.in_dim <= 128 and self.divide_input else 1):
+            return False
+        if any(t.training for t in self._modules["towers"]._modules.values()):
+            return False
+        return not (torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in self.parameters())))
+
     def forward(self, g, h, e, snorm_n):
-        h_cat = _towers_forward(list(self.towers), as_graph(g), h, e, snorm_n, self.divide_input)
+        graph = as_graph(g)
+        if self._small_batch_path(graph, h):
+            t0 = self.towers[0]
+            return PF.tower_layer_small(self, list(self.towers), self.mixing_network, graph, h, snorm_n,
+                                        _row_scales(graph, t0.scalers, t0.avg_d, h.device), self.divide_input, self.residual)
+        h_cat = _towers_forward(list(self.towers), graph, h, e, snorm_n, self.divide_input)
         mix = self.mixing_network
         if (h_cat.shape[1] >= 4 and isinstance(mix.activation, nn.LeakyReLU) and mix.b_norm is None and (mix.dropout is None or not self.training)
                 and not (torch.is_grad_enabled() and (h_cat.requires_grad or any(p.requires_grad for p in mix.parameters())))):

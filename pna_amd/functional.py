@@ -1,6 +1,8 @@
 """Graph-level functional API used by the layers: `aggregate` (gather + segment-reduce kernel) and
 `posttrans` (MFMA contraction), both differentiable through custom autograd Functions.
 """
+import os
+
 import torch
 
 from . import ops
@@ -157,3 +159,129 @@ def linear_act(x, weight, bias, leaky_slope=None, relu=False, residual=None, out
     w = weight if weight.stride(-1) == 1 else weight.contiguous()
     return ops.posttrans(_unit_stride(x), x.shape[1], w, [None], bias, out=out, relu=relu, leaky_slope=leaky_slope,
                          residual=_unit_stride(residual))
+
+
+# ---- molecule-sized batches: the whole tower layer as one C call (pna_tower_layer_f32) --------------------------------------
+SMALL_TOWER_ROWS = int(os.environ.get("PNA_AMD_SMALL_TOWER_ROWS", "32768"))   # batches up to this many nodes take that path
+
+
+def small_tower_fits(T, Fi, Fo, divided, No=None):
+    """Mirror of pna_tower_layer_f32's LDS check for a single tower per pass (the smallest tile it can run with)."""
+    quads = lambda k: (k + 15) // 16   # noqa: E731
+    No = T * Fo if No is None else No
+    floats = 16 * (quads(4 * Fi) * 16 + 4) + (T if divided else 1) * 16 * (quads(Fi) * 16 + 4) + 16 * (quads(T * Fo) * 16 + 4) + \
+        16 * 256 + 3 * quads(T * Fo) * 16 + quads(No) * 16 + 64
+    return floats * 4 <= 160 * 1024
+
+
+class _SmallTowerPlan:
+    """Everything pna_tower_layer_f32 reads besides the graph and h -- the packed projection / posttrans / mixing images, the
+    concatenated biases and folded BatchNorm constants -- and a pre-filled argument block, built once per weight state.  The
+    host side of this path is on the critical path (the two launches take ~50 us for a 128-molecule batch), so a call only
+    compares the parameters' version counters and fills in the per-call pointers."""
+
+    def __init__(self, towers, mix, divide_input):
+        import ctypes
+        from . import _lib
+        t0 = towers[0]
+        pre = [t.pretrans.fully_connected[0].linear for t in towers]
+        post = [t.posttrans.fully_connected[0].linear for t in towers]
+        ts = [p for l in pre + post for p in (l.weight, l.bias) if p is not None]
+        if t0.batch_norm:
+            for t in towers:
+                bn = t.batchnorm_h
+                if bn.training:
+                    raise RuntimeError("only an eval-mode BatchNorm (running statistics) can be folded into the epilogue")
+                ts += [x for x in (bn.weight, bn.bias, bn.running_mean, bn.running_var) if x is not None]
+        if mix is not None:
+            ts += [p for p in (mix.linear.weight, mix.linear.bias) if p is not None]
+        self.ts = ts
+        self.versions = [x._version for x in ts]
+        T, Fi, Fo, S = len(towers), t0.in_dim, t0.out_dim, len(t0.scalers)
+        self.T, self.Fi, self.Fo, self.S, self.divide_input = T, Fi, Fo, S, divide_input
+        with torch.no_grad():
+            Wa = [l.weight[:, :Fi] for l in pre]
+            Wb = [l.weight[:, Fi:2 * Fi] for l in pre]
+            if divide_input:
+                Wcat = torch.cat([torch.block_diag(*Wa), torch.block_diag(*Wb)], dim=0)
+            else:
+                Wcat = torch.cat(Wa + Wb, dim=0)
+            b = torch.cat([l.bias if l.bias is not None else torch.zeros(Fi, device=Wcat.device) for l in pre])
+            keep = dict(proj_img=ops.pack_small(Wcat.contiguous()), proj_bias=torch.cat([torch.zeros_like(b), b]).contiguous(),
+                        post_img=ops.pack_tower_post([l.weight for l in post], Fi, Fo, S),
+                        post_bias=torch.cat([l.bias for l in post]).contiguous() if post[0].bias is not None else None)
+            if t0.batch_norm:
+                folds = [_fold_batchnorm(t.batchnorm_h) for t in towers]
+                keep["col_scale"] = torch.cat([f[0] for f in folds]).contiguous()
+                keep["col_shift"] = torch.cat([f[1] for f in folds]).contiguous()
+            if mix is not None:
+                keep["mix_img"] = ops.pack_small(mix.linear.weight)
+                keep["mix_bias"] = mix.linear.bias.detach().contiguous() if mix.linear.bias is not None else None
+        self.keep = keep                                       # the device buffers the argument block points into
+        self.device = Wcat.device
+        self.width = mix.linear.weight.shape[0] if mix is not None else T * Fo
+        self.xw = 2 * T * Fi
+        self.graph_norm = bool(t0.graph_norm)
+        a = _lib.PnaTowerLayerArgs()
+        a.n_tower, a.Fi, a.Fo, a.divide_input, a.n_scaler = T, Fi, Fo, 1 if divide_input else 0, S
+        for k, v in keep.items():
+            if v is not None:
+                setattr(a, k, _lib.dev_ptr(v, torch.float32, k))
+        if mix is not None:
+            a.No = self.width
+            if isinstance(mix.activation, torch.nn.LeakyReLU):
+                a.mix_act, a.mix_slope = 2, float(mix.activation.negative_slope)
+            elif mix.activation is not None:
+                a.mix_act = 1
+        self.args, self.ref = a, ctypes.byref(a)
+        self.fn = _lib.lib().pna_tower_layer_f32
+        self.check, self.stream_ptr = _lib.check, _lib.stream_ptr
+
+    def stale(self):
+        return [x._version for x in self.ts] != self.versions
+
+    def run(self, graph, h, snorm_n, row_scales, residual):
+        if h.stride(-1) != 1:
+            h = h.contiguous()
+        dev = h.device
+        if dev != self.device:
+            raise RuntimeError(f"layer parameters live on {self.device}, features on {dev}")
+        V = h.shape[0]
+        csr = graph.csr
+        out = torch.empty((V, self.width), dtype=torch.float32, device=dev)
+        xc = torch.empty((V, self.xw), dtype=torch.float32, device=dev)
+        a = self.args
+        a.rowptr, a.col, a.V = csr.rowptr.data_ptr(), csr.col.data_ptr(), V
+        a.h, a.ldh = h.data_ptr(), h.stride(0)
+        a.x_cat, a.ldx = xc.data_ptr(), self.xw
+        for i in range(self.S):
+            rs = row_scales[i]
+            a.row_scale[i] = None if rs is None else rs.data_ptr()
+        if self.graph_norm and snorm_n is not None:
+            if snorm_n.dtype != torch.float32 or snorm_n.numel() != V or snorm_n.device != dev or not snorm_n.is_contiguous():
+                snorm_n = snorm_n.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+                if snorm_n.numel() != V:
+                    raise ValueError("snorm_n must hold one factor per node")
+            a.row_post = snorm_n.data_ptr()
+        else:
+            a.row_post = None
+        if residual:
+            a.residual, a.ld_res = a.h, a.ldh
+        else:
+            a.residual = None
+        a.y, a.ldy = out.data_ptr(), self.width
+        rc = self.fn(self.ref, self.stream_ptr(dev))
+        if rc != 0:
+            self.check(rc, "pna_tower_layer_f32")
+        del snorm_n, xc                                      # (stream-ordered allocator: safe to release after the launch)
+        return out
+
+
+def tower_layer_small(owner, towers, mix, graph, h, snorm_n, row_scales, divide_input, residual):
+    """models/dgl/pna_layer.py:133-148 in eval mode through pna_tower_layer_f32.  `mix`: the mixing FCLayer (Linear + LeakyReLU /
+    ReLU / none, no batch-norm) or None.  The plan is cached on `owner` (dropped by PNALayer._apply on device / dtype moves)."""
+    plan = owner.__dict__.get("_pna_amd_small")
+    if plan is None or plan.divide_input != divide_input or plan.stale():
+        plan = _SmallTowerPlan(towers, mix, divide_input)
+        owner.__dict__["_pna_amd_small"] = plan
+    return plan.run(graph, h, snorm_n, row_scales, residual)

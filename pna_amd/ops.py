@@ -334,3 +334,91 @@ def posttrans_towers(agg: torch.Tensor, K: int, weights: Sequence[torch.Tensor],
     rc = getattr(_lib.lib(), fn)(ctypes.byref(g), _lib.stream_ptr(agg.device))
     _lib.check(rc, fn)
     return out
+
+
+# ---- the molecule-batch tower layer (pna_tower_fused.hip): one C call, two launches -----------------------------------------
+def pack_small(weight: torch.Tensor) -> torch.Tensor:
+    """MFMA-fragment image of an nn.Linear weight (N, K) for small_linear / tower_layer (pna_small_pack_f32).  Not cached here:
+    callers cache the bundle of images a layer needs (functional.tower_layer_bundle)."""
+    w = weight.detach()
+    w = w if w.stride(-1) == 1 else w.contiguous()
+    N, K = w.shape
+    L = _lib.lib()
+    img = torch.empty(L.pna_small_packed_floats(N, K), dtype=torch.float32, device=w.device)
+    rc = L.pna_small_pack_f32(_lib.dev_ptr(w, torch.float32, "weight"), _ld(w), N, K, _lib.dev_ptr(img, torch.float32, "img"),
+                              _lib.stream_ptr(w.device))
+    _lib.check(rc, "pna_small_pack_f32")
+    return img
+
+
+def pack_tower_post(weights: Sequence[torch.Tensor], Fi: int, Fo: int, n_scaler: int) -> torch.Tensor:
+    """The T posttrans weights (Fo, Fi + n_scaler*4*Fi) of a layer's towers as one buffer of pna_tower_post_pack_f32 images."""
+    L = _lib.lib()
+    per = L.pna_tower_post_packed_floats(Fi, Fo, n_scaler)
+    dev = weights[0].device
+    img = torch.empty(per * len(weights), dtype=torch.float32, device=dev)
+    for t, w in enumerate(weights):
+        w = w.detach()
+        w = w if w.stride(-1) == 1 else w.contiguous()
+        if tuple(w.shape) != (Fo, Fi * (1 + 4 * n_scaler)):
+            raise ValueError(f"posttrans weight of tower {t} is {tuple(w.shape)}, expected {(Fo, Fi * (1 + 4 * n_scaler))}")
+        rc = L.pna_tower_post_pack_f32(_lib.dev_ptr(w, torch.float32, "weight"), _ld(w), Fi, Fo, n_scaler,
+                                       ctypes.c_void_p(img.data_ptr() + 4 * per * t), _lib.stream_ptr(dev))
+        _lib.check(rc, "pna_tower_post_pack_f32")
+    return img
+
+
+def small_linear(x: torch.Tensor, img: torch.Tensor, N: int, bias: Optional[torch.Tensor] = None, *, act: int = 0, slope: float = 0.0,
+                 residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = residual + act(x W^T + bias) with W given as its pack_small image (pna_small_linear_f32): one workgroup per 16 rows."""
+    M, K = x.shape
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    g = _lib.PnaSmallLinearArgs()
+    g.x, g.ldx, g.M, g.K, g.N, g.act = _lib.dev_ptr(x, torch.float32, "x"), _ld(x), M, K, N, act
+    g.img, g.bias, g.act_slope = _lib.dev_ptr(img, torch.float32, "img"), _lib.dev_ptr(bias, torch.float32, "bias"), slope
+    if residual is not None:
+        g.residual, g.ld_res = _lib.dev_ptr(residual, torch.float32, "residual"), _ld(residual)
+    g.y, g.ldy = _lib.dev_ptr(out, torch.float32, "y"), _ld(out)
+    rc = _lib.lib().pna_small_linear_f32(ctypes.byref(g), _lib.stream_ptr(x.device))
+    _lib.check(rc, "pna_small_linear_f32")
+    return out
+
+
+def tower_layer(rowptr: torch.Tensor, col: torch.Tensor, h: torch.Tensor, *, n_tower: int, Fi: int, Fo: int, divide_input: bool,
+                proj_img: torch.Tensor, proj_bias: Optional[torch.Tensor], row_scales: Sequence[Optional[torch.Tensor]],
+                post_img: torch.Tensor, post_bias: Optional[torch.Tensor], row_post: Optional[torch.Tensor] = None,
+                col_scale: Optional[torch.Tensor] = None, col_shift: Optional[torch.Tensor] = None,
+                mix_img: Optional[torch.Tensor] = None, mix_bias: Optional[torch.Tensor] = None, n_out: int = 0, mix_act: int = 0,
+                mix_slope: float = 0.0, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                x_cat: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """pna_tower_layer_f32 (include/pna_amd.h): projection launch + one launch for gather, tower contractions, graph-norm / eval
+    BatchNorm and the mixing network of models/dgl/pna_layer.py:133-148, per 16 destination rows."""
+    V = rowptr.numel() - 1
+    dev = h.device
+    width = n_out if mix_img is not None else n_tower * Fo
+    if out is None:
+        out = torch.empty(V, width, dtype=torch.float32, device=dev)
+    if x_cat is None:
+        x_cat = torch.empty(V, 2 * n_tower * Fi, dtype=torch.float32, device=dev)
+    g = _lib.PnaTowerLayerArgs()
+    g.rowptr, g.col, g.V = _lib.dev_ptr(rowptr, torch.int32, "rowptr"), _lib.dev_ptr(col, torch.int32, "col"), V
+    g.n_tower, g.Fi, g.Fo, g.divide_input, g.n_scaler = n_tower, Fi, Fo, 1 if divide_input else 0, len(row_scales)
+    g.h, g.ldh = _lib.dev_ptr(h, torch.float32, "h"), _ld(h)
+    g.x_cat, g.ldx = _lib.dev_ptr(x_cat, torch.float32, "x_cat"), _ld(x_cat)
+    g.proj_img, g.proj_bias = _lib.dev_ptr(proj_img, torch.float32, "proj_img"), _lib.dev_ptr(proj_bias, torch.float32, "proj_bias")
+    for i, rs in enumerate(row_scales):
+        if rs is not None:
+            g.row_scale[i] = _lib.dev_ptr(rs, torch.float32, "row_scale").value
+    g.post_img, g.post_bias = _lib.dev_ptr(post_img, torch.float32, "post_img"), _lib.dev_ptr(post_bias, torch.float32, "post_bias")
+    g.row_post = _lib.dev_ptr(row_post, torch.float32, "row_post")
+    g.col_scale, g.col_shift = _lib.dev_ptr(col_scale, torch.float32, "col_scale"), _lib.dev_ptr(col_shift, torch.float32, "col_shift")
+    if mix_img is not None:
+        g.mix_img, g.mix_bias = _lib.dev_ptr(mix_img, torch.float32, "mix_img"), _lib.dev_ptr(mix_bias, torch.float32, "mix_bias")
+        g.No, g.mix_act, g.mix_slope = n_out, mix_act, mix_slope
+    if residual is not None:
+        g.residual, g.ld_res = _lib.dev_ptr(residual, torch.float32, "residual"), _ld(residual)
+    g.y, g.ldy = _lib.dev_ptr(out, torch.float32, "y"), _ld(out)
+    rc = _lib.lib().pna_tower_layer_f32(ctypes.byref(g), _lib.stream_ptr(dev))
+    _lib.check(rc, "pna_tower_layer_f32")
+    return out

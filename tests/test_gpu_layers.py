@@ -45,8 +45,15 @@ def test_simple_layer_golden(cuda_device, name):
     torch.testing.assert_close(out, a["out"], **TOL)
 
 
+@pytest.mark.parametrize("path", ["small-batch", "large-graph"])
 @pytest.mark.parametrize("name", golden_names("dgl_tower"))
-def test_tower_layer_golden(cuda_device, name):
+def test_tower_layer_golden(cuda_device, monkeypatch, name, path):
+    """Both code paths of PNALayer.forward against the reference's own outputs: the one-call layer of molecule-sized batches
+    (pna_tower_layer_f32; fixtures it does not cover -- edge features, deeper MLPs -- fall through to the other) and the
+    large-graph kernels (forced by setting the row limit of the former to 0)."""
+    from pna_amd import functional as PF
+    if path == "large-graph":
+        monkeypatch.setattr(PF, "SMALL_TOWER_ROWS", 0)
     meta, a, sd = load_golden(name)
     layer = PNALayer(meta["in_dim"], meta["out_dim"], meta["aggregators"], meta["scalers"], {"log": a["avg_log"]}, 0.0,
                      meta["graph_norm"], meta["batch_norm"], towers=meta["towers"],

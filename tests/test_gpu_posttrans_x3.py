@@ -11,6 +11,7 @@ CASES = [  # M, K, N, S, Kh, input scale
     (1000, 300, 75, 3, 0, 1.0), (257, 300, 75, 3, 0, 1.0), (64, 32, 16, 1, 0, 1.0), (100, 12, 5, 2, 0, 1.0),
     (300, 280, 70, 3, 70, 1.0), (129, 33, 40, 2, 7, 1.0), (50, 4, 80, 3, 4, 1.0), (513, 900, 150, 1, 0, 1.0),
     (1000, 300, 75, 3, 0, 1e4), (777, 64, 48, 3, 16, 1e-3), (5000, 75, 75, 3, 75, 1.0), (1, 300, 75, 3, 0, 1.0),
+    (3000, 512, 128, 3, 0, 1.0), (1001, 512, 128, 3, 128, 1.0), (333, 100, 97, 2, 0, 1.0), (40000, 512, 128, 3, 0, 1.0),   # one 128-column block
 ]
 
 
@@ -82,6 +83,9 @@ def test_bf16x3_fused_tail_matches_f32_kernel():
     (777, 15, 15, True, True, False, False),     # tower layer: h block, one column tile
     (192, 75, 0, False, False, False, False),    # exactly one tile, nothing optional
     (5000, 40, 7, True, True, True, True),       # everything at once
+    (1000, 128, 0, False, True, True, True),     # the 128-column block (80 < N <= 128; BASELINE configs[4]'s F): whole + tail rows
+    (2005, 100, 100, True, True, True, True),    # ... partial last column tile, h block, everything
+    (640, 81, 0, False, False, False, False),    # ... its narrowest case
 ])
 def test_bf16x3_straight_line_epilogue_every_flag_combination(M, N, Kh, post, bn, relu, resid):
     """The straight-line epilogue (whole tiles) and the generic one (the matrix's last tile) against torch, elementwise,
@@ -124,7 +128,8 @@ def test_bf16x3_straight_line_epilogue_every_flag_combination(M, N, Kh, post, bn
 
 
 @pytest.mark.parametrize("K", [32, 64, 96, 160])
-@pytest.mark.parametrize("N,S,Kh", [(16, 3, 0), (16, 1, 0), (75, 3, 0), (15, 3, 15), (40, 2, 40), (75, 1, 75)])
+@pytest.mark.parametrize("N,S,Kh", [(16, 3, 0), (16, 1, 0), (75, 3, 0), (15, 3, 15), (40, 2, 40), (75, 1, 75), (128, 3, 0), (128, 1, 128),
+                                    (96, 2, 20)])
 def test_bf16x3_short_k_every_pipeline_repeated(K, N, S, Kh):
     """Few K chunks per tile (1 .. 5 plus the h chunks) and few MFMA groups per chunk: the A fragment of the next chunk is
     consumed a few hundred cycles after its load was issued, so any use of an asm-loaded register ahead of its wait (a

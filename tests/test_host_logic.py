@@ -119,6 +119,12 @@ def test_ctypes_struct_layout_matches_header_field_order():
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = [re.sub(r"\[.*\]", "", f.strip().split()[-1].lstrip("*")) for f in body.split(";") if f.strip()]
     assert fields == [n for n, _ in _lib.PnaFusedSimpleArgs._fields_]
+    for cname, mirror in (("pna_small_linear_args", _lib.PnaSmallLinearArgs), ("pna_tower_layer_args", _lib.PnaTowerLayerArgs),
+                          ("pna_segreduce_bwd_args", _lib.PnaSegreduceBwdArgs)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), text, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        fields = [re.sub(r"\[.*\]", "", f.strip().split()[-1].lstrip("*")) for f in body.split(";") if f.strip()]
+        assert fields == [n for n, _ in mirror._fields_], cname
 
 
 @pytest.mark.parametrize("name", golden_names("dgl_tower"))

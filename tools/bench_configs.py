@@ -76,7 +76,32 @@ with torch.no_grad():
     err = (gf(hd).cpu() - ref).abs().max().item()
     cpu = cpu_ms(lambda: O.dgl_layer_forward(sd, src, dst, V, h, None, snorm.cpu(), AGG.split(), SCA.split(), avg["log"], 5,
                                              False, True, True, True, False))
-out["zinc_tower_layer"] = dict(graphs=128, V=V, E=E, hidden=75, towers=5, eager_ms=eager, hipgraph_ms=graphed,
+
+
+def build_batch(srcs_l, dsts_l, sizes_l, avg_log):
+    """What a data loader's collate does per batch: local edge lists (host) -> batched Graph on the device with every index
+    structure the first layer needs (CSR, work list, degree scalers, graph-size norm)."""
+    gb = Graph.collate(srcs_l, dsts_l, sizes_l, device=dev)
+    gb.work_items()
+    gb.degree_scalers(avg_log)
+    gb.snorm_n()
+    return gb
+
+
+def split_members(src, dst, sizes):
+    """Per-graph local edge lists of a batched edge list (members are contiguous in node id and in edge order)."""
+    offs = torch.cumsum(torch.tensor([0] + list(sizes)), 0)
+    gid = torch.bucketize(dst, offs[1:], right=True)
+    cnt = torch.bincount(gid, minlength=len(sizes)).tolist()
+    ss, dd = torch.split(src - offs[gid], cnt), torch.split(dst - offs[gid], cnt)
+    return list(ss), list(dd)
+
+
+ss, dd = split_members(src, dst, sizes)
+t_build = gpu_ms(lambda: build_batch(ss, dd, sizes, float(avg["log"])), iters=20)
+with torch.no_grad():
+    t_build_first = gpu_ms(lambda: lay(build_batch(ss, dd, sizes, float(avg["log"])), hd, None, snorm), iters=20)
+out["zinc_tower_layer"] = dict(batch_build_ms=t_build, batch_build_plus_first_layer_ms=t_build_first, graphs=128, V=V, E=E, hidden=75, towers=5, eager_ms=eager, hipgraph_ms=graphed,
                                edges_per_s_hipgraph=E / graphed * 1e3, cpu_oracle_ms=cpu, max_abs_err_vs_oracle=err, max_rel_err_vs_oracle=err / ref.abs().max().item())
 
 # ---- configs[3]: MolHIV-shaped batch, PNASimpleLayer hidden 80, 2048 graphs ----
@@ -98,7 +123,11 @@ with torch.no_grad():
     ref = O.simple_layer_forward(sd, src, dst, V, h, AGG.split(), SCA.split(), avg["log"])
     err = (gf(hd).cpu() - ref).abs().max().item()
     cpu = cpu_ms(lambda: O.simple_layer_forward(sd, src, dst, V, h, AGG.split(), SCA.split(), avg["log"]))
-out["molhiv_simple_layer"] = dict(graphs=2048, V=V, E=E, hidden=80, eager_ms=eager, hipgraph_ms=graphed,
+ss, dd = split_members(src, dst, sizes)
+t_build = gpu_ms(lambda: build_batch(ss, dd, sizes, float(avg["log"])), iters=10)
+with torch.no_grad():
+    t_build_first = gpu_ms(lambda: lay(build_batch(ss, dd, sizes, float(avg["log"])), hd), iters=10)
+out["molhiv_simple_layer"] = dict(batch_build_ms=t_build, batch_build_plus_first_layer_ms=t_build_first, graphs=2048, V=V, E=E, hidden=80, eager_ms=eager, hipgraph_ms=graphed,
                                   edges_per_s_hipgraph=E / graphed * 1e3, cpu_oracle_ms=cpu, max_abs_err_vs_oracle=err, max_rel_err_vs_oracle=err / ref.abs().max().item())
 
 # ---- the whole MolHIV net of the reference's README (PNASimpleLayer x 4, hidden 80, mean readout), same batch ----
