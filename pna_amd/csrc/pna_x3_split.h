@@ -1,0 +1,93 @@
+// pna_x3_split.h -- the exact fp32 -> 3 x bf16 operand split shared by the bf16x3 contraction kernels
+// (pna_posttrans_x3w.hip; pna_posttrans_x3.hip carries its own identical copy from round 1).
+//   x = x0 + x1 + x2,   x0 = top 16 bits of x,  x1 = top 16 bits of (x - x0),  x2 = top 16 bits of (x - x0 - x1)
+// by truncation, so every term is exact and finite inputs never overflow.  See include/pna_amd.h for the non-finite rules.
+#ifndef PNA_X3_SPLIT_H
+#define PNA_X3_SPLIT_H
+#include <hip/hip_runtime.h>
+
+namespace pna_x3 {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef short bf8 __attribute__((ext_vector_type(8)));       // 8 bf16 = one MFMA A/B fragment
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) f4u { f4 v; };
+
+__device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float bfloat(unsigned u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ float top16(float x) { return bfloat(fbits(x) & 0xFFFF0000u); }
+// upper halves of (even, odd) -> one dword {odd.hi16, even.hi16}
+__device__ __forceinline__ unsigned pack_hi(float even, float odd) { return __builtin_amdgcn_perm(fbits(odd), fbits(even), 0x07060302u); }
+
+// 8 floats -> the three bf16 fragments
+__device__ __forceinline__ void split8(const f4 lo, const f4 hi, bf8& t0, bf8& t1, bf8& t2) {
+  const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  u4 p0, p1, p2;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float xe = x[2 * j], xo = x[2 * j + 1];
+    const float re = xe - top16(xe), ro = xo - top16(xo);
+    const float se = re - top16(re), so = ro - top16(ro);
+    p0[j] = pack_hi(xe, xo);
+    p1[j] = pack_hi(re, ro);
+    p2[j] = pack_hi(se, so);
+  }
+  t0 = __builtin_bit_cast(bf8, p0); t1 = __builtin_bit_cast(bf8, p1); t2 = __builtin_bit_cast(bf8, p2);
+}
+
+// The same for a fragment that holds +-Inf: an infinite element is carried by its LOWEST term alone (t0 = t1 = 0,
+// t2 = +-Inf): of the six partial products only a2*b0 sees it, and b0 = 0 only where the fp32 product Inf * w is NaN too.
+__device__ __forceinline__ void split8_inf(const f4 lo, const f4 hi, bf8& t0, bf8& t1, bf8& t2) {
+  const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  u4 p0, p1, p2;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float xe = x[2 * j], xo = x[2 * j + 1];
+    const bool ie = __builtin_fabsf(xe) == INFINITY, io = __builtin_fabsf(xo) == INFINITY;
+    const float fe = ie ? 0.f : xe, fo = io ? 0.f : xo;
+    const float re = fe - top16(fe), ro = fo - top16(fo);
+    const float se = re - top16(re), so = ro - top16(ro);
+    p0[j] = pack_hi(fe, fo);
+    p1[j] = pack_hi(re, ro);
+    p2[j] = pack_hi(ie ? xe : se, io ? xo : so);
+  }
+  t0 = __builtin_bit_cast(bf8, p0); t1 = __builtin_bit_cast(bf8, p1); t2 = __builtin_bit_cast(bf8, p2);
+}
+
+// largest magnitude of the 8 floats (NaN operands are ignored by v_max3: they need no special path)
+__device__ __forceinline__ float absmax8(const f4 lo, const f4 hi) {
+  float m;
+  asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(m) : "v"(lo.x), "v"(lo.y), "v"(lo.z));
+  asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(m) : "v"(m), "v"(lo.w), "v"(hi.x));
+  asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(m) : "v"(m), "v"(hi.y), "v"(hi.z));
+  asm("v_max_f32 %0, %1, |%2|" : "=v"(m) : "v"(m), "v"(hi.w));
+  return m;
+}
+
+// A 16-byte window [kk, kk+4) with kk = max(0, min(k, kmax-4)) was loaded instead of [k, k+4): realign it to the elements
+// [k, k+4) and zero those at or beyond kmax.
+__device__ __forceinline__ f4 fix4(int k, int kmax, f4 t) {
+  const int d = k - max(0, min(k, kmax - 4));
+  f4 v;
+  v.x = d == 0 ? t.x : d == 1 ? t.y : d == 2 ? t.z : t.w;
+  v.y = d == 0 ? t.y : d == 1 ? t.z : t.w;
+  v.z = d == 0 ? t.z : t.w;
+  v.w = t.w;
+  v.x = (k < kmax && d <= 3) ? v.x : 0.f;
+  v.y = (k + 1 < kmax && d <= 2) ? v.y : 0.f;
+  v.z = (k + 2 < kmax && d <= 1) ? v.z : 0.f;
+  v.w = (k + 3 < kmax && d == 0) ? v.w : 0.f;
+  return v;
+}
+
+// one weight -> its bf16 term `term` (pack kernels); an infinite weight is carried by its lowest term alone
+__device__ __forceinline__ unsigned short weight_term(float w, int term) {
+  const bool winf = __builtin_fabsf(w) == INFINITY;
+  const float wf = winf ? 0.f : w;
+  const float r1 = wf - top16(wf), r2 = winf ? w : r1 - top16(r1);
+  const float t = term == 0 ? wf : term == 1 ? r1 : r2;
+  return (unsigned short)(fbits(t) >> 16);
+}
+
+}  // namespace pna_x3
+#endif

@@ -1,0 +1,31 @@
+import os, sys, time, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pna_amd import _lib
+_lib.LIB_PATH = os.path.join(ROOT, os.environ["PNA_AMD_LIB"])
+from pna_amd import ops
+dev = torch.device("cuda:0")
+M, K, N = 1_000_000, 300, int(os.environ.get("N", 75))
+a = torch.randn(M, K, device=dev)
+W = (torch.randn(N, 3 * K, device=dev) / 30)
+b = torch.randn(N, device=dev)
+sc = [None, torch.rand(M, device=dev) + 0.5, torch.rand(M, device=dev) + 0.5]
+res = torch.randn(M, 80, device=dev)[:, :N]
+y = torch.empty(M, 80, device=dev)[:, :N]
+cs, ct = torch.rand(N, device=dev) + 0.5, torch.randn(N, device=dev)
+out = []
+for tail in (False, True):
+    kw = dict(col_scale=cs, col_shift=ct, relu=True, residual=res) if tail else {}
+    fn = lambda: ops.posttrans(a, K, W, sc, b, arith="bf16x3", out=y, **kw)  # noqa: E731
+    for _ in range(3):
+        fn()
+    ms = 1e9
+    for _ in range(4):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        ms = min(ms, (time.perf_counter() - t) / 10 * 1e3)
+    out.append(ms)
+print(f"variant {sys.argv[1]:>3}: plain {out[0]:.3f} ms   tail {out[1]:.3f} ms", flush=True)
