@@ -32,6 +32,10 @@
 #include "pna_internal.h"
 #include "pna_x3_split.h"
 
+#ifndef X3W_SKIP
+#define X3W_SKIP 0     // development (tools/x3w_variants.sh; results are garbage): 1 cheap epilogue, 2 no MFMAs, 4 no B reads,
+#endif                 // 8 no weight copies, 16 no A loads, 32 no operand split, 64 no soft barrier
+
 namespace {
 
 using namespace pna_x3;
@@ -69,16 +73,13 @@ inline Plan make_plan(int N, int S) {
   p.ok = p.nt >= 1 && p.nt <= 8;
   return p;
 }
-inline int steps_of(int K) {          // K steps of 16: full 32-chunks are two steps; a remainder <= 16 is ONE step
-  const int nc2 = K / 32, rem = K % 32;
-  return 2 * nc2 + (rem == 0 ? 0 : rem <= 16 ? 1 : 2);
-}
-// k of element e of lane half g in step s.  A regular step pair reads 64 contiguous bytes per row and lane half
-// (k = 32 c + 16 g + 8 o + e, o = s & 1): A and B agree on the permutation, nothing else sees it.
+inline int steps_of(int K) { return (K + 15) / 16; }         // K advances 16 at a time
+// k of element 0 of lane half g in step s: k = 16 s + 8 g -- the two halves of a row read 64 contiguous bytes per step (one
+// sector; with k = 32 c + 16 g + 8 o they read two 32-byte pieces 64 bytes apart, every sector was requested by two steps
+// and the A stream ran at 2.7 TB/s).  A and B agree on it, nothing else sees it.
 __host__ __device__ inline int k_of(int s, int g, int K) {
-  const int nc2 = K / 32, rem = K % 32;
-  const bool one = rem != 0 && rem <= 16 && s == 2 * nc2;
-  return one ? 32 * nc2 + 8 * g : 32 * (s >> 1) + 16 * g + 8 * (s & 1);
+  (void)K;
+  return 16 * s + 8 * g;
 }
 
 struct WArgs {
@@ -135,7 +136,8 @@ __global__ void k_pack_x3w(const float* w_ref, long ldw, int K, int S, Plan p, i
 template <int S, int NTF, int NMIX, int NVC>
 __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
   constexpr int NT = S * NTF + NMIX;
-  constexpr int NP = (NT + 1) / 2;               // tile pairs: the MFMAs of a pair alternate between its two accumulators
+  static_assert(NT >= 4 && NT <= 8, "tile groups below assume 4 .. 8 packed tiles");
+  constexpr int NP = 4;                          // tile groups of 2 or 1 tiles: the MFMAs of a group alternate between its accumulators
   constexpr int STEPV = NT * 192;                // 16-byte pieces of one step image
   constexpr int STEPB = STEPV * 16;
   constexpr int NI = (STEPV + kThreads - 1) / kThreads;   // global_load_lds instructions per wavefront per step
@@ -154,6 +156,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
   float* const colc = reinterpret_cast<float*>(lds + kNBuf * STEPB) + (size_t)kWaves * kHalfRows * YP;   // [3][YP]: bias | scale | shift
   float* const rowf = colc + 3 * YP;                                                          // [8 waves][S + 1][32] per-row factors
   float* const wv = rowf + kWaves * (S + 1) * 32;                                             // [NS][2][8] (NVC only)
+  unsigned* const arrived = reinterpret_cast<unsigned*>(wv + (NVC ? NS * 16 : 0));            // the soft barrier's arrival counter
 
   f16v acc[NT];
 #pragma unroll
@@ -171,19 +174,29 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
     colc[2 * YP + i] = (g.col_shift && in) ? g.col_shift[col] : 0.f;
   }
   for (int i = tid; i < kWaves * (S + 1) * 32; i += kThreads) rowf[i] = 1.f;
+  if (tid == 0) *arrived = 0u;
   if constexpr (NVC) {
     for (int i = tid; i < NS * 16; i += kThreads) wv[i] = g.wv_img[(size_t)blockIdx.y * NS * 16 + i];
   }
 
   // step image -> LDS buffer, asynchronously: every wavefront issues exactly NI 1 KB copies per step (a slot past the
   // image re-copies an earlier piece: same bytes to the same address), destination = wave-uniform base + lane * 16
+  // The copies are issued through inline asm: an LDS-DMA copy hipcc can SEE makes it drain vmcnt(0) in front of the next LDS
+  // access it can see as well (the copy might alias it) -- at the top of every step, which serialised the whole prefetch.
+  auto lds_dma16 = [&](const void* src, const void* dst_wave_base) __attribute__((always_inline)) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                 : : "s"((unsigned)(size_t)(const __attribute__((address_space(3))) void*)dst_wave_base), "v"(src) : "memory", "m0");
+  };
+  auto lds_dma4 = [&](const void* src, const void* dst_wave_base) __attribute__((always_inline)) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
+                 : : "s"((unsigned)(size_t)(const __attribute__((address_space(3))) void*)dst_wave_base), "v"(src) : "memory", "m0");
+  };
   auto stage_piece = [&](int st, int buf, int i) __attribute__((always_inline)) {
     const unsigned char* src = img + (size_t)st * STEPB;
     unsigned char* dst = lds + (size_t)buf * STEPB;
     int w0 = (i * kWaves + wave) * 64;
     if (w0 >= STEPV) w0 = w0 % STEPV;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(w0 + lane) * 16),
-                                     (__attribute__((address_space(3))) void*)(dst + (size_t)w0 * 16), 16, 0, 0);
+    lds_dma16(src + (size_t)(w0 + lane) * 16, dst + (size_t)w0 * 16);
   };
 
   // ---- A operand -----------------------------------------------------------------------------------------------------
@@ -192,7 +205,11 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
   f4 raw[3][2];                                  // register ring: step j lives in slot j % 3
   u4 T[3], Tn[3];                                // the three bf16 terms (8 x bf16 each) of the step being multiplied | of the next
   auto load_a = [&](f4 (&dst)[2], int t, int s) __attribute__((always_inline)) {
+#if X3W_SKIP & 128       // development: every tile reads the first tile's rows (A comes from L2)
+    const int row = min(0 * t + wave * kWaveRows + lc, g.M - 1);
+#else
     const int row = min(t * kTileRows + wave * kWaveRows + lc, g.M - 1);
+#endif
     const int k = k_of(s, lh, g.K);
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
@@ -216,7 +233,18 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
   // chunk c of take_fast: c < 4 splits elements 2c, 2c+1 (dword c of each term); 4: is the slow path needed (wave-uniform);
   // 5: the VALU column's share
   auto take_chunk = [&](f4 (&cur)[2], int s, u4 (&Tu)[3], int c, bool& redo) __attribute__((always_inline)) {
-    if (c == 0) asm volatile("" : "+v"(cur[0]), "+v"(cur[1]) : : "memory");
+    if (c == 0) {
+      asm volatile("" : "+v"(cur[0]), "+v"(cur[1]) : : "memory");
+      // beyond K (only a row's last step reaches it; K % 4 == 0, so a 16-byte window is inside or outside as a whole):
+      // the clamped load returned other columns -- zero them (straight-line: 2 compares + 8 selects per step)
+      const int k = k_of(s, lh, g.K);
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        const bool in = k + 4 * w < g.K;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cur[w][e] = in ? cur[w][e] : 0.f;
+      }
+    }
     if (c < 4) {
       const float xe = cur[c >> 1][(2 * c) & 3], xo = cur[c >> 1][(2 * c + 1) & 3];
       const float re = xe - top16(xe), ro = xo - top16(xo);
@@ -226,7 +254,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
       Tu[2][c] = pack_hi(se, so);
       asm volatile("" : "+v"(Tu[0][c]), "+v"(Tu[1][c]), "+v"(Tu[2][c]));      // (pins the arithmetic HERE: the compiler would sink it to the use)
     } else if (c == 4) {
-      redo = (int)(__builtin_amdgcn_ballot_w64(absmax8(cur[0], cur[1]) == INFINITY) != 0) | (int)(k_of(s, 1, g.K) + 8 > g.K);   // (no branch)
+      redo = __builtin_amdgcn_ballot_w64(absmax8(cur[0], cur[1]) == INFINITY) != 0;        // wave-uniform
     } else {
       if constexpr (NVC) {
         vpend = vcol(cur[0], cur[1], s);
@@ -234,7 +262,12 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
       }
     }
   };
-  auto take_slow = [&](f4 (&cur)[2], int s, u4 (&Tu)[3]) __attribute__((always_inline)) {
+  // an infinite element (a pathological aggregate): the fragment is fetched AGAIN, synchronously, and split by the form that
+  // keeps infinities (the ring slot it came from already receives a later step's loads)
+  auto take_slow = [&](int t, int s, u4 (&Tu)[3]) __attribute__((always_inline)) {
+    f4 cur[2];
+    load_a(cur, t, s);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]) : : "memory");
     const int k = k_of(s, lh, g.K);
     const f4 lo4 = fix4(k, g.K, cur[0]), hi4 = fix4(k + 4, g.K, cur[1]);
     if constexpr (NVC) vpend = vcol(lo4, hi4, s);
@@ -258,9 +291,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
 #pragma unroll
       for (int f = 0; f <= S; ++f) {
         const float* src = f < S ? g.row_scale[f] : g.row_post;
-        if (src)                                                   // (wave-uniform)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + row),
-                                           (__attribute__((address_space(3))) void*)(myf_w + f * 32), 4, 0, 0);
+        if (src) lds_dma4(src + row, myf_w + f * 32);             // (wave-uniform)
       }
     }
   };
@@ -316,33 +347,34 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
     const int dq = 64 % NQF, drow = 64 / NQF;                         // (launcher: NB >= 4 when vec_ok)
     const int rrow0 = lane_ / NQF, rq0 = lane_ - rrow0 * NQF;
     const int xrow = REM == 1 ? lane_ : REM == 2 ? lane_ >> 1 : (lane_ * 171) >> 9, xe = lane_ - xrow * REM;   // remainder columns: lane / REM
-    // The residual: the loads of BOTH halves are issued here, ahead of the deposit, and waited for ONCE before the first
-    // store.  (A wait the compiler places itself is vmcnt(0) at every control-flow merge, and from the second one on it also
+    // The residual: the loads of a half are issued ahead of its deposit and waited for ONCE, before the half's first store.
+    // (A wait the compiler places itself is vmcnt(0) at every control-flow merge, and from the second one on it also
     // waits for the stores issued in between: one store round trip per slot.)
-    f4 res[2][NITF];
-    float resx[2];
-    if (g.vec_ok) {
+    f4 res[NITF];
+    float resx;
+    auto load_res = [&](int hf) __attribute__((always_inline)) {
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
+      for (int it = 0; it < NITF; ++it) res[it] = (f4){0.f, 0.f, 0.f, 0.f};
+      resx = 0.f;
+      if (g.vec_ok && g.residual) {
         int rr = rrow0, rq = rq0;
 #pragma unroll
         for (int it = 0; it < NITF; ++it) {
-          res[hf][it] = (f4){0.f, 0.f, 0.f, 0.f};
           const int row = row0 + kHalfRows * hf + rr;
-          if (g.residual && rr < kHalfRows && row < g.M) res[hf][it] = *reinterpret_cast<const f4*>(g.residual + (size_t)row * g.ld_res + n0 + 4 * rq);
+          if (rr < kHalfRows && row < g.M) res[it] = *reinterpret_cast<const f4*>(g.residual + (size_t)row * g.ld_res + n0 + 4 * rq);
           rq += dq; rr += drow;
           if (rq >= NQF) { rq -= NQF; ++rr; }
         }
-        resx[hf] = 0.f;
         const int row = row0 + kHalfRows * hf + xrow;
-        if (g.residual && REM != 0 && xrow < kHalfRows && row < g.M) resx[hf] = g.residual[(size_t)row * g.ld_res + n0 + 4 * NQF + xe];
+        if (REM != 0 && xrow < kHalfRows && row < g.M) resx = g.residual[(size_t)row * g.ld_res + n0 + 4 * NQF + xe];
       }
-    }
+    };
     // mixed tiles: packed column qi = 32 m + lc belongs to scaler qi / r and output column NFULL + qi % r.  The lanes of
     // scaler 0 (qi < r: all in mixed tile 0) gather the other scalers' products of their output column from the lanes that
     // hold them (ds_bpermute: a register exchange through the LDS crossbar, no memory) and add them in scaler order.
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
+      load_res(hf);
 #pragma unroll
       for (int qq = 0; qq < 2; ++qq) {
         const int q = 2 * hf + qq;
@@ -405,15 +437,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
       }
       asm volatile("" ::: "memory");
       X3W_ESTAMP(hf, 6);
+#pragma unroll
+      for (int it = 0; it < NITF; ++it) asm volatile("" : "+v"(res[it]));   // (unconditional: on every path the loads are waited for HERE)
+      asm volatile("" : "+v"(resx));
       if (g.vec_ok) {
-        if (hf == 0) {
-#pragma unroll
-          for (int h2 = 0; h2 < 2; ++h2) {
-#pragma unroll
-            for (int it = 0; it < NITF; ++it) asm volatile("" : "+v"(res[h2][it]));
-            asm volatile("" : "+v"(resx[h2]));
-          }
-        }
         X3W_ESTAMP(hf, 7);
         int rr = rrow0, rq = rq0;
 #pragma unroll
@@ -425,7 +452,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
                      ct = *reinterpret_cast<const f4*>(colc + 2 * YP + 4 * rq);
             const float rp = myf[S * 32 + kHalfRows * hf + rr];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = finish1(v[e], cb[e], cs[e], ct[e], rp, res[hf][it][e], lo, leaky);
+            for (int e = 0; e < 4; ++e) v[e] = finish1(v[e], cb[e], cs[e], ct[e], rp, res[it][e], lo, leaky);
             *reinterpret_cast<f4*>(g.y + (size_t)row * g.ldy + n0 + 4 * rq) = v;
           }
           rq += dq; rr += drow;
@@ -435,7 +462,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
           const int row = row0 + kHalfRows * hf + xrow;
           if (REM != 0 && xrow < kHalfRows && row < g.M) {
             const int c = 4 * NQF + xe;
-            const float v = finish1(ytile[xrow * YP + c], colc[c], colc[YP + c], colc[2 * YP + c], myf[S * 32 + kHalfRows * hf + xrow], resx[hf], lo, leaky);
+            const float v = finish1(ytile[xrow * YP + c], colc[c], colc[YP + c], colc[2 * YP + c], myf[S * 32 + kHalfRows * hf + xrow], resx, lo, leaky);
             g.y[(size_t)row * g.ldy + n0 + c] = v;
           }
         }
@@ -465,7 +492,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
   const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int nsteps = my_tiles * NS;
   int t = blockIdx.x, s = 0;                       // position of step j
-  int t3 = t, s3 = 0;                              // position of step j + 3
+  int t3 = t, s3 = 0;                              // position of step j + 3 (weight image) ...
+  int t4, s4;                                      // ... and of step j + 4 (A fragment)
   auto adv = [&](int& tt, int& ss) __attribute__((always_inline)) {
     if (++ss == NS) { ss = 0; tt += gridDim.x; }
   };
@@ -483,11 +511,47 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
     bool redo0 = false;
 #pragma unroll
     for (int c = 0; c < 6; ++c) take_chunk(raw[0], 0, T, c, redo0);
-    if (redo0) take_slow(raw[0], 0, T);
+    if (redo0) take_slow(t, 0, T);
   }
+  load_a(raw[0], t3, s3);                          // step 3's fragment: slot 0 is free again
+  t4 = t3; s4 = s3; adv(t4, s4);
 
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)lane * 16u;
   int buf = 0;                                     // j % 4
+  // tile groups: 2 tiles while more tiles than groups remain, then 1 (6 tiles: 2 2 1 1; 7: 2 2 2 1; 8: 2 2 2 2)
+  auto gstart = [](int gi) constexpr -> int { int st = 0; for (int i = 0; i < gi; ++i) st += (NT - st > NP - i) ? 2 : 1; return st; };
+  auto gcnt = [gstart](int gi) constexpr -> int { return (NT - gstart(gi) > NP - gi) ? 2 : 1; };
+  // B fragment (term tm, tile n): bytes (tm * NT + n) * 1024 + lane * 16 of the buffer; read by hand with counted
+  // lgkmcnt (LDS returns in order): the reads of group p+1 are issued behind those of group p
+  auto load_b = [&](bf8 (&B)[2][2][3], int gi, int slot, unsigned base) __attribute__((always_inline)) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      if (jj < gcnt(gi)) {
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(B[slot][jj][tm]) : "v"(base), "n"((tm * NT + gstart(gi) + jj) * 1024));
+      }
+    }
+  };
+  // Soft barrier: ARRIVE (one LDS atomic by lane 0) and WAIT (poll) are half a step apart.  A wavefront signals barrier j+1
+  // as soon as it (i) has read its last B fragment of step j and (ii) its own copies of step j+2's image have landed; it
+  // waits for all eight signals in the middle of step j+1, before it overwrites step j's buffer and before its first read of
+  // image j+2.  A wavefront that is late -- in its epilogue, or starved of the matrix pipe by its SIMD neighbour -- has
+  // signalled long before the others ask: with s_barrier the early wavefronts of every step idled ~1500 cycles.
+  const unsigned arr_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)arrived;
+  auto arrive = [&]() __attribute__((always_inline)) {
+    unsigned long long keep;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0"
+                 : "=&s"(keep) : "v"(arr_addr), "v"(1u) : "memory");
+  };
+  auto wait_all = [&](unsigned target) __attribute__((always_inline)) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(arr_addr) : "memory");
+    while (__builtin_amdgcn_readfirstlane(v) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(arr_addr) : "memory");
+    }
+  };
 #ifdef PNA_X3W_TIMERS
   auto stamp = [&](int j, int idx) __attribute__((always_inline)) {
     if (g.dbg && j < 64) {
@@ -511,71 +575,73 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
     const int buf3 = (buf + 3) & 3;
     const unsigned ba = lds_base + (unsigned)(buf * STEPB);
     bf8 B[2][2][3];
-    // B fragment (term tm, tile n): bytes (tm * NT + n) * 1024 + lane * 16 of the buffer; read by hand with counted
-    // lgkmcnt (LDS returns in order): the reads of pair p+1 are issued behind those of pair p
-    auto load_b = [&](int p, int slot) __attribute__((always_inline)) {
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int n = 2 * p + jj;
-        if (n < NT) {
-#pragma unroll
-          for (int tm = 0; tm < 3; ++tm)
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(B[slot][jj][tm]) : "v"(ba), "n"((tm * NT + n) * 1024));
-        }
-      }
-    };
-    constexpr int H = (NP - 1) / 2;                // the barrier follows the B prefetch of pair H
+    constexpr int H = 1;                           // the barrier follows the B prefetch of group H
     constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};   // smallest partial products first
-    load_b(0, 0);
+#if !(X3W_SKIP & 4)
+    load_b(B, 0, 0, ba);
+#endif
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      const bool two = 2 * p + 1 < NT;
+      const bool two = gcnt(p) == 2;
+      // the B fragments of the NEXT group are requested behind those of this one.  (Requesting the next STEP's first group
+      // behind the last one was measured: no gain, and 24 more registers live across the epilogue.)
+#if !(X3W_SKIP & 4)
       if (p + 1 < NP) {
-        load_b(p + 1, (p + 1) & 1);
-        if (2 * (p + 1) + 1 < NT) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        load_b(B, p + 1, (p + 1) & 1, ba);
+        if (gcnt(p + 1) == 2) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
+#endif
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj)
-        if (2 * p + jj < NT) asm volatile("" : "+v"(B[p & 1][jj][0]), "+v"(B[p & 1][jj][1]), "+v"(B[p & 1][jj][2]));
-      if (p == H) {
-        // in flight may stay: the NI copies and the 2 A loads of step j-1 (both issued behind B_{j-1}).  Everything older has
-        // landed: this wavefront's copies of step j+1's image (issued behind B_{j-2}) and the A fragment of step j+1.
-#ifdef PNA_X3W_TIMERS
-        X3W_STAMP(j, 1);
-        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 + NI) : "memory");
-        X3W_STAMP(j, 2);
-        asm volatile("s_barrier" ::: "memory");
-        X3W_STAMP(j, 3);
-#else
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"(2 + NI) : "memory");
+        if (jj < gcnt(p)) asm volatile("" : "+v"(B[p & 1][jj][0]), "+v"(B[p & 1][jj][1]), "+v"(B[p & 1][jj][2]));
+#if !(X3W_SKIP & 64)
+      if (p == H) wait_all((unsigned)kWaves * (unsigned)j);      // barrier j: signalled by every wavefront at the end of its step j-1
+#endif
+      if (p == NP - 1) {
+        // barrier j+1: this wavefront's reads of step j's buffer are complete (the wait above) and so are its copies of step
+        // j+2's image (issued in step j-1): in flight may stay what was issued behind them -- the 2 A loads of step j-1, the NI
+        // copies and the 2 A loads of this step.  Everything older has landed, the fragment of step j+2 (fetched in step j-2,
+        // 2.25 steps ago) included.  VMEM returns in order: a wait that covered younger A loads made every step wait for HBM.
+#if !(X3W_SKIP & 64)
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 + NI) : "memory");
+        arrive();
 #endif
       }
-      if (p >= H) {                                // always NI copies per step: the counted wait relies on it (beyond the
-#pragma unroll                                     // last step they fill a buffer nobody reads)
+      if (p >= H && p < NP - 1) {                  // always NI copies per step: the counted wait relies on it (beyond the
+#pragma unroll                                     // last step they fill a buffer nobody reads); all issued AHEAD of the arrive
         for (int i = 0; i < NI; ++i)
-          if ((NP - 1 > H ? H + (i * (NP - H)) / NI : H) == p) stage_piece(simg, buf3, i);
+          if (H + (i * (NP - 1 - H)) / NI == p && !(X3W_SKIP & 8)) stage_piece(simg, buf3, i);
       }
 #pragma unroll
       for (int pp = 0; pp < 6; ++pp) {
-        acc[2 * p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8m, T[TA[pp]]), __builtin_bit_cast(bf8m, B[p & 1][0][TB[pp]]), acc[2 * p], 0, 0, 0);
+#if X3W_SKIP & 2
+        if (pp == 0) asm volatile("" : "+v"(acc[gstart(p)]), "+v"(acc[gstart(p) + (two ? 1 : 0)]) : "v"(T[0]), "v"(B[p & 1][0][0]));
+        if (j < 0)
+#endif
+        acc[gstart(p)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8m, T[TA[pp]]), __builtin_bit_cast(bf8m, B[p & 1][0][TB[pp]]), acc[gstart(p)], 0, 0, 0);
+#if X3W_SKIP & 2
+        if (j < 0)
+#endif
         if (two)
-          acc[2 * p + (two ? 1 : 0)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8m, T[TA[pp]]), __builtin_bit_cast(bf8m, B[p & 1][1][TB[pp]]), acc[2 * p + (two ? 1 : 0)], 0, 0, 0);
+          acc[gstart(p) + (two ? 1 : 0)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8m, T[TA[pp]]), __builtin_bit_cast(bf8m, B[p & 1][1][TB[pp]]), acc[gstart(p) + (two ? 1 : 0)], 0, 0, 0);
         // The wavefront's own VALU work is PINNED between the MFMAs behind the barrier (the fences keep the compiler from
         // collecting it behind the last MFMA): the split of the next step's fragment (its loads landed before the counted
         // wait) behind pair H, the address arithmetic and the loads of step j+3's fragment behind the pair that follows.
         // A wavefront then keeps the matrix pipe busy on its own, whatever its SIMD neighbour is doing.
         if (p == H) {
           __builtin_amdgcn_sched_barrier(0);
-          take_chunk(raw[R1], s1, Tn, pp, redo);
+          if (!(X3W_SKIP & 32)) take_chunk(raw[R1], s1, Tn, pp, redo);
           __builtin_amdgcn_sched_barrier(0);
         }
         if (p == (H + 1 < NP ? H + 1 : H) && pp == (H + 1 < NP ? 0 : 5)) {
           __builtin_amdgcn_sched_barrier(0);
-          load_a(raw[R], t3, s3);                  // (rows clamp to M-1 beyond the last tile: harmless)
-          adv(t3, s3);
+          // step j+4's fragment, into the slot the split above has just emptied: 2.25 steps ahead of the counted wait that
+          // covers it (rows clamp to M-1 beyond the last tile: harmless)
+          if (!(X3W_SKIP & 16)) load_a(raw[R1], t4, s4);
+          adv(t3, s3); adv(t4, s4);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -584,7 +650,11 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
 #ifdef PNA_X3W_TIMERS
     dbg_j = j;
 #endif
-    if (redo) take_slow(raw[R1], s1, Tn);
+    if (redo && !(X3W_SKIP & 32)) {
+      int t1 = t, sx = s;
+      adv(t1, sx);
+      take_slow(t1, s1, Tn);
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) T[i] = Tn[i];
     if (s == NS - 1) {
@@ -613,14 +683,14 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
     if (j + 1 < nsteps) step(std::integral_constant<int, 1>{}, j + 1);
     if (j + 2 < nsteps) step(std::integral_constant<int, 2>{}, j + 2);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the copies and re-loads of the last steps
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // the copies, re-loads and B reads issued for a step that does not exist
 }
 
 template <int S, int NTF, int NMIX, int NVC>
 int launch_w(const WArgs& g, const Plan& p, int cus, hipStream_t st) {
   constexpr int NT = S * NTF + NMIX;
   const size_t lds = (size_t)kNBuf * NT * 3072 + (size_t)kWaves * kHalfRows * g.YP * 4 + (size_t)3 * g.YP * 4 + (size_t)kWaves * (S + 1) * 128 +
-                     (NVC ? (size_t)g.NS * 64 : 0);
+                     (NVC ? (size_t)g.NS * 64 : 0) + 16;
   if (lds > 160 * 1024) return -2;
   if (hipFuncSetAttribute((const void*)k_posttrans_x3w<S, NTF, NMIX, NVC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return -1;
@@ -644,7 +714,7 @@ bool have_kernel(int S, const Plan& p) {
 }  // namespace
 
 extern "C" int pna_posttrans_x3w_supported(int32_t K, int32_t N, int32_t n_scaler, int32_t Kh) {
-  if (K < 4 || Kh != 0) return 0;
+  if (K < 4 || K % 4 != 0 || Kh != 0) return 0;          // (K % 4: the in-stream tail handling of take_chunk)
   return have_kernel(n_scaler, make_plan(N, n_scaler)) ? 1 : 0;
 }
 
@@ -658,7 +728,7 @@ extern "C" int64_t pna_posttrans_x3w_packed_bytes(int32_t K, int32_t N, int32_t 
 extern "C" int pna_posttrans_x3w_pack_f32(const float* w_ref, int64_t ldw, int32_t N, int32_t K, int32_t n_scaler, void* w_img,
                                           pna_stream_t stream) {
   const Plan p = make_plan(N, n_scaler);
-  if (!w_ref || !w_img || K <= 0 || !have_kernel(n_scaler, p) || ldw < (int64_t)n_scaler * K)
+  if (!w_ref || !w_img || K <= 0 || K % 4 != 0 || !have_kernel(n_scaler, p) || ldw < (int64_t)n_scaler * K)
     return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3w_pack_f32: bad arguments / unsupported shape (see pna_posttrans_x3w_supported)");
   const int NS = steps_of(K);
   const int64_t nw = (int64_t)p.ny * NS * p.nt * 3072;
@@ -679,7 +749,7 @@ extern "C" int pna_posttrans_x3w_f32(const pna_posttrans_args* a, pna_stream_t s
   if (a->h != nullptr || a->n_tower > 1)
     return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3w_f32: the h panel and n_tower > 1 are served by pna_posttrans_x3_f32");
   const Plan p = make_plan(a->N, a->n_scaler);
-  if (!have_kernel(a->n_scaler, p)) return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3w_f32: unsupported shape (see pna_posttrans_x3w_supported)");
+  if (!have_kernel(a->n_scaler, p) || a->K % 4 != 0) return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3w_f32: unsupported shape (see pna_posttrans_x3w_supported)");
   if (a->lda < a->K || a->ldy < a->N) return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3w_f32: leading dimensions too small");
   if (a->residual && a->ld_res < a->N) return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3w_f32: ld_res too small");
   if ((a->col_scale == nullptr) != (a->col_shift == nullptr))

@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from pna_amd import ops  # noqa: E402
 
+ops.X3_WIDE = True
 dev = torch.device("cuda:0")
 
 

@@ -4,6 +4,7 @@ sys.path.insert(0, ROOT)
 from pna_amd import _lib
 _lib.LIB_PATH = os.path.join(ROOT, os.environ["PNA_AMD_LIB"])
 from pna_amd import ops
+ops.X3_WIDE = True
 dev = torch.device("cuda:0")
 M, K, N = 1_000_000, 300, int(os.environ.get("N", 75))
 a = torch.randn(M, K, device=dev)
