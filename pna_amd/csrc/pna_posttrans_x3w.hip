@@ -32,6 +32,9 @@
 #include "pna_internal.h"
 #include "pna_x3_split.h"
 
+#ifndef X3W_FINE
+#define X3W_FINE 1     // the operand split in 12 pieces, one behind each MFMA of group H (0: 6 pieces, one behind each MFMA pair)
+#endif
 #ifndef X3W_PF
 #define X3W_PF 0       // > 0: touch the A sectors this many steps ahead of their loads (L2 prefetch; measured)
 #endif
@@ -274,6 +277,50 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
     } else {
       if constexpr (NVC) {
         vpend = vcol(cur[0], cur[1], s);
+        asm volatile("" : "+v"(vpend));
+      }
+    }
+  };
+  // The same work in 12 pieces, one behind EACH of the 12 MFMAs of a two-tile group (2 MFMAs + 11 VALU left the pipe idle for
+  // the last VALU of every piece when the SIMD's other wavefront was not in its MFMA stream): 0/1 zero the windows beyond K and
+  // request the VALU column's weights, 2..9 the four element pairs in two halves each, 10 the infinity test, 11 the VALU column
+  struct TakeState { float re, ro, se, so; f4 w0, w1; };
+  auto take_micro = [&](f4 (&cur)[2], int s, u4 (&Tu)[3], int m, bool& redo, TakeState& ts) __attribute__((always_inline)) {
+    if (m < 2) {
+      if (m == 0) {
+        asm volatile("" : "+v"(cur[0]), "+v"(cur[1]) : : "memory");
+        if constexpr (NVC) {
+          ts.w0 = *reinterpret_cast<const f4*>(wv + (s * 2 + lh) * 8);
+          ts.w1 = *reinterpret_cast<const f4*>(wv + (s * 2 + lh) * 8 + 4);
+        }
+      }
+      const bool in = k_of(s, lh, g.K) + 4 * m < g.K;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cur[m][e] = in ? cur[m][e] : 0.f;
+      asm volatile("" : "+v"(cur[m]));
+    } else if (m < 10) {
+      const int c = (m - 2) >> 1;
+      const float xe = cur[c >> 1][(2 * c) & 3], xo = cur[c >> 1][(2 * c + 1) & 3];
+      if (((m - 2) & 1) == 0) {
+        ts.re = xe - top16(xe); ts.ro = xo - top16(xo);
+        ts.se = ts.re - top16(ts.re); ts.so = ts.ro - top16(ts.ro);
+        asm volatile("" : "+v"(ts.re), "+v"(ts.ro), "+v"(ts.se), "+v"(ts.so));
+      } else {
+        Tu[0][c] = pack_hi(xe, xo);
+        Tu[1][c] = pack_hi(ts.re, ts.ro);
+        Tu[2][c] = pack_hi(ts.se, ts.so);
+        asm volatile("" : "+v"(Tu[0][c]), "+v"(Tu[1][c]), "+v"(Tu[2][c]));
+      }
+    } else if (m == 10) {
+      redo = __builtin_amdgcn_ballot_w64(absmax8(cur[0], cur[1]) == INFINITY) != 0;        // wave-uniform
+    } else {
+      if constexpr (NVC) {
+        float v = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v = __builtin_fmaf(cur[0][e], ts.w0[e], v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v = __builtin_fmaf(cur[1][e], ts.w1[e], v);
+        vpend = v;
         asm volatile("" : "+v"(vpend));
       }
     }
@@ -587,6 +634,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
     if constexpr (NVC) vacc += vpend;
     const int simg = s3;                           // image index of step j + 3
     bool redo = false;
+    TakeState tks;
     int s1 = s + 1; if (s1 >= NS) s1 -= NS;
     const int buf3 = (buf + 3) & 3;
     const unsigned ba = lds_base + (unsigned)(buf * STEPB);
@@ -638,6 +686,13 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
         if (j < 0)
 #endif
         acc[gstart(p)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8m, T[TA[pp]]), __builtin_bit_cast(bf8m, B[p & 1][0][TB[pp]]), acc[gstart(p)], 0, 0, 0);
+#if X3W_FINE
+        if (p == H) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (!(X3W_SKIP & 32)) take_micro(raw[R1], s1, Tn, 2 * pp, redo, tks);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
 #if X3W_SKIP & 2
         if (j < 0)
 #endif
@@ -649,7 +704,11 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
         // A wavefront then keeps the matrix pipe busy on its own, whatever its SIMD neighbour is doing.
         if (p == H) {
           __builtin_amdgcn_sched_barrier(0);
+#if X3W_FINE
+          if (!(X3W_SKIP & 32)) take_micro(raw[R1], s1, Tn, 2 * pp + 1, redo, tks);
+#else
           if (!(X3W_SKIP & 32)) take_chunk(raw[R1], s1, Tn, pp, redo);
+#endif
           __builtin_amdgcn_sched_barrier(0);
         }
         if (p == (H + 1 < NP ? H + 1 : H) && pp == (H + 1 < NP ? 0 : 5)) {
