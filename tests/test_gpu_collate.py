@@ -50,3 +50,24 @@ def test_graph_on_device_uses_the_native_collate_and_layers_still_match(cuda_dev
     with torch.no_grad():
         out = layer(g, a["h"].to(cuda_device)).cpu()
     torch.testing.assert_close(out, a["out"], rtol=1e-5, atol=1e-5)
+
+
+def test_collate_flat_matches_collate(cuda_device):
+    """Graph.collate_flat (flat edge arrays + per-graph counts, no per-graph host work) builds the same batch as collate()."""
+    import torch
+    from pna_amd import Graph
+    gen = torch.Generator().manual_seed(11)
+    sizes = [int(n) for n in torch.randint(1, 40, (300,), generator=gen)]
+    srcs, dsts = [], []
+    for n in sizes:
+        e = int(torch.randint(0, 4 * n, (1,), generator=gen))
+        srcs.append(torch.randint(0, n, (e,), generator=gen))
+        dsts.append(torch.randint(0, n, (e,), generator=gen))
+    a = Graph.collate(srcs, dsts, sizes, device=cuda_device)
+    b = Graph.collate_flat(torch.cat(srcs), torch.cat(dsts), torch.tensor([s.numel() for s in srcs]), torch.tensor(sizes), device=cuda_device)
+    assert a.num_nodes == b.num_nodes and a.batch_num_nodes == b.batch_num_nodes
+    assert torch.equal(a.src, b.src) and torch.equal(a.dst, b.dst)
+    assert torch.equal(a.csr.rowptr, b.csr.rowptr) and torch.equal(a.csr.col, b.csr.col)
+    import pytest
+    with pytest.raises(ValueError):
+        Graph.collate_flat(torch.cat(srcs), torch.cat(dsts), torch.tensor([1, 2]), torch.tensor(sizes), device=cuda_device)

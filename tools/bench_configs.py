@@ -97,11 +97,22 @@ def split_members(src, dst, sizes):
     return list(ss), list(dd)
 
 
+def build_batch_flat(src_cat, dst_cat, counts, sizes_l, avg_log):
+    """The same from flat arrays (a data set stored as one edge array + per-graph counts): Graph.collate_flat."""
+    gb = Graph.collate_flat(src_cat, dst_cat, counts, sizes_l, device=dev)
+    gb.work_items()
+    gb.degree_scalers(avg_log)
+    gb.snorm_n()
+    return gb
+
+
 ss, dd = split_members(src, dst, sizes)
+flat = (torch.cat(ss), torch.cat(dd), torch.tensor([int(x.numel()) for x in ss]))
+t_build_flat = gpu_ms(lambda: build_batch_flat(*flat, sizes, float(avg["log"])), iters=20)
 t_build = gpu_ms(lambda: build_batch(ss, dd, sizes, float(avg["log"])), iters=20)
 with torch.no_grad():
     t_build_first = gpu_ms(lambda: lay(build_batch(ss, dd, sizes, float(avg["log"])), hd, None, snorm), iters=20)
-out["zinc_tower_layer"] = dict(batch_build_ms=t_build, batch_build_plus_first_layer_ms=t_build_first, graphs=128, V=V, E=E, hidden=75, towers=5, eager_ms=eager, hipgraph_ms=graphed,
+out["zinc_tower_layer"] = dict(batch_build_ms=t_build, batch_build_flat_ms=t_build_flat, batch_build_plus_first_layer_ms=t_build_first, graphs=128, V=V, E=E, hidden=75, towers=5, eager_ms=eager, hipgraph_ms=graphed,
                                edges_per_s_hipgraph=E / graphed * 1e3, cpu_oracle_ms=cpu, max_abs_err_vs_oracle=err, max_rel_err_vs_oracle=err / ref.abs().max().item())
 
 # ---- configs[3]: MolHIV-shaped batch, PNASimpleLayer hidden 80, 2048 graphs ----
@@ -124,10 +135,12 @@ with torch.no_grad():
     err = (gf(hd).cpu() - ref).abs().max().item()
     cpu = cpu_ms(lambda: O.simple_layer_forward(sd, src, dst, V, h, AGG.split(), SCA.split(), avg["log"]))
 ss, dd = split_members(src, dst, sizes)
+flat = (torch.cat(ss), torch.cat(dd), torch.tensor([int(x.numel()) for x in ss]))
+t_build_flat = gpu_ms(lambda: build_batch_flat(*flat, sizes, float(avg["log"])), iters=10)
 t_build = gpu_ms(lambda: build_batch(ss, dd, sizes, float(avg["log"])), iters=10)
 with torch.no_grad():
     t_build_first = gpu_ms(lambda: lay(build_batch(ss, dd, sizes, float(avg["log"])), hd), iters=10)
-out["molhiv_simple_layer"] = dict(batch_build_ms=t_build, batch_build_plus_first_layer_ms=t_build_first, graphs=2048, V=V, E=E, hidden=80, eager_ms=eager, hipgraph_ms=graphed,
+out["molhiv_simple_layer"] = dict(batch_build_ms=t_build, batch_build_flat_ms=t_build_flat, batch_build_plus_first_layer_ms=t_build_first, graphs=2048, V=V, E=E, hidden=80, eager_ms=eager, hipgraph_ms=graphed,
                                   edges_per_s_hipgraph=E / graphed * 1e3, cpu_oracle_ms=cpu, max_abs_err_vs_oracle=err, max_rel_err_vs_oracle=err / ref.abs().max().item())
 
 # ---- the whole MolHIV net of the reference's README (PNASimpleLayer x 4, hidden 80, mean readout), same batch ----
