@@ -334,8 +334,25 @@ class PNASimpleLayer(nn.Module):
         return PF.aggregate(graph, graph.source_features(h), self.in_dim, self.aggregators,
                             row_scales=_row_scales(graph, self.scalers, self.avg_d, h.device))
 
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop("_pna_amd_small", None)             # cached weight images follow the parameters' device / dtype
+        return super()._apply(fn, *args, **kwargs)
+
+    def _small_batch_path(self, graph, h):
+        """Whether this call is served by pna_tower_layer_f32 (one C call, two launches: functional._SmallSimplePlan):
+        inference on a whole graph of molecule-batch size with the four standard aggregators and a 1-layer posttrans."""
+        if self.training or not h.is_cuda or h.dtype != torch.float32 or type(graph) is not Graph:
+            return False
+        if not (tuple(self.aggregators) == ("mean", "max", "min", "std") and len(self.scalers) <= 3 and self.posttrans.is_affine
+                and (not self.residual or self.in_dim == self.out_dim) and 0 < h.shape[0] <= PF.SMALL_SIMPLE_ROWS
+                and PF.small_tower_fits(1, self.in_dim, self.out_dim, False, self.out_dim)):
+            return False
+        return not (torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in self.parameters())))
+
     def forward(self, g, h):
         graph = as_graph(g)
+        if self._small_batch_path(graph, h):
+            return PF.simple_layer_small(self, graph, h, _row_scales(graph, self.scalers, self.avg_d, h.device))
         h_in = h
         # (V, A*F), identity scaler only; on a sharded graph the halo exchange overlaps the rows that do not need it
         agg = PF.aggregate(graph, graph.source_features(h, defer=True), self.in_dim, self.aggregators)

@@ -277,6 +277,61 @@ class _SmallTowerPlan:
         return out
 
 
+class _SmallSimplePlan(_SmallTowerPlan):
+    """PNASimpleLayer (models/dgl/pna_layer.py:197-216, eval mode) on the same one-call kernel: a tower layer with ONE tower,
+    the identity as pretrans (messages are the raw source features: x_cat = [I ; 0] h), no self panel in the posttrans
+    (W_h = 0), and the identity as mixing network with the layer's ReLU and residual in its epilogue.  Products with 1 and sums
+    with 0 are exact: the result is the three-kernel path's up to the summation order of the contraction."""
+
+    def __init__(self, layer):
+        import ctypes
+        from . import _lib
+        lin = layer.posttrans.fully_connected[0].linear
+        bn = layer.batchnorm_h if layer.batch_norm else None
+        if bn is not None and bn.training:
+            raise RuntimeError("only an eval-mode BatchNorm (running statistics) can be folded into the epilogue")
+        self.ts = [x for x in (lin.weight, lin.bias) if x is not None] + \
+                  ([x for x in (bn.weight, bn.bias, bn.running_mean, bn.running_var) if x is not None] if bn is not None else [])
+        self.versions = [x._version for x in self.ts]
+        Fi, Fo, S = layer.in_dim, layer.out_dim, len(layer.scalers)
+        self.T, self.Fi, self.Fo, self.S, self.divide_input = 1, Fi, Fo, S, False
+        dev = lin.weight.device
+        with torch.no_grad():
+            eye = torch.eye(Fi, device=dev)
+            w_ext = torch.cat([torch.zeros(Fo, Fi, device=dev), lin.weight], dim=1).contiguous()      # [h panel = 0 | scaler blocks]
+            keep = dict(proj_img=ops.pack_small(torch.cat([eye, torch.zeros_like(eye)], dim=0).contiguous()),
+                        proj_bias=torch.zeros(2 * Fi, device=dev),
+                        post_img=ops.pack_tower_post([w_ext], Fi, Fo, S),
+                        post_bias=lin.bias.detach().contiguous() if lin.bias is not None else None,
+                        mix_img=ops.pack_small(torch.eye(Fo, device=dev)), mix_bias=None)
+            if bn is not None:
+                keep["col_scale"], keep["col_shift"] = (x.contiguous() for x in _fold_batchnorm(bn))
+        self.keep, self.device, self.width, self.xw, self.graph_norm = keep, dev, Fo, 2 * Fi, False
+        a = _lib.PnaTowerLayerArgs()
+        a.n_tower, a.Fi, a.Fo, a.divide_input, a.n_scaler = 1, Fi, Fo, 0, S
+        for k, v in keep.items():
+            if v is not None:
+                setattr(a, k, _lib.dev_ptr(v, torch.float32, k))
+        a.No, a.mix_act = Fo, 1                                # ReLU (pna_layer.py:211)
+        self.args, self.ref = a, ctypes.byref(a)
+        self.fn = _lib.lib().pna_tower_layer_f32
+        self.check, self.stream_ptr = _lib.check, _lib.stream_ptr
+
+
+SMALL_SIMPLE_ROWS = int(os.environ.get("PNA_AMD_SMALL_SIMPLE_ROWS", "4096"))   # PNASimpleLayer batches up to this many nodes (measured
+# crossover with the three-kernel path at hidden 80: 0.026 vs 0.048 ms at 1.6-3 k nodes, equal at 6.4 k, 0.087 vs 0.056 at 13 k:
+# profiles/r02_small_simple_layer.json)
+
+
+def simple_layer_small(layer, graph, h, row_scales):
+    """PNASimpleLayer.forward (eval) through pna_tower_layer_f32; the plan is cached on the layer."""
+    plan = layer.__dict__.get("_pna_amd_small")
+    if plan is None or plan.stale():
+        plan = _SmallSimplePlan(layer)
+        layer.__dict__["_pna_amd_small"] = plan
+    return plan.run(graph, h, None, row_scales, layer.residual)
+
+
 def tower_layer_small(owner, towers, mix, graph, h, snorm_n, row_scales, divide_input, residual):
     """models/dgl/pna_layer.py:133-148 in eval mode through pna_tower_layer_f32.  `mix`: the mixing FCLayer (Linear + LeakyReLU /
     ReLU / none, no batch-norm) or None.  The plan is cached on `owner` (dropped by PNALayer._apply on device / dtype moves)."""

@@ -18,8 +18,15 @@ pytestmark = pytest.mark.gpu
 TOL = dict(rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("path", ["small-batch", "large-graph"])
 @pytest.mark.parametrize("name", golden_names("dgl_simple"))
-def test_simple_layer_golden(cuda_device, name):
+def test_simple_layer_golden(cuda_device, monkeypatch, name, path):
+    """Both code paths of PNASimpleLayer.forward against the reference's own outputs: the one-call layer of molecule-sized
+    batches (pna_tower_layer_f32 with the identity as pretrans and mixing network; fixtures it does not cover -- deeper
+    posttrans MLPs, other aggregator sets -- fall through) and the large-graph kernels (row limit of the former set to 0)."""
+    from pna_amd import functional as PF
+    if path == "large-graph":
+        monkeypatch.setattr(PF, "SMALL_SIMPLE_ROWS", 0)
     meta, a, sd = load_golden(name)
     layer = PNASimpleLayer(meta["F"], meta["out_dim"], meta["aggregators"], meta["scalers"], {"log": a["avg_log"]}, 0.0,
                            True, meta["residual"], posttrans_layers=meta["posttrans_layers"])
@@ -161,7 +168,7 @@ def test_dense_registry_operators(cuda_device):
         torch.testing.assert_close(got, O.dense_scale(name, m, adj, avg_d), rtol=1e-6, atol=1e-7)
 
 
-def test_sharded_layer_single_rank_rccl(cuda_device):
+def test_sharded_layer_single_rank_rccl(cuda_device, monkeypatch):
     """The multi-GPU code path (dst-range shard, halo all-to-all over RCCL, layer over [local | halo]) on a
     1-rank process group: exercises the NCCL/RCCL calls and shows the sharded layer equals the plain one."""
     import os
@@ -171,6 +178,8 @@ def test_sharded_layer_single_rank_rccl(cuda_device):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from pna_amd import functional as PF
+    monkeypatch.setattr(PF, "SMALL_SIMPLE_ROWS", 0)          # both sides on the large-graph kernels: bit-identical
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda_device)
     try:
         V, E, F = 3000, 30000, 20

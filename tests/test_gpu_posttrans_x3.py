@@ -273,6 +273,8 @@ def test_bf16x3_rejects_more_than_three_scalers():
 def _force_x3(monkeypatch):
     from pna_amd import ops
     monkeypatch.setattr(ops, "POSTTRANS_ARITH", "bf16x3")
+    from pna_amd import functional as PF
+    monkeypatch.setattr(PF, "SMALL_SIMPLE_ROWS", 0)          # (the one-call small-batch path has its own contraction)
 
 
 @pytest.mark.parametrize("name", __import__("conftest").golden_names("dgl_simple"))

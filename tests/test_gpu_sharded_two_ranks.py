@@ -31,7 +31,8 @@ def _worker(rank, world, port, V, E, F):
     torch.cuda.set_device(dev)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from pna_amd import Graph
+        from pna_amd import Graph, functional as PF
+        PF.SMALL_SIMPLE_ROWS = 0      # the unsharded reference below runs the large-graph kernels too (bit-identity is between those)
         from pna_amd.dgl.pna_layer import PNALayer, PNASimpleLayer
         from pna_amd.shard import shard_graph
         from pna_amd.synth import powerlaw_graph
