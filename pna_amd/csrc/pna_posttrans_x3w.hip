@@ -35,9 +35,6 @@
 #ifndef X3W_FINE
 #define X3W_FINE 1     // the operand split in 12 pieces, one behind each MFMA of group H (0: 6 pieces, one behind each MFMA pair)
 #endif
-#ifndef X3W_PF
-#define X3W_PF 0       // > 0: touch the A sectors this many steps ahead of their loads (L2 prefetch; measured)
-#endif
 #ifndef X3W_SKIP
 #define X3W_SKIP 0     // development (tools/x3w_variants.sh; results are garbage): 1 cheap epilogue, 2 no MFMAs, 4 no B reads,
 #endif                 // 8 no weight copies, 16 no A loads, 32 no operand split, 64 no soft barrier
@@ -224,19 +221,6 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[w]) : "v"(ptr) : "memory");
     }
   };
-#if X3W_PF > 0
-  // L2 touch: one 4-byte load per lane into a register nobody reads, X3W_PF (+1 for the upper lane half) steps ahead of the
-  // fragment loads, so that those find their 64-byte sector in L2 (they are covered by a counted wait 2.25 steps after issue:
-  // ~3 us at the pipe-bound step rate, which is what an HBM access takes under this load -- every hiccup stalled a step)
-  float pf_sink = 0.f;       // kept live to the end of the kernel: the loads land in it at unknown times
-  auto touch_a = [&](int t, int s) __attribute__((always_inline)) {
-    int ss = s + X3W_PF + lh, tt = t;
-    while (ss >= NS) { ss -= NS; tt += gridDim.x; }
-    const int row = min(tt * kTileRows + wave * kWaveRows + lc, g.M - 1);
-    const float* ptr = g.a + (size_t)row * g.lda + min(16 * ss, g.K - 4);
-    asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(ptr) : "memory");
-  };
-#endif
   // slot -> the three bf16 terms (the slot's loads are known to have landed: see the counted wait of the step loop).
   // take_fast is straight-line code, so that it can be scheduled between the MFMAs of a step; the rare cases it does not
   // handle -- a row's last K step reaching beyond K, an infinite element -- are redone by take_slow behind the MFMA stream.
@@ -670,7 +654,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
         // copies and the 2 A loads of this step.  Everything older has landed, the fragment of step j+2 (fetched in step j-2,
         // 2.25 steps ago) included.  VMEM returns in order: a wait that covered younger A loads made every step wait for HBM.
 #if !(X3W_SKIP & 64)
-        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 + NI + (X3W_PF > 0 ? 2 : 0)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 + NI) : "memory");
         arrive();
 #endif
       }
@@ -715,9 +699,6 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
           __builtin_amdgcn_sched_barrier(0);
           // step j+4's fragment, into the slot the split above has just emptied: 2.25 steps ahead of the counted wait that
           // covers it (rows clamp to M-1 beyond the last tile: harmless)
-#if X3W_PF > 0
-          touch_a(t4, s4);                         // (one more VMEM instruction per step, ahead of the loads: counted below)
-#endif
           if (!(X3W_SKIP & 16)) load_a(raw[R1], t4, s4);
           adv(t3, s3); adv(t4, s4);
           __builtin_amdgcn_sched_barrier(0);
@@ -762,9 +743,6 @@ __global__ __launch_bounds__(kThreads, 1) void k_posttrans_x3w(const WArgs g) {
     if (j + 2 < nsteps) step(std::integral_constant<int, 2>{}, j + 2);
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // the copies, re-loads and B reads issued for a step that does not exist
-#if X3W_PF > 0
-  asm volatile("" : : "v"(pf_sink));
-#endif
 }
 
 template <int S, int NTF, int NMIX, int NVC>
