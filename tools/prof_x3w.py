@@ -20,7 +20,7 @@ sc = [None, torch.rand(M, device=dev) + 0.5, torch.rand(M, device=dev) + 0.5]
 res = torch.randn(M, 80, device=dev)[:, :N]
 y = torch.empty(M, 80, device=dev)[:, :N]
 cs, ct = torch.rand(N, device=dev) + 0.5, torch.randn(N, device=dev)
-for wide in (False, True):
+for wide in (False, True):  # both kernels, same inputs
     ops.X3_WIDE = wide
     for _ in range(n):
         ops.posttrans(a, K, W, sc, b, arith="bf16x3", out=y, col_scale=cs, col_shift=ct, relu=True, residual=res)
