@@ -55,9 +55,63 @@ def parse():
                    help="c3 = BASELINE.json configs[2] (1M nodes / 10M edges per GPU, F=75: the configuration the metric is quoted on); "
                         "c5 = configs[4] (2M nodes / 20M edges per GPU, F=128: V=16M E=160M over 8 GPUs)")
     p.add_argument("--balance", choices=("nodes", "edges"), default="nodes", help="N > 1: destination ranges of equal node or in-edge counts")
+    p.add_argument("--no-power-probe", action="store_true", help="skip the rocm-smi power / clock samples (2 x ~1.5 s)")
     p.add_argument("--no-cold", action="store_true", help="skip the cold-cache leg (3 rotating copies of the inputs)")
     p.add_argument("--check-rows", type=int, default=96, help="rows re-computed on the host after the timed loop")
     return p.parse_args()
+
+
+def power_probe(fn, seconds=1.5):
+    """{"socket_w", "sclk_mhz"}: medians of rocm-smi samples taken while `fn` is launched back to back for `seconds`; None
+    when rocm-smi is missing or its output is not understood (reported, never fatal)."""
+    import shutil
+    import subprocess
+    import threading
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+    rows, stop = [], [False]
+
+    def poll():
+        while not stop[0]:
+            try:
+                out = subprocess.run([exe, "--showpower", "--showclocks", "--csv"], capture_output=True, text=True, timeout=5).stdout
+                lines = [ln for ln in out.strip().splitlines() if ln.startswith(("device", "card"))]
+                if len(lines) >= 2:
+                    rows.append(dict(zip(lines[0].split(","), lines[1].split(","))))
+            except Exception:                                         # noqa: BLE001
+                pass
+            time.sleep(0.2)
+
+    th = threading.Thread(target=poll, daemon=True)
+    try:
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        th.start()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+    finally:
+        stop[0] = True
+        if th.is_alive():
+            th.join(timeout=6)
+    watts, mhz = [], []
+    for r in rows[1:] or rows:                                         # (the first sample may predate the load)
+        for k, v in r.items():
+            try:
+                if "Power (W)" in k:
+                    watts.append(float(v))
+                elif k.startswith("sclk clock speed"):
+                    mhz.append(float(v.strip("()").lower().replace("mhz", "")))
+            except ValueError:
+                pass
+    if not watts or not mhz:
+        return None
+    med = lambda xs: sorted(xs)[len(xs) // 2]   # noqa: E731
+    return {"socket_w": med(watts), "sclk_mhz": med(mhz), "samples": len(watts)}
 
 
 def event_time_ms(fn, iters, warmup=3):
@@ -324,6 +378,13 @@ def main():
         t_post = event_time_ms(lambda: PF.posttrans(agg, 4 * F, lin.weight, lin.bias, [None, amp, att]), args.kernel_iters)
         t_post_f32 = event_time_ms(lambda: _ops.posttrans(agg, 4 * F, lin.weight, [None, amp, att], lin.bias, arith="f32"), args.kernel_iters)
         t_halo = event_time_ms(lambda: g.source_features(h), args.kernel_iters) if world > 1 else 0.0
+        # socket power and shader clock while each kernel runs alone (rocm-smi; best effort, N = 1 only): the bf16x3 contraction
+        # runs at the package power cap and the firmware lowers the clock to hold it -- the dense MFMA peak at THAT clock is the
+        # ceiling the kernel can be priced against (DESIGN.md 4.2c point 6, profiles/r02_power_probe.txt)
+        power = None
+        if world == 1 and not args.no_power_probe:
+            power = {"contraction": power_probe(lambda: PF.posttrans(agg, 4 * F, lin.weight, lin.bias, [None, amp, att])),
+                     "segment_reduce": power_probe(lambda: PF.aggregate(g, x_ext, F, AGGREGATORS.split()))}
     alg_read = e_local * (4 * F + 4) + 4 * (n_local + 1)
     alg_write = n_local * 16 * F
     alg_bytes = alg_read + alg_write
@@ -354,6 +415,8 @@ def main():
                          "frac": flops / (t_post * 1e-3) / (MFMA_BF16_PEAK / 6), "ms_per_launch": t_post, "traffic": traffic_post,
                          "traffic_source": traffic_source,
                          "bf16_tflops_issued": 6 * flops / (t_post * 1e-3) / 1e12,
+                         "frac_at_sustained_clock": (flops / (t_post * 1e-3) / (MFMA_BF16_PEAK / 6 * power["contraction"]["sclk_mhz"] / 2400.0)
+                                                     if power and power.get("contraction") else None),
                          "exact_f32_mfma_kernel": {"kernel": "k_posttrans<3,false,5> (pna_posttrans_f32)", "ms_per_launch": t_post_f32,
                                                    "achieved": flops / (t_post_f32 * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12,
                                                    "frac": flops / (t_post_f32 * 1e-3) / MFMA_F32_PEAK}}
@@ -385,6 +448,7 @@ def main():
                    "interior_rows_rank0": int(g.interior_mask().sum().item()) if world > 1 else None,
                    "local_rows_rank0": n_local, "local_edges_rank0": e_local, "partition_balance": args.balance if world > 1 else None},
         "roofline": roofline, "roofline_posttrans": roofline_post, "roofline_layer": roofline_layer,
+        "power_probe": power,
         "ms_per_step_cold": ms_per_step_cold, "value_cold": (E / (ms_per_step_cold * 1e-3)) if ms_per_step_cold else None,
         "parity_check": check,
         "kernel_ms": {"segreduce": t_seg, "posttrans": t_post, "posttrans_exact_f32_mfma": t_post_f32, "halo_all_to_all": t_halo,
