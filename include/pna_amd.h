@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define PNA_ABI_VERSION 8 /* 8: + pna_posttrans_x3w_* (the bf16x3 contraction on 32x32 matrix-core tiles).
+#define PNA_ABI_VERSION 9 /* 9: pna_posttrans_args.row_perm / tile_image / image_stride (degree-grouped contraction),
+                                pna_segreduce_args.heavy_out_rows.
+                             8: + pna_posttrans_x3w_* (the bf16x3 contraction on 32x32 matrix-core tiles).
                              7: + pna_small_*, pna_tower_post_*, pna_tower_layer_f32 (the molecule-batch tower layer).
                              6: pna_posttrans_args: act_slope (LeakyReLU), n_tower + tower strides.
                              5: pna_posttrans_args.pipeline; the hand-scheduled gather takes dst_term; + pna_pack_rows_f32.
@@ -168,6 +170,11 @@ typedef struct pna_segreduce_args {
   int32_t _pad2;
   int64_t n_edges; /* = rowptr[V] (length of col); required with work_items */
   pna_tuning tune;
+  /* ABI 9: where the aggregate of heavy row i (heavy_rows[i]) is written, as a row index of `out` (nullable: the row itself).
+   * Together with work_items whose `row` field holds the OUTPUT row of a whole-row record (the hand-scheduled kernel uses that
+   * field for nothing else when there is no dst_term) this lets a caller have the aggregate written in any row order -- e.g.
+   * grouped by in-degree for pna_posttrans_args.row_perm.  `out` must then have as many rows as the largest index + 1. */
+  const int32_t* heavy_out_rows;
 } pna_segreduce_args;
 
 /* Launches the kernels described above on `stream`. */
@@ -323,6 +330,20 @@ typedef struct pna_posttrans_args {
   int64_t tower_stride_w;
   int64_t tower_stride_wh;
   int64_t tower_stride_y;
+  /* Degree-grouped rows (ABI 9, pna_posttrans_x3_f32 only; NULL = off).  Every PNA scaler is a function of the in-degree
+   * alone (models/dgl/scalers.py:7-19), so for the rows of ONE degree D the three scaler blocks of the posttrans weight
+   * collapse into one:  sum_s scale_s(D) (W_s a) = (sum_s scale_s(D) W_s) a  -- a third of the multiply-adds.  The caller
+   * orders the rows by degree: `a`, `row_scale[]`, `row_post` are indexed by a VIRTUAL row v in [0, M) (M a multiple of 192:
+   * every degree group padded to whole 192-row tiles), row_perm[v] is the row of `y` / `residual` that virtual row v is (or
+   * -1: padding, nothing is stored), and tile t (virtual rows [192 t, 192 t + 192)) multiplies by the weight image number
+   * tile_image[t] of a buffer of images packed one after the other, image_stride BYTES apart (pna_posttrans_x3_pack_f32 of a
+   * (G * 80, K) matrix whose rows [80 g, 80 g + N) are group g's combined weight: G column blocks = G images).  tile_image
+   * NULL: every tile uses w_img as it is (the rows no group holds, with their per-row scalers: n_scaler = 3).
+   * Needs 64 < N <= 80, no h panel, n_tower <= 1, n_scaler 1 or 3.  pna_segreduce_args.work_items (row = output row) and
+   * heavy_out_rows write the aggregate in that virtual order in the first place. */
+  const int32_t* row_perm;
+  const int32_t* tile_image;
+  int64_t image_stride;
 } pna_posttrans_args;
 
 int pna_posttrans_f32(const pna_posttrans_args* args, pna_stream_t stream);

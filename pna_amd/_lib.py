@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to the HI
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpna_amd.so")
 
-PNA_ABI_VERSION = 8
+PNA_ABI_VERSION = 9
 PNA_MAX_AGGR = 8
 PNA_MAX_SCALER = 8
 
@@ -46,6 +46,7 @@ class PnaSegreduceArgs(ctypes.Structure):
         ("work_items", ctypes.c_void_p), ("n_work_items", ctypes.c_int32), ("_pad2", ctypes.c_int32),
         ("n_edges", ctypes.c_int64),
         ("tune", PnaTuning),
+        ("heavy_out_rows", ctypes.c_void_p),
     ]
 
 
@@ -85,6 +86,7 @@ class PnaPosttransArgs(ctypes.Structure):
         ("n_tower", ctypes.c_int32), ("_pad_t", ctypes.c_int32),
         ("tower_stride_a", ctypes.c_int64), ("tower_stride_h", ctypes.c_int64), ("tower_stride_w", ctypes.c_int64),
         ("tower_stride_wh", ctypes.c_int64), ("tower_stride_y", ctypes.c_int64),
+        ("row_perm", ctypes.c_void_p), ("tile_image", ctypes.c_void_p), ("image_stride", ctypes.c_int64),
     ]
 
 

@@ -58,6 +58,9 @@ struct XArgs {
   int M, K, N, Kh, relu, grid_x;
   float slope;                 // LeakyReLU slope (relu == 2), 0 for ReLU
   unsigned long long* dbg;     // experiments build only: per-wavefront phase timers (null otherwise)
+  // grouped mode (GRP kernels: pna_posttrans_args.row_perm): rows of `a` / row_scale / row_post are in a VIRTUAL order,
+  // perm[virtual row] = row of y / residual (or -1: padding, nothing stored); tile t multiplies by weight image tile_image[t]
+  const int* perm; const int* tile_image; long img_stride;
 };
 
 __device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(unsigned, x); }
@@ -150,8 +153,9 @@ __global__ void k_pack_x3(const float* w_ref, long ldw, int N, int K, int S, int
 // GEN: the generic epilogue (any M; rows and columns predicated per element) -- used only for the < 16 rows a matrix has
 // beyond a multiple of 16; otherwise the straight-line one, with wavefront tiles entirely past M skipped.  (Both in one
 // kernel made the compiler drain vmcnt at the top of every chunk: its scoreboard merges the two paths conservatively.)
-template <int S, bool HAS_H, int kNW, int NT, int RT, int WAVES, int NBUF, bool GEN>
+template <int S, bool HAS_H, int kNW, int NT, int RT, int WAVES, int NBUF, bool GEN, bool GRP = false>
 __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
+  static_assert(!GRP || (NBUF == 3 && !GEN && !HAS_H && RT == 1), "grouped mode: 3-buffer pipeline, straight-line epilogue, no h panel");
   constexpr int kPanelB = panel_bytes(kNW), kPanelV = kPanelB / 16;
   constexpr int kThreads = WAVES * 64;
   constexpr int kChunkV = 3 * S * kPanelV;     // 16-byte pieces of an aggregate chunk image (the h chunk is 3 * kPanelV)
@@ -184,8 +188,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
   // chunk image -> LDS buffer, asynchronously; every wavefront copies whole 1 KB pieces (the piece counts are
   // multiples of 64), destination = wave-uniform base + lane * 16
   constexpr int NI = (kChunkV + kThreads - 1) / kThreads;   // global_load_lds instructions per wavefront per chunk
-  auto stage_piece = [&](int c, int buf, int i) __attribute__((always_inline)) {
-    const unsigned char* src = img_a + (size_t)c * kChunkV * 16;
+  auto stage_piece = [&](int c, int buf, int i, long ib = 0) __attribute__((always_inline)) {   // ib: byte offset of the tile's image (GRP)
+    const unsigned char* src = img_a + ib + (size_t)c * kChunkV * 16;
     int pieces = kChunkV;
     if constexpr (HAS_H) {
       if (c >= nca) { src = img_h + (size_t)(c - nca) * 3 * kPanelV * 16; pieces = 3 * kPanelV; }
@@ -202,9 +206,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(w0 + lane) * 16),
                                      (__attribute__((address_space(3))) void*)(dst + (size_t)w0 * 16), 16, 0, 0);
   };
-  auto stage = [&](int c, int buf) __attribute__((always_inline)) {
+  auto stage = [&](int c, int buf, long ib = 0) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) stage_piece(c, buf, i);
+    for (int i = 0; i < NI; ++i) stage_piece(c, buf, i, ib);
   };
 
   // A operand of (tile t, chunk c), row tile r: floats [k, k+4) and [k+16, k+20) of the lane's row, k = 32c + 4 lg, as two
@@ -390,14 +394,20 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
       for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 4; ++r) res[n][r] = 0.f;
+      // GRP: the lane's four rows of y / residual are perm[row0 + rl .. + 3] (one 16-byte load; -1 = padding: loads re-read
+      // row 0, stores are skipped)
+      typedef int i4 __attribute__((ext_vector_type(4)));
+      i4 pr = (i4){0, 0, 0, 0};
+      if constexpr (GRP) pr = *reinterpret_cast<const i4*>(g.perm + row0 + (int)rl);
       if (g.residual) {
-        const char* rbase = reinterpret_cast<const char*>(g.residual + (size_t)row0 * g.ld_res);
+        const char* rbase = reinterpret_cast<const char*>(g.residual + (GRP ? (size_t)0 : (size_t)row0 * g.ld_res));
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const unsigned cc = (unsigned)min(n0 + n * 16 + li_, g.N - 1);
-          const unsigned vo = rl * ldrb + cc * 4u;
+          const unsigned vo = (GRP ? 0u : rl * ldrb) + cc * 4u;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) res[n][r] = *reinterpret_cast<const float*>(rbase + (size_t)r * ldrb + vo);
+          for (int r = 0; r < 4; ++r)
+            res[n][r] = *reinterpret_cast<const float*>(rbase + (GRP ? (size_t)(unsigned)max(pr[r], 0) * ldrb : (size_t)r * ldrb) + vo);
         }
       }
       // Every load above is waited for HERE, once, ahead of the first (predicated) store: otherwise the compiler
@@ -408,8 +418,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
       asm volatile("" : "+v"(rpv));
 #pragma unroll
       for (int n = 0; n < NT; ++n) asm volatile("" : "+v"(res[n][0]), "+v"(res[n][1]), "+v"(res[n][2]), "+v"(res[n][3]));
-      char* const ybase = reinterpret_cast<char*>(g.y + (size_t)row0 * g.ldy);
-      const unsigned yo = rl * ldyb + (unsigned)(n0 + li_) * 4u;
+      asm volatile("" : "+v"(pr));
+      char* const ybase = reinterpret_cast<char*>(g.y + (GRP ? (size_t)0 : (size_t)row0 * g.ldy));
+      const unsigned yo = (GRP ? 0u : rl * ldyb) + (unsigned)(n0 + li_) * 4u;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const int cl = n * 16 + li_;
@@ -427,7 +438,13 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
 #pragma unroll
           for (int p = 0; p < P; ++p) acc[rt][p][n][r] = 0.f;
         }
-        if (n0 + (n + 1) * 16 <= g.N) {                 // wave-uniform: the whole column tile exists
+        if constexpr (GRP) {
+          if (n0 + cl < g.N) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (pr[r] >= 0) *reinterpret_cast<float*>(ybase + (size_t)(unsigned)pr[r] * ldyb + (yo + n * 64u)) = v[r];
+          }
+        } else if (n0 + (n + 1) * 16 <= g.N) {                 // wave-uniform: the whole column tile exists
 #pragma unroll
           for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(ybase + (size_t)r * ldyb + (yo + n * 64u)) = v[r];
         } else if (n0 + cl < g.N) {
@@ -531,8 +548,22 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
     const int nsteps = my_tiles * nc;
     int t = blockIdx.x, c = 0, buf = 0;
     if (t >= ntiles) return;
-    stage(0, 0);
-    if (nsteps > 1) stage(nc > 1 ? 1 : 0, 1);
+    // GRP: the weight image of a tile is tile_image[tile]; the ids of this workgroup's tiles sit in an LDS table that the
+    // step loop reads through inline asm when the tile of step k+2 changes (an LDS read the compiler can see would make it
+    // drain vmcnt(0) first: the LDS-DMA copies in flight might alias it)
+    int* const timg = reinterpret_cast<int*>(colc + 3 * kNW);
+    long ib2 = 0;                                // byte offset of the image of step k+2's tile
+    int ti = 0, ti2_seen = -1;                   // local index of step k's tile | of the tile ib2 belongs to
+    if constexpr (GRP) {
+      for (int i = tid; i < my_tiles; i += kThreads) timg[i] = g.tile_image ? g.tile_image[blockIdx.x + i * (int)gridDim.x] : 0;
+      const long ib0 = g.tile_image ? (long)g.tile_image[t] * g.img_stride : 0;
+      const long ib1 = (nc > 1 || my_tiles < 2 || !g.tile_image) ? ib0 : (long)g.tile_image[t + (int)gridDim.x] * g.img_stride;
+      stage(0, 0, ib0);
+      if (nsteps > 1) stage(nc > 1 ? 1 : 0, 1, ib1);
+    } else {
+      stage(0, 0);
+      if (nsteps > 1) stage(nc > 1 ? 1 : 0, 1);
+    }
     load_a(nxt[0], t, 0);
     take(nxt[0], 0, 0);                         // vmcnt(0): both images and the first A fragment have landed
     {
@@ -554,6 +585,16 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
       int t2 = tn, c2 = cn + 1;
       if (c2 == nc) { t2 = tn + gridDim.x; c2 = 0; }       // (tile, chunk) of step k+2
       const bool more1 = k + 1 < nsteps, more2 = k + 2 < nsteps;
+      if constexpr (GRP) {
+        const int ti2 = min(ti + (c + 1 == nc ? 1 : 0) + (cn + 1 == nc ? 1 : 0), my_tiles - 1);
+        if (ti2 != ti2_seen) {                             // (wave-uniform; once per tile)
+          int v;
+          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v)
+                       : "v"((unsigned)(size_t)(__attribute__((address_space(3))) int*)(timg + ti2)) : "memory");
+          ib2 = (long)v * g.img_stride;
+          ti2_seen = ti2;
+        }
+      }
       const int buf2 = buf == 0 ? 2 : buf - 1;             // (k + 2) % 3
       const bool is_h = HAS_H && c >= nca;
       const unsigned baddr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(buf * kChunkV + lg * kNW + li) * 16u;
@@ -603,7 +644,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
           if (more2) {
 #pragma unroll
             for (int i = 0; i < NI; ++i)
-              if (gi >= H && (NG - 1 > H ? H + 1 + (i * (NG - 1 - H)) / NI : H) == gi) stage_piece(c2, buf2, i);
+              if (gi >= H && (NG - 1 > H ? H + 1 + (i * (NG - 1 - H)) / NI : H) == gi) stage_piece(c2, buf2, i, GRP ? ib2 : 0);
           }
 #pragma unroll
           for (int pp = 0; pp < 6; ++pp)
@@ -639,6 +680,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
         tacc[6] += 1;
       }
 #endif
+      if (GRP && cn == 0) ++ti;
       t = tn; c = cn; buf = buf == 2 ? 0 : buf + 1;
     };
 #ifdef PNA_AMD_EXPERIMENTS
@@ -667,6 +709,21 @@ int launch_v(const XArgs& g, hipStream_t st) {
   const int ntiles = (g.M + WAVES * 16 * RT - 1) / (WAVES * 16 * RT);
   const dim3 grid((unsigned)(ntiles < g.grid_x ? ntiles : g.grid_x), (unsigned)((g.N + kNW - 1) / kNW));
   hipLaunchKernelGGL((k_posttrans_x3<S, HAS_H, kNW, NT, RT, WAVES, NBUF, GEN>), grid, dim3(WAVES * 64), lds, st, g);
+  return 0;
+}
+
+// grouped mode (XArgs.perm): M is a multiple of the workgroup tile, N in (64, 80], no h panel
+template <int S>
+int launch_grouped(const XArgs& g, hipStream_t st) {
+  constexpr int kNW = 80, NT = 5, RT = 1, WAVES = 12, NBUF = 3;
+  const int ntiles = g.M / (WAVES * 16 * RT);
+  const int gx = ntiles < g.grid_x ? ntiles : g.grid_x;
+  const int per_wg = (ntiles + gx - 1) / gx;
+  const size_t lds = (size_t)NBUF * 3 * S * panel_bytes(kNW) + (size_t)(3 * kNW) * sizeof(float) + (size_t)per_wg * sizeof(int);
+  if (lds > 160 * 1024 ||
+      hipFuncSetAttribute((const void*)k_posttrans_x3<S, false, kNW, NT, RT, WAVES, NBUF, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return -1;
+  hipLaunchKernelGGL((k_posttrans_x3<S, false, kNW, NT, RT, WAVES, NBUF, false, true>), dim3((unsigned)gx, 1), dim3(WAVES * 64), lds, st, g);
   return 0;
 }
 
@@ -786,6 +843,18 @@ extern "C" int pna_posttrans_x3_f32(const pna_posttrans_args* p, pna_stream_t st
     g.grid_x = (cus + ny - 1) / ny;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (p->row_perm) {
+    // rows in a virtual order (degree groups): see include/pna_amd.h
+    if (has_h || T > 1 || p->N <= 64 || p->N > 80 || p->M % 192 != 0 || (p->n_scaler != 1 && p->n_scaler != 3) || (p->pipeline != 0 && p->pipeline != 3) ||
+        (p->tile_image && p->image_stride <= 0) || (int64_t)p->ldy * 4 >= (1ll << 32) || (p->residual && (int64_t)p->ld_res * 4 >= (1ll << 32)))
+      return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3_f32: row_perm needs 64 < N <= 80, M % 192 == 0, 1 or 3 scalers, no h panel / towers");
+    g.perm = p->row_perm; g.tile_image = p->tile_image; g.img_stride = p->tile_image ? p->image_stride : 0;
+    const int rc2 = p->n_scaler == 1 ? launch_grouped<1>(g, st) : launch_grouped<3>(g, st);
+    if (rc2 != 0) return pna_set_error(PNA_E_LAUNCH, "pna_posttrans_x3_f32: could not reserve LDS (grouped mode)");
+    hipError_t e2 = hipGetLastError();
+    if (e2 != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e2));
+    return PNA_OK;
+  }
   const int nt = p->N >= 80 ? 5 : (p->N + 15) / 16;      // (80-column blocks; launch_nt switches to one 128-column block itself)
   int rc;
   const int pl = p->pipeline, shape = 0;

@@ -57,6 +57,7 @@ struct KArgs {
   const float* row_scale[PNA_MAX_SCALER];
   float* out; int32_t* argmax; int32_t* argmin;
   const int32_t* heavy_rows; const int32_t* heavy_segptr; const int32_t* seg_heavy; float* partials;
+  const int32_t* heavy_out;   // nullable: output row of heavy row i (pna_segreduce_args.heavy_out_rows), else the row itself
   long ldx, ld_dst, ld_edge, ldo, ld_arg, ts_in, ts_out;
   int V, F, n_aggr, n_scaler, block_stride;
   int aggr[PNA_MAX_AGGR];
@@ -241,7 +242,8 @@ __device__ __forceinline__ void walk(const KArgs& a, Acc<VEC, EXTRA>& acc, int r
 // scaler-major / aggregator-minor block order.
 template <int VEC, bool EXTRA>
 __device__ __forceinline__ void finalize_store(const KArgs& a, const Acc<VEC, EXTRA>& acc, int row, int deg,
-                                               long offi, long offo) {
+                                               long offi, long offo, int orow = -1) {
+  if (orow < 0) orow = row;                                // (orow: where the row's aggregate goes when the caller re-orders rows)
   float mean[VEC], var[VEC], vraw[VEC], sd[VEC], mx[VEC], mn[VEC];
   const bool empty = deg <= 0;
   const float D = (EXTRA && a.ew) ? acc.wsum : (float)deg;
@@ -279,7 +281,7 @@ __device__ __forceinline__ void finalize_store(const KArgs& a, const Acc<VEC, EX
         }
         o[k] = empty ? 0.f : v * sc;
       }
-      Ld<VEC>::store(a.out + (size_t)row * a.ldo + (size_t)(s * a.n_aggr + i) * a.block_stride + offo, o, a.nt != 0);
+      Ld<VEC>::store(a.out + (size_t)orow * a.ldo + (size_t)(s * a.n_aggr + i) * a.block_stride + offo, o, a.nt != 0);
     }
   }
   if constexpr (EXTRA) {
@@ -695,7 +697,8 @@ __global__ __launch_bounds__(kBlock) void k_heavy_finalize(const KArgs a) {
     const float pw = EXTRA ? __shfl(acc.wsum, src) : 0.f;
     if (grp == 0) merge(ps, pq, pmx, pmn, pax, pan, pw);
   }
-  if (grp == 0 && chunk < nchunks) finalize_store<VEC, EXTRA>(a, acc, row, a.rowptr[row + 1] - a.rowptr[row], offi, offo);
+  if (grp == 0 && chunk < nchunks)
+    finalize_store<VEC, EXTRA>(a, acc, row, a.rowptr[row + 1] - a.rowptr[row], offi, offo, a.heavy_out ? a.heavy_out[hi] : -1);
 }
 
 // models/dgl/scalers.py:12-19 with the reference's rounding sequence (see pna_amd.h).
@@ -774,6 +777,7 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
   for (int s = 0; s < p->n_scaler; ++s) k.row_scale[s] = p->row_scale[s];
   k.out = p->out; k.argmax = p->argmax; k.argmin = p->argmin;
   k.heavy_rows = p->heavy_rows; k.heavy_segptr = p->heavy_segptr; k.seg_heavy = p->seg_heavy; k.partials = p->partials;
+  k.heavy_out = p->heavy_out_rows;
   k.ldx = p->ldx; k.ld_dst = p->ld_dst; k.ld_edge = p->ld_edge; k.ldo = p->ldo; k.ld_arg = p->ld_arg;
   k.V = p->V; k.F = p->F; k.n_aggr = p->n_aggr; k.n_scaler = p->n_scaler; k.block_stride = p->block_stride;
   for (int i = 0; i < p->n_aggr; ++i) k.aggr[i] = p->aggr[i];

@@ -1,0 +1,132 @@
+"""Degree-grouped posttrans of PNASimpleLayer (inference, large graphs).
+
+Every PNA scaler is a function of the destination's in-degree alone (models/dgl/scalers.py:7-19: identity, amplification
+log(D+1)/delta, attenuation delta/log(D+1), ...).  The posttrans Linear of the simple layer (models/dgl/pna_layer.py:206) sees
+[s_0(D) a | s_1(D) a | s_2(D) a] with the SAME aggregate `a` in every block, so for all rows of one in-degree D
+
+    sum_s s_s(D) (W_s a)  =  (sum_s s_s(D) W_s) a  =  W_D a            (K = 4F instead of 3 * 4F multiply-adds per output)
+
+The reference never uses this (it concatenates 12F columns and calls nn.Linear); here the rows are ordered by degree once per
+graph, the gather kernel writes the aggregate in that order (its work list carries the output row), and the bf16x3 contraction
+runs with ONE scaler block and a per-tile weight image W_D.  On the power-law benchmark graph 58 degree values cover 99.5 % of
+the rows; the rest (rare degrees, hub rows) go through the ordinary three-block contraction over a compacted row list.
+Both launches scatter their output rows back to node order (pna_posttrans_args.row_perm), so nothing else sees the order.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+TILE = 192                 # rows of a workgroup tile of k_posttrans_x3 (12 wavefronts x 16 rows)
+MIN_ROWS = 1 << 17         # graphs smaller than this keep the ordinary path (the grouping is worth it when launches are long)
+ENABLED = True
+
+
+class DegreePlan:
+    """Row order, work list and tile -> group table of one graph (cached on the Graph; independent of weights / scalers)."""
+
+    def __init__(self, graph):
+        csr, hs = graph.csr, graph.heavy_schedule()
+        dev = csr.rowptr.device
+        rp = csr.rowptr.long()
+        deg = rp[1:] - rp[:-1]
+        V = deg.numel()
+        order = torch.sort(deg, stable=True).indices                     # rows by in-degree (ties: ascending row id)
+        ud, cnt = torch.unique_consecutive(deg[order], return_counts=True)
+        big = (cnt >= TILE) & (ud <= hs.threshold)                       # degree values with at least one whole tile of light rows
+        start = torch.cumsum(cnt, 0) - cnt
+        gid = torch.repeat_interleave(torch.arange(ud.numel(), device=dev), cnt)     # group of every sorted row
+        in_big = big[gid]
+        padded = (cnt[big] + TILE - 1) // TILE * TILE
+        vstart = torch.cumsum(padded, 0) - padded
+        big_index = torch.cumsum(big.long(), 0) - 1
+        self.NV = int(padded.sum().item()) if padded.numel() else 0
+        self.G = int(big.sum().item())
+        perm = torch.full((max(self.NV, 1),), -1, dtype=torch.int32, device=dev)
+        rank = torch.arange(V, device=dev) - start[gid]
+        vpos = (vstart[big_index[gid].clamp(min=0)] + rank)[in_big]
+        perm[vpos] = order[in_big].to(torch.int32)
+        self.perm = perm[:self.NV].contiguous()
+        self.tile_image = torch.repeat_interleave(torch.arange(self.G, device=dev, dtype=torch.int32), padded // TILE).contiguous()
+        self.group_first_row = order[start[big]] if self.G else order[:0]           # a row of each group (its scalers = the group's)
+        self.group_degree = ud[big]
+        rest = order[~in_big]
+        self.NR = int(rest.numel())
+        self.NRp = (self.NR + TILE - 1) // TILE * TILE
+        perm_rest = torch.full((max(self.NRp, 1),), -1, dtype=torch.int32, device=dev)
+        perm_rest[:self.NR] = rest.to(torch.int32)
+        self.perm_rest = perm_rest[:self.NRp].contiguous()
+        self.rest_rows = rest
+        # virtual position of every node in the (NV + NRp)-row aggregate buffer
+        vmap = torch.empty(V, dtype=torch.long, device=dev)
+        vmap[order[in_big]] = vpos
+        vmap[rest] = self.NV + torch.arange(self.NR, device=dev)
+        items = graph.work_items().clone()
+        n_seg = hs.n_seg if hs.n_heavy > 0 else 0
+        items[n_seg:, 0] = vmap[items[n_seg:, 0].long()].to(torch.int32)  # whole-row records: `row` = output row (nothing else uses it)
+        self.items = items.contiguous()
+        self.heavy_out = vmap[hs.heavy_rows.long()].to(torch.int32).contiguous() if hs.n_heavy > 0 else None
+        self.rows = self.NV + self.NRp
+        self._rest_scales = {}
+
+    def rest_scales(self, key, row_scales):
+        """The per-row scalers of the rest rows in their virtual order (padding: 0), cached per scaler set."""
+        hit = self._rest_scales.get(key)
+        if hit is None:
+            out = []
+            for rs in row_scales:
+                if rs is None:
+                    out.append(None)
+                else:
+                    v = torch.zeros(max(self.NRp, 1), dtype=torch.float32, device=rs.device)
+                    v[:self.NR] = rs[self.rest_rows]
+                    out.append(v[:self.NRp].contiguous())
+            hit = self._rest_scales[key] = out
+        return hit
+
+
+def plan_of(graph):
+    plan = graph.__dict__.get("_pna_amd_degree_plan")
+    if plan is None:
+        plan = graph.__dict__["_pna_amd_degree_plan"] = DegreePlan(graph)
+    return plan
+
+
+def combined_images(weight, K, row_scales, plan):
+    """Packed bf16x3 images of W_D = sum_s s_s(D) W_s for every group of `plan` (one buffer, image_stride bytes apart), cached
+    on the weight per (version, scaler tensors, plan)."""
+    key = (weight._version, weight.data_ptr(), str(weight.device), tuple(weight.shape), K, id(plan),
+           tuple(None if rs is None else (rs.data_ptr(), rs._version) for rs in row_scales))
+    hit = getattr(weight, "_pna_amd_group_img", None)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    N, G = weight.shape[0], plan.G
+    with torch.no_grad():
+        wc = None
+        for s, rs in enumerate(row_scales):
+            ws = weight[:, s * K:(s + 1) * K]
+            term = ws.unsqueeze(0).expand(G, N, K) if rs is None else rs[plan.group_first_row].view(G, 1, 1) * ws.unsqueeze(0)
+            wc = term.clone() if wc is None else wc + term          # scaler order, like the reference's blocks
+        w_all = torch.zeros(G, 80, K, dtype=torch.float32, device=weight.device)
+        w_all[:, :N] = wc
+        w_all = w_all.view(G * 80, K)
+    L = _lib.lib()
+    nh = ctypes.c_int64(0)
+    nb = L.pna_posttrans_x3_packed_bytes(K, G * 80, 1, 0, ctypes.byref(nh))
+    img = torch.empty(nb // 4, dtype=torch.float32, device=weight.device)
+    rc = L.pna_posttrans_x3_pack_f32(_lib.dev_ptr(w_all, torch.float32, "weight"), K, G * 80, K, 1, 0,
+                                     _lib.dev_ptr(img, torch.float32, "w_img"), None, _lib.stream_ptr(weight.device))
+    _lib.check(rc, "pna_posttrans_x3_pack_f32")
+    stride = nb // G
+    try:
+        weight._pna_amd_group_img = (key, img, stride)
+    except AttributeError:
+        pass
+    return img, stride
+
+
+def applies(graph, V, N, n_scaler, aggregators):
+    from .graph import Graph
+    return (ENABLED and type(graph) is Graph and V >= MIN_ROWS and 64 < N <= 80 and n_scaler == 3
+            and tuple(aggregators) == ("mean", "max", "min", "std") and V * 80 * 4 < (1 << 32))

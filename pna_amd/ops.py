@@ -44,7 +44,7 @@ def segreduce(rowptr: torch.Tensor, col: Optional[torch.Tensor], x: torch.Tensor
               out: Optional[torch.Tensor] = None, block_stride: Optional[int] = None,
               tower_stride_out: Optional[int] = None, want_arg: bool = False,
               heavy: Optional[HeavySchedule] = None, workspace=None, tune: Optional[dict] = None,
-              items: Optional[torch.Tensor] = None):
+              items: Optional[torch.Tensor] = None, heavy_out: Optional[torch.Tensor] = None):
     """out[v, t*tso + (s*A + a)*bs + f] = aggregators[a]({m_k}) [f] * row_scales[s][v]   (see pna_amd.h).
 
     rowptr:int32[V+1]; col:int32[E] or None (x edge-resident); x:(rows, >= T*F) fp32.
@@ -90,6 +90,8 @@ def segreduce(rowptr: torch.Tensor, col: Optional[torch.Tensor], x: torch.Tensor
     if heavy is not None and heavy.n_heavy > 0:
         a.heavy_threshold, a.seg_len, a.n_heavy, a.n_seg = heavy.threshold, heavy.seg_len, heavy.n_heavy, heavy.n_seg
         a.heavy_rows = _lib.dev_ptr(heavy.heavy_rows, torch.int32, "heavy_rows")
+        if heavy_out is not None:                  # output row of every heavy row (re-ordered aggregates: include/pna_amd.h)
+            a.heavy_out_rows = _lib.dev_ptr(heavy_out, torch.int32, "heavy_out")
         a.heavy_segptr = _lib.dev_ptr(heavy.heavy_segptr, torch.int32, "heavy_segptr")
         a.seg_heavy = _lib.dev_ptr(heavy.seg_heavy, torch.int32, "seg_heavy")
         nbytes = _lib.lib().pna_segreduce_partials_bytes(heavy.n_seg, F, T)
@@ -189,14 +191,20 @@ def posttrans(a_mat: torch.Tensor, K: int, weight: torch.Tensor, row_scales: Seq
               bias: Optional[torch.Tensor] = None, h: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
               row_post: Optional[torch.Tensor] = None, col_scale: Optional[torch.Tensor] = None,
               col_shift: Optional[torch.Tensor] = None, relu: bool = False, residual: Optional[torch.Tensor] = None,
-              arith: Optional[str] = None, pipeline: int = 0, leaky_slope: Optional[float] = None):
+              arith: Optional[str] = None, pipeline: int = 0, leaky_slope: Optional[float] = None,
+              row_perm: Optional[torch.Tensor] = None, tile_image: Optional[torch.Tensor] = None, w_img=None, image_stride: int = 0,
+              n_out: Optional[int] = None):
     """y = residual + act(((bias + h@Wh^T + sum_s row_scales[s][:,None] * (a[:, :K] @ W_s^T)) * row_post[:,None]) *
     col_scale + col_shift)                                                                      (see pna_amd.h).
 
     a_mat:(M, >=K) fp32; weight:(N, Kh + S*K) in the reference nn.Linear layout (columns [h | scaler blocks]).
     """
-    M, S, N = a_mat.shape[0], len(row_scales), weight.shape[0]
+    M, S = a_mat.shape[0], len(row_scales)
+    N = weight.shape[0] if n_out is None else n_out
     Kh = 0 if h is None else h.shape[1]
+    if row_perm is not None:
+        return _posttrans_grouped(a_mat, K, weight, row_scales, bias, out, row_post, col_scale, col_shift, relu, residual, leaky_slope,
+                                  row_perm, tile_image, w_img, image_stride, N)
     if weight.shape[1] != Kh + S * K:
         raise ValueError(f"weight has {weight.shape[1]} input columns, expected Kh + n_scaler*K = {Kh + S * K}")
     dev = a_mat.device
@@ -241,6 +249,40 @@ def posttrans(a_mat: torch.Tensor, K: int, weight: torch.Tensor, row_scales: Seq
     fn = "pna_posttrans_x3w_f32" if wide else "pna_posttrans_x3_f32" if x3 else "pna_posttrans_f32"
     rc = getattr(_lib.lib(), fn)(ctypes.byref(g), _lib.stream_ptr(dev))
     _lib.check(rc, fn)
+    return out
+
+
+def _posttrans_grouped(a_mat, K, weight, row_scales, bias, out, row_post, col_scale, col_shift, relu, residual, leaky_slope,
+                       row_perm, tile_image, w_img, image_stride, N):
+    """pna_posttrans_x3_f32 with rows in a virtual order (include/pna_amd.h, pna_posttrans_args.row_perm): `a_mat`, `row_scales`,
+    `row_post` are indexed by virtual row, `out` / `residual` by row_perm[virtual row].  `w_img`: a packed bf16x3 image buffer
+    (tile_image given: image tile_image[t] for tile t, image_stride bytes apart) or None (pack `weight` as usual)."""
+    M, S = a_mat.shape[0], len(row_scales)
+    if out is None:
+        raise ValueError("grouped posttrans writes into a caller-provided `out` (rows in real order)")
+    if w_img is None:
+        w_img, _ = pack_posttrans_weight_x3(weight, K, S, 0)
+    g = _lib.PnaPosttransArgs()
+    g.a, g.lda, g.M, g.K, g.N, g.n_scaler = _lib.dev_ptr(a_mat, torch.float32, "a"), _ld(a_mat), M, K, N, S
+    for i, rs in enumerate(row_scales):
+        if rs is not None:
+            g.row_scale[i] = _lib.dev_ptr(rs, torch.float32, "row_scale").value
+    g.w_img = _lib.dev_ptr(w_img, torch.float32, "w_img")
+    g.bias = _lib.dev_ptr(bias, torch.float32, "bias")
+    if row_post is not None:
+        g.row_post = _lib.dev_ptr(row_post, torch.float32, "row_post")
+    g.col_scale = _lib.dev_ptr(col_scale, torch.float32, "col_scale")
+    g.col_shift = _lib.dev_ptr(col_shift, torch.float32, "col_shift")
+    g.relu = 2 if leaky_slope is not None else (1 if relu else 0)
+    g.act_slope = float(leaky_slope) if leaky_slope is not None else 0.0
+    if residual is not None:
+        g.residual, g.ld_res = _lib.dev_ptr(residual, torch.float32, "residual"), _ld(residual)
+    g.y, g.ldy = _lib.dev_ptr(out, torch.float32, "y"), _ld(out)
+    g.row_perm = _lib.dev_ptr(row_perm, torch.int32, "row_perm")
+    if tile_image is not None:
+        g.tile_image, g.image_stride = _lib.dev_ptr(tile_image, torch.int32, "tile_image"), int(image_stride)
+    rc = _lib.lib().pna_posttrans_x3_f32(ctypes.byref(g), _lib.stream_ptr(a_mat.device))
+    _lib.check(rc, "pna_posttrans_x3_f32 (grouped)")
     return out
 
 

@@ -1,0 +1,86 @@
+"""Degree-grouped posttrans (pna_amd/degree_groups.py): for the rows of one in-degree the three scaler blocks of the posttrans
+weight collapse into one combined weight -- same result as the ordinary three-block path to fp32 noise, every row written
+exactly once, the plan's bookkeeping consistent."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _layer(F, N, dev, residual=True, seed=0):
+    from pna_amd.dgl.pna_layer import PNASimpleLayer
+    torch.manual_seed(seed)
+    layer = PNASimpleLayer(F, N, "mean max min std", "identity amplification attenuation", {"log": torch.tensor(2.3)}, 0.0, True, residual)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.copy_(torch.randn_like(p) / (p.shape[-1] ** 0.5 if p.dim() == 2 else 3.0))
+        layer.batchnorm_h.running_mean.normal_()
+        layer.batchnorm_h.running_var.uniform_(0.5, 2.0)
+    return layer.to(dev).eval()
+
+
+@pytest.mark.parametrize("V,E,F", [(200_000, 2_000_000, 75), (140_000, 700_000, 80), (300_000, 4_000_000, 66)])
+def test_grouped_layer_equals_plain_layer(cuda_device, V, E, F):
+    from pna_amd import Graph, degree_groups as DG
+    from pna_amd.synth import powerlaw_graph
+    src, dst = powerlaw_graph(V, E, seed=V % 97, device=cuda_device)
+    g = Graph(src, dst, V)
+    layer = _layer(F, F, cuda_device)
+    h = torch.randn(V, F, device=cuda_device)
+    with torch.no_grad():
+        assert layer._degree_grouped_path(g, h)
+        y_grouped = layer(g, h)
+        keep, DG.ENABLED = DG.ENABLED, False
+        try:
+            assert not layer._degree_grouped_path(g, h)
+            y_plain = layer(g, h)
+        finally:
+            DG.ENABLED = keep
+    assert torch.isfinite(y_grouped).all()
+    scale = y_plain.abs().max().item()
+    assert (y_grouped - y_plain).abs().max().item() <= 2e-5 * scale
+    # the plan: every node exactly once, groups are whole tiles of one degree, hub rows in the compacted rest
+    plan = DG.plan_of(g)
+    deg = g.in_degrees()
+    covered = torch.cat([plan.perm[plan.perm >= 0], plan.perm_rest[plan.perm_rest >= 0]]).long()
+    assert covered.numel() == V and torch.equal(torch.sort(covered).values, torch.arange(V, device=cuda_device))
+    assert plan.NV % DG.TILE == 0 and plan.NRp % DG.TILE == 0 and plan.tile_image.numel() == plan.NV // DG.TILE
+    tiles = plan.perm.view(-1, DG.TILE)
+    d = torch.where(tiles >= 0, deg[tiles.clamp(min=0).long()], torch.full_like(tiles, -1, dtype=torch.long))
+    dmax = d.max(dim=1).values
+    assert ((d == dmax[:, None]) | (d < 0)).all()                                 # one degree per tile
+    assert torch.equal(dmax, plan.group_degree[plan.tile_image.long()])
+    assert (deg[plan.perm_rest[plan.perm_rest >= 0].long()] > g.heavy_schedule().threshold).sum() == g.heavy_schedule().n_heavy
+
+
+def test_grouped_layer_rows_vs_float64(cuda_device):
+    """Sampled rows (frequent degrees, rare degrees, hubs) of the grouped layer against a float64 restatement."""
+    from pna_amd import Graph
+    from pna_amd.synth import powerlaw_graph
+    V, E, F = 250_000, 2_500_000, 75
+    src, dst = powerlaw_graph(V, E, seed=5, device=cuda_device)
+    g = Graph(src, dst, V)
+    layer = _layer(F, F, cuda_device, seed=3)
+    h = torch.randn(V, F, device=cuda_device)
+    with torch.no_grad():
+        assert layer._degree_grouped_path(g, h)
+        y = layer(g, h)
+    deg = g.in_degrees()
+    rows = torch.cat([torch.arange(0, 2000, device=cuda_device), torch.topk(deg, 50).indices, torch.nonzero(deg == 0).flatten()[:20]])
+    csr = g.csr
+    amp, att = g.degree_scalers(2.3)
+    lin, bn = layer.posttrans.fully_connected[0].linear, layer.batchnorm_h
+    W, b = lin.weight.double(), lin.bias.double()
+    worst = 0.0
+    for v in rows.tolist():
+        lo, hi = int(csr.rowptr[v]), int(csr.rowptr[v + 1])
+        if hi > lo:
+            m = h[csr.col[lo:hi].long()].double()
+            a = torch.cat([m.mean(0), m.max(0).values, m.min(0).values, torch.sqrt(torch.relu((m * m).mean(0) - m.mean(0) ** 2) + 1e-5)])
+        else:
+            a = torch.zeros(4 * F, dtype=torch.float64, device=cuda_device)
+        z = b + W @ torch.cat([a, a * amp[v].double(), a * att[v].double()])
+        z = (z - bn.running_mean.double()) / torch.sqrt(bn.running_var.double() + bn.eps) * bn.weight.double() + bn.bias.double()
+        ref = h[v].double() + torch.relu(z)
+        worst = max(worst, (y[v].double() - ref).abs().max().item() / max(1.0, ref.abs().max().item()))
+    assert worst <= 2e-5, worst
