@@ -377,6 +377,20 @@ def main():
         amp, att = g.degree_scalers(float(avg_log))
         t_post = event_time_ms(lambda: PF.posttrans(agg, 4 * F, lin.weight, lin.bias, [None, amp, att]), args.kernel_iters)
         t_post_f32 = event_time_ms(lambda: _ops.posttrans(agg, 4 * F, lin.weight, [None, amp, att], lin.bias, arith="f32"), args.kernel_iters)
+        # what the timed step actually launches when the layer groups its rows by in-degree (pna_amd/degree_groups.py): the same
+        # gather writing in degree order, then one combined scaler block per degree tile + the three-block rest
+        grouped = None
+        if hasattr(layer, "_degree_grouped_path") and layer._degree_grouped_path(g, h):
+            from pna_amd import degree_groups as DG
+            plan = DG.plan_of(g)
+            agg_g = PF.degree_grouped_aggregate(layer, g, h, plan)
+            y_g = torch.empty(n_local, F, device=dev)
+            t_seg_plain, t_post_plain = t_seg, t_post
+            t_seg = event_time_ms(lambda: PF.degree_grouped_aggregate(layer, g, h, plan, out=agg_g), args.kernel_iters)
+            t_post = event_time_ms(lambda: PF.degree_grouped_posttrans(layer, g, h, agg_g, plan, out=y_g), args.kernel_iters)
+            grouped = {"degree_groups": plan.G, "rows_in_groups": int((plan.perm >= 0).sum().item()), "padded_rows": plan.NV,
+                       "rest_rows": plan.NR, "tile_rows": DG.TILE,
+                       "segreduce_natural_order_ms": t_seg_plain, "three_block_contraction_ms": t_post_plain}
         t_halo = event_time_ms(lambda: g.source_features(h), args.kernel_iters) if world > 1 else 0.0
         # socket power and shader clock while each kernel runs alone (rocm-smi; best effort, N = 1 only): the bf16x3 contraction
         # runs at the package power cap and the firmware lowers the clock to hold it -- the dense MFMA peak at THAT clock is the
@@ -385,6 +399,8 @@ def main():
         if world == 1 and not args.no_power_probe:
             power = {"contraction": power_probe(lambda: PF.posttrans(agg, 4 * F, lin.weight, lin.bias, [None, amp, att])),
                      "segment_reduce": power_probe(lambda: PF.aggregate(g, x_ext, F, AGGREGATORS.split()))}
+            if grouped is not None:
+                power["contraction_degree_grouped"] = power_probe(lambda: PF.degree_grouped_posttrans(layer, g, h, agg_g, plan, out=y_g))
     alg_read = e_local * (4 * F + 4) + 4 * (n_local + 1)
     alg_write = n_local * 16 * F
     alg_bytes = alg_read + alg_write
@@ -401,7 +417,7 @@ def main():
                               + tj.get("collected", "round 1") + "; NOT measured in this run")
         except Exception:
             traffic = traffic_post = traffic_source = None
-    roofline = {"bound": "hbm", "kernel": "k_segreduce_fast<4> + k_heavy_finalize (pna_segreduce_fwd_f32)",
+    roofline = {"bound": "hbm", "kernel": "k_segreduce_fast<4> + k_heavy_finalize (pna_segreduce_fwd_f32)" + (", aggregate written in degree order" if grouped else ""),
                 "achieved": alg_bytes / (t_seg * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": alg_bytes / (t_seg * 1e-3) / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source,
                 "ms_per_launch": t_seg, "algorithmic_bytes_per_launch": alg_bytes,
@@ -409,7 +425,27 @@ def main():
                 "edges_per_s_kernel_only": e_local / (t_seg * 1e-3),
                 "heavy_rows": hs.n_heavy, "heavy_segments": hs.n_seg}
     flops = 2.0 * n_local * (12 * F) * F
-    if arith == "bf16x3":     # fp32-equivalent FLOP/s against the bf16 pipe's peak / 6 (six bf16 partial products per multiply)
+    if grouped is not None:
+        # one combined block per degree tile: a third of the multiply-adds, and the kernel is no longer matrix-pipe bound -- it
+        # streams the aggregate (4 * 4F per row), the residual and y (4F each): priced against HBM, the pipe fractions beside it
+        flops_exec = 2.0 * (grouped["padded_rows"] * (4 * F) + (grouped["rest_rows"]) * (12 * F)) * F
+        post_bytes = n_local * (16 * F + 4 * F + 4 * F)
+        roofline_post = {"bound": "hbm", "kernel": "k_posttrans_x3<S=1,...,GRP> over the degree tiles + k_posttrans_x3<S=3,...,GRP> over the rest "
+                                                   "(pna_posttrans_x3_f32, row_perm / tile_image)",
+                         "achieved": post_bytes / (t_post * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": post_bytes / (t_post * 1e-3) / HBM_PEAK, "ms_per_launch": t_post, "algorithmic_bytes_per_launch": post_bytes,
+                         "mfma_frac_executed_flops": flops_exec / (t_post * 1e-3) / (MFMA_BF16_PEAK / 6),
+                         "mfma_frac_reference_flops": flops / (t_post * 1e-3) / (MFMA_BF16_PEAK / 6),
+                         "fp32_equivalent_tflops_reference_formulation": flops / (t_post * 1e-3) / 1e12,
+                         "degree_grouping": grouped,
+                         "three_block_kernel": {"kernel": "k_posttrans_x3<S=3,NT=5,RT=1,12 wavefronts, 3 weight buffers>", "ms_per_launch": grouped["three_block_contraction_ms"],
+                                                "frac": flops / (grouped["three_block_contraction_ms"] * 1e-3) / (MFMA_BF16_PEAK / 6),
+                                                "frac_at_sustained_clock": (flops / (grouped["three_block_contraction_ms"] * 1e-3) / (MFMA_BF16_PEAK / 6 * power["contraction"]["sclk_mhz"] / 2400.0)
+                                                                            if power and power.get("contraction") else None)},
+                         "exact_f32_mfma_kernel": {"kernel": "k_posttrans<3,false,5> (pna_posttrans_f32)", "ms_per_launch": t_post_f32,
+                                                   "achieved": flops / (t_post_f32 * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12,
+                                                   "frac": flops / (t_post_f32 * 1e-3) / MFMA_F32_PEAK}}
+    elif arith == "bf16x3":     # fp32-equivalent FLOP/s against the bf16 pipe's peak / 6 (six bf16 partial products per multiply)
         roofline_post = {"bound": "mfma", "kernel": "k_posttrans_x3<S=3,NT=5,RT=1,12 wavefronts, 3 weight buffers> (pna_posttrans_x3_f32)",
                          "achieved": flops / (t_post * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK / 6 / 1e12, "unit": "TFLOP/s (fp32-equivalent)",
                          "frac": flops / (t_post * 1e-3) / (MFMA_BF16_PEAK / 6), "ms_per_launch": t_post, "traffic": traffic_post,

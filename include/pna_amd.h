@@ -333,9 +333,9 @@ typedef struct pna_posttrans_args {
   /* Degree-grouped rows (ABI 9, pna_posttrans_x3_f32 only; NULL = off).  Every PNA scaler is a function of the in-degree
    * alone (models/dgl/scalers.py:7-19), so for the rows of ONE degree D the three scaler blocks of the posttrans weight
    * collapse into one:  sum_s scale_s(D) (W_s a) = (sum_s scale_s(D) W_s) a  -- a third of the multiply-adds.  The caller
-   * orders the rows by degree: `a`, `row_scale[]`, `row_post` are indexed by a VIRTUAL row v in [0, M) (M a multiple of 192:
-   * every degree group padded to whole 192-row tiles), row_perm[v] is the row of `y` / `residual` that virtual row v is (or
-   * -1: padding, nothing is stored), and tile t (virtual rows [192 t, 192 t + 192)) multiplies by the weight image number
+   * orders the rows by degree: `a`, `row_scale[]`, `row_post` are indexed by a VIRTUAL row v in [0, M) (M a multiple of the
+   * workgroup tile R = 128 rows for n_scaler = 1, 192 for n_scaler = 3: every degree group padded to whole tiles), row_perm[v] is
+   * the row of `y` / `residual` that virtual row v is (or -1: padding, nothing is stored), and tile t (virtual rows [R t, R t + R)) multiplies by the weight image number
    * tile_image[t] of a buffer of images packed one after the other, image_stride BYTES apart (pna_posttrans_x3_pack_f32 of a
    * (G * 80, K) matrix whose rows [80 g, 80 g + N) are group g's combined weight: G column blocks = G images).  tile_image
    * NULL: every tile uses w_img as it is (the rows no group holds, with their per-row scalers: n_scaler = 3).

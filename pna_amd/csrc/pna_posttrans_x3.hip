@@ -155,7 +155,7 @@ __global__ void k_pack_x3(const float* w_ref, long ldw, int N, int K, int S, int
 // kernel made the compiler drain vmcnt at the top of every chunk: its scoreboard merges the two paths conservatively.)
 template <int S, bool HAS_H, int kNW, int NT, int RT, int WAVES, int NBUF, bool GEN, bool GRP = false>
 __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
-  static_assert(!GRP || (NBUF == 3 && !GEN && !HAS_H && RT == 1), "grouped mode: 3-buffer pipeline, straight-line epilogue, no h panel");
+  static_assert(!GRP || (NBUF == 3 && !GEN && !HAS_H), "grouped mode: 3-buffer pipeline, straight-line epilogue, no h panel");
   constexpr int kPanelB = panel_bytes(kNW), kPanelV = kPanelB / 16;
   constexpr int kThreads = WAVES * 64;
   constexpr int kChunkV = 3 * S * kPanelV;     // 16-byte pieces of an aggregate chunk image (the h chunk is 3 * kPanelV)
@@ -713,11 +713,12 @@ int launch_v(const XArgs& g, hipStream_t st) {
 }
 
 // grouped mode (XArgs.perm): M is a multiple of the workgroup tile, N in (64, 80], no h panel
-template <int S>
+template <int S, int RT, int WAVES>
 int launch_grouped(const XArgs& g, hipStream_t st) {
-  constexpr int kNW = 80, NT = 5, RT = 1, WAVES = 12, NBUF = 3;
+  constexpr int kNW = 80, NT = 5, NBUF = 3;
   const int ntiles = g.M / (WAVES * 16 * RT);
-  const int gx = ntiles < g.grid_x ? ntiles : g.grid_x;
+  const int wgs = WAVES <= 8 ? 2 * g.grid_x : g.grid_x;      // 8-wavefront workgroups (one block, 115 registers, 50 KB of LDS): two per CU
+  const int gx = ntiles < wgs ? ntiles : wgs;
   const int per_wg = (ntiles + gx - 1) / gx;
   const size_t lds = (size_t)NBUF * 3 * S * panel_bytes(kNW) + (size_t)(3 * kNW) * sizeof(float) + (size_t)per_wg * sizeof(int);
   if (lds > 160 * 1024 ||
@@ -845,11 +846,15 @@ extern "C" int pna_posttrans_x3_f32(const pna_posttrans_args* p, pna_stream_t st
   hipStream_t st = (hipStream_t)stream;
   if (p->row_perm) {
     // rows in a virtual order (degree groups): see include/pna_amd.h
-    if (has_h || T > 1 || p->N <= 64 || p->N > 80 || p->M % 192 != 0 || (p->n_scaler != 1 && p->n_scaler != 3) || (p->pipeline != 0 && p->pipeline != 3) ||
+    // one scaler block: 115 registers and 50 KB of LDS per workgroup, so TWO workgroups of 8 wavefronts per CU (independent
+    // barriers), workgroup tile 128 rows (measured: 12 wavefronts 1.27 ms/step, 16 wavefronts 1.30, 12 x 2 row tiles 1.31 with
+    // spills); three blocks: 12 wavefronts, 192 rows
+    const int tile_rows = p->n_scaler == 1 ? 128 : 192;
+    if (has_h || T > 1 || p->N <= 64 || p->N > 80 || p->M % tile_rows != 0 || (p->n_scaler != 1 && p->n_scaler != 3) || (p->pipeline != 0 && p->pipeline != 3) ||
         (p->tile_image && p->image_stride <= 0) || (int64_t)p->ldy * 4 >= (1ll << 32) || (p->residual && (int64_t)p->ld_res * 4 >= (1ll << 32)))
-      return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3_f32: row_perm needs 64 < N <= 80, M % 192 == 0, 1 or 3 scalers, no h panel / towers");
+      return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3_f32: row_perm needs 64 < N <= 80, M % 128 == 0 (1 scaler) / M % 192 == 0 (3 scalers), no h panel / towers");
     g.perm = p->row_perm; g.tile_image = p->tile_image; g.img_stride = p->tile_image ? p->image_stride : 0;
-    const int rc2 = p->n_scaler == 1 ? launch_grouped<1>(g, st) : launch_grouped<3>(g, st);
+    const int rc2 = p->n_scaler == 1 ? launch_grouped<1, 1, 8>(g, st) : launch_grouped<3, 1, 12>(g, st);
     if (rc2 != 0) return pna_set_error(PNA_E_LAUNCH, "pna_posttrans_x3_f32: could not reserve LDS (grouped mode)");
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e2));

@@ -18,7 +18,8 @@ import torch
 
 from . import _lib
 
-TILE = 192                 # rows of a workgroup tile of k_posttrans_x3 (12 wavefronts x 16 rows)
+TILE = 128                 # rows of a workgroup tile of the one-block grouped kernel (8 wavefronts x 16 rows, two workgroups per CU)
+TILE_REST = 192            # ... of the three-block kernel that takes the rest (12 wavefronts x 16 rows)
 MIN_ROWS = 1 << 17         # graphs smaller than this keep the ordinary path (the grouping is worth it when launches are long)
 ENABLED = True
 
@@ -53,7 +54,7 @@ class DegreePlan:
         self.group_degree = ud[big]
         rest = order[~in_big]
         self.NR = int(rest.numel())
-        self.NRp = (self.NR + TILE - 1) // TILE * TILE
+        self.NRp = (self.NR + TILE_REST - 1) // TILE_REST * TILE_REST
         perm_rest = torch.full((max(self.NRp, 1),), -1, dtype=torch.int32, device=dev)
         perm_rest[:self.NR] = rest.to(torch.int32)
         self.perm_rest = perm_rest[:self.NRp].contiguous()

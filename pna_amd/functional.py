@@ -277,24 +277,30 @@ class _SmallTowerPlan:
         return out
 
 
-def simple_layer_degree_grouped(layer, graph, h):
-    """PNASimpleLayer.forward (eval) with the rows grouped by in-degree (pna_amd/degree_groups.py): the gather writes the
-    aggregate in degree order, the contraction multiplies every 192-row tile by its degree's combined weight W_D = sum_s s_s(D) W_s
-    (one scaler block instead of three), the rows of rare degrees and the hub rows take the ordinary three-block contraction
-    over a compacted list; both scatter their rows back to node order, with BatchNorm / ReLU / residual in the epilogue."""
+def degree_grouped_aggregate(layer, graph, h, plan, out=None):
+    """The (plan.rows, 4F) aggregate in the plan's row order (degree groups padded to whole tiles, then the rest): the gather's
+    work list carries the output row of every whole-row record, heavy_out the output rows of the hub rows."""
+    F = layer.in_dim
+    K = len(layer.aggregators) * F
+    x = _unit_stride(graph.source_features(h))
+    csr = graph.csr
+    if out is None:
+        out = torch.empty(plan.rows, K, dtype=torch.float32, device=h.device)
+    ops.segreduce(csr.rowptr, csr.col, x, F, layer.aggregators, (None,), tower_stride_in=F, out=out,
+                  heavy=graph.heavy_schedule(), workspace=graph.workspace, items=plan.items, heavy_out=plan.heavy_out, tune=dict(generic=2))
+    return out
+
+
+def degree_grouped_posttrans(layer, graph, h, agg, plan, out=None):
+    """The two contractions over `agg` (degree_grouped_aggregate): one combined block per degree tile, three blocks for the rest;
+    both scatter their rows to node order with BatchNorm / ReLU / residual in the epilogue."""
     from . import degree_groups as DG
     from .dgl.pna_layer import _row_scales
-    plan = DG.plan_of(graph)
     F, N = layer.in_dim, layer.out_dim
     K = len(layer.aggregators) * F
     lin = layer.posttrans.fully_connected[0].linear
     scales = _row_scales(graph, layer.scalers, layer.avg_d, h.device)
-    x = _unit_stride(graph.source_features(h))
-    csr = graph.csr
-    agg = torch.empty(plan.rows, K, dtype=torch.float32, device=h.device)
-    ops.segreduce(csr.rowptr, csr.col, x, F, layer.aggregators, (None,), tower_stride_in=F, out=agg,
-                  heavy=graph.heavy_schedule(), workspace=graph.workspace, items=plan.items, heavy_out=plan.heavy_out, tune=dict(generic=2))
-    y = torch.empty(h.shape[0], N, dtype=torch.float32, device=h.device)
+    y = torch.empty(h.shape[0], N, dtype=torch.float32, device=h.device) if out is None else out
     cs = ct = None
     if layer.batch_norm:
         cs, ct = _fold_batchnorm(layer.batchnorm_h)
@@ -303,11 +309,21 @@ def simple_layer_degree_grouped(layer, graph, h):
         img, stride = DG.combined_images(lin.weight, K, scales, plan)
         ops.posttrans(agg[:plan.NV], K, lin.weight, [None], lin.bias, out=y, col_scale=cs, col_shift=ct, relu=True, residual=res,
                       row_perm=plan.perm, tile_image=plan.tile_image, w_img=img, image_stride=stride, n_out=N)
-    if plan.NR:
+    if plan.NR:                 # (on a side stream beside the grouped launch: measured, no gain -- one after the other)
         rest_scales = plan.rest_scales(tuple(layer.scalers) + (float(layer.avg_d["log"]),), scales)
         ops.posttrans(agg[plan.NV:], K, lin.weight, rest_scales, lin.bias, out=y, col_scale=cs, col_shift=ct, relu=True, residual=res,
                       row_perm=plan.perm_rest, n_out=N)
     return y
+
+
+def simple_layer_degree_grouped(layer, graph, h):
+    """PNASimpleLayer.forward (eval) with the rows grouped by in-degree (pna_amd/degree_groups.py): the gather writes the
+    aggregate in degree order, the contraction multiplies every tile by its degree's combined weight W_D = sum_s s_s(D) W_s
+    (one scaler block instead of three), the rows of rare degrees and the hub rows take the ordinary three-block contraction
+    over a compacted list."""
+    from . import degree_groups as DG
+    plan = DG.plan_of(graph)
+    return degree_grouped_posttrans(layer, graph, h, degree_grouped_aggregate(layer, graph, h, plan), plan)
 
 
 class _SmallSimplePlan(_SmallTowerPlan):

@@ -44,7 +44,7 @@ def test_grouped_layer_equals_plain_layer(cuda_device, V, E, F):
     deg = g.in_degrees()
     covered = torch.cat([plan.perm[plan.perm >= 0], plan.perm_rest[plan.perm_rest >= 0]]).long()
     assert covered.numel() == V and torch.equal(torch.sort(covered).values, torch.arange(V, device=cuda_device))
-    assert plan.NV % DG.TILE == 0 and plan.NRp % DG.TILE == 0 and plan.tile_image.numel() == plan.NV // DG.TILE
+    assert plan.NV % DG.TILE == 0 and plan.NRp % DG.TILE_REST == 0 and plan.tile_image.numel() == plan.NV // DG.TILE
     tiles = plan.perm.view(-1, DG.TILE)
     d = torch.where(tiles >= 0, deg[tiles.clamp(min=0).long()], torch.full_like(tiles, -1, dtype=torch.long))
     dmax = d.max(dim=1).values
