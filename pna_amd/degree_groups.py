@@ -22,6 +22,7 @@ TILE = 128                 # rows of a workgroup tile of the one-block grouped k
 TILE_REST = 192            # ... of the three-block kernel that takes the rest (12 wavefronts x 16 rows)
 MIN_ROWS = 1 << 17         # graphs smaller than this keep the ordinary path (the grouping is worth it when launches are long)
 ENABLED = True
+AGG_ALIGN = 32             # the aggregate's row pitch is rounded up to this many floats (32 = 128-byte lines; 1 = packed rows), see agg_pitch
 
 
 class DegreePlan:
@@ -85,6 +86,15 @@ class DegreePlan:
                     out.append(v[:self.NRp].contiguous())
             hit = self._rest_scales[key] = out
         return hit
+
+
+def agg_pitch(K):
+    """Row pitch (floats) of the plan-ordered aggregate.  The contraction reads a row as 128-byte strips, one per chunk of 32
+    columns; with packed rows of 4F = 300 floats (1200 bytes) 7 strips in 8 straddle two 128-byte lines.  Measured on the
+    one-block kernel, 1 M rows (tools/x3_pitch_time.py, one run, best of 5 x 20 launches): pitch 300 / 304 / 320 / 352 floats
+    -> 0.457 / 0.434 / 0.422 / 0.419 ms (the three-block kernel, bound by its matrix work, does not care: 0.75 ms at all four)."""
+    a = max(1, int(AGG_ALIGN))
+    return (K + a - 1) // a * a
 
 
 def plan_of(graph):

@@ -285,7 +285,8 @@ def degree_grouped_aggregate(layer, graph, h, plan, out=None):
     x = _unit_stride(graph.source_features(h))
     csr = graph.csr
     if out is None:
-        out = torch.empty(plan.rows, K, dtype=torch.float32, device=h.device)
+        from . import degree_groups as DG
+        out = torch.empty(plan.rows, DG.agg_pitch(K), dtype=torch.float32, device=h.device)[:, :K]     # line-aligned rows
     ops.segreduce(csr.rowptr, csr.col, x, F, layer.aggregators, (None,), tower_stride_in=F, out=out,
                   heavy=graph.heavy_schedule(), workspace=graph.workspace, items=plan.items, heavy_out=plan.heavy_out, tune=dict(generic=2))
     return out

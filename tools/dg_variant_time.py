@@ -32,9 +32,11 @@ def ev(fn, n=20):
     return best
 
 
-with torch.no_grad():
+for align in [int(v) for v in os.environ.get("DG_ALIGN", "1,32").split(",")] * int(os.environ.get("DG_REPEAT", "2")):
+  with torch.no_grad():
+    DG.AGG_ALIGN = align
     agg = PF.degree_grouped_aggregate(layer, g, h, plan)
     y = torch.empty(V, F, device=dev)
-    print(sys.argv[1] if len(sys.argv) > 1 else "", f"gather {ev(lambda: PF.degree_grouped_aggregate(layer, g, h, plan, out=agg)):.3f} ms",
+    print(sys.argv[1] if len(sys.argv) > 1 else "", f"pitch {agg.stride(0)}: gather {ev(lambda: PF.degree_grouped_aggregate(layer, g, h, plan, out=agg)):.3f} ms",
           f"contraction (grouped + rest) {ev(lambda: PF.degree_grouped_posttrans(layer, g, h, agg, plan, out=y)):.3f} ms",
           f"layer {ev(lambda: layer(g, h)):.3f} ms", flush=True)
