@@ -34,6 +34,10 @@
 #include "pna_amd.h"
 #include "pna_internal.h"
 
+#ifndef X3_GRP_NBUF
+#define X3_GRP_NBUF 3      // weight buffers of the one-block grouped kernel (development: 4 = fragments and images 3 steps ahead; measured equal)
+#endif
+
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -155,7 +159,8 @@ __global__ void k_pack_x3(const float* w_ref, long ldw, int N, int K, int S, int
 // kernel made the compiler drain vmcnt at the top of every chunk: its scoreboard merges the two paths conservatively.)
 template <int S, bool HAS_H, int kNW, int NT, int RT, int WAVES, int NBUF, bool GEN, bool GRP = false>
 __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
-  static_assert(!GRP || (NBUF == 3 && !GEN && !HAS_H), "grouped mode: 3-buffer pipeline, straight-line epilogue, no h panel");
+  static_assert(!GRP || (NBUF >= 3 && !GEN && !HAS_H), "grouped mode: 3- or 4-buffer pipeline, straight-line epilogue, no h panel");
+  static_assert(NBUF >= 2 && NBUF <= 4, "2, 3 or 4 weight buffers");
   constexpr int kPanelB = panel_bytes(kNW), kPanelV = kPanelB / 16;
   constexpr int kThreads = WAVES * 64;
   constexpr int kChunkV = 3 * S * kPanelV;     // 16-byte pieces of an aggregate chunk image (the h chunk is 3 * kPanelV)
@@ -196,8 +201,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
     }
     unsigned char* dst = lds + (size_t)buf * kChunkV * 16;
     int w0 = (i * WAVES + wave) * 64;                    // first piece of this wavefront (wave-uniform)
-    if constexpr (NBUF == 3) {
-      // the 3-buffer pipeline waits with COUNTED vmcnt: every wavefront issues exactly NI copies per chunk; a slot past
+    if constexpr (NBUF >= 3) {
+      // the 3- / 4-buffer pipeline waits with COUNTED vmcnt: every wavefront issues exactly NI copies per chunk; a slot past
       // the image re-copies an earlier piece (same bytes to the same LDS address: harmless)
       if (w0 >= pieces) w0 = w0 % pieces;
     } else {
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
     v.w = (k + 3 < kmax && d == 0) ? v.w : 0.f;
     return v;
   };
-  f4 nxt[2][RT][2];                            // A fragments in flight: one set (2-buffer pipeline) or two (3-buffer: 2 chunks ahead)
+  f4 nxt[NBUF == 4 ? 3 : 2][RT][2];            // A fragments in flight: one set (2-buffer pipeline), NBUF - 1 (3 / 4 buffers: that many chunks ahead)
   bf8 A[3][RT];                                // the three bf16 terms of the chunk being multiplied
   // Issued by hand (hipcc would hoist plain loads into one burst at the top of the interval, and a burst of scattered-row
   // loads from all wavefronts stalls them at the TA).  Rules for a register written by an asm load: it is written on EVERY
@@ -551,42 +556,50 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
     // GRP: the weight image of a tile is tile_image[tile]; the ids of this workgroup's tiles sit in an LDS table that the
     // step loop reads through inline asm when the tile of step k+2 changes (an LDS read the compiler can see would make it
     // drain vmcnt(0) first: the LDS-DMA copies in flight might alias it)
+    constexpr int D = NBUF - 1;                  // pipeline depth: fragments and images are fetched D steps ahead
     int* const timg = reinterpret_cast<int*>(colc + 3 * kNW);
-    long ib2 = 0;                                // byte offset of the image of step k+2's tile
+    long ib2 = 0;                                // byte offset of the image of step k+D's tile
     int ti = 0, ti2_seen = -1;                   // local index of step k's tile | of the tile ib2 belongs to
     if constexpr (GRP) {
       for (int i = tid; i < my_tiles; i += kThreads) timg[i] = g.tile_image ? g.tile_image[blockIdx.x + i * (int)gridDim.x] : 0;
-      const long ib0 = g.tile_image ? (long)g.tile_image[t] * g.img_stride : 0;
-      const long ib1 = (nc > 1 || my_tiles < 2 || !g.tile_image) ? ib0 : (long)g.tile_image[t + (int)gridDim.x] * g.img_stride;
-      stage(0, 0, ib0);
-      if (nsteps > 1) stage(nc > 1 ? 1 : 0, 1, ib1);
-    } else {
-      stage(0, 0);
-      if (nsteps > 1) stage(nc > 1 ? 1 : 0, 1);
     }
-    load_a(nxt[0], t, 0);
-    take(nxt[0], 0, 0);                         // vmcnt(0): both images and the first A fragment have landed
-    {
-      int t1 = t, c1 = 1;
-      if (c1 == nc) { t1 = t + gridDim.x; c1 = 0; }
-      const bool m1 = nsteps > 1;
-      load_a(nxt[1], m1 ? t1 : t, m1 ? c1 : 0);   // step 1's fragment (a harmless re-load when there is no step 1)
+    // steps 0 .. D-1: their images into buffers 0 .. D-1; the fragments of steps 0 .. D-2 before the vmcnt(0), step D-1's after
+    // it (a step that does not exist re-loads step 0's fragment: harmless)
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (d < nsteps) {
+        const int tl = d / nc;
+        long ib = 0;
+        if constexpr (GRP) ib = g.tile_image ? (long)g.tile_image[(int)blockIdx.x + tl * (int)gridDim.x] * g.img_stride : 0;
+        stage(d % nc, d, ib);
+      }
     }
+    auto load_step = [&](aset_t& dst, int d) __attribute__((always_inline)) {
+      const bool ex = d < nsteps;
+      load_a(dst, ex ? t + (d / nc) * (int)gridDim.x : t, ex ? d % nc : 0);
+    };
+#pragma unroll
+    for (int d = 0; d + 1 < D; ++d) load_step(nxt[d], d);
+    take(nxt[0], 0, 0);                         // vmcnt(0): the images and the first D-1 fragments have landed
+    load_step(nxt[D - 1], D - 1);
     __syncthreads();
 #ifdef PNA_AMD_EXPERIMENTS
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // phase timers, tools/x3_timers.py
 #endif
     auto step = [&](auto par_c, int k) __attribute__((always_inline)) {
-      constexpr int PAR = decltype(par_c)::value;
-      aset_t& mine = nxt[PAR];           // free now (held step k's fragment): receives step k+2's
-      aset_t& other = nxt[PAR ^ 1];      // holds step k+1's
+      constexpr int PAR = decltype(par_c)::value;           // k % D
+      aset_t& mine = nxt[PAR];              // free now (held step k's fragment): receives step k+D's
+      aset_t& other = nxt[(PAR + 1) % D];   // holds step k+1's
       int tn = t, cn = c + 1;
       if (cn == nc) { tn = t + gridDim.x; cn = 0; }
-      int t2 = tn, c2 = cn + 1;
-      if (c2 == nc) { t2 = tn + gridDim.x; c2 = 0; }       // (tile, chunk) of step k+2
-      const bool more1 = k + 1 < nsteps, more2 = k + 2 < nsteps;
+      int t2 = tn, c2 = cn, wraps = cn == 0 ? 1 : 0;
+#pragma unroll
+      for (int d = 1; d < D; ++d) {                         // (tile, chunk) of step k+D
+        if (++c2 == nc) { t2 += gridDim.x; c2 = 0; ++wraps; }
+      }
+      const bool more1 = k + 1 < nsteps, more2 = k + D < nsteps;
       if constexpr (GRP) {
-        const int ti2 = min(ti + (c + 1 == nc ? 1 : 0) + (cn + 1 == nc ? 1 : 0), my_tiles - 1);
+        const int ti2 = min(ti + wraps, my_tiles - 1);
         if (ti2 != ti2_seen) {                             // (wave-uniform; once per tile)
           int v;
           asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v)
@@ -595,7 +608,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
           ti2_seen = ti2;
         }
       }
-      const int buf2 = buf == 0 ? 2 : buf - 1;             // (k + 2) % 3
+      const int buf2 = buf == 0 ? NBUF - 1 : buf - 1;      // (k + D) % NBUF
       const bool is_h = HAS_H && c >= nca;
       const unsigned baddr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(buf * kChunkV + lg * kNW + li) * 16u;
       load_a(mine, more2 ? t2 : t, more2 ? c2 : c);       // (a harmless re-load of this step's fragment near the end)
@@ -610,6 +623,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
         constexpr int NPN = decltype(npanel_c)::value;
         constexpr int NG = NPN * NT;
         constexpr int H = (NG - 1) / 2;                    // the barrier follows the B prefetch of group H
+        constexpr int kPend = (D - 1) * 2 * RT + (D - 2) * NI;   // VMEM operations that may stay in flight across the barrier
         bf8 B[2][3];
         auto load_b = [&](unsigned ba, int gi, int slot) __attribute__((always_inline)) {
           const int p = gi / NT, n = gi % NT;
@@ -629,22 +643,25 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(B[gi & 1][0]), "+v"(B[gi & 1][1]), "+v"(B[gi & 1][2]));
           }
           if (gi == H) {
-            // everything older than the 2*RT A loads issued at the top of this step has landed: this wavefront's copies
-            // of step k+1's image AND step k+1's A fragment
+            // D = 2: everything older than the 2*RT A loads issued at the top of this step has landed: this wavefront's
+            // copies of step k+1's image AND step k+1's A fragment.  D = 3: the loads of this step's top, the NI copies of
+            // step k-1 and the loads of step k-1's top may stay in flight (issued in that order, returned in order): what is
+            // older -- the image copied during step k-2 (step k+1's) and the fragment loaded at step k-2's top (step k+1's)
+            // -- has landed.  The counts are exact: with D = 3 every step issues its NI copies, needed or not.
 #ifdef PNA_AMD_EXPERIMENTS
             tm1 = clock64();
-            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * RT) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kPend) : "memory");
             tm1b = clock64();
             asm volatile("s_barrier" : : : "memory");
             tm2 = clock64();
 #else
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"(2 * RT) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"(kPend) : "memory");
 #endif
           }
-          if (more2) {
+          if (more2 || D > 2) {                           // (D = 3, no step k+D: the step's own image again, into a free buffer)
 #pragma unroll
             for (int i = 0; i < NI; ++i)
-              if (gi >= H && (NG - 1 > H ? H + 1 + (i * (NG - 1 - H)) / NI : H) == gi) stage_piece(c2, buf2, i, GRP ? ib2 : 0);
+              if (gi >= H && (NG - 1 > H ? H + 1 + (i * (NG - 1 - H)) / NI : H) == gi) stage_piece(more2 ? c2 : c, buf2, i, GRP ? ib2 : 0);
           }
 #pragma unroll
           for (int pp = 0; pp < 6; ++pp)
@@ -681,14 +698,17 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
       }
 #endif
       if (GRP && cn == 0) ++ti;
-      t = tn; c = cn; buf = buf == 2 ? 0 : buf + 1;
+      t = tn; c = cn; buf = buf == NBUF - 1 ? 0 : buf + 1;
     };
 #ifdef PNA_AMD_EXPERIMENTS
     const unsigned long long tstart = clock64();
 #endif
-    for (int k = 0; k < nsteps; k += 2) {
+    for (int k = 0; k < nsteps; k += D) {
       step(std::integral_constant<int, 0>{}, k);
       if (k + 1 < nsteps) step(std::integral_constant<int, 1>{}, k + 1);
+      if constexpr (D > 2) {
+        if (k + 2 < nsteps) step(std::integral_constant<int, 2>{}, k + 2);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the re-loads of the last steps
 #ifdef PNA_AMD_EXPERIMENTS
@@ -713,9 +733,9 @@ int launch_v(const XArgs& g, hipStream_t st) {
 }
 
 // grouped mode (XArgs.perm): M is a multiple of the workgroup tile, N in (64, 80], no h panel
-template <int S, int RT, int WAVES>
+template <int S, int RT, int WAVES, int NBUF = 3>
 int launch_grouped(const XArgs& g, hipStream_t st) {
-  constexpr int kNW = 80, NT = 5, NBUF = 3;
+  constexpr int kNW = 80, NT = 5;
   const int ntiles = g.M / (WAVES * 16 * RT);
   const int wgs = WAVES <= 8 ? 2 * g.grid_x : g.grid_x;      // 8-wavefront workgroups (one block, 115 registers, 50 KB of LDS): two per CU
   const int gx = ntiles < wgs ? ntiles : wgs;
@@ -854,7 +874,9 @@ extern "C" int pna_posttrans_x3_f32(const pna_posttrans_args* p, pna_stream_t st
         (p->tile_image && p->image_stride <= 0) || (int64_t)p->ldy * 4 >= (1ll << 32) || (p->residual && (int64_t)p->ld_res * 4 >= (1ll << 32)))
       return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3_f32: row_perm needs 64 < N <= 80, M % 128 == 0 (1 scaler) / M % 192 == 0 (3 scalers), no h panel / towers");
     g.perm = p->row_perm; g.tile_image = p->tile_image; g.img_stride = p->tile_image ? p->image_stride : 0;
-    const int rc2 = p->n_scaler == 1 ? launch_grouped<1, 1, 8>(g, st) : launch_grouped<3, 1, 12>(g, st);
+    // (the short rest list of a degree plan -- ~26 tiles, one step-latency-bound tile per workgroup, 44 us -- on 4-wavefront
+    // workgroups of 64 rows over 3x the CUs: measured, layer 1.245 vs 1.230 ms, not kept)
+    const int rc2 = p->n_scaler == 1 ? launch_grouped<1, 1, 8, X3_GRP_NBUF>(g, st) : launch_grouped<3, 1, 12>(g, st);
     if (rc2 != 0) return pna_set_error(PNA_E_LAUNCH, "pna_posttrans_x3_f32: could not reserve LDS (grouped mode)");
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e2));
