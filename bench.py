@@ -386,7 +386,7 @@ def main():
             agg_g = PF.degree_grouped_aggregate(layer, g, h, plan)
             y_g = torch.empty(n_local, F, device=dev)
             t_seg_plain, t_post_plain = t_seg, t_post
-            t_seg = event_time_ms(lambda: PF.degree_grouped_aggregate(layer, g, h, plan, out=agg_g), args.kernel_iters)
+            t_seg = event_time_ms(lambda: PF.degree_grouped_aggregate(layer, g, h, plan, out=agg_g, x=x_ext), args.kernel_iters)
             t_post = event_time_ms(lambda: PF.degree_grouped_posttrans(layer, g, h, agg_g, plan, out=y_g), args.kernel_iters)
             grouped = {"degree_groups": plan.G, "rows_in_groups": int((plan.perm >= 0).sum().item()), "padded_rows": plan.NV,
                        "rest_rows": plan.NR, "tile_rows": DG.TILE,

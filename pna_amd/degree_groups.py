@@ -68,9 +68,24 @@ class DegreePlan:
         n_seg = hs.n_seg if hs.n_heavy > 0 else 0
         items[n_seg:, 0] = vmap[items[n_seg:, 0].long()].to(torch.int32)  # whole-row records: `row` = output row (nothing else uses it)
         self.items = items.contiguous()
+        self._vmap, self._n_seg, self._split = vmap, n_seg, None
         self.heavy_out = vmap[hs.heavy_rows.long()].to(torch.int32).contiguous() if hs.n_heavy > 0 else None
         self.rows = self.NV + self.NRp
         self._rest_scales = {}
+
+    def split_items(self, graph):
+        """(interior, boundary) work lists of a sharded graph (HaloGraph.split_work_lists: the rows that read only local
+        sources | everything else incl. the hub segments) with the plan's output rows: the halo overlap of
+        functional.aggregate, writing in degree order."""
+        if self._split is None:
+            _, items_in, items_bd = graph.split_work_lists()
+
+            def remap(items, n_seg):
+                it = items.clone()
+                it[n_seg:, 0] = self._vmap[it[n_seg:, 0].long()].to(torch.int32)
+                return it.contiguous()
+            self._split = (remap(items_in, 0), remap(items_bd, self._n_seg))
+        return self._split
 
     def rest_scales(self, key, row_scales):
         """The per-row scalers of the rest rows in their virtual order (padding: 0), cached per scaler set."""
@@ -139,5 +154,6 @@ def combined_images(weight, K, row_scales, plan):
 
 def applies(graph, V, N, n_scaler, aggregators):
     from .graph import Graph
-    return (ENABLED and type(graph) is Graph and V >= MIN_ROWS and 64 < N <= 80 and n_scaler == 3
+    from .shard import HaloGraph
+    return (ENABLED and type(graph) in (Graph, HaloGraph) and V >= MIN_ROWS and 64 < N <= 80 and n_scaler == 3
             and tuple(aggregators) == ("mean", "max", "min", "std") and V * 80 * 4 < (1 << 32))

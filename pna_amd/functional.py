@@ -277,16 +277,33 @@ class _SmallTowerPlan:
         return out
 
 
-def degree_grouped_aggregate(layer, graph, h, plan, out=None):
+def degree_grouped_aggregate(layer, graph, h, plan, out=None, x=None):
     """The (plan.rows, 4F) aggregate in the plan's row order (degree groups padded to whole tiles, then the rest): the gather's
-    work list carries the output row of every whole-row record, heavy_out the output rows of the hub rows."""
+    work list carries the output row of every whole-row record, heavy_out the output rows of the hub rows.  On a sharded
+    graph the halo exchange is started first and the rows that read only local sources are aggregated while it is in flight
+    (two launches, like functional.aggregate); `x`: the source table with the halo already in place (no exchange here)."""
     F = layer.in_dim
     K = len(layer.aggregators) * F
-    x = _unit_stride(graph.source_features(h))
+    if x is None:
+        x = graph.source_features(h, defer=True)
+    x = _unit_stride(x)
     csr = graph.csr
     if out is None:
         from . import degree_groups as DG
         out = torch.empty(plan.rows, DG.agg_pitch(K), dtype=torch.float32, device=h.device)[:, :K]     # line-aligned rows
+    if getattr(graph, "_pending", None) is not None:
+        items_in, items_bd = plan.split_items(graph)
+        try:
+            if items_in.shape[0]:
+                ops.segreduce(csr.rowptr, csr.col, x, F, layer.aggregators, (None,), tower_stride_in=F, out=out, items=items_in,
+                              tune=dict(generic=2))
+        finally:
+            graph.finish_exchange()
+        if items_bd.shape[0]:
+            ops.segreduce(csr.rowptr, csr.col, x, F, layer.aggregators, (None,), tower_stride_in=F, out=out,
+                          heavy=graph.heavy_schedule(), workspace=graph.workspace, items=items_bd, heavy_out=plan.heavy_out,
+                          tune=dict(generic=2))
+        return out
     ops.segreduce(csr.rowptr, csr.col, x, F, layer.aggregators, (None,), tower_stride_in=F, out=out,
                   heavy=graph.heavy_schedule(), workspace=graph.workspace, items=plan.items, heavy_out=plan.heavy_out, tune=dict(generic=2))
     return out

@@ -95,3 +95,56 @@ def _worker(rank, world, port, V, E, F):
 
 def test_two_rank_sharded_layers_on_one_gpu():
     mp.spawn(_worker, args=(2, _free_port(), 4000, 40000, 20), nprocs=2, join=True)
+
+
+def _worker_grouped(rank, world, port, V, E, F):
+    """The degree-grouped contraction on shards: every rank plans its OWN rows (a row's in-degree is global: the shard holds all
+    its in-edges), the interior rows are gathered in degree order while the exchange is in flight, boundary rows and hub
+    segments after it.  Against the unsharded three-block path: equal to the rounding of the combined weights (2e-5 of max|y|,
+    the bar of tests/test_gpu_degree_groups.py); the aggregate itself stays bit-identical."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pna_amd import Graph, functional as PF, degree_groups as DG
+        PF.SMALL_SIMPLE_ROWS = 0
+        from pna_amd.dgl.pna_layer import PNASimpleLayer
+        from pna_amd.shard import shard_graph
+        from pna_amd.synth import powerlaw_graph
+        torch.manual_seed(0)
+        layer = PNASimpleLayer(F, F, "mean max min std", "identity amplification attenuation", {"log": torch.tensor(2.0)},
+                               0.0, True, True).to(dev).eval()
+        h = torch.randn(V, F, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+        for seed, edges, balance in ((11, E, "nodes"), (12, 2 * V + 600, "edges")):      # locality-free | mostly interior rows
+            src, dst = powerlaw_graph(V, edges, seed=seed, device=dev)
+            gs, g = shard_graph(src, dst, V, balance=balance), Graph(src, dst, V)
+            lo, hi = gs.lo, gs.hi
+            hr = gs.alloc_features(F)
+            hr.copy_(h[lo:hi])
+            with torch.no_grad():
+                DG.ENABLED = False
+                want = layer(g, h)[lo:hi]
+                agg_want = PF.aggregate(g, h, F, layer.aggregators)[lo:hi]
+                DG.ENABLED, DG.MIN_ROWS = True, 1
+                assert layer._degree_grouped_path(gs, hr)
+                got = layer(gs, hr)
+                plan = DG.plan_of(gs)
+                assert plan._split is not None and gs._pending is None           # the two-launch overlap path ran and was drained
+                agg = PF.degree_grouped_aggregate(layer, gs, hr, plan)
+                got_plain_tensor = layer(gs, h[lo:hi].clone())                   # not in the resident table: synchronous exchange
+            assert plan.G > 0 and plan.NR > 0
+            tol = 2e-5 * want.abs().max().item()
+            assert (got - want).abs().max().item() <= tol and (got_plain_tensor - want).abs().max().item() <= tol
+            # the plan-ordered aggregate holds the natural-order rows, bit for bit
+            real = plan.perm >= 0
+            assert torch.equal(agg[:plan.NV][real], agg_want[plan.perm[real].long()])
+            assert torch.equal(agg[plan.NV:plan.NV + plan.NR], agg_want[plan.rest_rows])
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_degree_grouped_layer_on_one_gpu():
+    mp.spawn(_worker_grouped, args=(2, _free_port(), 12000, 120000, 75), nprocs=2, join=True)
