@@ -430,15 +430,19 @@ def main():
         # streams the aggregate (4 * 4F per row), the residual and y (4F each): priced against HBM, the pipe fractions beside it
         flops_exec = 2.0 * (grouped["padded_rows"] * (4 * F) + (grouped["rest_rows"]) * (12 * F)) * F
         post_bytes = n_local * (16 * F + 4 * F + 4 * F)
-        roofline_post = {"bound": "hbm", "kernel": "k_posttrans_x3<S=1,...,GRP> over the degree tiles + k_posttrans_x3<S=3,...,GRP> over the rest "
-                                                   "(pna_posttrans_x3_f32, row_perm / tile_image)",
+        k3 = ("k_posttrans_x3<S=3,NT=5,RT=1,12 wavefronts, 3 weight buffers>" if F <= 80
+              else "k_posttrans_x3<S=3,NT=8 (one 128-column block),RT=1,8 wavefronts, 2 weight buffers>")
+        roofline_post = {"bound": "hbm", "kernel": ("k_posttrans_x3<S=1,...,GRP> over the degree tiles + k_posttrans_x3<S=3,...,GRP> over the rest "
+                                                    "(pna_posttrans_x3_f32, row_perm / tile_image)") if F <= 80 else
+                                                   ("k_posttrans_x3<S=1,128-column block,GRP> over the degree tiles (pna_posttrans_x3_f32, row_perm / tile_image)"
+                                                    " + the ordinary three-block kernel over the compact rest list and an index scatter"),
                          "achieved": post_bytes / (t_post * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": post_bytes / (t_post * 1e-3) / HBM_PEAK, "ms_per_launch": t_post, "algorithmic_bytes_per_launch": post_bytes,
                          "mfma_frac_executed_flops": flops_exec / (t_post * 1e-3) / (MFMA_BF16_PEAK / 6),
                          "mfma_frac_reference_flops": flops / (t_post * 1e-3) / (MFMA_BF16_PEAK / 6),
                          "fp32_equivalent_tflops_reference_formulation": flops / (t_post * 1e-3) / 1e12,
                          "degree_grouping": grouped,
-                         "three_block_kernel": {"kernel": "k_posttrans_x3<S=3,NT=5,RT=1,12 wavefronts, 3 weight buffers>", "ms_per_launch": grouped["three_block_contraction_ms"],
+                         "three_block_kernel": {"kernel": k3, "ms_per_launch": grouped["three_block_contraction_ms"],
                                                 "frac": flops / (grouped["three_block_contraction_ms"] * 1e-3) / (MFMA_BF16_PEAK / 6),
                                                 "frac_at_sustained_clock": (flops / (grouped["three_block_contraction_ms"] * 1e-3) / (MFMA_BF16_PEAK / 6 * power["contraction"]["sclk_mhz"] / 2400.0)
                                                                             if power and power.get("contraction") else None)},

@@ -733,11 +733,12 @@ int launch_v(const XArgs& g, hipStream_t st) {
 }
 
 // grouped mode (XArgs.perm): M is a multiple of the workgroup tile, N in (64, 80], no h panel
-template <int S, int RT, int WAVES, int NBUF = 3>
+template <int S, int RT, int WAVES, int NBUF = 3, int kNW = 80, int NT = 5>
 int launch_grouped(const XArgs& g, hipStream_t st) {
-  constexpr int kNW = 80, NT = 5;
   const int ntiles = g.M / (WAVES * 16 * RT);
-  const int wgs = WAVES <= 8 ? 2 * g.grid_x : g.grid_x;      // 8-wavefront workgroups (one block, 115 registers, 50 KB of LDS): two per CU
+  // 8-wavefront workgroups of the 80-column block (117 registers, 50 KB of LDS): two per CU; the 128-column block (79 KB, > 128
+  // registers) and the 12-wavefront three-block kernel: one
+  const int wgs = (WAVES <= 8 && kNW == 80) ? 2 * g.grid_x : g.grid_x;
   const int gx = ntiles < wgs ? ntiles : wgs;
   const int per_wg = (ntiles + gx - 1) / gx;
   const size_t lds = (size_t)NBUF * 3 * S * panel_bytes(kNW) + (size_t)(3 * kNW) * sizeof(float) + (size_t)per_wg * sizeof(int);
@@ -870,13 +871,15 @@ extern "C" int pna_posttrans_x3_f32(const pna_posttrans_args* p, pna_stream_t st
     // barriers), workgroup tile 128 rows (measured: 12 wavefronts 1.27 ms/step, 16 wavefronts 1.30, 12 x 2 row tiles 1.31 with
     // spills); three blocks: 12 wavefronts, 192 rows
     const int tile_rows = p->n_scaler == 1 ? 128 : 192;
-    if (has_h || T > 1 || p->N <= 64 || p->N > 80 || p->M % tile_rows != 0 || (p->n_scaler != 1 && p->n_scaler != 3) || (p->pipeline != 0 && p->pipeline != 3) ||
+    const bool wide = p->N > 80;                 // one 128-column block (one scaler block only: the caller sends its rest rows through the ordinary path)
+    if (has_h || T > 1 || p->N <= 64 || p->N > 128 || (wide && p->n_scaler != 1) || p->M % tile_rows != 0 || (p->n_scaler != 1 && p->n_scaler != 3) || (p->pipeline != 0 && p->pipeline != 3) ||
         (p->tile_image && p->image_stride <= 0) || (int64_t)p->ldy * 4 >= (1ll << 32) || (p->residual && (int64_t)p->ld_res * 4 >= (1ll << 32)))
-      return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3_f32: row_perm needs 64 < N <= 80, M % 128 == 0 (1 scaler) / M % 192 == 0 (3 scalers), no h panel / towers");
+      return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3_f32: row_perm needs 64 < N <= 80 (1 or 3 scalers) or 80 < N <= 128 (1 scaler), M % 128 == 0 (1 scaler) / M % 192 == 0 (3 scalers), no h panel / towers");
     g.perm = p->row_perm; g.tile_image = p->tile_image; g.img_stride = p->tile_image ? p->image_stride : 0;
     // (the short rest list of a degree plan -- ~26 tiles, one step-latency-bound tile per workgroup, 44 us -- on 4-wavefront
     // workgroups of 64 rows over 3x the CUs: measured, layer 1.245 vs 1.230 ms, not kept)
-    const int rc2 = p->n_scaler == 1 ? launch_grouped<1, 1, 8, X3_GRP_NBUF>(g, st) : launch_grouped<3, 1, 12>(g, st);
+    const int rc2 = wide ? launch_grouped<1, 1, 8, 3, 128, 8>(g, st)
+                    : p->n_scaler == 1 ? launch_grouped<1, 1, 8, X3_GRP_NBUF>(g, st) : launch_grouped<3, 1, 12>(g, st);
     if (rc2 != 0) return pna_set_error(PNA_E_LAUNCH, "pna_posttrans_x3_f32: could not reserve LDS (grouped mode)");
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e2));

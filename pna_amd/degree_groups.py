@@ -19,6 +19,7 @@ import torch
 from . import _lib
 
 TILE = 128                 # rows of a workgroup tile of the one-block grouped kernel (8 wavefronts x 16 rows, two workgroups per CU)
+                           # (64 < out_dim <= 80 and 80 < out_dim <= 128 alike: the 128-column block runs one 8-wavefront workgroup per CU)
 TILE_REST = 192            # ... of the three-block kernel that takes the rest (12 wavefronts x 16 rows)
 MIN_ROWS = 1 << 17         # graphs smaller than this keep the ordinary path (the grouping is worth it when launches are long)
 ENABLED = True
@@ -121,7 +122,8 @@ def plan_of(graph):
 
 def combined_images(weight, K, row_scales, plan):
     """Packed bf16x3 images of W_D = sum_s s_s(D) W_s for every group of `plan` (one buffer, image_stride bytes apart), cached
-    on the weight per (version, scaler tensors, plan)."""
+    on the weight per (version, scaler tensors, plan).  out_dim <= 80: ONE pack call over a (G * 80, K) matrix whose 80-column
+    blocks are the images; 80 < out_dim <= 128: one pack call per image (the packer cuts wider matrices into 80-column blocks)."""
     key = (weight._version, weight.data_ptr(), str(weight.device), tuple(weight.shape), K, id(plan),
            tuple(None if rs is None else (rs.data_ptr(), rs._version) for rs in row_scales))
     hit = getattr(weight, "_pna_amd_group_img", None)
@@ -134,17 +136,25 @@ def combined_images(weight, K, row_scales, plan):
             ws = weight[:, s * K:(s + 1) * K]
             term = ws.unsqueeze(0).expand(G, N, K) if rs is None else rs[plan.group_first_row].view(G, 1, 1) * ws.unsqueeze(0)
             wc = term.clone() if wc is None else wc + term          # scaler order, like the reference's blocks
-        w_all = torch.zeros(G, 80, K, dtype=torch.float32, device=weight.device)
+        BW = 80 if N <= 80 else 128
+        w_all = torch.zeros(G, BW, K, dtype=torch.float32, device=weight.device)
         w_all[:, :N] = wc
-        w_all = w_all.view(G * 80, K)
     L = _lib.lib()
     nh = ctypes.c_int64(0)
-    nb = L.pna_posttrans_x3_packed_bytes(K, G * 80, 1, 0, ctypes.byref(nh))
-    img = torch.empty(nb // 4, dtype=torch.float32, device=weight.device)
-    rc = L.pna_posttrans_x3_pack_f32(_lib.dev_ptr(w_all, torch.float32, "weight"), K, G * 80, K, 1, 0,
-                                     _lib.dev_ptr(img, torch.float32, "w_img"), None, _lib.stream_ptr(weight.device))
-    _lib.check(rc, "pna_posttrans_x3_pack_f32")
-    stride = nb // G
+    if BW == 80:
+        nb = L.pna_posttrans_x3_packed_bytes(K, G * 80, 1, 0, ctypes.byref(nh))
+        img = torch.empty(nb // 4, dtype=torch.float32, device=weight.device)
+        rc = L.pna_posttrans_x3_pack_f32(_lib.dev_ptr(w_all.view(G * 80, K), torch.float32, "weight"), K, G * 80, K, 1, 0,
+                                         _lib.dev_ptr(img, torch.float32, "w_img"), None, _lib.stream_ptr(weight.device))
+        _lib.check(rc, "pna_posttrans_x3_pack_f32")
+        stride = nb // G
+    else:
+        stride = L.pna_posttrans_x3_packed_bytes(K, 128, 1, 0, ctypes.byref(nh))
+        img = torch.empty(G * stride // 4, dtype=torch.float32, device=weight.device)
+        for i in range(G):
+            rc = L.pna_posttrans_x3_pack_f32(_lib.dev_ptr(w_all[i], torch.float32, "weight"), K, 128, K, 1, 0,
+                                             _lib.dev_ptr(img[i * stride // 4:], torch.float32, "w_img"), None, _lib.stream_ptr(weight.device))
+            _lib.check(rc, "pna_posttrans_x3_pack_f32")
     try:
         weight._pna_amd_group_img = (key, img, stride)
     except AttributeError:
@@ -155,5 +165,5 @@ def combined_images(weight, K, row_scales, plan):
 def applies(graph, V, N, n_scaler, aggregators):
     from .graph import Graph
     from .shard import HaloGraph
-    return (ENABLED and type(graph) in (Graph, HaloGraph) and V >= MIN_ROWS and 64 < N <= 80 and n_scaler == 3
-            and tuple(aggregators) == ("mean", "max", "min", "std") and V * 80 * 4 < (1 << 32))
+    return (ENABLED and type(graph) in (Graph, HaloGraph) and V >= MIN_ROWS and 64 < N <= 128 and n_scaler == 3
+            and tuple(aggregators) == ("mean", "max", "min", "std") and V * (80 if N <= 80 else 128) * 4 < (1 << 32))

@@ -19,7 +19,9 @@ def _layer(F, N, dev, residual=True, seed=0):
     return layer.to(dev).eval()
 
 
-@pytest.mark.parametrize("V,E,F", [(200_000, 2_000_000, 75), (140_000, 700_000, 80), (300_000, 4_000_000, 66)])
+# (F = 128, 96: the 128-column block -- one workgroup per CU, the rest rows through the ordinary kernel and an index scatter)
+@pytest.mark.parametrize("V,E,F", [(200_000, 2_000_000, 75), (140_000, 700_000, 80), (300_000, 4_000_000, 66), (200_000, 2_000_000, 128),
+                                   (150_000, 1_200_000, 96)])
 def test_grouped_layer_equals_plain_layer(cuda_device, V, E, F):
     from pna_amd import Graph, degree_groups as DG
     from pna_amd.synth import powerlaw_graph
