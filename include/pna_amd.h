@@ -339,7 +339,8 @@ typedef struct pna_posttrans_args {
    * tile_image[t] of a buffer of images packed one after the other, image_stride BYTES apart (pna_posttrans_x3_pack_f32 of a
    * (G * 80, K) matrix whose rows [80 g, 80 g + N) are group g's combined weight: G column blocks = G images).  tile_image
    * NULL: every tile uses w_img as it is (the rows no group holds, with their per-row scalers: n_scaler = 3).
-   * Needs 64 < N <= 80, no h panel, n_tower <= 1, n_scaler 1 or 3 -- or 80 < N <= 128 with n_scaler = 1 (one 128-column
+   * Needs N <= 80 (one 80-column block whatever N: the grouped kernel is bound by its A stream, not by the matrix pipe), no h
+   * panel, n_tower <= 1, n_scaler 1 or 3 -- or 80 < N <= 128 with n_scaler = 1 (one 128-column
    * block; its images are packed one by one, pna_posttrans_x3_pack_f32 of a (128, K) matrix each, image_stride =
    * pna_posttrans_x3_packed_bytes(K, 128, 1, 0); the caller sends the rows no group holds through an ordinary call).
    * pna_segreduce_args.work_items (row = output row) and heavy_out_rows write the aggregate in that virtual order in the

@@ -872,9 +872,9 @@ extern "C" int pna_posttrans_x3_f32(const pna_posttrans_args* p, pna_stream_t st
     // spills); three blocks: 12 wavefronts, 192 rows
     const int tile_rows = p->n_scaler == 1 ? 128 : 192;
     const bool wide = p->N > 80;                 // one 128-column block (one scaler block only: the caller sends its rest rows through the ordinary path)
-    if (has_h || T > 1 || p->N <= 64 || p->N > 128 || (wide && p->n_scaler != 1) || p->M % tile_rows != 0 || (p->n_scaler != 1 && p->n_scaler != 3) || (p->pipeline != 0 && p->pipeline != 3) ||
+    if (has_h || T > 1 || p->N < 1 || p->N > 128 || (wide && p->n_scaler != 1) || p->M % tile_rows != 0 || (p->n_scaler != 1 && p->n_scaler != 3) || (p->pipeline != 0 && p->pipeline != 3) ||
         (p->tile_image && p->image_stride <= 0) || (int64_t)p->ldy * 4 >= (1ll << 32) || (p->residual && (int64_t)p->ld_res * 4 >= (1ll << 32)))
-      return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3_f32: row_perm needs 64 < N <= 80 (1 or 3 scalers) or 80 < N <= 128 (1 scaler), M % 128 == 0 (1 scaler) / M % 192 == 0 (3 scalers), no h panel / towers");
+      return pna_set_error(PNA_E_INVALID, "pna_posttrans_x3_f32: row_perm needs N <= 80 (1 or 3 scalers) or 80 < N <= 128 (1 scaler), M % 128 == 0 (1 scaler) / M % 192 == 0 (3 scalers), no h panel / towers");
     g.perm = p->row_perm; g.tile_image = p->tile_image; g.img_stride = p->tile_image ? p->image_stride : 0;
     // (the short rest list of a degree plan -- ~26 tiles, one step-latency-bound tile per workgroup, 44 us -- on 4-wavefront
     // workgroups of 64 rows over 3x the CUs: measured, layer 1.245 vs 1.230 ms, not kept)

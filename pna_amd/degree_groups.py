@@ -23,6 +23,11 @@ TILE = 128                 # rows of a workgroup tile of the one-block grouped k
 TILE_REST = 192            # ... of the three-block kernel that takes the rest (12 wavefronts x 16 rows)
 MIN_ROWS = 1 << 17         # graphs smaller than this keep the ordinary path (the grouping is worth it when launches are long)
 ENABLED = True
+# Where the grouping pays (tools/dg_shapes_time.py, 1 M nodes / 10 M edges, one run, grouped vs ordinary layer, ms): 3 scalers
+# F = 20: 0.524 / 0.497, 32: 0.524 / 0.519, 50: 0.973 / 1.017, 64: 0.908 / 1.058, 75: 1.296 / 1.441, 96: 1.426 / 1.998;
+# 2 scalers F = 75: 1.297 / 1.288, 128: 1.880 / 2.277.
+MIN_OUT = 40               # narrower outputs keep the ordinary path (no gain measured at 20 and 32)
+TWO_SCALER_MIN_OUT = 81    # two scaler blocks -> one saves half, not two thirds: a gain only on the 128-column block
 AGG_ALIGN = 32             # the aggregate's row pitch is rounded up to this many floats (32 = 128-byte lines; 1 = packed rows), see agg_pitch
 
 
@@ -165,5 +170,5 @@ def combined_images(weight, K, row_scales, plan):
 def applies(graph, V, N, n_scaler, aggregators):
     from .graph import Graph
     from .shard import HaloGraph
-    return (ENABLED and type(graph) in (Graph, HaloGraph) and V >= MIN_ROWS and 64 < N <= 128 and n_scaler == 3
+    return (ENABLED and type(graph) in (Graph, HaloGraph) and V >= MIN_ROWS and MIN_OUT <= N <= 128 and (n_scaler == 3 or (n_scaler == 2 and N >= TWO_SCALER_MIN_OUT))
             and tuple(aggregators) == ("mean", "max", "min", "std") and V * (80 if N <= 80 else 128) * 4 < (1 << 32))

@@ -329,12 +329,13 @@ def degree_grouped_posttrans(layer, graph, h, agg, plan, out=None):
                       row_perm=plan.perm, tile_image=plan.tile_image, w_img=img, image_stride=stride, n_out=N)
     if plan.NR:                 # (on a side stream beside the grouped launch: measured, no gain -- one after the other)
         rest_scales = plan.rest_scales(tuple(layer.scalers) + (float(layer.avg_d["log"]),), scales)
-        if N <= 80:
+        if N <= 80 and len(scales) == 3:
             ops.posttrans(agg[plan.NV:], K, lin.weight, rest_scales, lin.bias, out=y, col_scale=cs, col_shift=ct, relu=True, residual=res,
                           row_perm=plan.perm_rest, n_out=N)
         else:
-            # 128-column block: three blocks x three weight buffers do not fit the LDS, so the few rest rows take the ordinary
-            # three-block kernel over their compact list and are scattered by index (three small torch kernels)
+            # 128-column block (three blocks x three weight buffers do not fit the LDS) or two scalers (no grouped instantiation):
+            # the few rest rows take the ordinary kernel over their compact list and are scattered by index (three small torch
+            # kernels)
             rr = plan.rest_rows
             y_r = ops.posttrans(agg[plan.NV:plan.NV + plan.NR], K, lin.weight, [None if r is None else r[:plan.NR] for r in rest_scales],
                                 lin.bias, col_scale=cs, col_shift=ct, relu=True, residual=None if res is None else res.index_select(0, rr),

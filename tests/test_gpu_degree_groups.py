@@ -7,10 +7,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _layer(F, N, dev, residual=True, seed=0):
+def _layer(F, N, dev, residual=True, seed=0, scalers="identity amplification attenuation"):
     from pna_amd.dgl.pna_layer import PNASimpleLayer
     torch.manual_seed(seed)
-    layer = PNASimpleLayer(F, N, "mean max min std", "identity amplification attenuation", {"log": torch.tensor(2.3)}, 0.0, True, residual)
+    layer = PNASimpleLayer(F, N, "mean max min std", scalers, {"log": torch.tensor(2.3)}, 0.0, True, residual)
     with torch.no_grad():
         for p in layer.parameters():
             p.copy_(torch.randn_like(p) / (p.shape[-1] ** 0.5 if p.dim() == 2 else 3.0))
@@ -86,3 +86,47 @@ def test_grouped_layer_rows_vs_float64(cuda_device):
         ref = h[v].double() + torch.relu(z)
         worst = max(worst, (y[v].double() - ref).abs().max().item() / max(1.0, ref.abs().max().item()))
     assert worst <= 2e-5, worst
+
+
+@pytest.mark.parametrize("F,N,scalers,residual", [
+    (32, 32, "identity amplification attenuation", True),          # narrow outputs: still the 80-column block (predicated columns)
+    (50, 50, "identity amplification attenuation", True),          # (32 and the two-scaler 75 are off by default -- no gain
+                                                                   #  measured -- and enabled here for the code path)
+    (75, 75, "identity amplification", True),                      # two scalers: W_D = W_0 + amp(D) W_1, rest rows by index scatter
+    (75, 75, "amplification attenuation", True),                   # no identity block
+    (40, 100, "identity amplification attenuation", False),        # in_dim != out_dim (no residual), the 128-column block
+    (90, 70, "identity attenuation", False),
+])
+def test_grouped_layer_other_shapes(cuda_device, F, N, scalers, residual):
+    from pna_amd import Graph, degree_groups as DG
+    from pna_amd.synth import powerlaw_graph
+    V, E = 160_000, 1_500_000
+    src, dst = powerlaw_graph(V, E, seed=F + N, device=cuda_device)
+    g = Graph(src, dst, V)
+    layer = _layer(F, N, cuda_device, residual=residual, seed=N, scalers=scalers)
+    h = torch.randn(V, F, device=cuda_device)
+    keep = (DG.ENABLED, DG.MIN_OUT, DG.TWO_SCALER_MIN_OUT)
+    DG.MIN_OUT, DG.TWO_SCALER_MIN_OUT = 1, 1
+    try:
+        with torch.no_grad():
+            assert layer._degree_grouped_path(g, h)
+            y_grouped = layer(g, h)
+            DG.ENABLED = False
+            y_plain = layer(g, h)
+    finally:
+        DG.ENABLED, DG.MIN_OUT, DG.TWO_SCALER_MIN_OUT = keep
+    assert y_grouped.shape == (V, N) and torch.isfinite(y_grouped).all()
+    assert (y_grouped - y_plain).abs().max().item() <= 2e-5 * y_plain.abs().max().item()
+
+
+def test_grouping_is_on_where_it_was_measured_to_pay(cuda_device):
+    from pna_amd import degree_groups as DG
+    from pna_amd import Graph
+    from pna_amd.synth import powerlaw_graph
+    V = DG.MIN_ROWS
+    src, dst = powerlaw_graph(V, 4 * V, seed=1, device=cuda_device)
+    g = Graph(src, dst, V)
+    aggr = ("mean", "max", "min", "std")
+    assert DG.applies(g, V, 75, 3, aggr) and DG.applies(g, V, 128, 3, aggr) and DG.applies(g, V, 128, 2, aggr) and DG.applies(g, V, 50, 3, aggr)
+    assert not DG.applies(g, V, 32, 3, aggr) and not DG.applies(g, V, 75, 2, aggr) and not DG.applies(g, V, 75, 1, aggr)
+    assert not DG.applies(g, V - 1, 75, 3, aggr) and not DG.applies(g, V, 75, 3, ("mean", "max")) and not DG.applies(g, V, 129, 3, aggr)
