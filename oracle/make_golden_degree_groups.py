@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""Golden vectors for the degree-grouped contraction, produced by the REFERENCE's own source.  TEST INFRASTRUCTURE ONLY.
+
+The fixtures of make_golden.py are molecule-sized: no in-degree value has the 128 rows a degree tile needs, so through the
+grouped path they only reach its rest list.  These graphs have a few thousand nodes (hundreds of rows per frequent degree,
+rare degrees and a few hubs as well); `models/dgl/pna_layer.py::PNASimpleLayer` runs unmodified over oracle/dgl_standin.py.
+Stored: graph, features, parameters and the layer OUTPUT (the (V, 12F) reduce tensor would be megabytes; the small fixtures
+pin it).  Kind "dgl_simple_groups".
+
+Run in the build container only (the GPU box has no /root/reference):
+    python oracle/make_golden_degree_groups.py            # writes tests/golden/groups_*.npz
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import make_golden as MG  # noqa: E402  (installs the DGL stand-in, imports the reference layers)
+from oracle import dgl_standin  # noqa: E402
+
+
+def golden_groups(name, seed, N, E, F, out_dim, scalers=MG.SCA3, residual=True, hubs=3):
+    rng = np.random.default_rng(seed)
+    gen = torch.Generator().manual_seed(seed)
+    src, dst = MG.powerlaw_graph(rng, N, E)
+    # a few hub rows far above every other in-degree (the hub rows of the gather's heavy path at full size)
+    hub_dst = np.repeat(rng.choice(N, size=hubs, replace=False), 300)
+    src = np.concatenate([src, rng.integers(0, N, size=hub_dst.size)]).astype(np.int64)
+    dst = np.concatenate([dst, hub_dst]).astype(np.int64)
+    deg = np.bincount(dst, minlength=N)
+    avg_log = torch.tensor(float(np.mean(np.log(deg + 1))), dtype=torch.float32)
+    torch.manual_seed(seed)
+    layer = MG.RefSimpleLayer(F, out_dim, MG.AGG4, scalers, {"log": avg_log}, 0.0, True, residual, posttrans_layers=1).eval()
+    MG.randomise(layer, gen)
+    h = torch.randn(N, F, generator=gen)
+    g = dgl_standin.StandinGraph(src, dst, N)
+    with torch.no_grad():
+        out = layer(g, h)
+    cnt = np.bincount(deg)
+    meta = dict(kind="dgl_simple_groups", seed=seed, N=N, F=F, out_dim=out_dim, aggregators=MG.AGG4, scalers=scalers,
+                residual=residual, batch_norm=True, posttrans_layers=1, degrees_with_128_rows=int((cnt >= 128).sum()),
+                max_in_degree=int(deg.max()))
+    MG.save(name, meta, dict(src=src.astype(np.int32), dst=dst.astype(np.int32), h=h, avg_log=avg_log, out=out), layer)
+
+
+def main():
+    os.makedirs(MG.OUT, exist_ok=True)
+    torch.set_num_threads(1)
+    golden_groups("groups_f44", 11, N=2600, E=9000, F=44, out_dim=44)                                  # 80-column block, 3 scalers
+    golden_groups("groups_f96_two_scalers", 12, N=1500, E=5000, F=96, out_dim=96, scalers="identity amplification")   # 128-column block
+
+
+if __name__ == "__main__":
+    main()

@@ -130,3 +130,33 @@ def test_grouping_is_on_where_it_was_measured_to_pay(cuda_device):
     assert DG.applies(g, V, 75, 3, aggr) and DG.applies(g, V, 128, 3, aggr) and DG.applies(g, V, 128, 2, aggr) and DG.applies(g, V, 50, 3, aggr)
     assert not DG.applies(g, V, 32, 3, aggr) and not DG.applies(g, V, 75, 2, aggr) and not DG.applies(g, V, 75, 1, aggr)
     assert not DG.applies(g, V - 1, 75, 3, aggr) and not DG.applies(g, V, 75, 3, ("mean", "max")) and not DG.applies(g, V, 129, 3, aggr)
+
+
+@pytest.mark.parametrize("path", ["degree-grouped", "ordinary"])
+@pytest.mark.parametrize("name", __import__("conftest").golden_names("dgl_simple_groups"))
+def test_grouped_layer_vs_reference_golden(cuda_device, name, path):
+    """The REFERENCE's own output (models/dgl/pna_layer.py::PNASimpleLayer run by oracle/make_golden_degree_groups.py) on graphs
+    where degree tiles exist: through the grouped path (thresholds lowered so that it takes these few thousand rows) and through
+    the ordinary one."""
+    from conftest import load_golden
+    from pna_amd import Graph, degree_groups as DG, functional as PF
+    from pna_amd.dgl.pna_layer import PNASimpleLayer
+    meta, a, sd = load_golden(name)
+    layer = PNASimpleLayer(meta["F"], meta["out_dim"], meta["aggregators"], meta["scalers"], {"log": a["avg_log"]}, 0.0, True, meta["residual"])
+    layer.load_state_dict(sd)
+    layer = layer.to(cuda_device).eval()
+    g = Graph(a["src"].long(), a["dst"].long(), meta["N"]).to(cuda_device)
+    h = a["h"].to(cuda_device)
+    keep = (DG.ENABLED, DG.MIN_ROWS, DG.MIN_OUT, DG.TWO_SCALER_MIN_OUT, PF.SMALL_SIMPLE_ROWS)
+    PF.SMALL_SIMPLE_ROWS = 0
+    DG.ENABLED, DG.MIN_ROWS, DG.MIN_OUT, DG.TWO_SCALER_MIN_OUT = path == "degree-grouped", 1, 1, 1
+    try:
+        with torch.no_grad():
+            assert layer._degree_grouped_path(g, h) == (path == "degree-grouped")
+            out = layer(g, h).cpu()
+        if path == "degree-grouped":
+            plan = DG.plan_of(g)
+            assert plan.G >= meta["degrees_with_128_rows"] - 1 and plan.G > 0 and plan.NR > 0
+    finally:
+        DG.ENABLED, DG.MIN_ROWS, DG.MIN_OUT, DG.TWO_SCALER_MIN_OUT, PF.SMALL_SIMPLE_ROWS = keep
+    torch.testing.assert_close(out, a["out"], rtol=1e-5, atol=1e-5)
