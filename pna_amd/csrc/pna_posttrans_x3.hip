@@ -248,8 +248,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
   auto load_a_piece = [&](aset_t& dst, int t, int c, int r, int w) __attribute__((always_inline)) {
     const float* src; long ld; int kmax, k;
     a_src(c, src, ld, kmax, k);
-#ifdef X3_DEV_A_FROM_L2     // development: every tile reads the first tile's rows (how much of the kernel is A latency?)
+#if defined(X3_DEV_A_FROM_L2)     // development: every tile reads the first tile's rows (how much of the kernel is A latency?)
     const int row = min((0 * t + wave) * (16 * RT) + 16 * r + li, g.M - 1);
+#elif defined(X3_DEV_A_WRAP_ROWS) // development: the A rows wrap around a window that fits the Infinity Cache
+    const int row = min(((t * WAVES + wave) * (16 * RT) + 16 * r + li) % (X3_DEV_A_WRAP_ROWS), g.M - 1);
 #else
     const int row = min((t * WAVES + wave) * (16 * RT) + 16 * r + li, g.M - 1);
 #endif
