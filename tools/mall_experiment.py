@@ -49,6 +49,10 @@ def ev(fn, n=20):
 
 
 tag = os.environ.get("PNA_AMD_LIB", "shipped library")
+if os.environ.get("NT_STORE"):          # NT_STORE=-1: ordinary (cache-allocating) output stores instead of the non-temporal default
+    from pna_amd import ops
+    ops.set_tuning(nt_store=int(os.environ["NT_STORE"]))
+    tag += f", nt_store={os.environ['NT_STORE']}"
 with torch.no_grad():
     agg = PF.degree_grouped_aggregate(layer, g, h, plan)
     y = torch.empty(V, F, device=dev)
