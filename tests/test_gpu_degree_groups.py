@@ -40,7 +40,7 @@ def test_grouped_layer_equals_plain_layer(cuda_device, V, E, F):
             DG.ENABLED = keep
     assert torch.isfinite(y_grouped).all()
     scale = y_plain.abs().max().item()
-    assert (y_grouped - y_plain).abs().max().item() <= 2e-5 * scale
+    assert (y_grouped - y_plain).abs().max().item() <= 2e-6 * scale          # (measured: ~1e-7; the combined weights are rounded once)
     # the plan: every node exactly once, groups are whole tiles of one degree, hub rows in the compacted rest
     plan = DG.plan_of(g)
     deg = g.in_degrees()
@@ -116,7 +116,7 @@ def test_grouped_layer_other_shapes(cuda_device, F, N, scalers, residual):
     finally:
         DG.ENABLED, DG.MIN_OUT, DG.TWO_SCALER_MIN_OUT = keep
     assert y_grouped.shape == (V, N) and torch.isfinite(y_grouped).all()
-    assert (y_grouped - y_plain).abs().max().item() <= 2e-5 * y_plain.abs().max().item()
+    assert (y_grouped - y_plain).abs().max().item() <= 2e-6 * y_plain.abs().max().item()
 
 
 def test_grouping_is_on_where_it_was_measured_to_pay(cuda_device):

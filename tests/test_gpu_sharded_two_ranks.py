@@ -100,7 +100,7 @@ def test_two_rank_sharded_layers_on_one_gpu():
 def _worker_grouped(rank, world, port, V, E, F):
     """The degree-grouped contraction on shards: every rank plans its OWN rows (a row's in-degree is global: the shard holds all
     its in-edges), the interior rows are gathered in degree order while the exchange is in flight, boundary rows and hub
-    segments after it.  Against the unsharded three-block path: equal to the rounding of the combined weights (2e-5 of max|y|,
+    segments after it.  Against the unsharded three-block path: equal to the rounding of the combined weights (2e-6 of max|y|,
     the bar of tests/test_gpu_degree_groups.py); the aggregate itself stays bit-identical."""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -135,7 +135,7 @@ def _worker_grouped(rank, world, port, V, E, F):
                 agg = PF.degree_grouped_aggregate(layer, gs, hr, plan)
                 got_plain_tensor = layer(gs, h[lo:hi].clone())                   # not in the resident table: synchronous exchange
             assert plan.G > 0 and plan.NR > 0
-            tol = 2e-5 * want.abs().max().item()
+            tol = 2e-6 * want.abs().max().item()          # (measured on one GPU: ~1e-7)
             assert (got - want).abs().max().item() <= tol and (got_plain_tensor - want).abs().max().item() <= tol
             # the plan-ordered aggregate holds the natural-order rows, bit for bit
             real = plan.perm >= 0
