@@ -32,6 +32,8 @@ def test_grouped_layer_equals_plain_layer(cuda_device, V, E, F):
     with torch.no_grad():
         assert layer._degree_grouped_path(g, h)
         y_grouped = layer(g, h)
+        for _ in range(3):                                   # run-to-run identical bits (two workgroups per CU share LDS-DMA'd weights)
+            assert torch.equal(layer(g, h), y_grouped)
         keep, DG.ENABLED = DG.ENABLED, False
         try:
             assert not layer._degree_grouped_path(g, h)
@@ -160,3 +162,20 @@ def test_grouped_layer_vs_reference_golden(cuda_device, name, path):
     finally:
         DG.ENABLED, DG.MIN_ROWS, DG.MIN_OUT, DG.TWO_SCALER_MIN_OUT, PF.SMALL_SIMPLE_ROWS = keep
     torch.testing.assert_close(out, a["out"], rtol=1e-5, atol=1e-5)
+
+
+def test_grouped_layer_is_deterministic_at_full_size(cuda_device):
+    """The C3 shape, ten runs of the degree-grouped layer: identical bits (an experimental fused kernel with the same weight
+    pipeline was NOT, with two workgroups per CU -- DESIGN.md 4.7 point 7; the shipped kernels are checked for the same symptom)."""
+    from pna_amd import Graph
+    from pna_amd.synth import powerlaw_graph
+    V, E, F = 1_000_000, 10_000_000, 75
+    src, dst = powerlaw_graph(V, E, seed=1234, device=cuda_device)
+    g = Graph(src, dst, V)
+    layer = _layer(F, F, cuda_device, seed=7)
+    h = torch.randn(V, 80, device=cuda_device)[:, :F]
+    with torch.no_grad():
+        assert layer._degree_grouped_path(g, h)
+        y0 = layer(g, h).clone()
+        for _ in range(10):
+            assert torch.equal(layer(g, h), y0)

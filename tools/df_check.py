@@ -6,8 +6,8 @@ point 7) against the shipped two-kernel degree-grouped layer and the ordinary la
           tools/ubench/degree_fused.hip -o tools/ubench/libdegree_fused.so
     [DF_WGS=1|2] [DF_DEBUG_AGG=1] python tools/df_check.py [time]
 
-DF_WGS: workgroups per CU (1: exact, 2.15 ms on C3; 2 -- the kernel's default --: 1.405 ms, whole 16-row tiles wrong at the 1e-5
-level, not reproducible run to run).  DF_DEBUG_AGG=1: the kernel dumps the statistics its contraction sees; compared bit for bit
+DF_WGS: workgroups per CU (1: exact, 1.84 ms on C3; 2 -- the kernel's default --: 1.231 ms, whole 16-row tiles wrong at the 1e-5
+level, not reproducible run to run).  DF_LIB: another build of the experiment (e.g. -DDF_WAVES=8 -> libdegree_fused_w8.so).  DF_DEBUG_AGG=1: the kernel dumps the statistics its contraction sees; compared bit for bit
 with the production aggregate.  Nothing here is part of the product: the group rows go through the experimental kernel, the
 rest rows through the shipped gather + grouped contraction over their own work list.
 """
@@ -25,7 +25,7 @@ from pna_amd.synth import powerlaw_graph  # noqa: E402
 
 dev = torch.device("cuda:0")
 WGS = int(os.environ.get("DF_WGS", "0"))
-X = ctypes.CDLL(os.path.join(ROOT, "tools", "ubench", "libdegree_fused.so"))
+X = ctypes.CDLL(os.path.join(ROOT, "tools", "ubench", os.environ.get("DF_LIB", "libdegree_fused.so")))
 
 
 class Args(ctypes.Structure):

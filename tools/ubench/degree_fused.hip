@@ -1,10 +1,11 @@
 // degree_fused.hip -- EXPERIMENT, NOT PART OF THE SHIPPED LIBRARY (DESIGN.md 4.7 point 7): gather + degree-grouped contraction of
 // PNASimpleLayer in ONE kernel, the 4F aggregate never in HBM.  First version, kept for the next round:
-//   * with ONE workgroup per CU its statistics are the production gather's bits and y agrees with the two-kernel path to 6.6e-8
-//     of max|y| -- but it takes 2.15 ms on the C3 layer (two-kernel degree-grouped path: 1.24-1.26 ms);
-//   * with TWO workgroups per CU (1.405 ms) whole 16-row wavefront tiles come out wrong, differently from run to run: ONE running
-//     sum (one VGPR, lanes 48-63) differs from the production value; also without any scratch use (F = 64: 185 registers).
-//     Not understood.  tools/df_check.py drives it.
+//   * with ONE workgroup per CU (one wavefront per SIMD) its statistics are the production gather's bits and y agrees with the
+//     two-kernel path to 1.1e-7 of max|y| on five shapes -- 1.84 ms on the C3 layer (two-kernel degree-grouped path: 1.23-1.26);
+//   * with TWO workgroups per CU (1.231 ms) whole 16-row wavefront tiles come out wrong, differently from run to run: a running
+//     sum differs from the production value; also without any scratch use (F = 64: 191 registers); with one 8-wavefront
+//     workgroup per CU (-DDF_WAVES=8, 1.341 ms) it still happens, less often: the trigger is two wavefronts per SIMD.
+//     Not understood.  tools/df_check.py drives it (DF_WGS, DF_LIB, DF_DEBUG_AGG).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC -Iinclude -Ipna_amd/csrc tools/ubench/degree_fused.hip -o tools/ubench/libdegree_fused.so
 //
 //   y[perm[v]] = epilogue( bias + W_D . [mean | max | min | std](messages into perm[v]) ),   W_D = sum_s scale_s(D) W_s
@@ -64,7 +65,10 @@ struct DFArgs {
 float* g_agg_dbg = nullptr;
 long g_ld_dbg = 0;
 
-constexpr int kNW = 80, kNT = 5, kWaves = 4, kThreads = 256, kNBuf = 3;
+#ifndef DF_WAVES
+#define DF_WAVES 4          // wavefronts per workgroup (development: 8 = one 128-row workgroup per CU instead of two of 64 rows)
+#endif
+constexpr int kNW = 80, kNT = 5, kWaves = DF_WAVES, kThreads = 64 * DF_WAVES, kNBuf = 3;
 constexpr int kChunkV = 3 * 4 * kNW;                      // 16-byte pieces of one chunk image: [term][lane group][80 cols][8 k] bf16
 constexpr int kNI = (kChunkV + kThreads - 1) / kThreads;  // global_load_lds instructions per wavefront per chunk
 #ifndef DF_KU
@@ -148,20 +152,22 @@ __global__ __launch_bounds__(kThreads, 2) DF_ATTR void k_degree_fused(const DFAr
           v[u][fb][1] = *reinterpret_cast<const f4*>(p + f0[fb] + 4);
         }
       }
+      // branch-free tail (as the production gather's partial batch): a slot past the row holds a copy of the row's last edge --
+      // idempotent for max / min, replaced by +0 for the sums -- so that all kU edges' loads stay in flight together
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
-        if (e + u < D) {                                  // (wave-uniform)
+        const bool on = e + u < D;                        // (wave-uniform)
 #pragma unroll
-          for (int fb = 0; fb < NFB; ++fb)
+        for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float m = v[u][fb][j >> 2][j & 3];
-              S_[fb][j] = S_[fb][j] + m;
-              Q_[fb][j] = Q_[fb][j] + m * m;
-              MX[fb][j] = vmax(MX[fb][j], m);
-              MN[fb][j] = vmin(MN[fb][j], m);
-            }
-        }
+          for (int j = 0; j < 8; ++j) {
+            const float m = v[u][fb][j >> 2][j & 3];
+            const float ms = on ? m : 0.f;
+            S_[fb][j] = S_[fb][j] + ms;
+            Q_[fb][j] = Q_[fb][j] + ms * ms;
+            MX[fb][j] = vmax(MX[fb][j], m);
+            MN[fb][j] = vmin(MN[fb][j], m);
+          }
       }
     }
   };
@@ -347,7 +353,7 @@ extern "C" int degree_fused_f32(const degree_fused_args* p, void* stream) {
   const int nfb = (p->F + 31) / 32;
   if (p->ldx < (p->F + 7) / 8 * 8 || p->ldx % 4 != 0 || ((uintptr_t)p->x & 15) != 0)
     return PNA_E_INVALID;
-  if (p->M < 0 || p->M % 64 != 0 || (p->tile_rows != 64 && p->tile_rows != 128))
+  if (p->M < 0 || p->M % (kWaves * 16) != 0 || (p->tile_rows != 64 && p->tile_rows != 128))
     return PNA_E_INVALID;
   if (p->ldy < p->N || (int64_t)p->ldy * 4 >= (1ll << 32) || (p->residual && (p->ld_res < p->N || (int64_t)p->ld_res * 4 >= (1ll << 32))) || p->image_stride <= 0)
     return PNA_E_INVALID;
@@ -359,9 +365,10 @@ extern "C" int degree_fused_f32(const degree_fused_args* p, void* stream) {
   g.perm = p->row_perm; g.tile_image = p->tile_image; g.w_img = (const unsigned char*)p->w_img; g.img_stride = p->image_stride;
   g.bias = p->bias; g.col_scale = p->col_scale; g.col_shift = p->col_shift; g.residual = p->residual; g.y = p->y;
   g.ldy = p->ldy; g.ld_res = p->ld_res; g.M = (int)p->M; g.N = p->N; g.relu = p->relu; g.slope = p->act_slope;
-  g.tile_shift = p->tile_rows == 128 ? 1 : 0;
+  g.tile_shift = (p->tile_rows == 128 ? 1 : 0) - (kWaves == 8 ? 1 : 0);
+  if (g.tile_shift < 0) return PNA_E_INVALID;
   g.agg_dbg = g_agg_dbg; g.ld_dbg = g_ld_dbg;
-  const int ntiles = (int)(p->M / 64);
+  const int ntiles = (int)(p->M / (kWaves * 16));
   const int per_cu = p->workgroups_per_cu > 0 ? p->workgroups_per_cu : 2;
   const int wgs = ntiles < per_cu * cus ? ntiles : per_cu * cus;
   hipStream_t st = (hipStream_t)stream;
