@@ -53,7 +53,10 @@ class DegreePlan:
         self.G = int(big.sum().item())
         perm = torch.full((max(self.NV, 1),), -1, dtype=torch.int32, device=dev)
         rank = torch.arange(V, device=dev) - start[gid]
-        vpos = (vstart[big_index[gid].clamp(min=0)] + rank)[in_big]
+        if self.G:
+            vpos = (vstart[big_index[gid].clamp(min=0)] + rank)[in_big]
+        else:                                                            # no degree value fills a tile: every row is a rest row
+            vpos = torch.zeros(0, dtype=torch.long, device=dev)
         perm[vpos] = order[in_big].to(torch.int32)
         self.perm = perm[:self.NV].contiguous()
         self.tile_image = torch.repeat_interleave(torch.arange(self.G, device=dev, dtype=torch.int32), padded // TILE).contiguous()

@@ -1,0 +1,103 @@
+"""Host logic of the degree-grouped contraction (pna_amd/degree_groups.py) on CPU tensors: the plan's bookkeeping, the work
+list it hands the gather, and the algebra the grouped kernels rely on -- in float64, with the plan's own tables:
+    y[perm[v]] = W_D[tile_image[v // TILE]] a[perm[v]],  W_D = W_0 + amp(D) W_1 + att(D) W_2,  scalers taken at group_first_row
+equals the reference formulation Linear([a | amp a | att a]) (models/dgl/pna_layer.py:203-206) row for row."""
+import pytest
+import torch
+
+from pna_amd import Graph, degree_groups as DG
+from pna_amd.synth import powerlaw_graph
+
+
+@pytest.fixture(scope="module")
+def graph_and_plan():
+    V, E = 30_000, 240_000
+    src, dst = powerlaw_graph(V, E, seed=5)
+    g = Graph(src, dst, V)
+    return g, DG.DegreePlan(g)
+
+
+def test_plan_covers_every_node_once_in_single_degree_tiles(graph_and_plan):
+    g, plan = graph_and_plan
+    V = g.num_nodes
+    deg = g.in_degrees().long()
+    covered = torch.cat([plan.perm[plan.perm >= 0], plan.perm_rest[plan.perm_rest >= 0]]).long()
+    assert covered.numel() == V and torch.equal(torch.sort(covered).values, torch.arange(V))
+    assert plan.G > 0 and plan.NR > 0
+    assert plan.NV % DG.TILE == 0 and plan.NRp % DG.TILE_REST == 0 and plan.rows == plan.NV + plan.NRp
+    assert plan.tile_image.numel() == plan.NV // DG.TILE and plan.perm.numel() == plan.NV and plan.perm_rest.numel() == plan.NRp
+    tiles = plan.perm.view(-1, DG.TILE).long()
+    d = torch.where(tiles >= 0, deg[tiles.clamp(min=0)], torch.full_like(tiles, -1))
+    assert bool(((d == d.max(dim=1, keepdim=True).values) | (d < 0)).all())                 # one in-degree per tile
+    assert torch.equal(d.max(dim=1).values, plan.group_degree[plan.tile_image.long()].long())
+    assert bool((tiles[:, 0] >= 0).all())                                                  # padding only trails a group
+    assert torch.equal(deg[plan.group_first_row.long()], plan.group_degree.long())         # the row whose scalers stand for the group
+    assert bool((torch.bincount(plan.tile_image.long(), minlength=plan.G) > 0).all())
+    hs = g.heavy_schedule()
+    rest = plan.perm_rest[plan.perm_rest >= 0].long()
+    assert int((deg[rest] > hs.threshold).sum()) == hs.n_heavy                            # every hub row is a rest row
+    in_group = plan.perm[plan.perm >= 0].long()
+    counts = torch.bincount(deg[in_group])
+    assert bool((counts[counts > 0] >= DG.TILE).all())                                     # only degrees with a whole tile of rows
+
+
+def test_plan_work_list_is_the_graphs_with_output_rows(graph_and_plan):
+    g, plan = graph_and_plan
+    base = g.work_items()
+    hs = g.heavy_schedule()
+    n_seg = hs.n_seg if hs.n_heavy > 0 else 0
+    assert plan.items.shape == base.shape and torch.equal(plan.items[:, 1:], base[:, 1:])
+    assert torch.equal(plan.items[:n_seg], base[:n_seg])
+    where = torch.cat([plan.perm, plan.perm_rest]).long()
+    vrows = plan.items[n_seg:, 0].long()
+    assert torch.equal(where[vrows], base[n_seg:, 0].long()) and torch.unique(vrows).numel() == vrows.numel()
+    if hs.n_heavy:
+        assert torch.equal(where[plan.heavy_out.long()], hs.heavy_rows.long()) and bool((plan.heavy_out >= plan.NV).all())
+
+
+def test_combined_weight_algebra_with_the_plans_tables(graph_and_plan):
+    g, plan = graph_and_plan
+    V, F, N = g.num_nodes, 6, 5
+    K = 4 * F
+    gen = torch.Generator().manual_seed(0)
+    a = torch.randn(V, K, generator=gen, dtype=torch.float64)
+    W = torch.randn(N, 3 * K, generator=gen, dtype=torch.float64)
+    deg = g.in_degrees().double()
+    delta = torch.log(deg + 1).mean()
+    amp = torch.log(deg + 1) / delta                                                      # models/dgl/scalers.py:12-14
+    att = torch.where(deg > 0, delta / torch.log(deg + 1), torch.zeros_like(deg))        # :17-19 (rows without in-edges: aggregate is 0)
+    want = torch.cat([a, a * amp[:, None], a * att[:, None]], dim=1) @ W.t()
+    first = plan.group_first_row.long()
+    W_D = W[None, :, :K] + amp[first, None, None] * W[None, :, K:2 * K] + att[first, None, None] * W[None, :, 2 * K:]
+    got = torch.full((V, N), float("nan"), dtype=torch.float64)
+    img = plan.tile_image.long().repeat_interleave(DG.TILE)                               # image of every virtual row
+    real = plan.perm >= 0
+    nodes = plan.perm[real].long()
+    got[nodes] = torch.einsum("vnk,vk->vn", W_D[img[real]], a[nodes])
+    rest = plan.perm_rest[plan.perm_rest >= 0].long()
+    sc = plan.rest_scales(("t",), [None, amp.float(), att.float()])
+    assert sc[0] is None and torch.equal(sc[1][:plan.NR], amp.float()[rest]) and bool((sc[1][plan.NR:] == 0).all())
+    got[rest] = want[rest]
+    assert not bool(torch.isnan(got).any())
+    assert (got - want).abs().max().item() <= 1e-12 * want.abs().max().item()
+
+
+def test_aggregate_pitch_and_gating():
+    assert DG.agg_pitch(300) == 320 and DG.agg_pitch(512) == 512 and DG.agg_pitch(4) == 32
+    V = DG.MIN_ROWS
+    src, dst = powerlaw_graph(V, 4 * V, seed=1)
+    g = Graph(src, dst, V)
+    aggr = ("mean", "max", "min", "std")
+    assert DG.applies(g, V, 75, 3, aggr) and DG.applies(g, V, 128, 3, aggr) and DG.applies(g, V, 128, 2, aggr) and DG.applies(g, V, 50, 3, aggr)
+    assert not DG.applies(g, V, 32, 3, aggr) and not DG.applies(g, V, 75, 2, aggr) and not DG.applies(g, V, 75, 1, aggr)
+    assert not DG.applies(g, V - 1, 75, 3, aggr) and not DG.applies(g, V, 75, 3, ("mean", "max")) and not DG.applies(g, V, 129, 3, aggr)
+
+
+def test_plan_without_any_group():
+    """No in-degree value fills a 128-row tile (a small graph): the plan is all rest rows, nothing crashes."""
+    src, dst = powerlaw_graph(500, 5000, seed=1)
+    g = Graph(src, dst, 500)
+    plan = DG.DegreePlan(g)
+    assert plan.G == 0 and plan.NV == 0 and plan.NR == 500 and plan.NRp == 576 and plan.perm.numel() == 0 and plan.tile_image.numel() == 0
+    assert torch.equal(torch.sort(plan.perm_rest[:500].long()).values, torch.arange(500)) and bool((plan.perm_rest[500:] < 0).all())
+    assert torch.equal(torch.sort(plan.items[:, 0].long()).values, torch.arange(500))

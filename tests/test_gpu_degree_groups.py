@@ -179,3 +179,28 @@ def test_grouped_layer_is_deterministic_at_full_size(cuda_device):
         y0 = layer(g, h).clone()
         for _ in range(10):
             assert torch.equal(layer(g, h), y0)
+
+
+def test_grouped_path_on_a_graph_without_any_group(cuda_device):
+    """No degree value fills a tile: the plan is all rest rows (the three-block grouped kernel over the whole graph)."""
+    from pna_amd import Graph, degree_groups as DG
+    from pna_amd.synth import powerlaw_graph
+    V, E, F = 700, 7000, 75
+    src, dst = powerlaw_graph(V, E, seed=2, device=cuda_device)
+    g = Graph(src, dst, V)
+    layer = _layer(F, F, cuda_device, seed=1)
+    h = torch.randn(V, F, device=cuda_device)
+    keep = (DG.ENABLED, DG.MIN_ROWS)
+    from pna_amd import functional as PF
+    keep_small, PF.SMALL_SIMPLE_ROWS = PF.SMALL_SIMPLE_ROWS, 0
+    try:
+        with torch.no_grad():
+            DG.ENABLED, DG.MIN_ROWS = True, 1
+            assert layer._degree_grouped_path(g, h) and DG.plan_of(g).G == 0
+            y_grouped = layer(g, h)
+            DG.ENABLED = False
+            y_plain = layer(g, h)
+    finally:
+        DG.ENABLED, DG.MIN_ROWS = keep
+        PF.SMALL_SIMPLE_ROWS = keep_small
+    assert (y_grouped - y_plain).abs().max().item() <= 2e-6 * y_plain.abs().max().item()

@@ -98,6 +98,19 @@ def _worker(rank, world, port, V, E, F):
         assert not bool(interior[halo_rows].any())
         if hs.n_heavy:
             assert not bool(interior[hs.heavy_rows.long()].any())
+        # 7b. the degree plan of a shard (pna_amd/degree_groups.py): its interior / boundary work lists are the shard's, record for
+        #     record, with the whole-row records' `row` replaced by the row's position in the plan-ordered aggregate
+        from pna_amd import degree_groups as DG
+        plan = DG.DegreePlan(g)
+        pin, pbd = plan.split_items(g)
+        n_seg = hs.n_seg if hs.n_heavy > 0 else 0
+        assert pin.shape == items_in.shape and pbd.shape == items_bd.shape
+        assert torch.equal(pin[:, 1:], items_in[:, 1:]) and torch.equal(pbd[:, 1:], items_bd[:, 1:])
+        assert torch.equal(pbd[:n_seg], items_bd[:n_seg])                                   # hub segments: untouched
+        vrows = torch.cat([pin[:, 0], pbd[n_seg:, 0]]).long()
+        nodes = torch.cat([items_in[:, 0], items_bd[n_seg:, 0]]).long()
+        where = torch.cat([plan.perm, plan.perm_rest]).long()                             # node of every virtual row (-1: padding)
+        assert torch.equal(where[vrows], nodes) and torch.unique(vrows).numel() == vrows.numel()
         # 8. edge-balanced partition: same identities, bounds monotone, edge counts within one max-degree of each other
         g2 = shard_graph(src, dst, V, balance="edges")
         b2 = partition_bounds(V, world, dst, "edges")
