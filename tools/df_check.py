@@ -6,8 +6,9 @@ point 7) against the shipped two-kernel degree-grouped layer and the ordinary la
           tools/ubench/degree_fused.hip -o tools/ubench/libdegree_fused.so
     [DF_WGS=1|2] [DF_DEBUG_AGG=1] python tools/df_check.py [time]
 
-DF_WGS: workgroups per CU (1: exact, 1.84 ms on C3; 2 -- the kernel's default --: 1.231 ms, whole 16-row tiles wrong at the 1e-5
-level, not reproducible run to run).  DF_LIB: another build of the experiment (e.g. -DDF_WAVES=8 -> libdegree_fused_w8.so).  DF_DEBUG_AGG=1: the kernel dumps the statistics its contraction sees; compared bit for bit
+DF_WGS: workgroups per CU (default 2: exact, 1.257 ms on C3 against 1.245 for the shipped path; 1: 1.84 ms).  DF_LIB: another
+build of the experiment -- -DDF_PACKED_FOLD (the fold as plain C++, which hipcc packs into v_pk_* ops): 1.231 ms and whole 16-row
+tiles wrong at the 1e-5 level, differently every run, unless DF_WGS=1; -DDF_WAVES=8: one 128-row workgroup per CU.  DF_DEBUG_AGG=1: the kernel dumps the statistics its contraction sees; compared bit for bit
 with the production aggregate.  Nothing here is part of the product: the group rows go through the experimental kernel, the
 rest rows through the shipped gather + grouped contraction over their own work list.
 """

@@ -1,11 +1,14 @@
 // degree_fused.hip -- EXPERIMENT, NOT PART OF THE SHIPPED LIBRARY (DESIGN.md 4.7 point 7): gather + degree-grouped contraction of
 // PNASimpleLayer in ONE kernel, the 4F aggregate never in HBM.  First version, kept for the next round:
-//   * with ONE workgroup per CU (one wavefront per SIMD) its statistics are the production gather's bits and y agrees with the
-//     two-kernel path to 1.1e-7 of max|y| on five shapes -- 1.84 ms on the C3 layer (two-kernel degree-grouped path: 1.23-1.26);
-//   * with TWO workgroups per CU (1.231 ms) whole 16-row wavefront tiles come out wrong, differently from run to run: a running
-//     sum differs from the production value; also without any scratch use (F = 64: 191 registers); with one 8-wavefront
-//     workgroup per CU (-DDF_WAVES=8, 1.341 ms) it still happens, less often: the trigger is two wavefronts per SIMD.
-//     Not understood.  tools/df_check.py drives it (DF_WGS, DF_LIB, DF_DEBUG_AGG).
+//   * as built by default (two workgroups per CU, the running sums folded by single v_add_f32 / v_mul_f32 instructions): statistics
+//     = the production gather's bits, y within 1.1e-7 of max|y| of the two-kernel path on five shapes, C3 layer 1.257 ms against
+//     1.245 ms for the shipped two-kernel degree-grouped path on the same box: correct, level, not yet faster;
+//   * with the fold written as plain C++ (-DDF_PACKED_FOLD: hipcc vectorises it into v_pk_add_f32 / v_pk_mul_f32 / v_pk_mov_b32
+//     with op_sel swizzles) whole 16-row wavefront tiles come out wrong, differently from run to run, whenever a second
+//     wavefront shares the SIMD (two 4-wavefront workgroups per CU, or one of 8: -DDF_WAVES=8); exact with one wavefront per
+//     SIMD (DF_WGS=1, 1.84 ms).  Replacing only the inline-asm v_max / v_min by fmaxf / fminf changes nothing.  The shipped
+//     kernels contain packed fp32 ops next to MFMAs too and do NOT show this (tests/test_gpu_determinism.py); what exactly
+//     the failing combination is, is open.  tools/df_check.py drives all of it (DF_WGS, DF_LIB, DF_DEBUG_AGG).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC -Iinclude -Ipna_amd/csrc tools/ubench/degree_fused.hip -o tools/ubench/libdegree_fused.so
 //
 //   y[perm[v]] = epilogue( bias + W_D . [mean | max | min | std](messages into perm[v]) ),   W_D = sum_s scale_s(D) W_s
@@ -163,10 +166,25 @@ __global__ __launch_bounds__(kThreads, 2) DF_ATTR void k_degree_fused(const DFAr
           for (int j = 0; j < 8; ++j) {
             const float m = v[u][fb][j >> 2][j & 3];
             const float ms = on ? m : 0.f;
+#if !defined(DF_PACKED_FOLD)     // the sums as single VALU instructions the compiler cannot pack (see the header: with the plain C++ below
+                                 // hipcc emits v_pk_add_f32 / v_pk_mul_f32 / v_pk_mov_b32 with op_sel swizzles, and the sums come out wrong
+                                 // in a few wavefront tiles per launch when a second wavefront shares the SIMD)
+            float s1, q1, p1;
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(s1) : "v"(S_[fb][j]), "v"(ms));
+            asm volatile("v_mul_f32 %0, %1, %1" : "=v"(p1) : "v"(ms));
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(q1) : "v"(Q_[fb][j]), "v"(p1));
+            S_[fb][j] = s1; Q_[fb][j] = q1;
+#else
             S_[fb][j] = S_[fb][j] + ms;
             Q_[fb][j] = Q_[fb][j] + ms * ms;
+#endif
+#if defined(DF_MINMAX_C)         // development: no inline-asm VALU in the gather (NaN handling differs: inputs here are finite)
+            MX[fb][j] = __builtin_fmaxf(MX[fb][j], m);
+            MN[fb][j] = __builtin_fminf(MN[fb][j], m);
+#else
             MX[fb][j] = vmax(MX[fb][j], m);
             MN[fb][j] = vmin(MN[fb][j], m);
+#endif
           }
       }
     }
