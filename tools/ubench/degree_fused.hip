@@ -290,12 +290,30 @@ __global__ __launch_bounds__(kThreads, 2) DF_ATTR void k_degree_fused(const DFAr
     bf8 B[2][3];                                         // B fragments of column tile n (slot n & 1): one ds_read_b128 per term
     constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
     constexpr int H = (kNT - 1) / 2;
+#if defined(DF_COUNTED_B)
+    // B fragments double buffered in registers, counted wait (the scheme of pna_posttrans_x3.hip): tile n+1's three reads are
+    // issued, then lgkmcnt(3) lets exactly those stay in flight behind tile n's MFMAs
+#pragma unroll
+    for (int tm = 0; tm < 3; ++tm)
+      asm volatile("ds_read_b128 %0, %1" : "=v"(B[0][tm]) : "v"(ba0 + (unsigned)(tm * 4 * kNW * 16)) : "memory");
+#pragma unroll
+    for (int n = 0; n < kNT; ++n) {
+      const int slot = n & 1;
+      if (n + 1 < kNT) {
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm)
+          asm volatile("ds_read_b128 %0, %1" : "=v"(B[slot ^ 1][tm]) : "v"(ba0 + (unsigned)(tm * 4 * kNW * 16 + (n + 1) * 256)) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(B[slot][0]), "+v"(B[slot][1]), "+v"(B[slot][2]) : : "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(B[slot][0]), "+v"(B[slot][1]), "+v"(B[slot][2]) : : "memory");
+      }
+#else
     // B fragments: column tile n+1's three reads are issued before tile n's MFMAs, but the wavefront waits for ALL of them
     // (lgkmcnt(0)) before it issues an MFMA: no LDS read lands while this wavefront's MFMAs are in flight.  The counted wait of
     // pna_posttrans_x3.hip (lgkmcnt(3): only tile n's fragments) gave errors of 2^-16 in whole 16-row tiles here, different
     // from run to run, when two of these 4-wavefront workgroups shared a CU -- exact with one workgroup per CU, with this wait,
     // or with 32 cycles of s_nop behind each tile's MFMAs; waiting with lgkmcnt(0) BEFORE issuing the next reads was not enough.
-    // The cause is not understood; the LDS latency this exposes is hidden by the other workgroup of the CU.
+    // (That was BEFORE the packed-fp32 fold was found to be what produced the wrong sums: -DDF_COUNTED_B restores the counted wait.)
 #pragma unroll
     for (int tm = 0; tm < 3; ++tm)
       asm volatile("ds_read_b128 %0, %1" : "=v"(B[0][tm]) : "v"(ba0 + (unsigned)(tm * 4 * kNW * 16)) : "memory");
@@ -308,6 +326,7 @@ __global__ __launch_bounds__(kThreads, 2) DF_ATTR void k_degree_fused(const DFAr
           asm volatile("ds_read_b128 %0, %1" : "=v"(B[slot ^ 1][tm]) : "v"(ba0 + (unsigned)(tm * 4 * kNW * 16 + (n + 1) * 256)) : "memory");
       }
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(B[0][0]), "+v"(B[0][1]), "+v"(B[0][2]), "+v"(B[1][0]), "+v"(B[1][1]), "+v"(B[1][2]) : : "memory");
+#endif
       if (n == H) {
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         if (c + 2 < NC) stage(c + 2, buf2, ib_cur);
