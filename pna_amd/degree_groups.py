@@ -8,9 +8,10 @@ log(D+1)/delta, attenuation delta/log(D+1), ...).  The posttrans Linear of the s
 
 The reference never uses this (it concatenates 12F columns and calls nn.Linear); here the rows are ordered by degree once per
 graph, the gather kernel writes the aggregate in that order (its work list carries the output row), and the bf16x3 contraction
-runs with ONE scaler block and a per-tile weight image W_D.  On the power-law benchmark graph 58 degree values cover 99.5 % of
+runs with ONE scaler block and a per-tile weight image W_D.  On the power-law benchmark graph 63 degree values hold 99.6 % of
 the rows; the rest (rare degrees, hub rows) go through the ordinary three-block contraction over a compacted row list.
 Both launches scatter their output rows back to node order (pna_posttrans_args.row_perm), so nothing else sees the order.
+Output widths up to 128, whole graphs and shards (every rank plans its own rows); DESIGN.md 4.2d has the measurements.
 """
 import ctypes
 
