@@ -32,10 +32,14 @@ TWO_SCALER_MIN_OUT = 81    # two scaler blocks -> one saves half, not two thirds
 AGG_ALIGN = 32             # the aggregate's row pitch is rounded up to this many floats (32 = 128-byte lines; 1 = packed rows), see agg_pitch
 
 
+_PLAN_SERIAL = __import__("itertools").count()
+
+
 class DegreePlan:
     """Row order, work list and tile -> group table of one graph (cached on the Graph; independent of weights / scalers)."""
 
     def __init__(self, graph):
+        self.serial = next(_PLAN_SERIAL)       # identifies the plan in cache keys (id() of a freed plan can come back for another graph)
         csr, hs = graph.csr, graph.heavy_schedule()
         dev = csr.rowptr.device
         rp = csr.rowptr.long()
@@ -133,7 +137,7 @@ def combined_images(weight, K, row_scales, plan):
     """Packed bf16x3 images of W_D = sum_s s_s(D) W_s for every group of `plan` (one buffer, image_stride bytes apart), cached
     on the weight per (version, scaler tensors, plan).  out_dim <= 80: ONE pack call over a (G * 80, K) matrix whose 80-column
     blocks are the images; 80 < out_dim <= 128: one pack call per image (the packer cuts wider matrices into 80-column blocks)."""
-    key = (weight._version, weight.data_ptr(), str(weight.device), tuple(weight.shape), K, id(plan),
+    key = (weight._version, weight.data_ptr(), str(weight.device), tuple(weight.shape), K, plan.serial, plan.G,
            tuple(None if rs is None else (rs.data_ptr(), rs._version) for rs in row_scales))
     hit = getattr(weight, "_pna_amd_group_img", None)
     if hit is not None and hit[0] == key:

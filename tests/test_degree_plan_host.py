@@ -101,3 +101,4 @@ def test_plan_without_any_group():
     assert plan.G == 0 and plan.NV == 0 and plan.NR == 500 and plan.NRp == 576 and plan.perm.numel() == 0 and plan.tile_image.numel() == 0
     assert torch.equal(torch.sort(plan.perm_rest[:500].long()).values, torch.arange(500)) and bool((plan.perm_rest[500:] < 0).all())
     assert torch.equal(torch.sort(plan.items[:, 0].long()).values, torch.arange(500))
+    assert DG.DegreePlan(g).serial != plan.serial                                          # cache keys tell two plans apart
