@@ -13,7 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "pna_amd", "csrc")
 
 
-@pytest.mark.parametrize("src,max_vgpr", [("pna_posttrans_x3.hip", {"k_posttrans_x3": 256}), ("pna_posttrans_x3w.hip", {"k_posttrans_x3w": 256}), ("pna_segreduce.hip", {"k_segreduce_fastILi4E": 80}),
+# (the grouped one-block kernel runs two 8-wavefront workgroups per CU: above 128 registers it would silently drop to one; the
+#  three-block grouped kernel runs 12 wavefronts per CU: 168)
+@pytest.mark.parametrize("src,max_vgpr", [("pna_posttrans_x3.hip", {"k_posttrans_x3": 256, "k_posttrans_x3ILi1ELb0ELi80ELi5ELi1ELi8ELi3ELb0ELb1EEE": 128,
+                                                                    "k_posttrans_x3ILi3ELb0ELi80ELi5ELi1ELi12ELi3ELb0ELb1EEE": 168}), ("pna_posttrans_x3w.hip", {"k_posttrans_x3w": 256}), ("pna_segreduce.hip", {"k_segreduce_fastILi4E": 80}),
                                           ("pna_posttrans.hip", {}), ("pna_pack.hip", {})])
 def test_no_kernel_uses_scratch(src, max_vgpr, tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
