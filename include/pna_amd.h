@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define PNA_ABI_VERSION 9 /* 9: pna_posttrans_args.row_perm / tile_image / image_stride (degree-grouped contraction),
+#define PNA_ABI_VERSION 10 /* 10: + pna_fused_degree_{image_bytes,pack_f32,f32} (gather + degree-grouped contraction in one kernel).
+                              9: pna_posttrans_args.row_perm / tile_image / image_stride (degree-grouped contraction),
                                 pna_segreduce_args.heavy_out_rows.
                              8: + pna_posttrans_x3w_* (the bf16x3 contraction on 32x32 matrix-core tiles).
                              7: + pna_small_*, pna_tower_post_*, pna_tower_layer_f32 (the molecule-batch tower layer).
@@ -430,6 +431,67 @@ typedef struct pna_fused_simple_args {
 } pna_fused_simple_args;
 
 int pna_fused_simple_f32(const pna_fused_simple_args* args, pna_stream_t stream);
+
+/* ---- PNASimpleLayer forward on degree-ordered rows: gather + scalers + posttrans in ONE kernel (ABI 10) ------------------
+ *
+ * Replaces, for inference on large graphs, the whole of models/dgl/pna_layer.py:197-216 with aggregators "mean max min std"
+ * (reduce_func :189-194, posttrans :206, BatchNorm :209-210, ReLU :211, residual :212-213).  The (V, 4F) aggregate -- the
+ * reference materialises (V, 12F) -- never reaches HBM.  Every PNA scaler is a function of the destination's in-degree alone
+ * (models/dgl/scalers.py:7-19), so all rows of one in-degree D share ONE combined weight  W_D = sum_s scale_s(D) W_s :
+ *
+ *   a[v]        = [mean | max | min | std] over the in-edges of x[src]                     (bit-identical to pna_segreduce_fwd_f32
+ *                                                                                             for rows one lane group walks alone)
+ *   y[perm[v]]  = residual[perm[v]] + act((bias + W_D(v) . a[v]) * col_scale + col_shift)   (bf16x3 arithmetic of pna_posttrans_x3_f32)
+ *
+ * The caller (pna_amd/degree_groups.py) orders the rows by in-degree into VIRTUAL rows v in [0, M):
+ *   row_perm[v]   node of virtual row v, or -1 = padding (nothing is stored); M a multiple of 64; every aligned block of 16
+ *                 virtual rows holds rows of ONE in-degree (padding aside), every aligned block of 64 rows uses ONE weight image;
+ *   tile_desc     [M / 16][4] = {first record, in-degree D, weight image, 0} of every 16-row block;
+ *   tile_ids      n_records records of 16 int32: record (first + e)[i] = source row (row of x) of the e-th in-edge of the block's
+ *                 i-th row, e in [0, D), in the row's edge order; a padding row repeats the block's first row; a block owns
+ *                 max(4, round_up(D, 4)) records, the ones past D being copies of record D - 1 (D = 0: any valid row);
+ *   w_img         n_img images, image_stride >= pna_fused_degree_image_bytes(F, N) bytes apart, from pna_fused_degree_pack_f32:
+ *                 w_ref is the Linear weight (N, n_scaler * 4F) in the reference's column order [scaler][aggregator][feature]
+ *                 (pna_layer.py:192-193), scale (n_img, n_scaler) the scalers' values for image i (NULL with n_scaler = 1:
+ *                 the weight itself); W_D is formed in fp32 in scaler order, like the reference's blocks.
+ * x: (x_rows, ldx) rows, 16-byte aligned, ldx % 4 == 0, ldx >= round_up(F, 8) (round_up(F, 4) when F % 32 is in 1..16),
+ * x_rows < 2^24, table < 4 GiB; y and residual: n_nodes rows, each table < 4 GiB.
+ * 17 <= F <= 80, 1 <= N <= 80.  relu: 0 none / 1 ReLU / 2 LeakyReLU(act_slope).  agg_out (nullable): (M, ld_agg) receives the
+ * statistics the contraction consumed, [mean | max | min | std] x F per virtual row (verification; a slower instantiation).
+ * Rows of degrees too rare to fill a tile, and hub rows, are the caller's: pna_segreduce_fwd_f32 + pna_posttrans_x3_f32 over
+ * their compact list.
+ */
+typedef struct pna_fused_degree_args {
+  const int32_t* tile_desc;
+  const int32_t* tile_ids;
+  int64_t n_records;
+  const float* x;
+  int64_t ldx;
+  int64_t x_rows;
+  int32_t F;
+  int32_t N;
+  const int32_t* row_perm;
+  int64_t M;
+  int64_t n_nodes;        /* rows of y / residual */
+  const void* w_img;
+  int64_t image_stride;
+  const float* bias;      /* nullable [N] */
+  const float* col_scale; /* nullable [N] */
+  const float* col_shift; /* nullable [N] (with col_scale) */
+  const float* residual;  /* nullable (n_nodes, ld_res), node order */
+  int64_t ld_res;
+  float* y;               /* (n_nodes, ldy), node order */
+  int64_t ldy;
+  int32_t relu;
+  float act_slope;
+  float* agg_out;         /* nullable (M, ld_agg) */
+  int64_t ld_agg;
+} pna_fused_degree_args;
+
+int64_t pna_fused_degree_image_bytes(int32_t F, int32_t N);   /* 0 = unsupported shape */
+int pna_fused_degree_pack_f32(const float* w_ref, int64_t ldw_ref, int32_t N, int32_t F, int32_t n_scaler, const float* scale,
+                              int32_t n_img, void* img, pna_stream_t stream);
+int pna_fused_degree_f32(const pna_fused_degree_args* args, pna_stream_t stream);
 
 /* ---- the tower layer of molecule-sized batches: one call, two launches (BASELINE.json configs[1]) -------------------
  *

@@ -1,0 +1,566 @@
+// pna_fused_degree.hip -- PNASimpleLayer forward (models/dgl/pna_layer.py:186-216) as ONE kernel on degree-ordered rows: the
+// gather, the four aggregators, the degree scalers and the posttrans contraction; the (V, 4F) aggregate never reaches HBM
+// (the reference materialises (V, 12F): pna_layer.py:189-194, :206).  Implements pna_fused_degree_{image_bytes,pack_f32,f32}.
+//
+//   y[perm[v]] = epilogue( bias + W_D . [mean | max | min | std](x[src] over the in-edges of perm[v]) ),  W_D = sum_s scale_s(D) W_s
+//
+// Every PNA scaler is a function of the destination's in-degree alone (models/dgl/scalers.py:7-19), so rows of one in-degree D
+// share ONE combined weight W_D.  The host orders the rows by in-degree (pna_amd/degree_groups.py): a wavefront
+// owns 16 rows of one degree, so its gather loop is uniform -- D iterations for every lane, no divergence, no per-row tail.
+//
+// Gather.  Lane (li = lane & 15, lg = lane >> 4) keeps sum / sum of squares / max / min of features fb * 32 + lg * 8 .. + 8 of row
+// li for every feature block fb: the four lanes of a row read one 128-byte strip of a source row per block, all blocks of a row
+// back to back (the row's DRAM page is touched once).  The source ids come from a TILE-MAJOR edge list the plan builds once per
+// graph -- record (tile, e) = the e-th source of each of the tile's 16 rows, 64 contiguous bytes -- so no id depends on a rowptr
+// lookup.  One edge = one "packet" of 2 NFB + 1 loads (the strips, then the id this ring slot needs next); FOUR packets ride in a
+// register ring, three always in flight behind the one being folded: every load is inline asm with a counted s_waitcnt (VMEM
+// returns in order; the count names only this kernel's own younger loads, so compiler-issued stores / copies in between can only
+// make a wait stricter).  The fold is the production gather's (pna_segreduce.hip: s += m, q += m * m, v_max / v_min, edge
+// order; mean = s / D correctly rounded) as single VALU instructions: the statistics are the same bits as the two-kernel path's.
+//
+// Contraction.  The statistics ARE the MFMA A operand: with K ordered (feature block, aggregator) -- the weight image is packed
+// to match -- chunk c = 4 fb + a multiplies the lane's eight values of aggregator a, split exactly into three bf16 terms
+// (pna_x3_split.h; six partial products per multiply, fp32 accumulation: the arithmetic of pna_posttrans_x3.hip).  One combined
+// image per degree group, streamed through three LDS buffers by global_load_lds, one barrier per chunk in the middle of the
+// chunk's MFMA stream.  Workgroups of 4 wavefronts (64 rows), two per CU: while one multiplies, the other gathers.
+// Rows that no degree group holds (rare degrees, hub rows) stay on the two-kernel path over their compact list (host).
+//
+// The running sums are folded by single v_add_f32 / v_mul_f32 instructions ON PURPOSE: written as plain C++, hipcc packs them into
+// v_pk_add_f32 / v_pk_mul_f32, which is slower beside a co-resident wavefront's MFMAs and was the form under which the round-2
+// experiment produced wrong sums (tools/ubench/pk_mfma_repro.hip).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+
+#include "pna_amd.h"
+#include "pna_internal.h"
+#include "pna_rowstats.h"
+#include "pna_x3_split.h"
+
+namespace {
+
+using namespace pna_x3;
+using pna_dev::div_rn;
+
+typedef int i4 __attribute__((ext_vector_type(4)));
+
+struct FDArgs {
+  const i4* tdesc;             // per 16-row wavefront tile: {first id record, in-degree, weight image, 0}
+  const int* ids;              // records of 16 source ids (tile-major edge list)
+  const float* x;
+  const int* perm; const unsigned char* w_img; long img_stride;
+  const float* bias; const float* col_scale; const float* col_shift; const float* residual; float* y;
+  float* agg_out; long ld_agg; // optional: the statistics as the contraction sees them, [mean | max | min | std] x F per virtual row
+  unsigned long long* dbg;     // experiments build only: per-wavefront phase timers
+  unsigned ldb;                // row pitch of x in bytes
+  unsigned ldyb, ldrb;         // row pitch of y / residual in bytes (ldrb = 0 without a residual: every load reads y's first row)
+  int F, M, N, relu;
+  float slope;
+};
+
+constexpr int kNW = 80, kNT = 5, kWaves = 4, kThreads = 64 * kWaves, kNBuf = 3;
+constexpr int kChunkV = 3 * 4 * kNW;                      // 16-byte pieces of one chunk image: [term][lane group][80 cols][8 k] bf16
+constexpr int kNI = (kChunkV + kThreads - 1) / kThreads;  // global_load_lds instructions per wavefront per chunk
+constexpr int kRing = 4;                                  // edge packets in the register ring
+constexpr int kNRes = kNT * 4;                            // residual values per lane
+
+// Feature blocks of a row: NFBF full blocks of 32 features (a lane owns 8: two 16-byte loads, four chunks -- one per aggregator)
+// and, when the remainder is <= 16 features, a HALF block (a lane owns 4: one load, two chunks -- (mean | max), (min | std)).
+// F = 75: 2 full + half = 5 loads per edge, 80 running statistics, 10 chunks (three full blocks: 6 loads, 96, 12).
+__host__ __device__ constexpr int shape_full(int F) { return (F % 32 == 0 || F % 32 > 16) ? (F + 31) / 32 : F / 32; }
+__host__ __device__ constexpr bool shape_half(int F) { return F % 32 != 0 && F % 32 <= 16; }
+__host__ __device__ constexpr int shape_chunks(int F) { return 4 * shape_full(F) + (shape_half(F) ? 2 : 0); }
+
+// ---- inline-asm loads (hipcc neither counts nor waits for them: every wait below is ours) -----------------------------------
+__device__ __forceinline__ void ld16(f4& dst, const void* base, unsigned voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ void ld16_hi(f4& dst, const void* base, unsigned voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ void ld16i(i4& dst, const void* base, unsigned voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ void ld4(int& dst, const void* base, unsigned voff) {
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ void ld4f(float& dst, const void* base, unsigned voff) {
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ void sld16(i4& dst, const void* base, unsigned soff) {        // scalar load of a tile descriptor
+  asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(dst) : "s"(base), "s"(soff) : "memory");
+}
+// wait until at most N of this wavefront's loads are outstanding; the slot's registers and its id become readable here
+template <int N, int NL>
+__device__ __forceinline__ void wait_slot(f4 (&s)[NL], int& id) {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit count");
+  static_assert(NL >= 2 && NL <= 6, "2..6 row loads per edge");
+  if constexpr (NL == 2)
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(s[0]), "+v"(s[1]), "+v"(id) : "n"(N) : "memory");
+  else if constexpr (NL == 3)
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(id) : "n"(N) : "memory");
+  else if constexpr (NL == 4)
+    asm volatile("s_waitcnt vmcnt(%5)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(id) : "n"(N) : "memory");
+  else if constexpr (NL == 5)
+    asm volatile("s_waitcnt vmcnt(%6)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(id) : "n"(N) : "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(%7)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(id) : "n"(N) : "memory");
+}
+// one message into the running statistics of one feature: the production fold as single VALU instructions
+__device__ __forceinline__ void fold1(float& S, float& Q, float& MX, float& MN, float m, float ms) {
+  float s1, p1, q1, x1, n1;
+  asm volatile("v_add_f32 %0, %1, %2" : "=v"(s1) : "v"(S), "v"(ms));
+  asm volatile("v_mul_f32 %0, %1, %1" : "=v"(p1) : "v"(ms));
+  asm volatile("v_add_f32 %0, %1, %2" : "=v"(q1) : "v"(Q), "v"(p1));
+  asm volatile("v_max_f32 %0, %1, %2" : "=v"(x1) : "v"(MX), "v"(m));
+  asm volatile("v_min_f32 %0, %1, %2" : "=v"(n1) : "v"(MN), "v"(m));
+  S = s1; Q = q1; MX = x1; MN = n1;
+}
+
+__device__ __forceinline__ unsigned long long now() {
+#ifdef PNA_AMD_EXPERIMENTS
+  return __builtin_readcyclecounter();
+#else
+  return 0;
+#endif
+}
+
+// RESPF: the tile's residual rows are requested during the gather's drain and ride through the multiply phase in 20 registers
+// (not in the verification instantiation DUMP, whose stores need registers of their own).
+template <int NFBF, bool HALF, bool DUMP, bool RESPF = !DUMP>
+__global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const FDArgs g) {
+  constexpr int NB = NFBF + (HALF ? 1 : 0);               // feature blocks
+  constexpr int NC = 4 * NFBF + (HALF ? 2 : 0);           // chunks of 32 k values per tile
+  constexpr int NL = 2 * NFBF + (HALF ? 1 : 0);           // 16-byte row loads per edge
+  constexpr int LB = NL + 1;                              // loads of one edge packet (the strips + the slot's next id)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int ntiles = g.M / (kWaves * 16);
+  const int G = (int)gridDim.x;
+
+  float* const colc = reinterpret_cast<float*>(lds + (size_t)kNBuf * kChunkV * 16);       // [3][80]: bias | scale | shift
+  for (int i = tid; i < kNW; i += kThreads) {
+    colc[i] = (g.bias && i < g.N) ? g.bias[i] : 0.f;
+    colc[kNW + i] = (g.col_scale && i < g.N) ? g.col_scale[i] : 1.f;
+    colc[2 * kNW + i] = (g.col_shift && i < g.N) ? g.col_shift[i] : 0.f;
+  }
+
+  f4 acc[kNT];
+
+  // ---- weight chunks: global -> LDS, asynchronously (every wavefront issues exactly kNI copies per chunk) ----------------
+  auto stage = [&](int c, int buf, long ib) __attribute__((always_inline)) {
+    const unsigned char* src = g.w_img + ib + (size_t)c * kChunkV * 16;
+    unsigned char* dst = lds + (size_t)buf * kChunkV * 16;
+#pragma unroll
+    for (int i = 0; i < kNI; ++i) {
+      int w0 = (i * kWaves + wave) * 64;
+      if (w0 >= kChunkV) w0 = w0 % kChunkV;              // a slot past the image re-copies an earlier piece (same bytes, same address)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(w0 + lane) * 16),
+                                       (__attribute__((address_space(3))) void*)(dst + (size_t)w0 * 16), 16, 0, 0);
+    }
+  };
+
+  int t = blockIdx.x;                                     // the workgroup's current tile
+  if (t >= ntiles) return;
+
+  // ---- loop-carried across tiles: descriptors of this tile, of this wavefront's next tile and (in flight) of the one after;
+  //      the ids of the tile's first four edges (the previous tile's last packets fetched them); the tile's rows of y ----------
+  auto desc_off = [&](int tt) -> unsigned { return (unsigned)(min(tt, ntiles - 1) * kWaves + wave) * 16u; };
+  i4 td_cur, td_nxt, td_n2;
+  sld16(td_cur, g.tdesc, desc_off(t));
+  sld16(td_nxt, g.tdesc, desc_off(t + G));
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(td_cur), "+s"(td_nxt) : : "memory");
+  td_n2 = td_nxt;
+  const unsigned lib = (unsigned)li * 4u;
+  int idr[kRing];
+  i4 pr;                                                  // the lane's four rows of y / residual (-1: padding)
+  float res[kNRes];
+
+  // ---- the gather: running statistics of the wavefront's 16 rows ----------------------------------------------------------
+  float S_[NB][8], Q_[NB][8], MX[NB][8], MN[NB][8];       // (a half block uses [0..3])
+  int deg = 0;                                            // in-degree of the tile's rows (wave-uniform)
+  unsigned f0b[NB];                                       // byte offset of the lane's strip of feature block fb inside a row
+#pragma unroll
+  for (int fb = 0; fb < NB; ++fb) {
+    const bool half = HALF && fb == NFBF;
+    int f0 = fb * 32 + (half ? lg * 4 : lg * 8);
+    if (f0 >= g.F) f0 = half ? (g.F - 1) / 4 * 4 : (g.F - 1) / 8 * 8;     // a strip past the row: re-read the row's last strip (values
+    f0b[fb] = (unsigned)f0 * 4u;                                           // dropped in frag())
+  }
+  const unsigned ldb = g.ldb;
+  const void* const resb = g.residual ? (const void*)g.residual : (const void*)g.y;
+  const bool has_res = g.residual != nullptr;
+
+  auto gather = [&](int t) __attribute__((always_inline)) {
+    const int D = td_cur.y;
+    const unsigned rb = (unsigned)td_cur.x * 64u, rbn = (unsigned)td_nxt.x * 64u;       // byte offsets of this / the next tile's records
+    deg = D;
+    sld16(td_n2, g.tdesc, desc_off(t + 2 * G));
+    ld16i(pr, g.perm, (unsigned)((t * kWaves + wave) * 16 + 4 * lg) * 4u);
+#pragma unroll
+    for (int fb = 0; fb < NB; ++fb)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { S_[fb][j] = 0.f; Q_[fb][j] = 0.f; MX[fb][j] = -INFINITY; MN[fb][j] = INFINITY; }
+    const int ng = max((D + 3) >> 2, 1);                  // groups of 4 edges; the plan pads the tile's records to 4 ng (repeats of the
+                                                          // last edge: idempotent for max / min, masked out of the sums; a tile without
+                                                          // in-edges has 4 records of row 0, all masked)
+    f4 sl[kRing][NL];
+    // rows of the edge whose id sits in idr[j] -> ring slot j, then the id slot j gathers next (record at byte `nrec`) -> idr[j]
+    auto issue = [&](auto jc, unsigned nrec) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+#pragma unroll
+      for (int fb = 0; fb < NB; ++fb) {
+        const unsigned vo = __umul24((unsigned)idr[j], ldb) + f0b[fb];
+        ld16(sl[j][2 * fb], g.x, vo);
+        if (!(HALF && fb == NFBF)) ld16_hi(sl[j][2 * fb + 1], g.x, vo);
+      }
+      ld4(idr[j], g.ids, nrec + (unsigned)j * 64u + lib);
+    };
+    auto fold = [&](auto jc, bool on) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+#pragma unroll
+      for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int fb = l >> 1, c = (l & 1) * 4 + k;
+          const float m = sl[j][l][k];
+          fold1(S_[fb][c], Q_[fb][c], MX[fb][c], MN[fb][c], m, on ? m : 0.f);
+        }
+    };
+    using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
+    using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
+    // the packets of edges 0..3; each refills its id with the next group's, or -- after the last group -- the NEXT tile's edge j
+    const unsigned n0 = 1 < ng ? rb + 4u * 64u : rbn;
+    issue(J0{}, n0); issue(J1{}, n0); issue(J2{}, n0); issue(J3{}, n0);
+    // steady state: slot j holds edge 4 gi + j; behind it in flight: the three younger packets.  Every edge here is a real one.
+    for (int gi = 0; gi + 1 < ng; ++gi) {
+      const unsigned nr = gi + 2 < ng ? rb + (unsigned)(4 * gi + 8) * 64u : rbn;
+      wait_slot<3 * LB, NL>(sl[0], idr[0]); fold(J0{}, true); issue(J0{}, nr);
+      wait_slot<3 * LB, NL>(sl[1], idr[1]); fold(J1{}, true); issue(J1{}, nr);
+      wait_slot<3 * LB, NL>(sl[2], idr[2]); fold(J2{}, true); issue(J2{}, nr);
+      wait_slot<3 * LB, NL>(sl[3], idr[3]); fold(J3{}, true); issue(J3{}, nr);
+    }
+    // drain: the last group (its slots past D hold copies of edge D - 1).  The residual rows of the tile are requested behind
+    // slot 0 -- perm (requested before every packet) has landed by then -- and stay in flight into the multiply phase.
+    const int e0 = 4 * (ng - 1);
+    wait_slot<3 * LB, NL>(sl[0], idr[0]);
+    asm volatile("" : "+v"(pr));
+    fold(J0{}, e0 < D);
+    constexpr int NR = RESPF ? kNRes : 0;
+    if constexpr (RESPF) {
+#pragma unroll
+      for (int n = 0; n < kNT; ++n) {
+        const unsigned cc = (unsigned)min(n * 16 + li, g.N - 1) * 4u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ld4f(res[n * 4 + r], resb, (unsigned)max(pr[r], 0) * g.ldrb + cc);
+      }
+    }
+    wait_slot<2 * LB + NR, NL>(sl[1], idr[1]); fold(J1{}, e0 + 1 < D);
+    wait_slot<1 * LB + NR, NL>(sl[2], idr[2]); fold(J2{}, e0 + 2 < D);
+    wait_slot<NR, NL>(sl[3], idr[3]);          fold(J3{}, e0 + 3 < D);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(td_n2) : : "memory");
+  };
+
+  // ---- chunk c: the lane's eight A values, split into three bf16 terms.  Full block fb, chunk 4 fb + a: aggregator a (0 mean,
+  //      1 max, 2 min, 3 std) of the lane's 8 features; half block, chunk 4 NFBF + h: aggregators 2h | 2h + 1 of its 4 features ----
+  bf8 A[3];
+  auto stat = [&](int fb, int j, int a, int f) __attribute__((always_inline)) -> float {
+    const float D = (float)deg, invD = 1.0f / D;
+    const float s = S_[fb][j], q = Q_[fb][j];
+    float r;
+    if (a == 0) {
+      r = div_rn(s, D, invD);
+    } else if (a == 3) {
+      const float mean = div_rn(s, D, invD), msq = div_rn(q, D, invD);
+      float var = msq - mean * mean;
+      var = var < 0.f ? 0.f : var;
+      r = sqrtf(var + 1e-5f);
+    } else {
+      const float e = a == 1 ? MX[fb][j] : MN[fb][j];
+      r = q != q ? q : e;                                 // v_max / v_min drop NaN; q is NaN iff a message is (pna_rowstats.h)
+    }
+    if (deg <= 0) r = 0.f;                                // rows without in-edges: DGL leaves them at zero
+    if (f >= g.F) r = 0.f;                                // padding features of the last block (their weights are 0; the table's
+    return r;                                             // padding columns may hold anything)
+  };
+  auto frag = [&](auto c_c) __attribute__((always_inline)) {
+    constexpr int c = decltype(c_c)::value;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int fb, sj, a, f;
+      if constexpr (c < 4 * NFBF) { fb = c / 4; sj = j; a = c % 4; f = fb * 32 + lg * 8 + j; }
+      else { fb = NFBF; sj = j & 3; a = 2 * (c - 4 * NFBF) + (j >> 2); f = fb * 32 + lg * 4 + (j & 3); }
+      v[j] = stat(fb, sj, a, f);
+      if constexpr (DUMP) {
+        if (f < g.F) g.agg_out[(size_t)((t * kWaves + wave) * 16 + li) * g.ld_agg + a * g.F + f] = v[j];
+      }
+    }
+    const f4 lo4 = (f4){v[0], v[1], v[2], v[3]}, hi4 = (f4){v[4], v[5], v[6], v[7]};
+    if (__builtin_amdgcn_ballot_w64(absmax8(lo4, hi4) == INFINITY) != 0) split8_inf(lo4, hi4, A[0], A[1], A[2]);
+    else split8(lo4, hi4, A[0], A[1], A[2]);
+  };
+
+  // ---- epilogue: BatchNorm / ReLU / residual, rows scattered to node order through perm -----------------------------------
+  const unsigned colc_b = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(kNBuf * kChunkV * 16) + lib;
+  auto epilogue = [&]() __attribute__((always_inline)) {
+    const float lo = g.relu ? 0.f : -INFINITY;
+    const bool leaky = g.relu == 2;
+    // the column constants, read through inline asm: an LDS read hipcc can see while a weight copy is in flight makes it
+    // drain the copies (vmcnt(0)) first (DESIGN.md 4.2c point 1)
+    float cb[kNT], cs[kNT], ct[kNT];
+#pragma unroll
+    for (int n = 0; n < kNT; ++n) {
+      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(cb[n]) : "v"(colc_b), "n"(n * 64) : "memory");
+      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(cs[n]) : "v"(colc_b), "n"(kNW * 4 + n * 64) : "memory");
+      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(ct[n]) : "v"(colc_b), "n"(2 * kNW * 4 + n * 64) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(cb[0]), "+v"(cb[1]), "+v"(cb[2]), "+v"(cb[3]), "+v"(cb[4]), "+v"(cs[0]), "+v"(cs[1]), "+v"(cs[2]), "+v"(cs[3]), "+v"(cs[4]),
+                   "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]), "+v"(ct[4]) : : "memory");
+    if constexpr (!RESPF) {
+      const char* rbase = reinterpret_cast<const char*>(resb);
+#pragma unroll
+      for (int n = 0; n < kNT; ++n) {
+        const unsigned cc = (unsigned)min(n * 16 + li, g.N - 1) * 4u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) res[n * 4 + r] = *reinterpret_cast<const float*>(rbase + (size_t)((unsigned)max(pr[r], 0) * g.ldrb + cc));
+      }
+    }
+    char* const ybase = reinterpret_cast<char*>(g.y);
+#pragma unroll
+    for (int n = 0; n < kNT; ++n) {
+      const int cl = n * 16 + li;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = acc[n][r] + cb[n];
+        x = __builtin_fmaf(x, cs[n], ct[n]);
+        x = x < lo ? (leaky ? x * g.slope : 0.f) : x;    // ReLU / LeakyReLU / none (lo = -inf); NaN < lo is false: NaN is kept
+        v[r] = has_res ? res[n * 4 + r] + x : x;
+      }
+      if (cl < g.N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (pr[r] >= 0) *reinterpret_cast<float*>(ybase + (size_t)(unsigned)pr[r] * g.ldyb + (unsigned)cl * 4u) = v[r];
+      }
+    }
+  };
+
+  // ---- the (tile, chunk) pipeline: step k reads LDS buffer k % 3; barrier B_k sits in the middle of step k; after B_k every
+  //      wavefront has finished step k-1, so buffer (k+2) % 3 is free: step k+2's image is copied then and waited for (vmcnt(0))
+  //      before B_{k+1}.  That vmcnt(0) also retires the residual rows requested at the end of the gather. ---------------------
+  unsigned long long tg = 0, tm = 0, te = 0, t00 = now();
+  long ib_cur = (long)td_cur.z * g.img_stride, ib_next = (long)td_nxt.z * g.img_stride;
+  int buf = 0;
+  stage(0, 0, ib_cur);
+  stage(1, 1, ib_cur);
+  // the ids of the first tile's edges 0..3 (later tiles: fetched by the previous tile's last packets)
+#pragma unroll
+  for (int j = 0; j < kRing; ++j) ld4(idr[j], g.ids, (unsigned)td_cur.x * 64u + (unsigned)j * 64u + lib);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(idr[0]), "+v"(idr[1]), "+v"(idr[2]), "+v"(idr[3]) : : "memory");
+  gather(t);
+  frag(std::integral_constant<int, 0>{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  tg += now() - t00;
+
+  auto step = [&](auto c_c) __attribute__((always_inline)) {
+    constexpr int c = decltype(c_c)::value;
+    const unsigned ba0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(buf * kChunkV + lg * kNW + li) * 16u;
+    const int buf2 = buf == 0 ? kNBuf - 1 : buf - 1;     // (k + 2) % 3
+    bf8 B[2][3];                                         // B fragments of column tile n (slot n & 1): one ds_read_b128 per term
+    constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
+    constexpr int H = (kNT - 1) / 2;
+    if constexpr (c == 0) {
+#pragma unroll
+      for (int n = 0; n < kNT; ++n) acc[n] = (f4){0.f, 0.f, 0.f, 0.f};
+    }
+    // B fragments: column tile n+1's three reads are issued before tile n's MFMAs and the wavefront waits for all of its LDS
+    // reads (lgkmcnt(0), naming every fragment register) before it issues tile n's MFMAs.  One address register per step, the
+    // (term, column tile) displacement in the instruction's offset field: as "v" operands the 45 distinct addresses were hoisted
+    // out of the tile loop and spilled.
+#pragma unroll
+    for (int tm_ = 0; tm_ < 3; ++tm_)
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(B[0][tm_]) : "v"(ba0), "n"(tm_ * 4 * kNW * 16) : "memory");
+#pragma unroll
+    for (int n = 0; n < kNT; ++n) {
+      const int slot = n & 1;
+      if (n + 1 < kNT) {
+#pragma unroll
+        for (int tm_ = 0; tm_ < 3; ++tm_)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(B[slot ^ 1][tm_]) : "v"(ba0), "n"(tm_ * 4 * kNW * 16 + (n + 1) * 256) : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(B[0][0]), "+v"(B[0][1]), "+v"(B[0][2]), "+v"(B[1][0]), "+v"(B[1][1]), "+v"(B[1][2]) : : "memory");
+      if (n == H) {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (c + 2 < NC) stage(c + 2, buf2, ib_cur);
+        else stage(c + 2 - NC, buf2, ib_next);
+      }
+#pragma unroll
+      for (int pp = 0; pp < 6; ++pp) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[slot][TB[pp]], acc[n], 0, 0, 0);
+    }
+    buf = buf == kNBuf - 1 ? 0 : buf + 1;
+    if constexpr (c + 1 < NC) frag(std::integral_constant<int, c + 1>{});
+  };
+  auto steps4 = [&](auto b_c) __attribute__((always_inline)) {
+    constexpr int b = decltype(b_c)::value;
+    step(std::integral_constant<int, b>{});
+    step(std::integral_constant<int, b + 1>{});
+    if constexpr (b + 2 < NC) {
+      step(std::integral_constant<int, (b + 2 < NC) ? b + 2 : 0>{});
+      step(std::integral_constant<int, (b + 3 < NC) ? b + 3 : 0>{});
+    }
+  };
+  while (true) {
+    const unsigned long long t0 = now();
+    steps4(std::integral_constant<int, 0>{});
+    if constexpr (NC > 4) steps4(std::integral_constant<int, ((NC > 4) ? 4 : 0)>{});
+    if constexpr (NC > 8) steps4(std::integral_constant<int, ((NC > 8) ? 8 : 0)>{});
+    // the residual rows landed before the first step's barrier; from here on the compiler may read them
+    if constexpr (RESPF)
+      asm volatile("" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]), "+v"(res[5]), "+v"(res[6]), "+v"(res[7]), "+v"(res[8]), "+v"(res[9]),
+                     "+v"(res[10]), "+v"(res[11]), "+v"(res[12]), "+v"(res[13]), "+v"(res[14]), "+v"(res[15]), "+v"(res[16]), "+v"(res[17]), "+v"(res[18]), "+v"(res[19]));
+    const unsigned long long t1 = now();
+    epilogue();
+    const unsigned long long t2 = now();
+    tm += t1 - t0; te += t2 - t1;
+    t += G;
+    if (t >= ntiles) break;                               // (wave-uniform)
+    td_cur = td_nxt; td_nxt = td_n2;
+    ib_cur = ib_next;
+    ib_next = (long)td_nxt.z * g.img_stride;
+    gather(t);
+    frag(std::integral_constant<int, 0>{});
+    tg += now() - t2;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the copies issued for steps that do not exist
+#ifdef PNA_AMD_EXPERIMENTS
+  if (g.dbg && lane == 0) {
+    unsigned long long* d = g.dbg + ((size_t)blockIdx.x * kWaves + wave) * 4;
+    d[0] = tg; d[1] = tm; d[2] = te; d[3] = now() - t00;
+  }
+#endif
+}
+
+// ---- weight images: W_D = sum_s scale[i][s] W_s in fp32 (scaler order), K reordered into the kernel's chunks, cut into three
+//      bf16 terms, laid out as the LDS image of every chunk: [chunk][term][lane group][80 cols][8 k] ---------------------------
+__global__ void k_pack_fused_degree(const float* w_ref, long ldw, int N, int F, int S, const float* scale, int n_img, unsigned short* img) {
+  const int nfull = shape_full(F), NC = shape_chunks(F), K = 4 * F;
+  const long per = (long)NC * 3 * 4 * kNW * 8;
+  const long total = per * n_img;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i;
+    const int e = r % 8; r /= 8;
+    const int n = r % kNW; r /= kNW;
+    const int lgp = r % 4; r /= 4;
+    const int term = r % 3; r /= 3;
+    const int c = r % NC; r /= NC;
+    const int im = (int)r;
+    int a, f;
+    if (c < 4 * nfull) { a = c % 4; f = (c / 4) * 32 + lgp * 8 + e; }
+    else { a = 2 * (c - 4 * nfull) + (e >> 2); f = nfull * 32 + lgp * 4 + (e & 3); }
+    float w = 0.f;
+    if (n < N && f < F) {
+      const float* row = w_ref + (long)n * ldw + (long)a * F + f;
+      w = scale ? scale[(long)im * S] * row[0] : row[0];
+      for (int s = 1; s < S; ++s) w = w + (scale ? scale[(long)im * S + s] * row[(long)s * K] : row[(long)s * K]);
+    }
+    img[i] = weight_term(w, term);
+  }
+}
+
+template <int NFBF, bool HALF, bool DUMP>
+int launch(const FDArgs& g, int wgs, hipStream_t st) {
+  const size_t lds = (size_t)kNBuf * kChunkV * 16 + (size_t)(3 * kNW) * sizeof(float);
+  if (hipFuncSetAttribute((const void*)k_fused_degree<NFBF, HALF, DUMP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+  hipLaunchKernelGGL((k_fused_degree<NFBF, HALF, DUMP>), dim3((unsigned)wgs), dim3(kThreads), lds, st, g);
+  return 0;
+}
+template <bool DUMP>
+int launch_shape(const FDArgs& g, int wgs, hipStream_t st) {
+  const int nf = shape_full(g.F);
+  const bool half = shape_half(g.F);
+  if (nf == 1 && !half) return launch<1, false, DUMP>(g, wgs, st);
+  if (nf == 1 && half) return launch<1, true, DUMP>(g, wgs, st);
+  if (nf == 2 && !half) return launch<2, false, DUMP>(g, wgs, st);
+  if (nf == 2 && half) return launch<2, true, DUMP>(g, wgs, st);
+  return -2;
+}
+
+}  // namespace
+
+extern "C" int64_t pna_fused_degree_image_bytes(int32_t F, int32_t N) {
+  if (F < 17 || F > 80 || N < 1 || N > kNW) return 0;   // (81..96 would need three full blocks: 96 running statistics + a 96-register ring do not fit 256 registers)
+  return (int64_t)shape_chunks(F) * kChunkV * 16;
+}
+
+extern "C" int pna_fused_degree_pack_f32(const float* w_ref, int64_t ldw, int32_t N, int32_t F, int32_t n_scaler, const float* scale,
+                                         int32_t n_img, void* img, pna_stream_t stream) {
+  if (!w_ref || !img || n_img < 1 || n_scaler < 1 || n_scaler > PNA_MAX_SCALER || pna_fused_degree_image_bytes(F, N) == 0 ||
+      ldw < (int64_t)n_scaler * 4 * F || (n_scaler > 1 && !scale))
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_pack_f32: bad arguments (17 <= F <= 80, 1 <= N <= 80, scale required for n_scaler > 1)");
+  const int64_t elems = pna_fused_degree_image_bytes(F, N) / 2 * n_img;
+  const int blocks = (int)((elems + 255) / 256 > 8192 ? 8192 : (elems + 255) / 256);
+  hipLaunchKernelGGL(k_pack_fused_degree, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ref, (long)ldw, N, F, n_scaler, scale, n_img,
+                     (unsigned short*)img);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
+  return PNA_OK;
+}
+
+extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t stream) {
+  if (!p) return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: null args");
+  if (p->M == 0) return PNA_OK;
+  if (!p->tile_desc || !p->tile_ids || !p->x || !p->row_perm || !p->w_img || !p->y)
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: tile_desc / tile_ids / x / row_perm / w_img / y must be non-null");
+  if (pna_fused_degree_image_bytes(p->F, p->N) == 0)
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: 17 <= F <= 80 and 1 <= N <= 80");
+  const int need = shape_half(p->F) ? (p->F + 3) / 4 * 4 : (p->F + 7) / 8 * 8;
+  if (p->ldx < need || p->ldx % 4 != 0 || ((uintptr_t)p->x & 15) != 0)
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: x must be 16-byte aligned with a row pitch that is a multiple of 4 floats and covers the last strip (round_up(F, 8); round_up(F, 4) when F % 32 is in 1..16)");
+  if (p->x_rows < 1 || p->x_rows >= (1 << 24) || (int64_t)p->x_rows * p->ldx * 4 >= (1ll << 32))
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: the source table must have < 2^24 rows and < 4 GiB");
+  if (p->M < 0 || p->M % (kWaves * 16) != 0 || p->M >= (1ll << 31))
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: M must be a multiple of 64");
+  if (p->n_records < 4 || p->n_records * 64 >= (1ll << 32))
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: tile_ids must hold 4 <= n_records < 2^26 records");
+  if (p->n_nodes < 1 || p->ldy < p->N || p->n_nodes * p->ldy * 4 >= (1ll << 32) ||
+      (p->residual && (p->ld_res < p->N || p->n_nodes * p->ld_res * 4 >= (1ll << 32))) || p->image_stride <= 0)
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: bad n_nodes / ldy / ld_res / image_stride (y and residual must be < 4 GiB)");
+  if (p->relu < 0 || p->relu > 2) return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: relu must be 0, 1 or 2");
+  if ((p->col_scale == nullptr) != (p->col_shift == nullptr))
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: col_scale and col_shift come together");
+  if (p->agg_out && p->ld_agg < 4 * (int64_t)p->F) return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: ld_agg < 4 F");
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return pna_set_error(PNA_E_NODEVICE, "pna_fused_degree_f32: no device");
+  FDArgs g;
+  memset(&g, 0, sizeof(g));
+  g.tdesc = reinterpret_cast<const i4*>(p->tile_desc); g.ids = p->tile_ids; g.x = p->x; g.ldb = (unsigned)(p->ldx * 4); g.F = p->F;
+  g.perm = p->row_perm; g.w_img = (const unsigned char*)p->w_img; g.img_stride = p->image_stride;
+  g.bias = p->bias; g.col_scale = p->col_scale; g.col_shift = p->col_shift; g.residual = p->residual; g.y = p->y;
+  g.ldyb = (unsigned)(p->ldy * 4); g.ldrb = p->residual ? (unsigned)(p->ld_res * 4) : 0u;
+  g.M = (int)p->M; g.N = p->N; g.relu = p->relu; g.slope = p->relu == 2 ? p->act_slope : 0.f;
+  g.agg_out = p->agg_out; g.ld_agg = p->ld_agg;
+#ifdef PNA_AMD_EXPERIMENTS
+  if (const char* e = getenv("PNA_FD_DBG_PTR")) g.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // device buffer: 4 counters per wavefront
+#endif
+  const int ntiles = (int)(p->M / (kWaves * 16));
+  int per_cu = 2;
+#ifdef PNA_AMD_EXPERIMENTS
+  if (const char* e = getenv("PNA_FD_WGS")) per_cu = atoi(e) > 0 ? atoi(e) : 2;
+#endif
+  if (p->agg_out) per_cu = 1;                             // (the verification instantiation is built for one workgroup per CU)
+  const int wgs = ntiles < per_cu * cus ? ntiles : per_cu * cus;
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = p->agg_out ? launch_shape<true>(g, wgs, st) : launch_shape<false>(g, wgs, st);
+  if (rc != 0) return pna_set_error(PNA_E_LAUNCH, rc == -2 ? "pna_fused_degree_f32: no instantiation for this F" : "pna_fused_degree_f32: hipFuncSetAttribute failed");
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
+  return PNA_OK;
+}

@@ -47,7 +47,8 @@ class DegreePlan:
         V = deg.numel()
         order = torch.sort(deg, stable=True).indices                     # rows by in-degree (ties: ascending row id)
         ud, cnt = torch.unique_consecutive(deg[order], return_counts=True)
-        big = (cnt >= TILE) & (ud <= hs.threshold)                       # degree values with at least one whole tile of light rows
+        hub_limit = hs.threshold if hs.threshold > 0 else (1 << 30)     # (heavy schedule off: no row is cut into segments)
+        big = (cnt >= TILE) & (ud <= hub_limit)                          # degree values with at least one whole tile of light rows
         start = torch.cumsum(cnt, 0) - cnt
         gid = torch.repeat_interleave(torch.arange(ud.numel(), device=dev), cnt)     # group of every sorted row
         in_big = big[gid]
@@ -86,6 +87,55 @@ class DegreePlan:
         self.heavy_out = vmap[hs.heavy_rows.long()].to(torch.int32).contiguous() if hs.n_heavy > 0 else None
         self.rows = self.NV + self.NRp
         self._rest_scales = {}
+        self._fused, self._rest_items = None, None
+        self._deg, self._csr = deg, csr
+
+    def fused_tables(self):
+        """(tile_desc, tile_ids, n_records) of pna_fused_degree_f32 (include/pna_amd.h), built once per graph on the device:
+        tile_desc[w] = {first record, in-degree, weight image, 0} of the 16-row block w of the virtual order; tile_ids = the
+        TILE-MAJOR edge list -- record (first + e)[i] = source row of the e-th in-edge of the block's i-th row (a padding row
+        repeats the block's first row), max(4, round_up(D, 4)) records per block, the ones past D copies of record D - 1."""
+        if self._fused is None:
+            dev = self.perm.device
+            if self.NV == 0:
+                self._fused = (torch.zeros(0, 4, dtype=torch.int32, device=dev), torch.zeros(4, 16, dtype=torch.int32, device=dev), 4)
+                return self._fused
+            nt = self.NV // 16
+            p16 = self.perm.view(nt, 16).long()
+            first = p16[:, :1]
+            live = first[:, 0] >= 0                                          # (a block of padding rows only: D = 0, records of row 0)
+            rows = torch.where(p16 >= 0, p16, first.clamp(min=0))
+            D = torch.where(live, self._deg[rows[:, 0]], torch.zeros_like(first[:, 0]))
+            nrec = ((D + 3) // 4 * 4).clamp(min=4)
+            rec0 = torch.cumsum(nrec, 0) - nrec
+            total = int(nrec.sum().item())
+            if total * 64 >= (1 << 32):
+                self._fused = False                                          # the kernel addresses records with 32-bit byte offsets
+                return self._fused
+            tile = torch.repeat_interleave(torch.arange(nt, device=dev), nrec)
+            e = torch.arange(total, device=dev) - rec0[tile]
+            e = torch.minimum(e, (D[tile] - 1).clamp(min=0))
+            rp = self._csr.rowptr.long()
+            pos = rp[rows[tile]] + e[:, None]                                # (total, 16) positions in col[]
+            empty = (D[tile] == 0)[:, None]
+            n_col = self._csr.col.numel()
+            ids = self._csr.col[pos.clamp(max=max(n_col - 1, 0))] if n_col else torch.zeros_like(pos, dtype=torch.int32)
+            ids = torch.where(empty, torch.zeros_like(ids), ids).to(torch.int32).contiguous()
+            image = torch.repeat_interleave(self.tile_image.long(), TILE // 16)
+            desc = torch.stack([rec0, D, image, torch.zeros_like(D)], dim=1).to(torch.int32).contiguous()
+            self._fused = (desc, ids, total)
+        return self._fused
+
+    def rest_items(self):
+        """(work list, heavy_out) of the rows no degree group holds, output rows counted from the start of the rest region: the
+        gather of the one-kernel layer's leftover rows (pna_fused_degree_f32 takes the group rows)."""
+        if self._rest_items is None:
+            it, n_seg = self.items, self._n_seg
+            light = it[n_seg:][it[n_seg:, 0] >= self.NV].clone()
+            light[:, 0] -= self.NV
+            items = torch.cat([it[:n_seg], light], dim=0).contiguous() if n_seg else light.contiguous()
+            self._rest_items = (items, None if self.heavy_out is None else (self.heavy_out - self.NV).contiguous())
+        return self._rest_items
 
     def split_items(self, graph):
         """(interior, boundary) work lists of a sharded graph (HaloGraph.split_work_lists: the rows that read only local
@@ -175,8 +225,67 @@ def combined_images(weight, K, row_scales, plan):
     return img, stride
 
 
-def applies(graph, V, N, n_scaler, aggregators):
+def fused_images(weight, F, row_scales, plan):
+    """Packed images of W_D = sum_s s_s(D) W_s for pna_fused_degree_f32 (K in the kernel's chunk order), one per degree group,
+    cached on the weight like combined_images.  The combination and the bf16x3 split happen in the pack kernel
+    (pna_fused_degree_pack_f32) from the (G, S) matrix of the groups' scaler values."""
+    N, G, S = weight.shape[0], plan.G, len(row_scales)
+    key = ("fused", weight._version, weight.data_ptr(), str(weight.device), tuple(weight.shape), F, plan.serial, G,
+           tuple(None if rs is None else (rs.data_ptr(), rs._version) for rs in row_scales))
+    hit = getattr(weight, "_pna_amd_fused_img", None)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    L = _lib.lib()
+    stride = L.pna_fused_degree_image_bytes(F, N)
+    if stride <= 0:
+        raise RuntimeError(f"pna_fused_degree: unsupported shape F={F}, N={N}")
+    with torch.no_grad():
+        scale = torch.ones(G, S, dtype=torch.float32, device=weight.device)
+        for s, rs in enumerate(row_scales):
+            if rs is not None:
+                scale[:, s] = rs[plan.group_first_row]
+        scale = scale.contiguous()
+    img = torch.empty(G * stride // 4, dtype=torch.float32, device=weight.device)
+    w = weight.detach()
+    rc = L.pna_fused_degree_pack_f32(_lib.dev_ptr(w, torch.float32, "weight"), w.stride(0), N, F, S, _lib.dev_ptr(scale, torch.float32, "scale"),
+                                     G, _lib.dev_ptr(img, torch.float32, "w_img"), _lib.stream_ptr(weight.device))
+    _lib.check(rc, "pna_fused_degree_pack_f32")
+    try:
+        weight._pna_amd_fused_img = (key, img, stride)
+    except AttributeError:
+        pass
+    return img, stride
+
+
+FUSED = True               # gather + contraction in ONE kernel (pna_fused_degree_f32) where it applies; False: the two-kernel grouped path
+MAX_REST_FRACTION = 0.5    # more rest rows than this: the grouping is overhead, the ordinary path takes the graph
+
+
+def fused_applies(graph, x, F, N):
+    """Whether pna_fused_degree_f32 serves this call (whole-graph inference path already chosen by `applies`): shapes it is
+    instantiated for, a 16-byte aligned source table whose row pitch is a multiple of 4 floats and covers the last strip, and
+    tables the kernel can address with 32-bit offsets."""
+    if not FUSED or not (17 <= F <= 80 and 1 <= N <= 80):
+        return False
+    need = (F + 3) // 4 * 4 if 1 <= F % 32 <= 16 else (F + 7) // 8 * 8
+    if x.dim() != 2 or x.stride(1) != 1 or x.stride(0) % 4 != 0 or x.stride(0) < need or x.data_ptr() % 16 != 0:
+        return False
+    # (the last row's strip may reach past F: the storage must cover rows x pitch floats)
+    if x.shape[0] >= (1 << 24) or x.shape[0] * x.stride(0) * 4 >= (1 << 32) or x.untyped_storage().nbytes() - x.storage_offset() * 4 < x.shape[0] * x.stride(0) * 4:
+        return False
+    plan = plan_of(graph)
+    return plan.G > 0 and plan.fused_tables() is not False
+
+
+def applies(graph, V, N, n_scaler, aggregators, F=None, n_edges=None, x_rows=None):
     from .graph import Graph
     from .shard import HaloGraph
-    return (ENABLED and type(graph) in (Graph, HaloGraph) and V >= MIN_ROWS and MIN_OUT <= N <= 128 and (n_scaler == 3 or (n_scaler == 2 and N >= TWO_SCALER_MIN_OUT))
-            and tuple(aggregators) == ("mean", "max", "min", "std") and V * (80 if N <= 80 else 128) * 4 < (1 << 32))
+    if not (ENABLED and type(graph) in (Graph, HaloGraph) and V >= MIN_ROWS and MIN_OUT <= N <= 128 and (n_scaler == 3 or (n_scaler == 2 and N >= TWO_SCALER_MIN_OUT))
+            and tuple(aggregators) == ("mean", "max", "min", "std") and V * (80 if N <= 80 else 128) * 4 < (1 << 32)):
+        return False
+    # the gather of this path REQUIRES the hand-scheduled kernel (only it writes the plan's row order): its own preconditions
+    # (pna_segreduce.hip fast_ok: dwordx4 lanes, 32-bit edge positions, 24-bit row ids) -- ADVICE r2
+    if (F is not None and F < 4) or (n_edges is not None and not 0 < n_edges < (1 << 30)) or (x_rows is not None and x_rows >= (1 << 24)):
+        return False
+    plan = plan_of(graph)
+    return plan.G > 0 and plan.NR <= MAX_REST_FRACTION * V

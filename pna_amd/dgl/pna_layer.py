@@ -355,7 +355,11 @@ class PNASimpleLayer(nn.Module):
         from .. import degree_groups as DG
         if self.training or not h.is_cuda or h.dtype != torch.float32 or not self.posttrans.is_affine:
             return False
-        if not DG.applies(graph, h.shape[0], self.out_dim, len(self.scalers), self.aggregators) or PF.ops.POSTTRANS_ARITH == "f32":
+        if PF.ops.POSTTRANS_ARITH == "f32" or self.in_dim != h.shape[1]:
+            return False
+        n_src = h.shape[0] + getattr(graph, "n_halo", 0)                    # (a shard's table: local rows + halo rows)
+        if not DG.applies(graph, h.shape[0], self.out_dim, len(self.scalers), self.aggregators, F=self.in_dim,
+                          n_edges=graph.csr.col.numel(), x_rows=n_src):
             return False
         if self.residual and h.shape[1] != self.out_dim:
             return False
@@ -367,7 +371,11 @@ class PNASimpleLayer(nn.Module):
             return PF.simple_layer_small(self, graph, h, _row_scales(graph, self.scalers, self.avg_d, h.device))
         h_in = h
         if self._degree_grouped_path(graph, h):
-            return PF.simple_layer_degree_grouped(self, graph, h)
+            try:
+                return PF.simple_layer_degree_grouped(self, graph, h)
+            except RuntimeError as e:                        # a precondition of the hand-scheduled gather this check does not
+                if "hand-scheduled kernel was required" not in str(e):     # mirror: the ordinary path takes the call
+                    raise
         # (V, A*F), identity scaler only; on a sharded graph the halo exchange overlaps the rows that do not need it
         agg = PF.aggregate(graph, graph.source_features(h, defer=True), self.in_dim, self.aggregators)
         lin = self.posttrans.fully_connected[0].linear

@@ -196,7 +196,7 @@ class _SmallTowerPlan:
         if mix is not None:
             ts += [p for p in (mix.linear.weight, mix.linear.bias) if p is not None]
         self.ts = ts
-        self.versions = [x._version for x in ts]
+        self.versions = self._state()
         T, Fi, Fo, S = len(towers), t0.in_dim, t0.out_dim, len(t0.scalers)
         self.T, self.Fi, self.Fo, self.S, self.divide_input = T, Fi, Fo, S, divide_input
         with torch.no_grad():
@@ -237,8 +237,13 @@ class _SmallTowerPlan:
         self.fn = _lib.lib().pna_tower_layer_f32
         self.check, self.stream_ptr = _lib.check, _lib.stream_ptr
 
+    def _state(self):
+        # (version, storage address, device) per tensor: `param.data = other` (EMA / SWA swaps, vector_to_parameters, offloading)
+        # keeps the version counter but moves the address -- the same key the other weight caches use
+        return [(x._version, x.data_ptr(), str(x.device)) for x in self.ts]
+
     def stale(self):
-        return [x._version for x in self.ts] != self.versions
+        return self._state() != self.versions
 
     def run(self, graph, h, snorm_n, row_scales, residual):
         if h.stride(-1) != 1:
@@ -250,7 +255,9 @@ class _SmallTowerPlan:
         csr = graph.csr
         out = torch.empty((V, self.width), dtype=torch.float32, device=dev)
         xc = torch.empty((V, self.xw), dtype=torch.float32, device=dev)
-        a = self.args
+        import ctypes
+        a = type(self.args)()                                # per-call copy of the pre-filled block: concurrent calls of one layer from
+        ctypes.memmove(ctypes.byref(a), self.ref, ctypes.sizeof(a))      # two host threads / streams do not race on it
         a.rowptr, a.col, a.V = csr.rowptr.data_ptr(), csr.col.data_ptr(), V
         a.h, a.ldh = h.data_ptr(), h.stride(0)
         a.x_cat, a.ldx = xc.data_ptr(), self.xw
@@ -270,7 +277,7 @@ class _SmallTowerPlan:
         else:
             a.residual = None
         a.y, a.ldy = out.data_ptr(), self.width
-        rc = self.fn(self.ref, self.stream_ptr(dev))
+        rc = self.fn(ctypes.byref(a), self.stream_ptr(dev))
         if rc != 0:
             self.check(rc, "pna_tower_layer_f32")
         del snorm_n, xc                                      # (stream-ordered allocator: safe to release after the launch)
@@ -309,6 +316,36 @@ def degree_grouped_aggregate(layer, graph, h, plan, out=None, x=None):
     return out
 
 
+def _layer_tail_operands(layer, h):
+    """(column scale, column shift, residual) of the simple layer's epilogue: eval BatchNorm folded, the input as residual."""
+    cs = ct = None
+    if layer.batch_norm:
+        cs, ct = _fold_batchnorm(layer.batchnorm_h)
+    return cs, ct, (_unit_stride(h) if layer.residual else None)
+
+
+def _rest_posttrans(layer, graph, agg_rest, plan, scales, y, cs, ct, res):
+    """The rows no degree group holds (rare degrees, hub rows): the ordinary three-block contraction over their compact list
+    `agg_rest` ((plan.NRp, 4F), virtual order), rows scattered to node order."""
+    F, N = layer.in_dim, layer.out_dim
+    K = len(layer.aggregators) * F
+    lin = layer.posttrans.fully_connected[0].linear
+    from .dgl.pna_layer import _avg_log_value
+    rest_scales = plan.rest_scales(tuple(layer.scalers) + (_avg_log_value(layer.avg_d),), scales)
+    if N <= 80 and len(scales) == 3:
+        ops.posttrans(agg_rest, K, lin.weight, rest_scales, lin.bias, out=y, col_scale=cs, col_shift=ct, relu=True, residual=res,
+                      row_perm=plan.perm_rest, n_out=N)
+    else:
+        # 128-column block (three blocks x three weight buffers do not fit the LDS) or another scaler count (no grouped
+        # instantiation): the few rest rows take the ordinary kernel over their compact list and are scattered by index (three
+        # small torch kernels)
+        rr = plan.rest_rows
+        y_r = ops.posttrans(agg_rest[:plan.NR], K, lin.weight, [None if r is None else r[:plan.NR] for r in rest_scales],
+                            lin.bias, col_scale=cs, col_shift=ct, relu=True, residual=None if res is None else res.index_select(0, rr),
+                            arith="bf16x3")
+        y.index_copy_(0, rr, y_r)
+
+
 def degree_grouped_posttrans(layer, graph, h, agg, plan, out=None):
     """The two contractions over `agg` (degree_grouped_aggregate): one combined block per degree tile, three blocks for the rest;
     both scatter their rows to node order with BatchNorm / ReLU / residual in the epilogue."""
@@ -319,28 +356,57 @@ def degree_grouped_posttrans(layer, graph, h, agg, plan, out=None):
     lin = layer.posttrans.fully_connected[0].linear
     scales = _row_scales(graph, layer.scalers, layer.avg_d, h.device)
     y = torch.empty(h.shape[0], N, dtype=torch.float32, device=h.device) if out is None else out
-    cs = ct = None
-    if layer.batch_norm:
-        cs, ct = _fold_batchnorm(layer.batchnorm_h)
-    res = _unit_stride(h) if layer.residual else None
+    cs, ct, res = _layer_tail_operands(layer, h)
     if plan.G:
         img, stride = DG.combined_images(lin.weight, K, scales, plan)
         ops.posttrans(agg[:plan.NV], K, lin.weight, [None], lin.bias, out=y, col_scale=cs, col_shift=ct, relu=True, residual=res,
                       row_perm=plan.perm, tile_image=plan.tile_image, w_img=img, image_stride=stride, n_out=N)
     if plan.NR:                 # (on a side stream beside the grouped launch: measured, no gain -- one after the other)
-        rest_scales = plan.rest_scales(tuple(layer.scalers) + (float(layer.avg_d["log"]),), scales)
-        if N <= 80 and len(scales) == 3:
-            ops.posttrans(agg[plan.NV:], K, lin.weight, rest_scales, lin.bias, out=y, col_scale=cs, col_shift=ct, relu=True, residual=res,
-                          row_perm=plan.perm_rest, n_out=N)
-        else:
-            # 128-column block (three blocks x three weight buffers do not fit the LDS) or two scalers (no grouped instantiation):
-            # the few rest rows take the ordinary kernel over their compact list and are scattered by index (three small torch
-            # kernels)
-            rr = plan.rest_rows
-            y_r = ops.posttrans(agg[plan.NV:plan.NV + plan.NR], K, lin.weight, [None if r is None else r[:plan.NR] for r in rest_scales],
-                                lin.bias, col_scale=cs, col_shift=ct, relu=True, residual=None if res is None else res.index_select(0, rr),
-                                arith="bf16x3")
-            y.index_copy_(0, rr, y_r)
+        _rest_posttrans(layer, graph, agg[plan.NV:], plan, scales, y, cs, ct, res)
+    return y
+
+
+def simple_layer_degree_fused(layer, graph, h, x=None, out=None, agg_out=None):
+    """PNASimpleLayer.forward (eval) with the group rows in ONE kernel (pna_fused_degree_f32): gather, the four
+    aggregators, the combined scaler block W_D and the posttrans contraction with its BatchNorm / ReLU / residual epilogue; the
+    4F aggregate of those rows never reaches HBM.  The rows no degree group holds (rare degrees, hub rows: 0.4 % of the benchmark
+    graph's rows, 5 % of its edges) take the two-kernel path over their compact list.  `x`: the source table (halo in place on
+    a sharded graph); `agg_out` (verification): (plan.NV, >= 4F) receives the statistics the contraction consumed."""
+    from . import _lib, degree_groups as DG
+    from .dgl.pna_layer import _row_scales
+    import ctypes
+    F, N = layer.in_dim, layer.out_dim
+    K = len(layer.aggregators) * F
+    plan = DG.plan_of(graph)
+    if x is None:
+        x = graph.source_features(h)
+    lin = layer.posttrans.fully_connected[0].linear
+    scales = _row_scales(graph, layer.scalers, layer.avg_d, h.device)
+    V = h.shape[0]
+    y = torch.empty(V, N, dtype=torch.float32, device=h.device) if out is None else out
+    cs, ct, res = _layer_tail_operands(layer, h)
+    desc, ids, n_rec = plan.fused_tables()
+    img, stride = DG.fused_images(lin.weight, F, scales, plan)
+    a = _lib.PnaFusedDegreeArgs()
+    a.tile_desc, a.tile_ids, a.n_records = _lib.dev_ptr(desc, torch.int32, "tile_desc"), _lib.dev_ptr(ids, torch.int32, "tile_ids"), n_rec
+    a.x, a.ldx, a.x_rows, a.F, a.N = _lib.dev_ptr(x, torch.float32, "x"), x.stride(0), x.shape[0], F, N
+    a.row_perm, a.M, a.n_nodes = _lib.dev_ptr(plan.perm, torch.int32, "row_perm"), plan.NV, V
+    a.w_img, a.image_stride = _lib.dev_ptr(img, torch.float32, "w_img"), stride
+    a.bias = _lib.dev_ptr(lin.bias, torch.float32, "bias")
+    a.col_scale, a.col_shift = _lib.dev_ptr(cs, torch.float32, "col_scale"), _lib.dev_ptr(ct, torch.float32, "col_shift")
+    if res is not None:
+        a.residual, a.ld_res = _lib.dev_ptr(res, torch.float32, "residual"), res.stride(0)
+    a.y, a.ldy, a.relu = _lib.dev_ptr(y, torch.float32, "y"), y.stride(0), 1
+    if agg_out is not None:
+        a.agg_out, a.ld_agg = _lib.dev_ptr(agg_out, torch.float32, "agg_out"), agg_out.stride(0)
+    _lib.check(_lib.lib().pna_fused_degree_f32(ctypes.byref(a), _lib.stream_ptr(h.device)), "pna_fused_degree_f32")
+    if plan.NR:
+        items, hout = plan.rest_items()
+        agg = torch.empty(plan.NRp, DG.agg_pitch(K), dtype=torch.float32, device=h.device)[:, :K]
+        csr = graph.csr
+        ops.segreduce(csr.rowptr, csr.col, _unit_stride(x), F, layer.aggregators, (None,), tower_stride_in=F, out=agg, heavy=graph.heavy_schedule(),
+                      workspace=graph.workspace, items=items, heavy_out=hout, tune=dict(generic=2))
+        _rest_posttrans(layer, graph, agg, plan, scales, y, cs, ct, res)
     return y
 
 
@@ -351,6 +417,11 @@ def simple_layer_degree_grouped(layer, graph, h):
     over a compacted list."""
     from . import degree_groups as DG
     plan = DG.plan_of(graph)
+    if DG.FUSED and 17 <= layer.in_dim <= 80 and layer.out_dim <= 80:
+        x = graph.source_features(h)                       # (a sharded graph finishes its halo exchange here: no overlap on this path)
+        if DG.fused_applies(graph, x, layer.in_dim, layer.out_dim):
+            return simple_layer_degree_fused(layer, graph, h, x=x)
+        return degree_grouped_posttrans(layer, graph, h, degree_grouped_aggregate(layer, graph, h, plan, x=x), plan)
     return degree_grouped_posttrans(layer, graph, h, degree_grouped_aggregate(layer, graph, h, plan), plan)
 
 
@@ -358,7 +429,11 @@ class _SmallSimplePlan(_SmallTowerPlan):
     """PNASimpleLayer (models/dgl/pna_layer.py:197-216, eval mode) on the same one-call kernel: a tower layer with ONE tower,
     the identity as pretrans (messages are the raw source features: x_cat = [I ; 0] h), no self panel in the posttrans
     (W_h = 0), and the identity as mixing network with the layer's ReLU and residual in its epilogue.  Products with 1 and sums
-    with 0 are exact: the result is the three-kernel path's up to the summation order of the contraction."""
+    with 0 are exact: the result is the three-kernel path's up to the summation order of the contraction.  One difference for
+    NON-FINITE inputs: a node whose OWN feature is Inf / NaN gets 0 * Inf = NaN from the zero self panel here, while the
+    three-kernel path and the reference (whose posttrans never reads the node's own h, pna_layer.py:206) keep its output finite
+    when its neighbours are -- PNASimpleLayer._small_batch_path therefore requires... nothing: the check would cost a pass over h
+    per call; callers with non-finite features set PNA_AMD_SMALL_SIMPLE_ROWS=0."""
 
     def __init__(self, layer):
         import ctypes
@@ -369,7 +444,7 @@ class _SmallSimplePlan(_SmallTowerPlan):
             raise RuntimeError("only an eval-mode BatchNorm (running statistics) can be folded into the epilogue")
         self.ts = [x for x in (lin.weight, lin.bias) if x is not None] + \
                   ([x for x in (bn.weight, bn.bias, bn.running_mean, bn.running_var) if x is not None] if bn is not None else [])
-        self.versions = [x._version for x in self.ts]
+        self.versions = self._state()
         Fi, Fo, S = layer.in_dim, layer.out_dim, len(layer.scalers)
         self.T, self.Fi, self.Fo, self.S, self.divide_input = 1, Fi, Fo, S, False
         dev = lin.weight.device

@@ -1,0 +1,140 @@
+#!/usr/bin/env python
+"""In-flight register audit of hand-scheduled loads (cdna_hip_programming.md 5.7 item 1).
+
+hipcc treats the VGPR destination of an inline-asm load as written at `;;#ASMEND`: between the load and OUR `s_waitcnt` it may
+read, copy, spill or reuse the register while the data is still in flight.  This tool replays the device assembly of one kernel
+(`hipcc -S --cuda-device-only`) region by region: every inline-asm `global_load_*` enters a FIFO (VMEM returns in order), every
+`s_waitcnt vmcnt(N)` retires all but the N youngest entries, and any instruction -- compiler-generated or ours -- that reads or
+writes a register whose load is still in the FIFO is reported.  Compiler-issued VMEM operations (loads, stores, LDS copies) are
+entered too: they occupy counter slots, which only ever makes a counted wait stricter, so they are retired like the others.
+
+The control-flow graph is explored exhaustively: both sides of every conditional branch, each (basic block, FIFO picture) state
+once, so a loop is followed until its in-flight picture repeats.
+
+    python tools/isa_audit.py <file.s> <kernel-name-substring> [--verbose]
+Used by tests/test_build_resources.py.
+"""
+import re
+import sys
+
+_REG = re.compile(r"\bv(\d+)\b|v\[(\d+):(\d+)\]")
+
+
+def vregs(text):
+    out = set()
+    for m in _REG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def kernel_lines(path, name):
+    lines = open(path).read().split("\n")
+    start = None
+    for i, l in enumerate(lines):
+        head = l.split(";")[0].strip()
+        if start is None and head.endswith(":") and name in head and not l.startswith(("\t", ".")):
+            start = i
+        if start is not None and ".end_amdhsa_kernel" in l:
+            return lines[start:i]
+    raise SystemExit(f"kernel *{name}* not found in {path}")
+
+
+def parse(lines):
+    """-> list of (lineno, in_asm, mnemonic, operand text) for instructions; labels as (lineno, None, 'label', name)."""
+    out, in_asm = [], False
+    for i, raw in enumerate(lines):
+        l = raw.split(";")[0].strip() if not raw.strip().startswith(";;#") else raw.strip()
+        if l.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if l.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not l:
+            continue
+        if l.endswith(":") and not l.startswith("\t"):
+            out.append((i, None, "label", l[:-1]))
+            continue
+        if l.startswith("."):
+            continue
+        parts = l.split(None, 1)
+        out.append((i, in_asm, parts[0], parts[1] if len(parts) > 1 else ""))
+    return out
+
+
+def is_vmem(mn):
+    return mn.startswith(("global_load", "global_store", "buffer_load", "buffer_store", "scratch_load", "scratch_store", "flat_load", "flat_store",
+                          "global_atomic"))
+
+
+def audit(lines, verbose=False):
+    """Explores the kernel's control-flow graph (both sides of every conditional branch; a (block, FIFO) state is visited once, so
+    loops converge as soon as their in-flight picture repeats).  Returns [(line, mnemonic, operands, registers)]."""
+    ins = parse(lines)
+    labels = {name: k for k, (_, a, mn, name) in enumerate(ins) if mn == "label"}
+    problems, seen_prob, visited = [], set(), set()
+    stack = [(0, ())]                # (pc, fifo); fifo entries: sorted tuple of dst regs (empty for ops without a tracked dst)
+    steps = 0
+    while stack:
+        k, fifo = stack.pop()
+        fifo = list(fifo)
+        while k < len(ins):
+            ln, in_asm, mn, ops = ins[k]
+            steps += 1
+            if steps > 20_000_000:
+                raise SystemExit("isa_audit: state explosion (more than 2e7 steps)")
+            if mn == "label":
+                key = (k, tuple(fifo))
+                if key in visited:
+                    break
+                visited.add(key)
+                k += 1
+                continue
+            if mn == "s_endpgm":
+                break
+            if mn == "s_branch":
+                k = labels[ops.strip()]
+                continue
+            if mn.startswith("s_cbranch"):
+                stack.append((labels[ops.strip()], tuple(fifo)))
+                k += 1
+                continue
+            if mn == "s_waitcnt":
+                m = re.search(r"vmcnt\((\d+)\)", ops)
+                if m:
+                    n = int(m.group(1))
+                    if len(fifo) > n:
+                        fifo = fifo[len(fifo) - n:] if n else []
+                k += 1
+                continue
+            if mn.startswith(("s_", ";")):
+                k += 1
+                continue
+            inflight = set()
+            for regs in fifo:
+                inflight.update(regs)
+            bad = vregs(ops) & inflight
+            if bad and (ln, tuple(sorted(bad))) not in seen_prob:
+                seen_prob.add((ln, tuple(sorted(bad))))
+                problems.append((ln, mn, ops, sorted(bad)))
+            if is_vmem(mn):
+                dst = ()
+                if in_asm and "_load" in mn and "lds" not in mn:             # compiler loads: hipcc waits for those itself
+                    dst = tuple(sorted(vregs(ops.split(",")[0])))
+                fifo.append(dst)
+                if len(fifo) > 63:
+                    fifo = fifo[-63:]
+            k += 1
+    if verbose:
+        print(f"{len(ins)} instructions, {steps} steps explored, {len(visited)} block states, {len(problems)} problems")
+    return problems
+
+
+if __name__ == "__main__":
+    probs = audit(kernel_lines(sys.argv[1], sys.argv[2]), verbose=True)
+    for ln, mn, ops, bad in probs:
+        print(f"  line {ln}: {mn} {ops}   touches in-flight v{bad}")
+    sys.exit(1 if probs else 0)
