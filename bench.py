@@ -13,8 +13,10 @@ With N > 1 the graph has N x the nodes/edges (weak scaling), is sharded by desti
 step includes the RCCL halo all-to-all of source rows.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- the fused segment-reduce kernel vs the 8 TB/s HBM roofline, ALGORITHMIC bytes
-                  E*(4F+4) + 4(V+1) + V*16F per launch / its measured mean duration
+  roofline     -- the step's dominant kernel vs the 8 TB/s HBM roofline on ALGORITHMIC bytes / its measured mean
+                  duration (HIP events): the one-kernel layer pna_fused_degree_f32 (gather + aggregators + scalers + posttrans; the
+                  4F aggregate is never written: E_g (4F+4) + V_g (8F+4) bytes) where it runs, else the standalone segment-reduce
+                  (E (4F+4) + 4 (V+1) + V 16F); `read_only_frac` = the gather's reads alone (the north star's 60 % target)
   cpu_baseline -- the oracle's C port (oracle/pna_oracle.c, OpenMP) + torch CPU Linear/BN of the same
                   layer, timed on this box's host cores on a bounded sample (rank 0, N=1 only)
 """
@@ -197,14 +199,24 @@ def sampled_check(g, h_ext, y, layer_sd, avg_log, n_rows, lo=0):
     agg = c_oracle.segreduce(rp.cpu().numpy().astype(np.int32), inv.cpu().numpy().astype(np.int32), x_sub, x_sub.shape[1],
                              AGGREGATORS.split(), [None, amp, att])
     sd = {k: v.double().cpu() for k, v in layer_sd.items()}
-    z = torch.from_numpy(agg).double() @ sd["posttrans.fully_connected.0.linear.weight"].t() + sd["posttrans.fully_connected.0.linear.bias"]
-    z = (z - sd["batchnorm_h.running_mean"]) / torch.sqrt(sd["batchnorm_h.running_var"] + 1e-5) * sd["batchnorm_h.weight"] + sd["batchnorm_h.bias"]
+    W, b = sd["posttrans.fully_connected.0.linear.weight"], sd["posttrans.fully_connected.0.linear.bias"]
+    a64 = torch.from_numpy(agg).double()
+    z = a64 @ W.t() + b
+    bn_scale = sd["batchnorm_h.weight"] / torch.sqrt(sd["batchnorm_h.running_var"] + 1e-5)
+    z = (z - sd["batchnorm_h.running_mean"]) * bn_scale + sd["batchnorm_h.bias"]
     ref = h_ext[rows][:, :Fw].double().cpu() + torch.relu(z)
     got = y[rows].double().cpu()
-    err = (got - ref).abs().max().item()
+    # the north star's bar, per element: 1e-5 relative + the fp32 rounding floor of a K = 12F sum in another order,
+    # C_EPS x sum_k |w_k a_k| (tests/conftest.py check_blocks' floor model, C_EPS = 2e-6), carried through BatchNorm's scale
+    mass = (a64.abs() @ W.abs().t() + b.abs()) * bn_scale.abs()
+    tol = 1e-5 * ref.abs() + 2e-6 * mass
+    errs = (got - ref).abs()
+    err = errs.max().item()
     scale = ref.abs().max().item()
+    worst = (errs / tol.clamp(min=1e-30)).max().item()
     return {"rows": int(rows.numel()), "edges": int(rp[-1]), "max_abs_err": err, "max_abs_ref": scale, "rel_to_max": err / max(scale, 1e-30),
-            "ok": bool(err <= 1e-4 * max(scale, 1.0)), "tolerance": "1e-4 x max|y| (fp32 layer vs float64 contraction of the fp32 oracle aggregate)"}
+            "worst_err_over_tolerance": worst, "ok": bool(worst <= 1.0),
+            "tolerance": "per element 1e-5 |ref| + 2e-6 sum_k |w_k a_k| |bn scale| (fp32 layer vs float64 contraction of the fp32 oracle aggregate)"}
 
 
 def F_of(layer_sd):
@@ -391,6 +403,19 @@ def main():
             grouped = {"degree_groups": plan.G, "rows_in_groups": int((plan.perm >= 0).sum().item()), "padded_rows": plan.NV,
                        "rest_rows": plan.NR, "tile_rows": DG.TILE,
                        "segreduce_natural_order_ms": t_seg_plain, "three_block_contraction_ms": t_post_plain}
+        # ... and when the group rows run in ONE kernel (pna_fused_degree_f32): that launch, and the two-kernel path of the rest rows
+        fused = None
+        if grouped is not None:
+            from pna_amd import degree_groups as DG
+            if DG.fused_applies(g, x_ext, F, F):
+                call = PF.FusedDegreeCall(layer, g, h, x=x_ext)
+                t_fused = event_time_ms(call.group_rows, args.kernel_iters)
+                t_rest = event_time_ms(call.rest_rows, args.kernel_iters)
+                rows_g = grouped["rows_in_groups"]
+                deg_l = (csr.rowptr[1:] - csr.rowptr[:-1]).long()
+                e_g = int(deg_l[plan.perm[plan.perm >= 0].long()].sum().item())
+                fused = {"ms_group_rows_kernel": t_fused, "ms_rest_rows_two_kernel_path": t_rest, "rows": rows_g, "edges": e_g,
+                         "padded_rows": plan.NV, "id_records": plan.fused_tables()[2]}
         t_halo = event_time_ms(lambda: g.source_features(h), args.kernel_iters) if world > 1 else 0.0
         # socket power and shader clock while each kernel runs alone (rocm-smi; best effort, N = 1 only): the bf16x3 contraction
         # runs at the package power cap and the firmware lowers the clock to hold it -- the dense MFMA peak at THAT clock is the
@@ -424,6 +449,36 @@ def main():
                 "read_only_frac": alg_read / (t_seg * 1e-3) / HBM_PEAK,
                 "edges_per_s_kernel_only": e_local / (t_seg * 1e-3),
                 "heavy_rows": hs.n_heavy, "heavy_segments": hs.n_seg}
+    roofline_segreduce = None
+    if fused is not None:
+        # the dominant kernel of the step is the one-kernel layer over the group rows.  Algorithmic bytes of ITS units (SURVEY 8d,
+        # the aggregate never written): per edge 4F + 4 (source row + its id), per 16 rows a 16-byte descriptor, per row 4F read
+        # (residual) + 4F written (y) + 4 (perm).  The north star's "HBM-read roofline of the segment-reduce" is the gather part.
+        e_g, rows_g = fused["edges"], fused["rows"]
+        gather_read = e_g * (4 * F + 4) + plan.NV
+        fused_bytes = gather_read + rows_g * (8 * F + 4)
+        tf = fused["ms_group_rows_kernel"] * 1e-3
+        roofline_segreduce = roofline
+        roofline_segreduce["note"] = "the standalone gather kernel (still shipped: rest rows, tower layers, training); not on this step's path for the group rows"
+        roofline = {"bound": "hbm", "kernel": "k_fused_degree<2 full + half feature blocks> (pna_fused_degree_f32): gather + 4 aggregators + combined scaler block + posttrans "
+                                              "contraction + BN / ReLU / residual; the 4F aggregate never reaches HBM",
+                    "achieved": fused_bytes / tf / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": fused_bytes / tf / HBM_PEAK,
+                    "traffic": None, "traffic_source": None,
+                    "ms_per_launch": fused["ms_group_rows_kernel"], "algorithmic_bytes_per_launch": fused_bytes,
+                    "gather_read_bytes": gather_read, "read_only_frac": gather_read / tf / HBM_PEAK,
+                    "edges_per_s_kernel_only": e_g / tf, "rows": rows_g, "edges": e_g,
+                    "rest_rows_two_kernel_path_ms": fused["ms_rest_rows_two_kernel_path"],
+                    "mfma_frac_executed_flops": 2.0 * plan.NV * (4 * F) * F / tf / (MFMA_BF16_PEAK / 6),
+                    "note": "units of this launch: the rows of the degree groups (their edges); hub rows and rare degrees take the two-kernel rest path"}
+        ftp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(ftp) and args.workload == "c3" and world == 1 and args.nodes_per_gpu == V_PER_GPU and args.edges_per_gpu == E_PER_GPU:
+            try:
+                tj = json.load(open(ftp)).get("pna_fused_degree_c3")
+                if tj:
+                    roofline["traffic"] = tj.get("hbm_bytes_per_launch")
+                    roofline["traffic_source"] = "profiles/hbm_traffic.json (pna_fused_degree_c3): " + tj.get("collected", "") + "; NOT measured in this run"
+            except Exception:
+                pass
     flops = 2.0 * n_local * (12 * F) * F
     if grouped is not None:
         # one combined block per degree tile: a third of the multiply-adds, and the kernel is no longer matrix-pipe bound -- it
@@ -467,7 +522,7 @@ def main():
 
     # the LAYER against its own compulsory traffic: gathers + ids + rowptr, residual read, y written -- no 4F aggregate
     layer_bytes = e_local * (4 * F + 4) + 4 * (n_local + 1) + n_local * 4 * F * 2
-    roofline_layer = {"bound": "hbm", "kernel": "whole PNASimpleLayer step (segreduce + posttrans)", "algorithmic_bytes_per_step": layer_bytes,
+    roofline_layer = {"bound": "hbm", "kernel": "whole PNASimpleLayer step" + (" (one kernel over the degree groups + the two-kernel rest path)" if fused else " (segreduce + posttrans)"), "algorithmic_bytes_per_step": layer_bytes,
                       "achieved": layer_bytes / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                       "frac": layer_bytes / (ms_per_step * 1e-3) / HBM_PEAK,
                       "note": "E(4F+4) + 4(V+1) + 2*V*4F: what a layer that never materialised the 4F aggregate would have to move"}
@@ -487,11 +542,13 @@ def main():
                    "max_in_degree": int(csr.max_degree), "halo_rows_rank0": getattr(g, "n_halo", 0),
                    "interior_rows_rank0": int(g.interior_mask().sum().item()) if world > 1 else None,
                    "local_rows_rank0": n_local, "local_edges_rank0": e_local, "partition_balance": args.balance if world > 1 else None},
-        "roofline": roofline, "roofline_posttrans": roofline_post, "roofline_layer": roofline_layer,
+        "roofline": roofline, "roofline_segreduce_standalone": roofline_segreduce, "roofline_posttrans": roofline_post, "roofline_layer": roofline_layer,
         "power_probe": power,
         "ms_per_step_cold": ms_per_step_cold, "value_cold": (E / (ms_per_step_cold * 1e-3)) if ms_per_step_cold else None,
         "parity_check": check,
-        "kernel_ms": {"segreduce": t_seg, "posttrans": t_post, "posttrans_exact_f32_mfma": t_post_f32, "halo_all_to_all": t_halo,
+        "kernel_ms": {"fused_degree_group_rows": fused["ms_group_rows_kernel"] if fused else None,
+                      "fused_degree_rest_rows": fused["ms_rest_rows_two_kernel_path"] if fused else None,
+                      "segreduce": t_seg, "posttrans": t_post, "posttrans_exact_f32_mfma": t_post_f32, "halo_all_to_all": t_halo,
                       "csr_build_once_per_graph": csr_build_ms},
         "ms_per_step_exact_f32_mfma": ms_per_step_f32, "value_exact_f32_mfma": E / (ms_per_step_f32 * 1e-3),
     }

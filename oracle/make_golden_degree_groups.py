@@ -51,6 +51,11 @@ def main():
     torch.set_num_threads(1)
     golden_groups("groups_f44", 11, N=2600, E=9000, F=44, out_dim=44)                                  # 80-column block, 3 scalers
     golden_groups("groups_f96_two_scalers", 12, N=1500, E=5000, F=96, out_dim=96, scalers="identity amplification")   # 128-column block
+    # round 3: the TIMED shape (F = 75, three scalers: BASELINE configs[2]; the one-kernel path's 2 full + half feature
+    # blocks) and the C5 shape (out_dim = 128, three scalers: the 128-column grouped block), plus a width whose last block is full
+    golden_groups("groups_f75", 13, N=2400, E=8500, F=75, out_dim=75)
+    golden_groups("groups_f128", 14, N=1400, E=4800, F=128, out_dim=128)
+    golden_groups("groups_f64_n72", 15, N=2000, E=7000, F=64, out_dim=72, residual=False)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,238 @@
+"""pna_fused_degree_f32 (pna_amd/csrc/pna_fused_degree.hip): PNASimpleLayer.forward (models/dgl/pna_layer.py:186-216) with gather,
+aggregators, scalers and posttrans in ONE kernel on degree-ordered rows.  Parity chain: the statistics its contraction consumes
+are the production gather's BITS (which are the C oracle's for every row one lane group walks alone); the layer output matches
+the reference's own golden outputs (graphs with degree tiles, oracle/make_golden_degree_groups.py), the two-kernel grouped path,
+the ordinary path and a float64 restatement; 200 repeats at full size give identical bits."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _layer(F, N, dev, residual=True, seed=0, scalers="identity amplification attenuation"):
+    from pna_amd.dgl.pna_layer import PNASimpleLayer
+    torch.manual_seed(seed)
+    layer = PNASimpleLayer(F, N, "mean max min std", scalers, {"log": torch.tensor(2.3)}, 0.0, True, residual)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.copy_(torch.randn_like(p) / (p.shape[-1] ** 0.5 if p.dim() == 2 else 3.0))
+        layer.batchnorm_h.running_mean.normal_()
+        layer.batchnorm_h.running_var.uniform_(0.5, 2.0)
+    return layer.to(dev).eval()
+
+
+def _features(V, F, dev, seed=0):
+    """(V, F) view of a table whose rows are 16-byte aligned (pitch = round_up(F, 8) floats): what the one-kernel path needs."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    return torch.randn(V, (F + 7) // 8 * 8, device=dev, generator=g)[:, :F]
+
+
+class _Knobs:
+    """Degree-path switches for one test: thresholds lowered so that small graphs take the path, FUSED on / off."""
+
+    def __init__(self, fused, small_graphs=False, enabled=True):
+        self.fused, self.small, self.enabled = fused, small_graphs, enabled
+
+    def __enter__(self):
+        from pna_amd import degree_groups as DG, functional as PF
+        self.keep = (DG.ENABLED, DG.FUSED, DG.MIN_ROWS, DG.MIN_OUT, DG.TWO_SCALER_MIN_OUT, PF.SMALL_SIMPLE_ROWS)
+        DG.ENABLED, DG.FUSED = self.enabled, self.fused
+        if self.small:
+            DG.MIN_ROWS, DG.MIN_OUT, DG.TWO_SCALER_MIN_OUT, PF.SMALL_SIMPLE_ROWS = 1, 1, 1, 0
+        return self
+
+    def __exit__(self, *a):
+        from pna_amd import degree_groups as DG, functional as PF
+        DG.ENABLED, DG.FUSED, DG.MIN_ROWS, DG.MIN_OUT, DG.TWO_SCALER_MIN_OUT, PF.SMALL_SIMPLE_ROWS = self.keep
+
+
+# every instantiation: (feature blocks) F = 75: 2 full + half, 64: 2 full, 40: 1 full + half, 20 / 32: 1 full, 48: 1 + half, 80: 2 + half
+@pytest.mark.parametrize("V,E,F,N,scalers,residual", [
+    (200_000, 2_000_000, 75, 75, "identity amplification attenuation", True),
+    (131_072, 600_000, 64, 64, "identity amplification attenuation", True),
+    (160_000, 1_000_000, 40, 72, "identity amplification attenuation", False),
+    (140_000, 1_400_000, 50, 50, "identity amplification attenuation", True),
+    (150_000, 900_000, 80, 80, "identity amplification attenuation", True),
+    (140_000, 700_000, 32, 40, "identity amplification attenuation", False),
+    (140_000, 800_000, 20, 64, "amplification attenuation", False),
+    (135_000, 900_000, 48, 48, "identity amplification", True),
+    (135_000, 500_000, 17, 17, "identity amplification attenuation", True),
+])
+def test_fused_layer_equals_two_kernel_paths(cuda_device, V, E, F, N, scalers, residual):
+    from pna_amd import Graph, degree_groups as DG, functional as PF
+    from pna_amd.synth import powerlaw_graph
+    src, dst = powerlaw_graph(V, E, seed=V % 89, device=cuda_device)
+    g = Graph(src, dst, V)
+    layer = _layer(F, N, cuda_device, residual=residual, seed=N, scalers=scalers)
+    h = _features(V, F, cuda_device, seed=F)
+    with torch.no_grad():
+        with _Knobs(fused=True, small_graphs=True):
+            assert layer._degree_grouped_path(g, h) and DG.fused_applies(g, h, F, N)
+            plan = DG.plan_of(g)
+            # the statistics the contraction consumed == the production gather's aggregate, bit for bit
+            dump = torch.zeros(plan.NV, 4 * F, device=cuda_device)
+            y_dump = PF.simple_layer_degree_fused(layer, g, h, agg_out=dump)
+            y_f = layer(g, h)
+            for _ in range(3):
+                assert torch.equal(layer(g, h), y_f)
+            ref_agg = PF.degree_grouped_aggregate(layer, g, h, plan)[:plan.NV]
+            real = plan.perm >= 0
+            assert torch.equal(dump[real], ref_agg[real]), int((dump[real] != ref_agg[real]).any(dim=1).sum())
+        with _Knobs(fused=False, small_graphs=True):
+            assert layer._degree_grouped_path(g, h)
+            y_g = layer(g, h)
+        with _Knobs(fused=False, enabled=False):
+            assert not layer._degree_grouped_path(g, h)
+            y_p = layer(g, h)
+    assert torch.isfinite(y_f).all()
+    s = y_p.abs().max().item()
+    assert (y_dump - y_f).abs().max().item() <= 1e-6 * s       # (the verification instantiation runs one workgroup per CU: same arithmetic)
+    assert (y_f - y_g).abs().max().item() <= 2e-6 * s          # same W_D up to the order of its fp32 combination, same bf16x3 contraction
+    assert (y_f - y_p).abs().max().item() <= 2e-5 * s
+
+
+@pytest.mark.parametrize("name", [n for n in __import__("conftest").golden_names("dgl_simple_groups")])
+def test_fused_layer_vs_reference_golden(cuda_device, name):
+    """The REFERENCE's own PNASimpleLayer output (oracle/make_golden_degree_groups.py) on graphs where degree tiles exist, through
+    the one-kernel path (group rows) + the two-kernel rest path (rare degrees, three 300-edge hubs)."""
+    from conftest import load_golden
+    from pna_amd import Graph, degree_groups as DG
+    from pna_amd.dgl.pna_layer import PNASimpleLayer
+    meta, a, sd = load_golden(name)
+    F, N = meta["F"], meta["out_dim"]
+    if not (17 <= F <= 80 and N <= 80):
+        pytest.skip("shape outside the one-kernel path (covered by test_gpu_degree_groups.py)")
+    layer = PNASimpleLayer(F, N, meta["aggregators"], meta["scalers"], {"log": a["avg_log"]}, 0.0, True, meta["residual"])
+    layer.load_state_dict(sd)
+    layer = layer.to(cuda_device).eval()
+    g = Graph(a["src"].long(), a["dst"].long(), meta["N"]).to(cuda_device)
+    h = torch.zeros(meta["N"], (F + 7) // 8 * 8, device=cuda_device)[:, :F]
+    h.copy_(a["h"])
+    with torch.no_grad(), _Knobs(fused=True, small_graphs=True):
+        assert layer._degree_grouped_path(g, h) and DG.fused_applies(g, h, F, N)
+        plan = DG.plan_of(g)
+        assert plan.G > 0 and plan.NR > 0
+        out = layer(g, h).cpu()
+    torch.testing.assert_close(out, a["out"], rtol=1e-5, atol=1e-5)
+
+
+def test_fused_layer_isolated_nodes_and_nonfinite_features(cuda_device):
+    """A degree-0 group (rows without in-edges: the aggregate is 0, DGL's zero initialiser) and Inf / NaN features: the one-kernel
+    path has the two-kernel path's Inf / NaN pattern."""
+    from pna_amd import Graph
+    from pna_amd.synth import powerlaw_graph
+    V0, E, F, iso = 140_000, 900_000, 75, 400
+    src, dst = powerlaw_graph(V0, E, seed=3, device=cuda_device)
+    V = V0 + iso                                                   # `iso` nodes that only send
+    src = torch.cat([src, torch.arange(V0, V, device=cuda_device)])
+    dst = torch.cat([dst, torch.arange(0, iso, device=cuda_device)])
+    g = Graph(src, dst, V)
+    assert int((g.in_degrees() == 0).sum()) >= iso
+    layer = _layer(F, F, cuda_device, seed=2)
+    h = _features(V, F, cuda_device, seed=9)
+    h[5, 3] = float("inf"); h[77, 70] = float("-inf"); h[1234, 74] = float("nan"); h[V0 + 1, 0] = float("inf")
+    with torch.no_grad():
+        with _Knobs(fused=True, small_graphs=True):
+            y_f = layer(g, h)
+        with _Knobs(fused=False, small_graphs=True):
+            y_g = layer(g, h)
+    assert torch.equal(torch.isnan(y_f), torch.isnan(y_g)) and torch.equal(torch.isinf(y_f), torch.isinf(y_g))
+    fin = torch.isfinite(y_g)
+    assert torch.equal(torch.sign(y_f[~fin & ~torch.isnan(y_g)]), torch.sign(y_g[~fin & ~torch.isnan(y_g)]))
+    s = y_g[fin].abs().max().item()
+    assert (y_f[fin] - y_g[fin]).abs().max().item() <= 2e-6 * s
+    zero_rows = torch.nonzero(g.in_degrees() == 0).flatten()[:iso]
+    lin, bn = layer.posttrans.fully_connected[0].linear, layer.batchnorm_h
+    z = (lin.bias - bn.running_mean) / torch.sqrt(bn.running_var + bn.eps) * bn.weight + bn.bias
+    ref = h[zero_rows] + torch.relu(z)[None, :]
+    ok = torch.isfinite(ref)
+    assert (y_f[zero_rows][ok] - ref[ok]).abs().max().item() <= 1e-5
+
+
+@pytest.fixture(scope="module")
+def c3(cuda_device):
+    from pna_amd import Graph
+    from pna_amd.synth import powerlaw_graph
+    V, E, F = 1_000_000, 10_000_000, 75
+    src, dst = powerlaw_graph(V, E, seed=1234, device=cuda_device)
+    g = Graph(src, dst, V)
+    return g, _layer(F, F, cuda_device, seed=7), _features(V, F, cuda_device, seed=1)
+
+
+def test_fused_layer_rows_vs_float64_at_full_size(cuda_device, c3):
+    """BASELINE configs[2] (V = 1 M, E = 10 M, F = 75): sampled rows -- frequent degrees, rare degrees, the largest hubs -- of the
+    shipped layer (one-kernel path) against a float64 restatement of models/dgl/pna_layer.py:189-216."""
+    from pna_amd import degree_groups as DG
+    g, layer, h = c3
+    F = 75
+    with torch.no_grad():
+        assert layer._degree_grouped_path(g, h) and DG.fused_applies(g, h, F, F)
+        y = layer(g, h)
+    deg = g.in_degrees()
+    plan = DG.plan_of(g)
+    rows = torch.cat([torch.arange(0, 1500, device=cuda_device), torch.topk(deg, 40).indices, plan.rest_rows[:200],
+                      plan.perm[plan.perm >= 0][-300:].long()])
+    csr = g.csr
+    amp, att = g.degree_scalers(2.3)
+    lin, bn = layer.posttrans.fully_connected[0].linear, layer.batchnorm_h
+    W, b = lin.weight.double(), lin.bias.double()
+    worst = 0.0
+    for v in rows.tolist():
+        lo, hi = int(csr.rowptr[v]), int(csr.rowptr[v + 1])
+        m = h[csr.col[lo:hi].long()].double()
+        a = torch.cat([m.mean(0), m.max(0).values, m.min(0).values, torch.sqrt(torch.relu((m * m).mean(0) - m.mean(0) ** 2) + 1e-5)])
+        z = b + W @ torch.cat([a, a * amp[v].double(), a * att[v].double()])
+        z = (z - bn.running_mean.double()) / torch.sqrt(bn.running_var.double() + bn.eps) * bn.weight.double() + bn.bias.double()
+        ref = h[v].double() + torch.relu(z)
+        worst = max(worst, (y[v].double() - ref).abs().max().item() / max(1.0, ref.abs().max().item()))
+    assert worst <= 1e-5, worst
+
+
+def test_fused_layer_200_runs_identical_bits_at_full_size(cuda_device, c3):
+    """The round-2 experiment of this kernel produced wrong sums in a few wavefront tiles per launch, differently from run to run,
+    with its running sums folded by packed fp32 instructions.  The shipped fold is single v_add / v_mul: 200
+    launches at the C3 shape, identical bits -- and the statistics are the production gather's."""
+    from pna_amd import degree_groups as DG, functional as PF
+    g, layer, h = c3
+    with torch.no_grad():
+        assert DG.fused_applies(g, h, 75, 75)
+        y0 = layer(g, h).clone()
+        bad = 0
+        for _ in range(200):
+            bad += int(not torch.equal(layer(g, h), y0))
+        assert bad == 0, f"{bad} of 200 runs differ"
+        plan = DG.plan_of(g)
+        dump = torch.zeros(plan.NV, 300, device=cuda_device)
+        PF.simple_layer_degree_fused(layer, g, h, agg_out=dump)
+        ref = PF.degree_grouped_aggregate(layer, g, h, plan)[:plan.NV]
+        real = plan.perm >= 0
+        assert torch.equal(dump[real], ref[real])
+
+
+def test_fused_path_falls_back_without_an_aligned_table(cuda_device):
+    """Rows of pitch 75 floats are not 16-byte aligned: the layer takes the two-kernel grouped path, same result."""
+    from pna_amd import Graph, degree_groups as DG
+    from pna_amd.synth import powerlaw_graph
+    V, E, F = 140_000, 1_000_000, 75
+    src, dst = powerlaw_graph(V, E, seed=8, device=cuda_device)
+    g = Graph(src, dst, V)
+    layer = _layer(F, F, cuda_device, seed=4)
+    ha = _features(V, F, cuda_device, seed=2)
+    hp = ha.contiguous()
+    with torch.no_grad(), _Knobs(fused=True, small_graphs=True):
+        assert DG.fused_applies(g, ha, F, F) and not DG.fused_applies(g, hp, F, F)
+        ya, yp = layer(g, ha), layer(g, hp)
+    assert (ya - yp).abs().max().item() <= 2e-6 * yp.abs().max().item()
+
+
+def test_fused_entry_point_rejects_bad_arguments(cuda_device):
+    from pna_amd import _lib
+    L = _lib.lib()
+    a = _lib.PnaFusedDegreeArgs()
+    assert L.pna_fused_degree_f32(ctypes.byref(a), None) == 0            # M = 0: nothing to do
+    a.M = 64
+    assert L.pna_fused_degree_f32(ctypes.byref(a), None) == -1 and b"non-null" in L.pna_last_error()
+    assert L.pna_fused_degree_image_bytes(96, 80) == 0 and L.pna_fused_degree_image_bytes(75, 81) == 0 and L.pna_fused_degree_image_bytes(16, 16) == 0
+    assert L.pna_fused_degree_image_bytes(75, 75) == 10 * 15360 and L.pna_fused_degree_image_bytes(64, 80) == 8 * 15360

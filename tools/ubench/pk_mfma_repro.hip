@@ -1,0 +1,129 @@
+// pk_mfma_repro.hip -- minimal reproducer attempt for the packed-fp32 wrong-sum observation.
+// Two wavefronts per SIMD (one 512-thread workgroup per CU):
+//   role M (wavefronts 0-3): a chain of v_mfma_f32_16x16x32_bf16 on four accumulators, nothing else;
+//   role F (wavefronts 4-7): the fused kernel's fold -- per iteration two 16-byte loads per lane, then for the 8 values
+//     s += m, q += m * m with the packed instructions hipcc chose in the failing kernel (v_pk_add_f32 / v_pk_mul_f32, plain and with
+//     op_sel swizzles, v_pk_mov_b32 swaps), AND the same sums again from the SAME loaded registers with single v_add_f32 /
+//     v_mul_f32 instructions (the form that was exact).  Both run in one wavefront: any difference in the final bits is an
+//     instruction-level discrepancy, whatever its cause.  Differences are counted per lane.
+// mode 0: M + F (the failing co-residence); mode 1: F on all eight wavefronts; mode 2: F alone, one wavefront per SIMD (M idle).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/ubench/pk_mfma_repro.hip -o tools/ubench/pk_mfma_repro
+//   tools/ubench/pk_mfma_repro [iterations per launch] [launches]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef short bf8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(512, 2) void k_repro(const float* __restrict__ x, int rows, int iters, int mode, float* sink, unsigned* bad) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool fold_role = mode == 1 || wave >= 4;
+  if (mode == 2 && wave < 4) return;
+  if (!fold_role) {
+    f4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    bf8 a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = (short)(0x3f80 + lane + j); b[j] = (short)(0x3f00 + 2 * lane + j); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[n], 0, 0, 0);
+      asm volatile("" : "+v"(a), "+v"(b));
+    }
+    sink[blockIdx.x * 512 + threadIdx.x] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
+    return;
+  }
+  // packed accumulators: pair k = values (2k, 2k+1); pairs 0,1 folded with plain packed ops, pairs 2,3 with the op_sel swizzles
+  // hipcc emitted in the failing kernel (lo += hi-half of the operand, hi += lo-half) behind a v_pk_mov_b32 swap
+  f2 P[4], PQ[4];
+  float Sr[8], Qr[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { P[k] = (f2){0.f, 0.f}; PQ[k] = (f2){0.f, 0.f}; }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) Sr[j] = Qr[j] = 0.f;
+  unsigned row = (blockIdx.x * 8 + wave) * 64 + lane;
+  for (int it = 0; it < iters; it += 2) {
+    f4 v[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      row = (row * 1664525u + 1013904223u);
+      const float* p = x + (size_t)(row % (unsigned)rows) * 8;
+      v[u][0] = *reinterpret_cast<const f4*>(p);
+      v[u][1] = *reinterpret_cast<const f4*>(p + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f2 m = (f2){v[u][k >> 1][2 * (k & 1)], v[u][k >> 1][2 * (k & 1) + 1]};
+        f2 t;
+        if (k < 2) {
+          asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(P[k]) : "v"(P[k]), "v"(m));
+          asm volatile("v_pk_mul_f32 %0, %1, %1" : "=v"(t) : "v"(m));
+          asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(PQ[k]) : "v"(PQ[k]), "v"(t));
+        } else {
+          f2 sw;
+          asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(P[k]) : "v"(P[k]), "v"(m));       // lo += m.hi, hi += m.lo
+          asm volatile("v_pk_mov_b32 %0, %1, %1 op_sel:[1,0]" : "=v"(sw) : "v"(m));                                      // (m.hi, m.lo)
+          asm volatile("v_pk_mul_f32 %0, %1, %1" : "=v"(t) : "v"(sw));
+          asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(PQ[k]) : "v"(PQ[k]), "v"(t));
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {                       // the same from the same registers, one VALU instruction each
+        const float m = v[u][j >> 2][j & 3];
+        float s1, p1, q1;
+        asm volatile("v_add_f32 %0, %1, %2" : "=v"(s1) : "v"(Sr[j]), "v"(m));
+        asm volatile("v_mul_f32 %0, %1, %1" : "=v"(p1) : "v"(m));
+        asm volatile("v_add_f32 %0, %1, %2" : "=v"(q1) : "v"(Qr[j]), "v"(p1));
+        Sr[j] = s1; Qr[j] = q1;
+      }
+    }
+  }
+  unsigned nb = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int j0 = k < 2 ? 2 * k : 2 * k + 1, j1 = k < 2 ? 2 * k + 1 : 2 * k;      // swizzled pairs hold (value 2k+1, value 2k)
+    nb += (__builtin_bit_cast(unsigned, P[k][0]) != __builtin_bit_cast(unsigned, Sr[j0])) + (__builtin_bit_cast(unsigned, P[k][1]) != __builtin_bit_cast(unsigned, Sr[j1]));
+    nb += (__builtin_bit_cast(unsigned, PQ[k][0]) != __builtin_bit_cast(unsigned, Qr[j0])) + (__builtin_bit_cast(unsigned, PQ[k][1]) != __builtin_bit_cast(unsigned, Qr[j1]));
+  }
+  if (nb) atomicAdd(bad, nb);
+  sink[blockIdx.x * 512 + threadIdx.x] = P[0][0] + PQ[3][1];
+}
+
+int main(int argc, char** argv) {
+  const int iters = argc > 1 ? atoi(argv[1]) : 4096, launches = argc > 2 ? atoi(argv[2]) : 50;
+  const int rows = 1 << 22;                                // 128 MB table: the loads miss L2 like the gather's
+  int dev = 0, cus = 0;
+  hipGetDevice(&dev);
+  hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  float *x, *sink;
+  unsigned* bad;
+  hipMalloc(&x, (size_t)rows * 8 * 4);
+  hipMalloc(&sink, (size_t)cus * 512 * 4);
+  hipMalloc(&bad, 4);
+  std::vector<float> hx((size_t)rows * 8);
+  unsigned s = 12345;
+  for (auto& v : hx) { s = s * 1664525u + 1013904223u; v = ((int)(s >> 8) - (1 << 23)) * (1.0f / (1 << 22)); }
+  hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
+  for (int mode = 0; mode < 3; ++mode) {
+    hipMemset(bad, 0, 4);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    for (int l = 0; l < launches; ++l) hipLaunchKernelGGL(k_repro, dim3(cus), dim3(512), 0, 0, x, rows, iters, mode, sink, bad);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    unsigned hb = 0;
+    hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost);
+    printf("mode %d (%s): %d launches x %d CUs x %d iterations: %u differing sums, %.3f ms per launch\n", mode,
+           mode == 0 ? "MFMA wavefront + fold wavefront per SIMD" : mode == 1 ? "two fold wavefronts per SIMD" : "one fold wavefront per SIMD",
+           launches, cus, iters, hb, ms / launches);
+  }
+  return 0;
+}
