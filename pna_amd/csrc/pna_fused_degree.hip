@@ -60,7 +60,9 @@ struct FDArgs {
   float slope;
 };
 
-constexpr int kNW = 80, kNT = 5, kWaves = 4, kThreads = 64 * kWaves, kNBuf = 3;
+constexpr int kNW = 80, kNT = 5, kWaves = 4, kThreads = 64 * kWaves;
+constexpr int kNBuf = 5;                                  // LDS weight buffers: a chunk image is requested kNBuf - 1 steps before it is read
+constexpr int kAhead = kNBuf - 1;
 constexpr int kChunkV = 3 * 4 * kNW;                      // 16-byte pieces of one chunk image: [term][lane group][80 cols][8 k] bf16
 constexpr int kNI = (kChunkV + kThreads - 1) / kThreads;  // global_load_lds instructions per wavefront per chunk
 constexpr int kRing = 4;                                  // edge packets in the register ring
@@ -89,8 +91,12 @@ __device__ __forceinline__ void ld4(int& dst, const void* base, unsigned voff) {
 __device__ __forceinline__ void ld4f(float& dst, const void* base, unsigned voff) {
   asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
 }
-__device__ __forceinline__ void sld16(i4& dst, const void* base, unsigned soff) {        // scalar load of a tile descriptor
-  asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(dst) : "s"(base), "s"(soff) : "memory");
+// Scalar load of a tile descriptor, waited for INSIDE the statement: an SGPR result that is still in flight when the statement
+// ends may be SPILLED by hipcc (v_writelane of the stale value) -- the 2 full + half instantiation of the verification kernel did
+// exactly that with a descriptor requested at the top of the gather and waited for at its end: wild record offsets, a memory
+// fault.  (Nothing else of this wavefront is on the LGKM counter when these are issued.)
+__device__ __forceinline__ void sld16(i4& dst, const void* base, unsigned soff) {
+  asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(dst) : "s"(base), "s"(soff) : "memory");
 }
 // wait until at most N of this wavefront's loads are outstanding; the slot's registers and its id become readable here
 template <int N, int NL>
@@ -173,7 +179,6 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
   i4 td_cur, td_nxt, td_n2;
   sld16(td_cur, g.tdesc, desc_off(t));
   sld16(td_nxt, g.tdesc, desc_off(t + G));
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(td_cur), "+s"(td_nxt) : : "memory");
   td_n2 = td_nxt;
   const unsigned lib = (unsigned)li * 4u;
   int idr[kRing];
@@ -199,7 +204,6 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     const int D = td_cur.y;
     const unsigned rb = (unsigned)td_cur.x * 64u, rbn = (unsigned)td_nxt.x * 64u;       // byte offsets of this / the next tile's records
     deg = D;
-    sld16(td_n2, g.tdesc, desc_off(t + 2 * G));
     ld16i(pr, g.perm, (unsigned)((t * kWaves + wave) * 16 + 4 * lg) * 4u);
 #pragma unroll
     for (int fb = 0; fb < NB; ++fb)
@@ -236,6 +240,7 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     // the packets of edges 0..3; each refills its id with the next group's, or -- after the last group -- the NEXT tile's edge j
     const unsigned n0 = 1 < ng ? rb + 4u * 64u : rbn;
     issue(J0{}, n0); issue(J1{}, n0); issue(J2{}, n0); issue(J3{}, n0);
+    sld16(td_n2, g.tdesc, desc_off(t + 2 * G));           // (the descriptor after next: its latency sits behind the packets just issued)
     // steady state: slot j holds edge 4 gi + j; behind it in flight: the three younger packets.  Every edge here is a real one.
     for (int gi = 0; gi + 1 < ng; ++gi) {
       const unsigned nr = gi + 2 < ng ? rb + (unsigned)(4 * gi + 8) * 64u : rbn;
@@ -262,7 +267,6 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     wait_slot<2 * LB + NR, NL>(sl[1], idr[1]); fold(J1{}, e0 + 1 < D);
     wait_slot<1 * LB + NR, NL>(sl[2], idr[2]); fold(J2{}, e0 + 2 < D);
     wait_slot<NR, NL>(sl[3], idr[3]);          fold(J3{}, e0 + 3 < D);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(td_n2) : : "memory");
   };
 
   // ---- chunk c: the lane's eight A values, split into three bf16 terms.  Full block fb, chunk 4 fb + a: aggregator a (0 mean,
@@ -351,14 +355,18 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     }
   };
 
-  // ---- the (tile, chunk) pipeline: step k reads LDS buffer k % 3; barrier B_k sits in the middle of step k; after B_k every
-  //      wavefront has finished step k-1, so buffer (k+2) % 3 is free: step k+2's image is copied then and waited for (vmcnt(0))
-  //      before B_{k+1}.  That vmcnt(0) also retires the residual rows requested at the end of the gather. ---------------------
+  // ---- the (tile, chunk) pipeline: step k reads LDS buffer k % 5; barrier B_k sits in the middle of step k; after B_k every
+  //      wavefront has finished step k-1, so buffer (k-1) % 5 = (k+4) % 5 is free: step k+4's image is copied then.  Before B_k a
+  //      wavefront waits for ITS pieces of step k+1's image with a counted vmcnt that leaves the two younger images (steps k+2,
+  //      k+3) in flight: a copy has three steps to land.  (Round 3, first version: 3 buffers and vmcnt(0) -- one step of cover
+  //      against ~2 us of copy latency under the gather's load: the phase timers showed 45 % of a wavefront's time in the
+  //      multiply phase, 5x its matrix-pipe time.)  The same waits retire the residual rows requested at the end of the gather:
+  //      they are older than every copy issued during the steps. ------------------------------------------------------------------
   unsigned long long tg = 0, tm = 0, te = 0, t00 = now();
   long ib_cur = (long)td_cur.z * g.img_stride, ib_next = (long)td_nxt.z * g.img_stride;
   int buf = 0;
-  stage(0, 0, ib_cur);
-  stage(1, 1, ib_cur);
+#pragma unroll
+  for (int c = 0; c < kAhead; ++c) stage(c, c, ib_cur);   // (every shape has at least 4 chunks)
   // the ids of the first tile's edges 0..3 (later tiles: fetched by the previous tile's last packets)
 #pragma unroll
   for (int j = 0; j < kRing; ++j) ld4(idr[j], g.ids, (unsigned)td_cur.x * 64u + (unsigned)j * 64u + lib);
@@ -372,38 +380,61 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
   auto step = [&](auto c_c) __attribute__((always_inline)) {
     constexpr int c = decltype(c_c)::value;
     const unsigned ba0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(buf * kChunkV + lg * kNW + li) * 16u;
-    const int buf2 = buf == 0 ? kNBuf - 1 : buf - 1;     // (k + 2) % 3
+    const int buf2 = buf == 0 ? kNBuf - 1 : buf - 1;     // (k + kAhead) % kNBuf
     bf8 B[2][3];                                         // B fragments of column tile n (slot n & 1): one ds_read_b128 per term
     constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
-    constexpr int H = (kNT - 1) / 2;
     if constexpr (c == 0) {
 #pragma unroll
       for (int n = 0; n < kNT; ++n) acc[n] = (f4){0.f, 0.f, 0.f, 0.f};
     }
-    // B fragments: column tile n+1's three reads are issued before tile n's MFMAs and the wavefront waits for all of its LDS
-    // reads (lgkmcnt(0), naming every fragment register) before it issues tile n's MFMAs.  One address register per step, the
-    // (term, column tile) displacement in the instruction's offset field: as "v" operands the 45 distinct addresses were hoisted
-    // out of the tile loop and spilled.
+    // Column tiles in PAIRS (0,1) (2,3) (4): both tiles' B fragments are read (6 x ds_read_b128, ONE wait), then their 12 MFMAs are
+    // issued alternating between the two accumulators -- every accumulator sees an MFMA every other issue slot instead of six
+    // dependent ones back to back (round 3, first version: tile by tile, lgkmcnt(0) before every tile's six dependent MFMAs -- the
+    // phase timers put 44 % of a wavefront's time into the multiply phase, 2400 cycles per step against 480 of matrix-pipe time).
+    // The next pair's reads go into the registers the MFMAs just issued have read (the pattern of pna_posttrans_x3.hip).  One
+    // address register per step, the (term, column tile) displacement in the instruction's offset field: as "v" operands the
+    // 45 distinct addresses were hoisted out of the tile loop and spilled.
+#define FD_READ_B(slot, n)                                                                                                                  \
+    _Pragma("unroll") for (int tm_ = 0; tm_ < 3; ++tm_)                                                                                     \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(B[slot][tm_]) : "v"(ba0), "n"(tm_ * 4 * kNW * 16 + (n) * 256) : "memory")
+#ifdef FD_SCHED_FENCE
+#define FD_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define FD_FENCE()
+#endif
+#define FD_WAIT_B()                                                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(B[0][0]), "+v"(B[0][1]), "+v"(B[0][2]), "+v"(B[1][0]), "+v"(B[1][1]), "+v"(B[1][2]) : : "memory"); FD_FENCE()
+    static_assert(kNT == 5, "the pairing below is written for five column tiles");
+    FD_READ_B(0, 0); FD_READ_B(1, 1);
+    FD_WAIT_B();
 #pragma unroll
-    for (int tm_ = 0; tm_ < 3; ++tm_)
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(B[0][tm_]) : "v"(ba0), "n"(tm_ * 4 * kNW * 16) : "memory");
-#pragma unroll
-    for (int n = 0; n < kNT; ++n) {
-      const int slot = n & 1;
-      if (n + 1 < kNT) {
-#pragma unroll
-        for (int tm_ = 0; tm_ < 3; ++tm_)
-          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(B[slot ^ 1][tm_]) : "v"(ba0), "n"(tm_ * 4 * kNW * 16 + (n + 1) * 256) : "memory");
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(B[0][0]), "+v"(B[0][1]), "+v"(B[0][2]), "+v"(B[1][0]), "+v"(B[1][1]), "+v"(B[1][2]) : : "memory");
-      if (n == H) {
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if (c + 2 < NC) stage(c + 2, buf2, ib_cur);
-        else stage(c + 2 - NC, buf2, ib_next);
-      }
-#pragma unroll
-      for (int pp = 0; pp < 6; ++pp) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[slot][TB[pp]], acc[n], 0, 0, 0);
+    for (int pp = 0; pp < 6; ++pp) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[0][TB[pp]], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[1][TB[pp]], acc[1], 0, 0, 0);
     }
+    FD_FENCE();
+    FD_READ_B(0, 2); FD_READ_B(1, 3);
+    FD_WAIT_B();
+    // (the images of a tile's first kAhead - 1 steps were requested before its gather, whose waits retired them; waiting here
+    // would only wait for the residual rows requested at the end of the gather -- a full memory round trip per tile)
+    if constexpr (c >= kAhead - 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"((kAhead - 2) * kNI) : "memory");
+    else asm volatile("s_barrier" ::: "memory");
+    if (c + kAhead < NC) stage(c + kAhead, buf2, ib_cur);
+    else stage(c + kAhead - NC, buf2, ib_next);
+#pragma unroll
+    for (int pp = 0; pp < 6; ++pp) {
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[0][TB[pp]], acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[1][TB[pp]], acc[3], 0, 0, 0);
+    }
+    FD_FENCE();
+    FD_READ_B(0, 4);
+    FD_WAIT_B();
+#pragma unroll
+    for (int pp = 0; pp < 6; ++pp) acc[4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[0][TB[pp]], acc[4], 0, 0, 0);
+    FD_FENCE();
+#undef FD_READ_B
+#undef FD_WAIT_B
+#undef FD_FENCE
     buf = buf == kNBuf - 1 ? 0 : buf + 1;
     if constexpr (c + 1 < NC) frag(std::integral_constant<int, c + 1>{});
   };
@@ -421,7 +452,8 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     steps4(std::integral_constant<int, 0>{});
     if constexpr (NC > 4) steps4(std::integral_constant<int, ((NC > 4) ? 4 : 0)>{});
     if constexpr (NC > 8) steps4(std::integral_constant<int, ((NC > 8) ? 8 : 0)>{});
-    // the residual rows landed before the first step's barrier; from here on the compiler may read them
+    // the residual rows landed by the last step's counted wait (they are older than all but the first copies of the tile, and
+    // every shape has at least 4 steps); from here on the compiler may read them
     if constexpr (RESPF)
       asm volatile("" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]), "+v"(res[5]), "+v"(res[6]), "+v"(res[7]), "+v"(res[8]), "+v"(res[9]),
                      "+v"(res[10]), "+v"(res[11]), "+v"(res[12]), "+v"(res[13]), "+v"(res[14]), "+v"(res[15]), "+v"(res[16]), "+v"(res[17]), "+v"(res[18]), "+v"(res[19]));

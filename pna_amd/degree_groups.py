@@ -126,15 +126,22 @@ class DegreePlan:
             self._fused = (desc, ids, total)
         return self._fused
 
-    def rest_items(self):
-        """(work list, heavy_out) of the rows no degree group holds, output rows counted from the start of the rest region: the
-        gather of the one-kernel layer's leftover rows (pna_fused_degree_f32 takes the group rows)."""
+    def rest_items(self, graph):
+        """(work list, heavy_out, heavy schedule) of the rows no degree group holds, output rows counted from the start of the rest
+        region: the gather of the one-kernel layer's leftover rows (pna_fused_degree_f32 takes the group rows).  The hub rows are
+        cut into REST_SEG_LEN-edge segments here (the graph's own schedule: 128): this launch has only a few thousand items, and
+        a lane group walks its segment four edges per memory round trip -- shorter segments, more of them in flight."""
         if self._rest_items is None:
-            it, n_seg = self.items, self._n_seg
-            light = it[n_seg:][it[n_seg:, 0] >= self.NV].clone()
+            hs = graph.heavy_schedule(seg_len=REST_SEG_LEN)
+            it = graph.work_items(seg_len=REST_SEG_LEN)
+            n_seg = hs.n_seg if hs.n_heavy > 0 else 0
+            rows = it[n_seg:].clone()
+            rows[:, 0] = self._vmap[rows[:, 0].long()].to(torch.int32)
+            light = rows[rows[:, 0] >= self.NV]
             light[:, 0] -= self.NV
             items = torch.cat([it[:n_seg], light], dim=0).contiguous() if n_seg else light.contiguous()
-            self._rest_items = (items, None if self.heavy_out is None else (self.heavy_out - self.NV).contiguous())
+            hout = (self._vmap[hs.heavy_rows.long()] - self.NV).to(torch.int32).contiguous() if hs.n_heavy > 0 else None
+            self._rest_items = (items, hout, hs)
         return self._rest_items
 
     def split_items(self, graph):
@@ -257,6 +264,8 @@ def fused_images(weight, F, row_scales, plan):
     return img, stride
 
 
+REST_SEG_LEN = 128         # edges per hub-row segment in the rest launch of the one-kernel layer (see DegreePlan.rest_items)
+REST_ROWS_PER_GROUP = 1    # work items per lane group in that launch (the full-graph gather: 4): a few thousand items must spread over 256 CUs
 FUSED = True               # gather + contraction in ONE kernel (pna_fused_degree_f32) where it applies; False: the two-kernel grouped path
 MAX_REST_FRACTION = 0.5    # more rest rows than this: the grouping is overhead, the ordinary path takes the graph
 

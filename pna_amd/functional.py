@@ -412,11 +412,12 @@ class FusedDegreeCall:
             from . import degree_groups as DG
             F = layer.in_dim
             K = len(layer.aggregators) * F
-            items, hout = plan.rest_items()
+            items, hout, hs = plan.rest_items(graph)
             agg = torch.empty(plan.NRp, DG.agg_pitch(K), dtype=torch.float32, device=self.y.device)[:, :K]
             csr = graph.csr
             ops.segreduce(csr.rowptr, csr.col, _unit_stride(self.x), F, layer.aggregators, (None,), tower_stride_in=F, out=agg,
-                          heavy=graph.heavy_schedule(), workspace=graph.workspace, items=items, heavy_out=hout, tune=dict(generic=2))
+                          heavy=hs, workspace=graph.workspace, items=items, heavy_out=hout,
+                          tune=dict(generic=2, rows_per_group=DG.REST_ROWS_PER_GROUP))
             _rest_posttrans(layer, graph, agg, plan, self.scales, self.y, self.cs, self.ct, self.res)
         return self.y
 

@@ -73,6 +73,15 @@ with torch.no_grad():
         DG.FUSED = True
         print(f"rep {rep}: fused group-rows kernel {t_f:.3f} ms, rest path {t_r:.3f} ms, layer one-kernel {t_layer_f:.3f} ms, layer two-kernel {t_layer_g:.3f} ms", flush=True)
         out[f"rep{rep}"] = {"fused_group_rows_ms": t_f, "rest_rows_ms": t_r, "layer_one_kernel_ms": t_layer_f, "layer_two_kernel_ms": t_layer_g}
+    for seg, rpg in [(128, 4), (128, 1), (64, 1), (32, 1), (32, 2), (16, 1)]:          # the rest launch: hub segment length x items per lane group
+        DG.REST_SEG_LEN, DG.REST_ROWS_PER_GROUP, plan._rest_items = seg, rpg, None
+        c2 = PF.FusedDegreeCall(layer, g, h)
+        c2.group_rows()
+        y2 = c2.rest_rows().clone()
+        d = (y2 - y_g).abs().max().item() / s
+        out[f"rest_seg{seg}_rpg{rpg}_ms"] = ev(c2.rest_rows)
+        print(f"rest launch, {seg}-edge hub segments, {rpg} items per lane group: {out[f'rest_seg{seg}_rpg{rpg}_ms']:.3f} ms (max diff vs two-kernel {d:.1e})", flush=True)
+    DG.REST_SEG_LEN, DG.REST_ROWS_PER_GROUP, plan._rest_items = 32, 1, None
     if "exp" in os.path.basename(_lib.LIB_PATH):
         import ctypes
         props = torch.cuda.get_device_properties(0)

@@ -5,7 +5,8 @@ hipcc treats the VGPR destination of an inline-asm load as written at `;;#ASMEND
 read, copy, spill or reuse the register while the data is still in flight.  This tool replays the device assembly of one kernel
 (`hipcc -S --cuda-device-only`) region by region: every inline-asm `global_load_*` enters a FIFO (VMEM returns in order), every
 `s_waitcnt vmcnt(N)` retires all but the N youngest entries, and any instruction -- compiler-generated or ours -- that reads or
-writes a register whose load is still in the FIFO is reported.  Compiler-issued VMEM operations (loads, stores, LDS copies) are
+writes a register whose load is still in the FIFO is reported.  Inline-asm `ds_read_*` and `s_load_*` results are tracked the
+same way on the LGKM counter (SGPRs included: hipcc spilled an in-flight scalar-load result once, see pna_fused_degree.hip).  Compiler-issued VMEM operations (loads, stores, LDS copies) are
 entered too: they occupy counter slots, which only ever makes a counted wait stricter, so they are retired like the others.
 
 The control-flow graph is explored exhaustively: both sides of every conditional branch, each (basic block, FIFO picture) state
@@ -18,16 +19,26 @@ import re
 import sys
 
 _REG = re.compile(r"\bv(\d+)\b|v\[(\d+):(\d+)\]")
+_SREG = re.compile(r"\bs(\d+)\b|s\[(\d+):(\d+)\]")
+
+
+def _regs(rx, text, base=0):
+    out = set()
+    for m in rx.finditer(text):
+        if m.group(1) is not None:
+            out.add(base + int(m.group(1)))
+        else:
+            out.update(range(base + int(m.group(2)), base + int(m.group(3)) + 1))
+    return out
 
 
 def vregs(text):
-    out = set()
-    for m in _REG.finditer(text):
-        if m.group(1) is not None:
-            out.add(int(m.group(1)))
-        else:
-            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
-    return out
+    return _regs(_REG, text)
+
+
+def allregs(text):
+    """VGPRs as 0.., SGPRs as 1000.. (one namespace for the in-flight sets)."""
+    return _regs(_REG, text) | _regs(_SREG, text, 1000)
 
 
 def kernel_lines(path, name):
@@ -76,18 +87,18 @@ def audit(lines, verbose=False):
     ins = parse(lines)
     labels = {name: k for k, (_, a, mn, name) in enumerate(ins) if mn == "label"}
     problems, seen_prob, visited = [], set(), set()
-    stack = [(0, ())]                # (pc, fifo); fifo entries: sorted tuple of dst regs (empty for ops without a tracked dst)
+    stack = [(0, (), ())]            # (pc, VMEM fifo, LGKM fifo); entries: sorted tuple of dst regs (empty for ops without a tracked dst)
     steps = 0
     while stack:
-        k, fifo = stack.pop()
-        fifo = list(fifo)
+        k, fifo, lgkm = stack.pop()
+        fifo, lgkm = list(fifo), list(lgkm)
         while k < len(ins):
             ln, in_asm, mn, ops = ins[k]
             steps += 1
             if steps > 20_000_000:
                 raise SystemExit("isa_audit: state explosion (more than 2e7 steps)")
             if mn == "label":
-                key = (k, tuple(fifo))
+                key = (k, tuple(fifo), tuple(lgkm))
                 if key in visited:
                     break
                 visited.add(key)
@@ -99,7 +110,7 @@ def audit(lines, verbose=False):
                 k = labels[ops.strip()]
                 continue
             if mn.startswith("s_cbranch"):
-                stack.append((labels[ops.strip()], tuple(fifo)))
+                stack.append((labels[ops.strip()], tuple(fifo), tuple(lgkm)))
                 k += 1
                 continue
             if mn == "s_waitcnt":
@@ -108,18 +119,33 @@ def audit(lines, verbose=False):
                     n = int(m.group(1))
                     if len(fifo) > n:
                         fifo = fifo[len(fifo) - n:] if n else []
-                k += 1
-                continue
-            if mn.startswith(("s_", ";")):
+                m = re.search(r"lgkmcnt\((\d+)\)", ops)
+                if m:                # LDS reads return in order; scalar loads do not: only lgkmcnt(0) retires those
+                    n = int(m.group(1))
+                    if n == 0:
+                        lgkm = []
+                    elif not any(r and r[0] >= 1000 for r in lgkm) and len(lgkm) > n:
+                        lgkm = lgkm[len(lgkm) - n:]
                 k += 1
                 continue
             inflight = set()
             for regs in fifo:
                 inflight.update(regs)
-            bad = vregs(ops) & inflight
+            for regs in lgkm:
+                inflight.update(regs)
+            if in_asm and mn.startswith("s_load"):
+                lgkm.append(tuple(sorted(_regs(_SREG, ops.split(",")[0], 1000))))
+                k += 1
+                continue
+            if mn.startswith(";"):
+                k += 1
+                continue
+            bad = allregs(ops) & inflight
             if bad and (ln, tuple(sorted(bad))) not in seen_prob:
                 seen_prob.add((ln, tuple(sorted(bad))))
                 problems.append((ln, mn, ops, sorted(bad)))
+            if in_asm and mn.startswith("ds_read"):
+                lgkm.append(tuple(sorted(vregs(ops.split(",")[0]))))
             if is_vmem(mn):
                 dst = ()
                 if in_asm and "_load" in mn and "lds" not in mn:             # compiler loads: hipcc waits for those itself

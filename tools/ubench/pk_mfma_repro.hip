@@ -83,14 +83,22 @@ __global__ __launch_bounds__(512, 2) void k_repro(const float* __restrict__ x, i
       }
     }
   }
-  unsigned nb = 0;
+  // bad[0..3]: differing bits in plain sums | plain sums of squares | swizzled sums | swizzled sums of squares; bad[4..]: one example
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int j0 = k < 2 ? 2 * k : 2 * k + 1, j1 = k < 2 ? 2 * k + 1 : 2 * k;      // swizzled pairs hold (value 2k+1, value 2k)
-    nb += (__builtin_bit_cast(unsigned, P[k][0]) != __builtin_bit_cast(unsigned, Sr[j0])) + (__builtin_bit_cast(unsigned, P[k][1]) != __builtin_bit_cast(unsigned, Sr[j1]));
-    nb += (__builtin_bit_cast(unsigned, PQ[k][0]) != __builtin_bit_cast(unsigned, Qr[j0])) + (__builtin_bit_cast(unsigned, PQ[k][1]) != __builtin_bit_cast(unsigned, Qr[j1]));
+    const unsigned ds = (__builtin_bit_cast(unsigned, P[k][0]) != __builtin_bit_cast(unsigned, Sr[j0])) + (__builtin_bit_cast(unsigned, P[k][1]) != __builtin_bit_cast(unsigned, Sr[j1]));
+    const unsigned dq = (__builtin_bit_cast(unsigned, PQ[k][0]) != __builtin_bit_cast(unsigned, Qr[j0])) + (__builtin_bit_cast(unsigned, PQ[k][1]) != __builtin_bit_cast(unsigned, Qr[j1]));
+    if (ds) atomicAdd(bad + (k < 2 ? 0 : 2), ds);
+    if (dq) atomicAdd(bad + (k < 2 ? 1 : 3), dq);
+    if ((ds || dq) && atomicAdd(bad + 4, 1u) == 0) {
+      bad[5] = blockIdx.x; bad[6] = threadIdx.x; bad[7] = k;
+      bad[8] = __builtin_bit_cast(unsigned, P[k][0]); bad[9] = __builtin_bit_cast(unsigned, P[k][1]);
+      bad[10] = __builtin_bit_cast(unsigned, Sr[j0]); bad[11] = __builtin_bit_cast(unsigned, Sr[j1]);
+      bad[12] = __builtin_bit_cast(unsigned, PQ[k][0]); bad[13] = __builtin_bit_cast(unsigned, PQ[k][1]);
+      bad[14] = __builtin_bit_cast(unsigned, Qr[j0]); bad[15] = __builtin_bit_cast(unsigned, Qr[j1]);
+    }
   }
-  if (nb) atomicAdd(bad, nb);
   sink[blockIdx.x * 512 + threadIdx.x] = P[0][0] + PQ[3][1];
 }
 
@@ -104,13 +112,13 @@ int main(int argc, char** argv) {
   unsigned* bad;
   hipMalloc(&x, (size_t)rows * 8 * 4);
   hipMalloc(&sink, (size_t)cus * 512 * 4);
-  hipMalloc(&bad, 4);
+  hipMalloc(&bad, 64);
   std::vector<float> hx((size_t)rows * 8);
   unsigned s = 12345;
   for (auto& v : hx) { s = s * 1664525u + 1013904223u; v = ((int)(s >> 8) - (1 << 23)) * (1.0f / (1 << 22)); }
   hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
   for (int mode = 0; mode < 3; ++mode) {
-    hipMemset(bad, 0, 4);
+    hipMemset(bad, 0, 64);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
@@ -119,11 +127,13 @@ int main(int argc, char** argv) {
     hipDeviceSynchronize();
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    unsigned hb = 0;
-    hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost);
-    printf("mode %d (%s): %d launches x %d CUs x %d iterations: %u differing sums, %.3f ms per launch\n", mode,
+    unsigned hb[16];
+    hipMemcpy(hb, bad, 64, hipMemcpyDeviceToHost);
+    printf("mode %d (%s): %d launches x %d CUs x %d iterations: differing sums plain %u / %u (s / q), swizzled %u / %u, %.3f ms per launch\n", mode,
            mode == 0 ? "MFMA wavefront + fold wavefront per SIMD" : mode == 1 ? "two fold wavefronts per SIMD" : "one fold wavefront per SIMD",
-           launches, cus, iters, hb, ms / launches);
+           launches, cus, iters, hb[0], hb[1], hb[2], hb[3], ms / launches);
+    if (hb[4]) printf("   first: block %u thread %u pair %u: packed s = %08x %08x, single s = %08x %08x; packed q = %08x %08x, single q = %08x %08x\n",
+                      hb[5], hb[6], hb[7], hb[8], hb[9], hb[10], hb[11], hb[12], hb[13], hb[14], hb[15]);
   }
   return 0;
 }
