@@ -456,7 +456,7 @@ int pna_fused_simple_f32(const pna_fused_simple_args* args, pna_stream_t stream)
  *                 the weight itself); W_D is formed in fp32 in scaler order, like the reference's blocks.
  * x: (x_rows, ldx) rows, 16-byte aligned, ldx % 4 == 0, ldx >= round_up(F, 8) (round_up(F, 4) when F % 32 is in 1..16),
  * x_rows < 2^24, table < 4 GiB; y and residual: n_nodes rows, each table < 4 GiB.
- * 17 <= F <= 80, 1 <= N <= 80.  relu: 0 none / 1 ReLU / 2 LeakyReLU(act_slope).  agg_out (nullable): (M, ld_agg) receives the
+ * 17 <= F <= 80, 4 <= N <= 80.  relu: 0 none / 1 ReLU / 2 LeakyReLU(act_slope).  agg_out (nullable): (M, ld_agg) receives the
  * statistics the contraction consumed, [mean | max | min | std] x F per virtual row (verification; a slower instantiation).
  * Rows of degrees too rare to fill a tile, and hub rows, are the caller's: pna_segreduce_fwd_f32 + pna_posttrans_x3_f32 over
  * their compact list.

@@ -45,6 +45,7 @@ using namespace pna_x3;
 using pna_dev::div_rn;
 
 typedef int i4 __attribute__((ext_vector_type(4)));
+typedef f4 f4a4 __attribute__((aligned(4)));
 
 struct FDArgs {
   const i4* tdesc;             // per 16-row wavefront tile: {first id record, in-degree, weight image, 0}
@@ -58,7 +59,8 @@ struct FDArgs {
   unsigned ldyb, ldrb;         // row pitch of y / residual in bytes (ldrb = 0 without a residual: every load reads y's first row)
   int F, M, N, relu;
   float slope;
-};
+  int abl;                     // experiments build only: parts skipped for timing (bit 0 MFMAs, 1 fragment maths after the first chunk,
+};                             // 2 the fold, 3 the y stores, 4 the B-fragment reads): results are then meaningless
 
 constexpr int kNW = 80, kNT = 5, kWaves = 4, kThreads = 64 * kWaves;
 constexpr int kNBuf = 5;                                  // LDS weight buffers: a chunk image is requested kNBuf - 1 steps before it is read
@@ -66,7 +68,7 @@ constexpr int kAhead = kNBuf - 1;
 constexpr int kChunkV = 3 * 4 * kNW;                      // 16-byte pieces of one chunk image: [term][lane group][80 cols][8 k] bf16
 constexpr int kNI = (kChunkV + kThreads - 1) / kThreads;  // global_load_lds instructions per wavefront per chunk
 constexpr int kRing = 4;                                  // edge packets in the register ring
-constexpr int kNRes = kNT * 4;                            // residual values per lane
+constexpr int kNRes = kNT;                                // residual loads per lane (16 bytes each: 4 consecutive columns of one row)
 
 // Feature blocks of a row: NFBF full blocks of 32 features (a lane owns 8: two 16-byte loads, four chunks -- one per aggregator)
 // and, when the remainder is <= 16 features, a HALF block (a lane owns 4: one load, two chunks -- (mean | max), (min | std)).
@@ -125,6 +127,11 @@ __device__ __forceinline__ void fold1(float& S, float& Q, float& MX, float& MN, 
   S = s1; Q = q1; MX = x1; MN = n1;
 }
 
+#ifdef PNA_AMD_EXPERIMENTS
+#define FD_ABL(bit) ((g.abl >> (bit)) & 1)
+#else
+#define FD_ABL(bit) 0
+#endif
 __device__ __forceinline__ unsigned long long now() {
 #ifdef PNA_AMD_EXPERIMENTS
   return __builtin_readcyclecounter();
@@ -182,8 +189,8 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
   td_n2 = td_nxt;
   const unsigned lib = (unsigned)li * 4u;
   int idr[kRing];
-  i4 pr;                                                  // the lane's four rows of y / residual (-1: padding)
-  float res[kNRes];
+  i4 pr;                                                  // rows of y / residual of the lane's four C rows 4 lg + r (-1: padding)
+  f4 res[kNRes];                                          // residual, TRANSPOSED layout: row 4 lg + (li & 3), columns 16 n + 4 (li >> 2) .. + 4
 
   // ---- the gather: running statistics of the wavefront's 16 rows ----------------------------------------------------------
   float S_[NB][8], Q_[NB][8], MX[NB][8], MN[NB][8];       // (a half block uses [0..3])
@@ -199,6 +206,14 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
   const unsigned ldb = g.ldb;
   const void* const resb = g.residual ? (const void*)g.residual : (const void*)g.y;
   const bool has_res = g.residual != nullptr;
+
+  // The epilogue works on a 4 x 4 TRANSPOSE of the accumulator tiles inside every quad of lanes: lane (li = 4 q + s, lg) then holds
+  // row 4 lg + s, columns 16 n + 4 q .. + 4 of column tile n -- 16 contiguous bytes: the residual is 5 loads and y 5 stores of 16
+  // bytes per lane instead of 20 + 20 of 4 bytes (round 3, first version: per-element; skipping its stores took 0.10 of 0.84 ms).
+  const int sq = li & 3, qq = li >> 2;
+  auto prow = [&]() __attribute__((always_inline)) -> int { return sq == 0 ? pr[0] : sq == 1 ? pr[1] : sq == 2 ? pr[2] : pr[3]; };
+  // byte offset of the 16-byte window of column tile n inside a row; a window past N slides back to [N - 4, N) (realigned by fix4)
+  auto res_col = [&](int n) __attribute__((always_inline)) -> unsigned { return (unsigned)max(0, min(n * 16 + 4 * qq, g.N - 4)) * 4u; };
 
   auto gather = [&](int t) __attribute__((always_inline)) {
     const int D = td_cur.y;
@@ -226,6 +241,7 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     };
     auto fold = [&](auto jc, bool on) __attribute__((always_inline)) {
       constexpr int j = decltype(jc)::value;
+      if (FD_ABL(2)) { asm volatile("" : "+v"(sl[j][0])); return; }
 #pragma unroll
       for (int l = 0; l < NL; ++l)
 #pragma unroll
@@ -257,12 +273,9 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     fold(J0{}, e0 < D);
     constexpr int NR = RESPF ? kNRes : 0;
     if constexpr (RESPF) {
+      const unsigned rrow = (unsigned)max(prow(), 0) * g.ldrb;
 #pragma unroll
-      for (int n = 0; n < kNT; ++n) {
-        const unsigned cc = (unsigned)min(n * 16 + li, g.N - 1) * 4u;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ld4f(res[n * 4 + r], resb, (unsigned)max(pr[r], 0) * g.ldrb + cc);
-      }
+      for (int n = 0; n < kNT; ++n) ld16(res[n], resb, rrow + res_col(n));
     }
     wait_slot<2 * LB + NR, NL>(sl[1], idr[1]); fold(J1{}, e0 + 1 < D);
     wait_slot<1 * LB + NR, NL>(sl[2], idr[2]); fold(J2{}, e0 + 2 < D);
@@ -293,6 +306,7 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
   };
   auto frag = [&](auto c_c) __attribute__((always_inline)) {
     constexpr int c = decltype(c_c)::value;
+    if (c > 0 && FD_ABL(1)) { asm volatile("" : "+v"(A[0])); return; }
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -326,31 +340,53 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(cb[0]), "+v"(cb[1]), "+v"(cb[2]), "+v"(cb[3]), "+v"(cb[4]), "+v"(cs[0]), "+v"(cs[1]), "+v"(cs[2]), "+v"(cs[3]), "+v"(cs[4]),
                    "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]), "+v"(ct[4]) : : "memory");
+    const int row = prow();
     if constexpr (!RESPF) {
-      const char* rbase = reinterpret_cast<const char*>(resb);
+      const char* rbase = reinterpret_cast<const char*>(resb) + (size_t)((unsigned)max(row, 0) * g.ldrb);
 #pragma unroll
-      for (int n = 0; n < kNT; ++n) {
-        const unsigned cc = (unsigned)min(n * 16 + li, g.N - 1) * 4u;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) res[n * 4 + r] = *reinterpret_cast<const float*>(rbase + (size_t)((unsigned)max(pr[r], 0) * g.ldrb + cc));
-      }
+      for (int n = 0; n < kNT; ++n) res[n] = reinterpret_cast<const f4u*>(rbase + res_col(n))->v;
     }
-    char* const ybase = reinterpret_cast<char*>(g.y);
+    char* const yrow = reinterpret_cast<char*>(g.y) + (size_t)(unsigned)max(row, 0) * g.ldyb;
+    const bool odd = (sq & 1) != 0, upper = (sq & 2) != 0;
 #pragma unroll
     for (int n = 0; n < kNT; ++n) {
-      const int cl = n * 16 + li;
-      float v[4];
+      float x[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float x = acc[n][r] + cb[n];
-        x = __builtin_fmaf(x, cs[n], ct[n]);
-        x = x < lo ? (leaky ? x * g.slope : 0.f) : x;    // ReLU / LeakyReLU / none (lo = -inf); NaN < lo is false: NaN is kept
-        v[r] = has_res ? res[n * 4 + r] + x : x;
+        float v = acc[n][r] + cb[n];
+        v = __builtin_fmaf(v, cs[n], ct[n]);
+        x[r] = v < lo ? (leaky ? v * g.slope : 0.f) : v;  // ReLU / LeakyReLU / none (lo = -inf); NaN < lo is false: NaN is kept
       }
-      if (cl < g.N) {
+      // 4 x 4 transpose inside the quad: two butterfly stages (lane ^ 1, lane ^ 2), one DPP move + one select per element each
+      float y1[4], z[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (pr[r] >= 0) *reinterpret_cast<float*>(ybase + (size_t)(unsigned)pr[r] * g.ldyb + (unsigned)cl * 4u) = v[r];
+      for (int r = 0; r < 4; ++r) {
+        const float tq = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x[r ^ 1]), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+        y1[r] = (odd != ((r & 1) != 0)) ? tq : x[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float tq = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, y1[r ^ 2]), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+        z[r] = (upper != ((r & 2) != 0)) ? tq : y1[r];
+      }
+      // z[j] = column 16 n + 4 q + j of row 4 lg + s
+      const int c0 = n * 16 + 4 * qq;
+      if (has_res) {
+        const f4 rr = fix4(c0, g.N, res[n]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z[j] = rr[j] + z[j];
+      }
+      if (row >= 0 && c0 < g.N && !FD_ABL(3)) {
+        float* const o = reinterpret_cast<float*>(yrow + (unsigned)c0 * 4u);
+        if (c0 + 4 <= g.N) {
+          f4u w; w.v = (f4){z[0], z[1], z[2], z[3]};
+          if (FD_ABL(5)) __builtin_nontemporal_store(w.v, reinterpret_cast<f4a4*>(o));
+          else *reinterpret_cast<f4u*>(o) = w;
+        } else {                                          // the row's last, partial window
+          o[0] = z[0];
+          if (c0 + 1 < g.N) o[1] = z[1];
+          if (c0 + 2 < g.N) o[2] = z[2];
+        }
       }
     }
   };
@@ -405,15 +441,16 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
 #define FD_WAIT_B()                                                                                                                         \
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(B[0][0]), "+v"(B[0][1]), "+v"(B[0][2]), "+v"(B[1][0]), "+v"(B[1][1]), "+v"(B[1][2]) : : "memory"); FD_FENCE()
     static_assert(kNT == 5, "the pairing below is written for five column tiles");
-    FD_READ_B(0, 0); FD_READ_B(1, 1);
+    if (!FD_ABL(4)) { FD_READ_B(0, 0); FD_READ_B(1, 1); }
     FD_WAIT_B();
+    if (!FD_ABL(0))
 #pragma unroll
     for (int pp = 0; pp < 6; ++pp) {
       acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[0][TB[pp]], acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[1][TB[pp]], acc[1], 0, 0, 0);
     }
     FD_FENCE();
-    FD_READ_B(0, 2); FD_READ_B(1, 3);
+    if (!FD_ABL(4)) { FD_READ_B(0, 2); FD_READ_B(1, 3); }
     FD_WAIT_B();
     // (the images of a tile's first kAhead - 1 steps were requested before its gather, whose waits retired them; waiting here
     // would only wait for the residual rows requested at the end of the gather -- a full memory round trip per tile)
@@ -421,14 +458,16 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     else asm volatile("s_barrier" ::: "memory");
     if (c + kAhead < NC) stage(c + kAhead, buf2, ib_cur);
     else stage(c + kAhead - NC, buf2, ib_next);
+    if (!FD_ABL(0))
 #pragma unroll
     for (int pp = 0; pp < 6; ++pp) {
       acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[0][TB[pp]], acc[2], 0, 0, 0);
       acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[1][TB[pp]], acc[3], 0, 0, 0);
     }
     FD_FENCE();
-    FD_READ_B(0, 4);
+    if (!FD_ABL(4)) { FD_READ_B(0, 4); }
     FD_WAIT_B();
+    if (!FD_ABL(0))
 #pragma unroll
     for (int pp = 0; pp < 6; ++pp) acc[4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[0][TB[pp]], acc[4], 0, 0, 0);
     FD_FENCE();
@@ -449,16 +488,20 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
   };
   while (true) {
     const unsigned long long t0 = now();
+    // The multiplying wavefront goes ahead of the gathering one on its SIMD (the other workgroup's): its phase is issue-bound
+    // (~2500 instructions per tile at one per ~4 cycles) and while it lasts none of its loads are in flight, whereas the gathering
+    // wavefront mostly waits for memory and its fold hides behind that (skipping the fold entirely changes nothing).  Measured in
+    // the experiments build on the C3 layer: 0.873 -> 0.790 ms.
+    if (!FD_ABL(6)) __builtin_amdgcn_s_setprio(1);
     steps4(std::integral_constant<int, 0>{});
     if constexpr (NC > 4) steps4(std::integral_constant<int, ((NC > 4) ? 4 : 0)>{});
     if constexpr (NC > 8) steps4(std::integral_constant<int, ((NC > 8) ? 8 : 0)>{});
     // the residual rows landed by the last step's counted wait (they are older than all but the first copies of the tile, and
     // every shape has at least 4 steps); from here on the compiler may read them
-    if constexpr (RESPF)
-      asm volatile("" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]), "+v"(res[5]), "+v"(res[6]), "+v"(res[7]), "+v"(res[8]), "+v"(res[9]),
-                     "+v"(res[10]), "+v"(res[11]), "+v"(res[12]), "+v"(res[13]), "+v"(res[14]), "+v"(res[15]), "+v"(res[16]), "+v"(res[17]), "+v"(res[18]), "+v"(res[19]));
+    if constexpr (RESPF) asm volatile("" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]));
     const unsigned long long t1 = now();
     epilogue();
+    if (!FD_ABL(6)) __builtin_amdgcn_s_setprio(0);
     const unsigned long long t2 = now();
     tm += t1 - t0; te += t2 - t1;
     t += G;
@@ -527,7 +570,7 @@ int launch_shape(const FDArgs& g, int wgs, hipStream_t st) {
 }  // namespace
 
 extern "C" int64_t pna_fused_degree_image_bytes(int32_t F, int32_t N) {
-  if (F < 17 || F > 80 || N < 1 || N > kNW) return 0;   // (81..96 would need three full blocks: 96 running statistics + a 96-register ring do not fit 256 registers)
+  if (F < 17 || F > 80 || N < 4 || N > kNW) return 0;   // (81..96 would need three full blocks: 96 running statistics + a 96-register ring do not fit 256 registers)
   return (int64_t)shape_chunks(F) * kChunkV * 16;
 }
 
@@ -535,7 +578,7 @@ extern "C" int pna_fused_degree_pack_f32(const float* w_ref, int64_t ldw, int32_
                                          int32_t n_img, void* img, pna_stream_t stream) {
   if (!w_ref || !img || n_img < 1 || n_scaler < 1 || n_scaler > PNA_MAX_SCALER || pna_fused_degree_image_bytes(F, N) == 0 ||
       ldw < (int64_t)n_scaler * 4 * F || (n_scaler > 1 && !scale))
-    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_pack_f32: bad arguments (17 <= F <= 80, 1 <= N <= 80, scale required for n_scaler > 1)");
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_pack_f32: bad arguments (17 <= F <= 80, 4 <= N <= 80, scale required for n_scaler > 1)");
   const int64_t elems = pna_fused_degree_image_bytes(F, N) / 2 * n_img;
   const int blocks = (int)((elems + 255) / 256 > 8192 ? 8192 : (elems + 255) / 256);
   hipLaunchKernelGGL(k_pack_fused_degree, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ref, (long)ldw, N, F, n_scaler, scale, n_img,
@@ -551,7 +594,7 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
   if (!p->tile_desc || !p->tile_ids || !p->x || !p->row_perm || !p->w_img || !p->y)
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: tile_desc / tile_ids / x / row_perm / w_img / y must be non-null");
   if (pna_fused_degree_image_bytes(p->F, p->N) == 0)
-    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: 17 <= F <= 80 and 1 <= N <= 80");
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: 17 <= F <= 80 and 4 <= N <= 80");
   const int need = shape_half(p->F) ? (p->F + 3) / 4 * 4 : (p->F + 7) / 8 * 8;
   if (p->ldx < need || p->ldx % 4 != 0 || ((uintptr_t)p->x & 15) != 0)
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: x must be 16-byte aligned with a row pitch that is a multiple of 4 floats and covers the last strip (round_up(F, 8); round_up(F, 4) when F % 32 is in 1..16)");
@@ -581,6 +624,7 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
   g.agg_out = p->agg_out; g.ld_agg = p->ld_agg;
 #ifdef PNA_AMD_EXPERIMENTS
   if (const char* e = getenv("PNA_FD_DBG_PTR")) g.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // device buffer: 4 counters per wavefront
+  if (const char* e = getenv("PNA_FD_ABL")) g.abl = atoi(e);
 #endif
   const int ntiles = (int)(p->M / (kWaves * 16));
   int per_cu = 2;

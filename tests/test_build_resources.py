@@ -17,7 +17,10 @@ CSRC = os.path.join(ROOT, "pna_amd", "csrc")
 #  three-block grouped kernel runs 12 wavefronts per CU: 168)
 @pytest.mark.parametrize("src,max_vgpr", [("pna_posttrans_x3.hip", {"k_posttrans_x3": 256, "k_posttrans_x3ILi1ELb0ELi80ELi5ELi1ELi8ELi3ELb0ELb1EEE": 128,
                                                                     "k_posttrans_x3ILi3ELb0ELi80ELi5ELi1ELi12ELi3ELb0ELb1EEE": 168}), ("pna_posttrans_x3w.hip", {"k_posttrans_x3w": 256}), ("pna_segreduce.hip", {"k_segreduce_fastILi4E": 80}),
-                                          ("pna_posttrans.hip", {}), ("pna_pack.hip", {})])
+                                          ("pna_posttrans.hip", {}), ("pna_pack.hip", {}),
+                                          # the one-kernel layer: two 4-wavefront workgroups per CU (the production instantiations: DUMP = false)
+                                          ("pna_fused_degree.hip", {"k_fused_degreeILi1ELb0ELb0E": 256, "k_fused_degreeILi1ELb1ELb0E": 256,
+                                                                    "k_fused_degreeILi2ELb0ELb0E": 256, "k_fused_degreeILi2ELb1ELb0E": 256})])
 def test_no_kernel_uses_scratch(src, max_vgpr, tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -40,3 +43,24 @@ def test_no_kernel_uses_scratch(src, max_vgpr, tmp_path):
     for key, lim in max_vgpr.items():
         over = [(n, v) for n, v in zip(names, vgprs) if key in n and v > lim]
         assert not over, over[:5]
+
+
+def test_one_kernel_layer_never_touches_a_register_in_flight(tmp_path):
+    """pna_fused_degree.hip issues every gather load through inline asm and waits for it with counted s_waitcnt: hipcc neither
+    counts those loads nor knows that their destination registers are not valid yet.  tools/isa_audit.py replays the compiled
+    kernel's control-flow graph and reports any instruction -- compiler-generated or ours -- that reads or writes a register whose
+    load (VMEM, LDS or scalar) is still in flight.  All instantiations, production and verification."""
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_audit
+    out = str(tmp_path / "fd.s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+                    "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "pna_fused_degree.hip")], check=True, capture_output=True)
+    names = sorted(set(re.findall(r"^(_ZN\S*k_fused_degreeI\S+?):", open(out).read(), flags=re.M)))
+    assert len(names) == 8, names
+    for n in names:
+        probs = isa_audit.audit(isa_audit.kernel_lines(out, n))
+        assert not probs, (n, probs[:5])

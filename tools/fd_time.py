@@ -98,7 +98,14 @@ with torch.no_grad():
                                "multiply_frac": (d[:, 1] / d[:, 3]).mean().item(), "epilogue_frac": (d[:, 2] / d[:, 3]).mean().item(),
                                "total_cycles_min": d[:, 3].min().item(), "total_cycles_max": d[:, 3].max().item()}
         print("phase timers:", json.dumps(out["phase_timers"]), flush=True)
-        for wgs in (1, 2, 3):
+        for abl, what in [(0, "nothing skipped"), (1, "no MFMAs"), (2, "fragment maths only for the first chunk of a tile"), (3, "no MFMAs, no fragment maths"),
+                          (4, "no fold (loads still issued and waited for)"), (8, "no y stores"), (32, "non-temporal y stores"), (64, "NO s_setprio 1 through the multiply phase and epilogue"), (0, "nothing skipped (again)"), (16, "no B-fragment reads"), (19, "no MFMA / fragment maths / B reads"),
+                          (31, "everything skipped: loads, waits, barriers, weight copies, epilogue arithmetic")]:
+            os.environ["PNA_FD_ABL"] = str(abl)
+            out[f"ablation_{abl}_ms"] = ev(call.group_rows)
+            print(f"ablation {abl:2d} ({what}): {out[f'ablation_{abl}_ms']:.3f} ms", flush=True)
+        del os.environ["PNA_FD_ABL"]
+        for wgs in (1, 2):
             os.environ["PNA_FD_WGS"] = str(wgs)
             try:
                 out[f"wgs_per_cu_{wgs}_ms"] = ev(call.group_rows)
