@@ -440,11 +440,11 @@ def simple_layer_degree_grouped(layer, graph, h):
     over a compacted list."""
     from . import degree_groups as DG
     plan = DG.plan_of(graph)
-    if DG.FUSED and 17 <= layer.in_dim <= 80 and layer.out_dim <= 80:
-        x = graph.source_features(h)                       # (a sharded graph finishes its halo exchange here: no overlap on this path)
-        if DG.fused_applies(graph, x, layer.in_dim, layer.out_dim):
-            return simple_layer_degree_fused(layer, graph, h, x=x)
-        return degree_grouped_posttrans(layer, graph, h, degree_grouped_aggregate(layer, graph, h, plan, x=x), plan)
+    from .graph import Graph
+    # the one-kernel path takes whole graphs; a shard (HaloGraph) keeps the two-kernel path, whose gather is cut into the rows that
+    # read only local sources -- aggregated while the halo exchange is in flight -- and the rest
+    if type(graph) is Graph and DG.fused_applies(graph, h, layer.in_dim, layer.out_dim):
+        return simple_layer_degree_fused(layer, graph, h, x=h)
     return degree_grouped_posttrans(layer, graph, h, degree_grouped_aggregate(layer, graph, h, plan), plan)
 
 

@@ -182,7 +182,9 @@ def test_grouped_layer_is_deterministic_at_full_size(cuda_device):
 
 
 def test_grouped_path_on_a_graph_without_any_group(cuda_device):
-    """No degree value fills a tile: the plan is all rest rows (the three-block grouped kernel over the whole graph)."""
+    """No degree value fills a tile: the grouping would be pure overhead (every row in the rest list), so the layer takes the
+    ordinary path; the plan itself is still well-formed -- all rest rows -- and its two-kernel path still computes the
+    layer when called directly."""
     from pna_amd import Graph, degree_groups as DG
     from pna_amd.synth import powerlaw_graph
     V, E, F = 700, 7000, 75
@@ -196,8 +198,9 @@ def test_grouped_path_on_a_graph_without_any_group(cuda_device):
     try:
         with torch.no_grad():
             DG.ENABLED, DG.MIN_ROWS = True, 1
-            assert layer._degree_grouped_path(g, h) and DG.plan_of(g).G == 0
-            y_grouped = layer(g, h)
+            plan = DG.plan_of(g)
+            assert plan.G == 0 and plan.NR == V and not layer._degree_grouped_path(g, h)
+            y_grouped = PF.degree_grouped_posttrans(layer, g, h, PF.degree_grouped_aggregate(layer, g, h, plan), plan)
             DG.ENABLED = False
             y_plain = layer(g, h)
     finally:

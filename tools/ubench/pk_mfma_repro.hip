@@ -15,7 +15,7 @@
 #include <vector>
 
 typedef float f4 __attribute__((ext_vector_type(4)));
-typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long u64;                       // a 64-bit VGPR pair: (lo, hi) floats of a packed operand
 typedef short bf8 __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(512, 2) void k_repro(const float* __restrict__ x, int rows, int iters, int mode, float* sink, unsigned* bad) {
@@ -38,10 +38,14 @@ __global__ __launch_bounds__(512, 2) void k_repro(const float* __restrict__ x, i
   }
   // packed accumulators: pair k = values (2k, 2k+1); pairs 0,1 folded with plain packed ops, pairs 2,3 with the op_sel swizzles
   // hipcc emitted in the failing kernel (lo += hi-half of the operand, hi += lo-half) behind a v_pk_mov_b32 swap
-  f2 P[4], PQ[4];
+  // (the packed operands are u64, not float2: with ext-vector asm outputs in an array hipcc read element 0 for BOTH halves after
+  //  the loop -- the first version of this file reported hi == lo for every sum, a property of that build, not of the hardware)
+  u64 P[4], PQ[4];
   float Sr[8], Qr[8];
+  auto pack = [](float lo, float hi) -> u64 { return (u64)__builtin_bit_cast(unsigned, lo) | ((u64)__builtin_bit_cast(unsigned, hi) << 32); };
+  auto half = [](u64 v, int h) -> unsigned { return (unsigned)(v >> (32 * h)); };
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { P[k] = (f2){0.f, 0.f}; PQ[k] = (f2){0.f, 0.f}; }
+  for (int k = 0; k < 4; ++k) { P[k] = 0; PQ[k] = 0; }
 #pragma unroll
   for (int j = 0; j < 8; ++j) Sr[j] = Qr[j] = 0.f;
   unsigned row = (blockIdx.x * 8 + wave) * 64 + lane;
@@ -58,14 +62,14 @@ __global__ __launch_bounds__(512, 2) void k_repro(const float* __restrict__ x, i
     for (int u = 0; u < 2; ++u) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const f2 m = (f2){v[u][k >> 1][2 * (k & 1)], v[u][k >> 1][2 * (k & 1) + 1]};
-        f2 t;
+        const u64 m = pack(v[u][k >> 1][2 * (k & 1)], v[u][k >> 1][2 * (k & 1) + 1]);
+        u64 t;
         if (k < 2) {
           asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(P[k]) : "v"(P[k]), "v"(m));
           asm volatile("v_pk_mul_f32 %0, %1, %1" : "=v"(t) : "v"(m));
           asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(PQ[k]) : "v"(PQ[k]), "v"(t));
         } else {
-          f2 sw;
+          u64 sw;
           asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(P[k]) : "v"(P[k]), "v"(m));       // lo += m.hi, hi += m.lo
           asm volatile("v_pk_mov_b32 %0, %1, %1 op_sel:[1,0]" : "=v"(sw) : "v"(m));                                      // (m.hi, m.lo)
           asm volatile("v_pk_mul_f32 %0, %1, %1" : "=v"(t) : "v"(sw));
@@ -87,19 +91,19 @@ __global__ __launch_bounds__(512, 2) void k_repro(const float* __restrict__ x, i
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int j0 = k < 2 ? 2 * k : 2 * k + 1, j1 = k < 2 ? 2 * k + 1 : 2 * k;      // swizzled pairs hold (value 2k+1, value 2k)
-    const unsigned ds = (__builtin_bit_cast(unsigned, P[k][0]) != __builtin_bit_cast(unsigned, Sr[j0])) + (__builtin_bit_cast(unsigned, P[k][1]) != __builtin_bit_cast(unsigned, Sr[j1]));
-    const unsigned dq = (__builtin_bit_cast(unsigned, PQ[k][0]) != __builtin_bit_cast(unsigned, Qr[j0])) + (__builtin_bit_cast(unsigned, PQ[k][1]) != __builtin_bit_cast(unsigned, Qr[j1]));
+    const unsigned ds = (half(P[k], 0) != __builtin_bit_cast(unsigned, Sr[j0])) + (half(P[k], 1) != __builtin_bit_cast(unsigned, Sr[j1]));
+    const unsigned dq = (half(PQ[k], 0) != __builtin_bit_cast(unsigned, Qr[j0])) + (half(PQ[k], 1) != __builtin_bit_cast(unsigned, Qr[j1]));
     if (ds) atomicAdd(bad + (k < 2 ? 0 : 2), ds);
     if (dq) atomicAdd(bad + (k < 2 ? 1 : 3), dq);
     if ((ds || dq) && atomicAdd(bad + 4, 1u) == 0) {
       bad[5] = blockIdx.x; bad[6] = threadIdx.x; bad[7] = k;
-      bad[8] = __builtin_bit_cast(unsigned, P[k][0]); bad[9] = __builtin_bit_cast(unsigned, P[k][1]);
+      bad[8] = half(P[k], 0); bad[9] = half(P[k], 1);
       bad[10] = __builtin_bit_cast(unsigned, Sr[j0]); bad[11] = __builtin_bit_cast(unsigned, Sr[j1]);
-      bad[12] = __builtin_bit_cast(unsigned, PQ[k][0]); bad[13] = __builtin_bit_cast(unsigned, PQ[k][1]);
+      bad[12] = half(PQ[k], 0); bad[13] = half(PQ[k], 1);
       bad[14] = __builtin_bit_cast(unsigned, Qr[j0]); bad[15] = __builtin_bit_cast(unsigned, Qr[j1]);
     }
   }
-  sink[blockIdx.x * 512 + threadIdx.x] = P[0][0] + PQ[3][1];
+  sink[blockIdx.x * 512 + threadIdx.x] = __builtin_bit_cast(float, half(P[0], 0)) + __builtin_bit_cast(float, half(PQ[3], 1));
 }
 
 int main(int argc, char** argv) {
@@ -132,8 +136,21 @@ int main(int argc, char** argv) {
     printf("mode %d (%s): %d launches x %d CUs x %d iterations: differing sums plain %u / %u (s / q), swizzled %u / %u, %.3f ms per launch\n", mode,
            mode == 0 ? "MFMA wavefront + fold wavefront per SIMD" : mode == 1 ? "two fold wavefronts per SIMD" : "one fold wavefront per SIMD",
            launches, cus, iters, hb[0], hb[1], hb[2], hb[3], ms / launches);
-    if (hb[4]) printf("   first: block %u thread %u pair %u: packed s = %08x %08x, single s = %08x %08x; packed q = %08x %08x, single q = %08x %08x\n",
-                      hb[5], hb[6], hb[7], hb[8], hb[9], hb[10], hb[11], hb[12], hb[13], hb[14], hb[15]);
+    if (hb[4]) {
+      printf("   first: block %u thread %u pair %u: packed s = %08x %08x, single s = %08x %08x; packed q = %08x %08x, single q = %08x %08x\n",
+             hb[5], hb[6], hb[7], hb[8], hb[9], hb[10], hb[11], hb[12], hb[13], hb[14], hb[15]);
+      if (iters <= 2) {                                   // the host's own sums for that lane (two rows)
+        unsigned row = (hb[5] * 8 + (hb[6] >> 6)) * 64 + (hb[6] & 63);
+        float e0 = 0, e1 = 0;
+        for (int u = 0; u < 2; ++u) {
+          row = row * 1664525u + 1013904223u;
+          const float* pr = hx.data() + (size_t)(row % (unsigned)rows) * 8 + 2 * hb[7];
+          e0 += pr[0]; e1 += pr[1];
+        }
+        union { float f; unsigned u; } a, b; a.f = e0; b.f = e1;
+        printf("   host: sum of element 2k = %08x, of element 2k+1 = %08x\n", a.u, b.u);
+      }
+    }
   }
   return 0;
 }
