@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define PNA_ABI_VERSION 10 /* 10: + pna_fused_degree_{image_bytes,pack_f32,f32} (gather + degree-grouped contraction in one kernel).
+#define PNA_ABI_VERSION 11 /* 11: - pna_posttrans_x3w_* (ABI 8's contraction on 32x32 tiles: parity-green, 5 % slower than the 16x16 kernel on every
+                                  shape measured, never selected -- removed, round 3).
+                              10: + pna_fused_degree_{image_bytes,pack_f32,f32} (gather + degree-grouped contraction in one kernel).
                               9: pna_posttrans_args.row_perm / tile_image / image_stride (degree-grouped contraction),
                                 pna_segreduce_args.heavy_out_rows.
                              8: + pna_posttrans_x3w_* (the bf16x3 contraction on 32x32 matrix-core tiles).
@@ -374,27 +376,6 @@ int64_t pna_posttrans_x3_packed_bytes(int32_t K, int32_t N, int32_t n_scaler, in
 int pna_posttrans_x3_pack_f32(const float* w_ref, int64_t ldw_ref, int32_t N, int32_t K, int32_t n_scaler, int32_t Kh,
                               void* w_img, void* wh_img /* nullable when Kh == 0 */, pna_stream_t stream);
 int pna_posttrans_x3_f32(const pna_posttrans_args* args, pna_stream_t stream);
-
-/* ---- the bf16x3 contraction on 32x32 matrix-core tiles ("wide" form, ABI 8) -------------------------
- *
- * Same operation, arguments, epilogue, arithmetic (three exact bf16 terms per operand, six partial products, fp32
- * accumulation) and non-finite rules as pna_posttrans_x3_f32, for the shapes pna_posttrans_x3w_supported accepts:
- * no h panel (Kh = 0: models/dgl/pna_layer.py:206, the PNASimpleLayer posttrans), n_tower <= 1, 3 scalers, and
- * 64 <= N <= 80 or N a multiple of 64.  It uses v_mfma_f32_32x32x16_bf16 with the (scaler, output column) pairs of
- * the weight packed side by side into 32-column tiles (3 x 75 columns = 7 tiles + one column evaluated on the VALU),
- * K advanced 16 at a time, and a tail that goes through LDS so that every global access of the epilogue is a
- * coalesced 16-byte one (when y / residual rows are 16-byte aligned; any alignment is accepted).  Results agree with
- * pna_posttrans_x3_f32 to fp32 summation-order noise (the k order and the order in which the scaler blocks of a
- * column are combined differ); they are deterministic (no order-dependent atomics).
- * w_img is the image made by pna_posttrans_x3w_pack_f32 (pna_posttrans_x3w_packed_bytes bytes) from the reference
- * nn.Linear weight (N, n_scaler*K) -- a different format from the other two kernels'.  args->h must be NULL and
- * args->pipeline is ignored.
- */
-int pna_posttrans_x3w_supported(int32_t K, int32_t N, int32_t n_scaler, int32_t Kh);   /* 1 = the wide kernel serves the shape */
-int64_t pna_posttrans_x3w_packed_bytes(int32_t K, int32_t N, int32_t n_scaler);
-int pna_posttrans_x3w_pack_f32(const float* w_ref, int64_t ldw_ref, int32_t N, int32_t K, int32_t n_scaler, void* w_img,
-                               pna_stream_t stream);
-int pna_posttrans_x3w_f32(const pna_posttrans_args* args, pna_stream_t stream);
 
 /* ---- fused PNASimpleLayer forward (inference) -----------------------------------------------------
  *

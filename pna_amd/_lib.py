@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to the HI
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpna_amd.so")
 
-PNA_ABI_VERSION = 10
+PNA_ABI_VERSION = 11
 PNA_MAX_AGGR = 8
 PNA_MAX_SCALER = 8
 
@@ -175,15 +175,6 @@ def lib():
                                                 ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
                                                 ctypes.c_void_p]
         L.pna_posttrans_x3_pack_f32.restype = ctypes.c_int
-        L.pna_posttrans_x3w_supported.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
-        L.pna_posttrans_x3w_supported.restype = ctypes.c_int
-        L.pna_posttrans_x3w_packed_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
-        L.pna_posttrans_x3w_packed_bytes.restype = ctypes.c_int64
-        L.pna_posttrans_x3w_pack_f32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
-                                                 ctypes.c_void_p, ctypes.c_void_p]
-        L.pna_posttrans_x3w_pack_f32.restype = ctypes.c_int
-        L.pna_posttrans_x3w_f32.argtypes = [ctypes.POINTER(PnaPosttransArgs), ctypes.c_void_p]
-        L.pna_posttrans_x3w_f32.restype = ctypes.c_int
         L.pna_collate_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32]
         L.pna_collate_workspace_bytes.restype = ctypes.c_int64
         L.pna_collate_csr_i32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p,

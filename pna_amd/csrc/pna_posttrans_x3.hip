@@ -33,6 +33,7 @@
 
 #include "pna_amd.h"
 #include "pna_internal.h"
+#include "pna_x3_split.h"
 
 #ifndef X3_GRP_NBUF
 #define X3_GRP_NBUF 3      // weight buffers of the one-block grouped kernel (development: 4 = fragments and images 3 steps ahead; measured equal)
@@ -40,10 +41,7 @@
 
 namespace {
 
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef short bf8 __attribute__((ext_vector_type(8)));       // 8 bf16 = one MFMA A/B fragment
-typedef unsigned u4 __attribute__((ext_vector_type(4)));
-struct __attribute__((packed, aligned(4))) f4u { f4 v; };
+using namespace pna_x3;       // f4 / bf8 / u4 / f4u, split8 / split8_inf / absmax8 / top16 / pack_hi: the exact fp32 -> 3 x bf16 split (pna_x3_split.h)
 
 constexpr int kKC = 32;                       // k values per chunk
 constexpr int kDefaultNBuf = 3;              // weight buffers of the default pipeline (pna_posttrans_args.pipeline = 0)
@@ -66,59 +64,6 @@ struct XArgs {
   // perm[virtual row] = row of y / residual (or -1: padding, nothing stored); tile t multiplies by weight image tile_image[t]
   const int* perm; const int* tile_image; long img_stride;
 };
-
-__device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(unsigned, x); }
-__device__ __forceinline__ float bfloat(unsigned u) { return __builtin_bit_cast(float, u); }
-__device__ __forceinline__ float top16(float x) { return bfloat(fbits(x) & 0xFFFF0000u); }
-// upper halves of (even, odd) -> one dword {odd.hi16, even.hi16}
-__device__ __forceinline__ unsigned pack_hi(float even, float odd) { return __builtin_amdgcn_perm(fbits(odd), fbits(even), 0x07060302u); }
-
-// 8 floats -> the three bf16 fragments
-__device__ __forceinline__ void split8(const f4 lo, const f4 hi, bf8& t0, bf8& t1, bf8& t2) {
-  const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-  u4 p0, p1, p2;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float xe = x[2 * j], xo = x[2 * j + 1];
-    const float re = xe - top16(xe), ro = xo - top16(xo);
-    const float se = re - top16(re), so = ro - top16(ro);
-    p0[j] = pack_hi(xe, xo);
-    p1[j] = pack_hi(re, ro);
-    p2[j] = pack_hi(se, so);
-  }
-  t0 = __builtin_bit_cast(bf8, p0); t1 = __builtin_bit_cast(bf8, p1); t2 = __builtin_bit_cast(bf8, p2);
-}
-
-// The same for a fragment that holds +-Inf: x - top16(x) would be Inf - Inf = NaN and poison the whole row, and an Inf in
-// the top term would meet the other operand's residual terms, which are 0 for a bf16-representable value (Inf * 0 = NaN),
-// where the fp32 contraction gives +-Inf.  An infinite element is therefore carried by its LOWEST term alone (t0 = t1 = 0,
-// t2 = +-Inf): of the six partial products only a2*b0 sees it, and b0 = 0 only where the fp32 product Inf * w is NaN too
-// (w = 0).  NaN needs nothing: it propagates through the subtraction.
-__device__ __forceinline__ void split8_inf(const f4 lo, const f4 hi, bf8& t0, bf8& t1, bf8& t2) {
-  const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-  u4 p0, p1, p2;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float xe = x[2 * j], xo = x[2 * j + 1];
-    const bool ie = __builtin_fabsf(xe) == INFINITY, io = __builtin_fabsf(xo) == INFINITY;
-    const float fe = ie ? 0.f : xe, fo = io ? 0.f : xo;
-    const float re = fe - top16(fe), ro = fo - top16(fo);
-    const float se = re - top16(re), so = ro - top16(ro);
-    p0[j] = pack_hi(fe, fo);
-    p1[j] = pack_hi(re, ro);
-    p2[j] = pack_hi(ie ? xe : se, io ? xo : so);
-  }
-  t0 = __builtin_bit_cast(bf8, p0); t1 = __builtin_bit_cast(bf8, p1); t2 = __builtin_bit_cast(bf8, p2);
-}
-// largest magnitude of the 8 floats (NaN operands are ignored by v_max3: they need no special path)
-__device__ __forceinline__ float absmax8(const f4 lo, const f4 hi) {
-  float m;
-  asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(m) : "v"(lo.x), "v"(lo.y), "v"(lo.z));
-  asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(m) : "v"(m), "v"(lo.w), "v"(hi.x));
-  asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(m) : "v"(m), "v"(hi.y), "v"(hi.z));
-  asm("v_max_f32 %0, %1, |%2|" : "=v"(m) : "v"(m), "v"(hi.w));
-  return m;
-}
 
 // ---- weight packing ------------------------------------------------------------------------------------------------
 // w_img[ny][c][term][s][g][n][e]  = term(w_ref[ny*80 + n][Kh + s*K + c*32 + kperm(g, e)])   (0 outside K / N)

@@ -1,5 +1,5 @@
 // pna_x3_split.h -- the exact fp32 -> 3 x bf16 operand split shared by the bf16x3 contraction kernels
-// (pna_posttrans_x3w.hip; pna_posttrans_x3.hip carries its own identical copy from round 1).
+// (pna_posttrans_x3.hip, pna_fused_degree.hip).
 //   x = x0 + x1 + x2,   x0 = top 16 bits of x,  x1 = top 16 bits of (x - x0),  x2 = top 16 bits of (x - x0 - x1)
 // by truncation, so every term is exact and finite inputs never overflow.  See include/pna_amd.h for the non-finite rules.
 #ifndef PNA_X3_SPLIT_H

@@ -21,8 +21,6 @@ from .graph import HeavySchedule
 # persistent tiles (>= X3_MIN_ROWS rows), f32 otherwise.
 POSTTRANS_ARITH = os.environ.get("PNA_AMD_POSTTRANS", "auto")
 X3_MIN_ROWS = 16384
-# bf16x3 on 32x32 matrix-core tiles (pna_posttrans_x3w_f32): opt-in (PNA_AMD_X3_WIDE=1) while it is slower than the 16x16 kernel
-X3_WIDE = os.environ.get("PNA_AMD_X3_WIDE", "0") != "0"
 
 _TUNE = {}   # process-wide tuning overrides (set by tools/sweep.py and bench.py), see set_tuning()
 
@@ -161,32 +159,6 @@ def pack_posttrans_weight_x3(weight: torch.Tensor, K: int, n_scaler: int, Kh: in
     return w_img, wh_img
 
 
-def pack_posttrans_weight_x3w(weight: torch.Tensor, K: int, n_scaler: int):
-    """bf16x3 image of a reference-layout posttrans weight (N, n_scaler*K) for the 32x32-tile kernel
-    (pna_posttrans_x3w_pack_f32); cached like pack_posttrans_weight."""
-    key = (weight._version, weight.data_ptr(), str(weight.device), tuple(weight.shape), weight.stride(0), K, n_scaler)
-    hit = getattr(weight, "_pna_amd_pack_x3w", None)
-    if hit is not None and hit[0] == key:
-        return hit[1]
-    L = _lib.lib()
-    N = weight.shape[0]
-    nb = L.pna_posttrans_x3w_packed_bytes(K, N, n_scaler)
-    w_img = torch.empty((nb + 3) // 4, dtype=torch.float32, device=weight.device)
-    rc = L.pna_posttrans_x3w_pack_f32(_lib.dev_ptr(weight, torch.float32, "weight"), _ld(weight), N, K, n_scaler,
-                                      _lib.dev_ptr(w_img, torch.float32, "w_img"), _lib.stream_ptr(weight.device))
-    _lib.check(rc, "pna_posttrans_x3w_pack_f32")
-    try:
-        weight._pna_amd_pack_x3w = (key, w_img)
-    except AttributeError:
-        pass
-    return w_img
-
-
-def x3w_supported(K: int, N: int, n_scaler: int, Kh: int) -> bool:
-    """True when the 32x32-tile bf16x3 kernel (pna_posttrans_x3w_f32) serves the shape."""
-    return X3_WIDE and bool(_lib.lib().pna_posttrans_x3w_supported(K, N, n_scaler, Kh))
-
-
 def posttrans(a_mat: torch.Tensor, K: int, weight: torch.Tensor, row_scales: Sequence[Optional[torch.Tensor]],
               bias: Optional[torch.Tensor] = None, h: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
               row_post: Optional[torch.Tensor] = None, col_scale: Optional[torch.Tensor] = None,
@@ -217,11 +189,7 @@ def posttrans(a_mat: torch.Tensor, K: int, weight: torch.Tensor, row_scales: Seq
             raise ValueError("the bf16x3 posttrans kernel supports at most 3 scalers")
         arith = "f32"                              # the process-wide preference falls back where bf16x3 is not implemented
     x3 = arith == "bf16x3" or (arith == "auto" and S <= 3 and M >= X3_MIN_ROWS)
-    wide = x3 and pipeline == 0 and x3w_supported(K, N, S, Kh)
-    if wide:
-        w_img, wh_img = pack_posttrans_weight_x3w(weight, K, S), None
-    else:
-        w_img, wh_img = (pack_posttrans_weight_x3 if x3 else pack_posttrans_weight)(weight, K, S, Kh)
+    w_img, wh_img = (pack_posttrans_weight_x3 if x3 else pack_posttrans_weight)(weight, K, S, Kh)
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=dev)
     g = _lib.PnaPosttransArgs()
@@ -246,7 +214,7 @@ def posttrans(a_mat: torch.Tensor, K: int, weight: torch.Tensor, row_scales: Seq
         g.residual, g.ld_res = _lib.dev_ptr(residual, torch.float32, "residual"), _ld(residual)
     g.y, g.ldy = _lib.dev_ptr(out, torch.float32, "y"), _ld(out)
     g.pipeline = int(pipeline) if x3 else 0      # bf16x3 only: 0 = default, 2 / 3 = weight buffers in LDS (include/pna_amd.h)
-    fn = "pna_posttrans_x3w_f32" if wide else "pna_posttrans_x3_f32" if x3 else "pna_posttrans_f32"
+    fn = "pna_posttrans_x3_f32" if x3 else "pna_posttrans_f32"
     rc = getattr(_lib.lib(), fn)(ctypes.byref(g), _lib.stream_ptr(dev))
     _lib.check(rc, fn)
     return out

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Socket power and clocks (rocm-smi) while one kernel runs in a loop: is the contraction power-bound?
-    python tools/power_probe.py x3|x3w|segreduce|idle"""
+    python tools/power_probe.py x3|segreduce|idle"""
 import os, subprocess, sys, threading, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,7 +21,6 @@ if which == "segreduce":
 elif which == "f32":
     fn = lambda: ops.posttrans(a, K, W, sc, b, arith="f32", out=y)
 else:
-    ops.X3_WIDE = which == "x3w"
     fn = lambda: ops.posttrans(a, K, W, sc, b, arith="bf16x3", out=y)
 samples, stop = [], False
 def poll():

@@ -4,7 +4,6 @@ from pna_amd import _lib
 if os.environ.get("PNA_AMD_LIB"):
     _lib.LIB_PATH = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), os.environ["PNA_AMD_LIB"])
 from pna_amd import ops
-ops.X3_WIDE = False
 dev = torch.device("cuda:0")
 M, K, N = 1_000_000, 300, 75
 a = torch.randn(M, K, device=dev); W = torch.randn(N, 3 * K, device=dev) / 30; b = torch.randn(N, device=dev)
