@@ -1,0 +1,114 @@
+"""the multitask benchmark's TRAINING loop (multitask_benchmark/util/train.py:143-149) for two epochs, step by step
+against the loss trace the reference itself produced on CPU (oracle/make_golden_c1_train.py: reference GNN + reference PNALayer +
+reference data, labels and loss, seed 42).  Here the same network is assembled around pna_amd.pytorch.pna.layer.PNALayer -- HIP
+kernels forward and backward -- starts from the reference's initial state_dict (strict load) and must reproduce every step's loss
+to 1e-4 relative.
+
+The assembly around the layers (shared GRU between iterations, Set2Set readout, the two MLP heads; models/pytorch/gnn_framework.py
+:90-108, models/layers.py:21-99,:237-292) is OUT of the hot-path scope: it is restated here, in the test, from stock
+torch modules with the reference's parameter names so that the checkpoint loads key for key."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from conftest import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+class _GRU(nn.Module):                      # models/layers.py:237-265 (no padding needed: nfeat <= nhid is padded by the caller's sizes)
+    def __init__(self, n):
+        super().__init__()
+        self.n = n
+        self.gru = nn.GRU(input_size=n, hidden_size=n)
+
+    def forward(self, x, y):
+        B, N, _ = x.shape
+        x = x.reshape(1, B * N, -1)
+        y = y.reshape(1, B * N, -1)
+        if x.shape[-1] < self.n:
+            x = F.pad(x, [0, self.n - x.shape[-1]])
+        return self.gru(x.contiguous(), y.contiguous())[1].reshape(B, N, -1)
+
+
+class _Set2Set(nn.Module):                  # models/layers.py:21-99
+    def __init__(self, nin):
+        super().__init__()
+        self.nin, self.nhid = nin, 2 * nin
+        self.lstm = nn.LSTM(self.nhid, nin, num_layers=1, batch_first=True)
+
+    def forward(self, x):
+        B = x.shape[0]
+        h = (x.new_zeros((1, B, self.nin)), x.new_zeros((1, B, self.nin)))
+        q_star = x.new_zeros(B, 1, self.nhid)
+        for _ in range(x.shape[1]):
+            q, h = self.lstm(q_star, h)
+            a = torch.softmax(torch.matmul(x, q.transpose(1, 2)), dim=1)
+            q_star = torch.cat([q, torch.sum(a * x, dim=1, keepdim=True)], dim=-1)
+        return q_star.squeeze(1)
+
+
+class _Readout(nn.Module):                  # models/layers.py:268-292
+    def __init__(self, n, out):
+        super().__init__()
+        from pna_amd.layers import MLP
+        self.set2set = _Set2Set(n)
+        self.mlp = MLP(in_size=2 * n, hidden_size=n, out_size=out, layers=3, mid_activation="relu", last_activation="LeakyReLU",
+                       mid_b_norm=True, last_b_norm=False)
+
+    def forward(self, x):
+        return self.mlp(self.set2set(x))
+
+
+class _GNN(nn.Module):                      # models/pytorch/gnn_framework.py: fixed, variable N/2 layers, shared GRU, no skip
+    def __init__(self, layer_type, meta, avg_d, device):
+        super().__init__()
+        from pna_amd.layers import MLP
+        H = meta["hidden"]
+        conv = dict(aggregators=meta["aggregators"], scalers=meta["scalers"], avg_d=avg_d, towers=meta["towers"], self_loop=False,
+                    pretrans_layers=1, posttrans_layers=1, device=device)
+        self.conv_layers = nn.ModuleList([layer_type(2, H, divide_input=False, **conv), layer_type(H, H, divide_input=True, **conv)])
+        self.gru = _GRU(H)
+        self.nodes_read_out = MLP(in_size=H, hidden_size=H, out_size=3, layers=3, mid_activation="LeakyReLU", last_activation="LeakyReLU")
+        self.graph_read_out = _Readout(H, 3)
+
+    def forward(self, x, adj):
+        n_layers = adj.shape[1] // 2
+        for layer in range(n_layers):
+            y = self.conv_layers[0 if layer == 0 else 1](x, adj)
+            x = self.gru(x, y)
+        return self.nodes_read_out(x), self.graph_read_out(x)
+
+
+def _total_loss(out, target):               # multitask_benchmark/util/util.py:51-66 with loss = 'mse'
+    nodes, graph = F.mse_loss(out[0], target[0]), F.mse_loss(out[1], target[1])
+    return (nodes * out[0].shape[-1] + graph * out[1].shape[-1]) / (out[0].shape[-1] + out[1].shape[-1])
+
+
+@pytest.mark.parametrize("name", golden_names("c1_train_trace"))
+def test_two_epoch_loss_trace_matches_the_reference(cuda_device, name):
+    from pna_amd.pytorch.pna.layer import PNALayer
+    meta, a, sd = load_golden(name)
+    dev = cuda_device
+    avg_d = {k: a["avg_" + k].to(dev) for k in ("lin", "log", "exp")}
+    torch.manual_seed(0)
+    net = _GNN(PNALayer, meta, avg_d, dev)
+    assert sum(p.numel() for p in net.parameters()) == meta["n_parameters"] == 8350
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=meta["lr"], weight_decay=meta["weight_decay"])
+    B = meta["B"]
+    adj, x, nl, gl = (a[k].to(dev).split(B) for k in ("adj", "x", "node_labels", "graph_labels"))
+    want = a["out"].double().tolist()
+    got = []
+    for epoch in range(meta["epochs"]):
+        net.train()
+        for b in range(meta["batches"]):
+            opt.zero_grad()
+            loss = _total_loss(net(x[b], adj[b]), (nl[b], gl[b]))
+            loss.backward()
+            opt.step()
+            got.append(float(loss.item()))
+    rel = [abs(g - w) / abs(w) for g, w in zip(got, want)]
+    assert len(got) == len(want) == 8 and max(rel) <= 1e-4, (got, want, rel)
