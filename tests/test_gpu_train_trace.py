@@ -1,8 +1,15 @@
 """the multitask benchmark's TRAINING loop (multitask_benchmark/util/train.py:143-149) for two epochs, step by step
 against the loss trace the reference itself produced on CPU (oracle/make_golden_c1_train.py: reference GNN + reference PNALayer +
 reference data, labels and loss, seed 42).  Here the same network is assembled around pna_amd.pytorch.pna.layer.PNALayer -- HIP
-kernels forward and backward -- starts from the reference's initial state_dict (strict load) and must reproduce every step's loss
-to 1e-4 relative.
+kernels forward and backward -- starts from the reference's initial state_dict (strict load) and must reproduce the first loss
+to 1e-6, the oracle-autograd gradients of its parameters to 5e-4 and every step's loss to 1e-3 relative (see the test for why not 1e-4).
+
+Only the PNA layers run on the GPU; the recurrent / readout modules around them stay on the CPU, where they execute the very ops
+the reference run executed.  With those on the GPU as well the trace drifts by 1e-3 .. 1e-2 within eight Adam steps -- for the
+plain-torch restatement of the layer (oracle/torch_oracle.py on the GPU) exactly as for the HIP layer (tools/train_trace_diag.py,
+profiles/r03_train_trace_diag.txt): MIOpen's GRU / LSTM gradients differ from the CPU's at 1e-4 .. 5e-3 relative and Adam's
+normalised update amplifies that; the step-1 loss (forward only) agrees to 1e-7 either way.  That drift says nothing about the
+layer under test, so it is kept out of the comparison.
 
 The assembly around the layers (shared GRU between iterations, Set2Set readout, the two MLP heads; models/pytorch/gnn_framework.py
 :90-108, models/layers.py:21-99,:237-292) is OUT of the hot-path scope: it is restated here, in the test, from stock
@@ -75,8 +82,10 @@ class _GNN(nn.Module):                      # models/pytorch/gnn_framework.py: f
 
     def forward(self, x, adj):
         n_layers = adj.shape[1] // 2
+        cdev = next(self.conv_layers.parameters()).device         # the conv layers may live on another device than the rest
+        adj_c = adj.to(cdev)
         for layer in range(n_layers):
-            y = self.conv_layers[0 if layer == 0 else 1](x, adj)
+            y = self.conv_layers[0 if layer == 0 else 1](x.to(cdev), adj_c).to(x.device)
             x = self.gru(x, y)
         return self.nodes_read_out(x), self.graph_read_out(x)
 
@@ -86,21 +95,65 @@ def _total_loss(out, target):               # multitask_benchmark/util/util.py:5
     return (nodes * out[0].shape[-1] + graph * out[1].shape[-1]) / (out[0].shape[-1] + out[1].shape[-1])
 
 
+def _oracle_layer_type(meta, avg_d):
+    """The same module (same parameter names), forward through oracle/torch_oracle.py's plain torch ops: autograd gives the
+    reference gradients in whatever dtype the parameters have."""
+    from oracle import torch_oracle as TO
+    from pna_amd.pytorch.pna.layer import PNALayer
+
+    class OracleLayer(PNALayer):
+        def __init__(self, fin, fout, divide_input=True, **kw):
+            super().__init__(fin, fout, divide_input=divide_input, **kw)
+            self._div = divide_input
+
+        def forward(self, x, adj):
+            return TO.dense_layer_forward(dict(self.named_parameters()), x, adj, meta["aggregators"], meta["scalers"], avg_d, meta["towers"], self._div)
+    return OracleLayer
+
+
 @pytest.mark.parametrize("name", golden_names("c1_train_trace"))
 def test_two_epoch_loss_trace_matches_the_reference(cuda_device, name):
+    """(1) step 1 (forward only): the reference's loss to 1e-6; (2) step-1 gradients of every PNA-layer parameter against
+    autograd through the oracle's plain-torch restatement of the layer: 5e-4 of the parameter's largest gradient; (3) the eight-step
+    Adam trace: 1e-3 per step.  Why not 1e-4 for (3): Adam's update g / (|g| + eps) turns fp32-level differences in small
+    gradients into lr-sized parameter differences; the plain-torch restatement of the layer run on the GPU in this same harness
+    drifts from the CPU trace just as far (tools/train_trace_diag.py: 2e-5 .. 3e-4 per step over the eight steps for both)."""
     from pna_amd.pytorch.pna.layer import PNALayer
     meta, a, sd = load_golden(name)
     dev = cuda_device
     avg_d = {k: a["avg_" + k].to(dev) for k in ("lin", "log", "exp")}
     torch.manual_seed(0)
+    torch.set_num_threads(1)                                      # (the reference run's CPU summation order)
     net = _GNN(PNALayer, meta, avg_d, dev)
     assert sum(p.numel() for p in net.parameters()) == meta["n_parameters"] == 8350
     net.load_state_dict(sd, strict=True)
-    net = net.to(dev)
-    opt = torch.optim.Adam(net.parameters(), lr=meta["lr"], weight_decay=meta["weight_decay"])
+    net.conv_layers.to(dev)                                       # the hot path on the GPU, the assembly around it on the CPU
     B = meta["B"]
-    adj, x, nl, gl = (a[k].to(dev).split(B) for k in ("adj", "x", "node_labels", "graph_labels"))
+    adj, x, nl, gl = (a[k].split(B) for k in ("adj", "x", "node_labels", "graph_labels"))
     want = a["out"].double().tolist()
+
+    # (2) reference gradients at the initial parameters, batch 0: autograd through the oracle's plain-torch restatement of the layer
+    # in the same harness, fp32 on the CPU.  (Not float64: the first layer's inputs are one-hot / small-integer features, whole
+    # groups of messages tie exactly in fp32, and float64 breaks those ties differently -- max / min then route their gradient to
+    # another edge, a different but equally valid subgradient: 4e-2 apart.)
+    avg32 = {k: a["avg_" + k] for k in ("lin", "log", "exp")}
+    ref = _GNN(_oracle_layer_type(meta, avg32), meta, avg32, "cpu")
+    ref.load_state_dict(sd, strict=True)
+    ref.train()
+    _total_loss(ref(x[0], adj[0]), (nl[0], gl[0])).backward()
+    net.train()
+    loss0 = _total_loss(net(x[0], adj[0]), (nl[0], gl[0]))
+    loss0.backward()
+    assert abs(loss0.item() - want[0]) <= 1e-6 * abs(want[0])
+    worst = (0.0, "")
+    for (n, p), (_, q) in zip(net.conv_layers.named_parameters(), ref.conv_layers.named_parameters()):
+        scale = q.grad.abs().max().item()
+        if scale > 0:
+            worst = max(worst, ((p.grad.cpu() - q.grad).abs().max().item() / scale, n))
+    assert worst[0] <= 5e-4, worst
+
+    # (3) the trace
+    opt = torch.optim.Adam(net.parameters(), lr=meta["lr"], weight_decay=meta["weight_decay"])
     got = []
     for epoch in range(meta["epochs"]):
         net.train()
@@ -111,4 +164,4 @@ def test_two_epoch_loss_trace_matches_the_reference(cuda_device, name):
             opt.step()
             got.append(float(loss.item()))
     rel = [abs(g - w) / abs(w) for g, w in zip(got, want)]
-    assert len(got) == len(want) == 8 and max(rel) <= 1e-4, (got, want, rel)
+    assert len(got) == len(want) == 8 and max(rel) <= 1e-3, (got, want, rel)
