@@ -63,3 +63,30 @@ def test_tower_layer_large_and_small(cuda_device):
         hm = torch.randn(gm.num_nodes, 75, device=cuda_device)
         sm = torch.rand(gm.num_nodes, 1, device=cuda_device) + 0.5
         _same(lambda: layer(gm, hm, None, sm))
+
+
+def test_full_size_50_repeats_every_large_graph_path(cuda_device):
+    """BASELINE configs[2] (V = 1 M, E = 10 M, F = 75), 50 repeats each, identical bits: the three-block bf16x3 contraction over all
+    rows, the degree-grouped two-kernel path (gather in plan order + one-block GRP contraction + three-block GRP rest) and the
+    one-kernel path (pna_fused_degree_f32; its own 200-repeat test is tests/test_gpu_fused_degree.py).  VERDICT r2 asked for >= 50
+    full-size repeats of the x3 / GRP kernels after the packed-fp32 observation (the instruction forms are
+    exonerated, tools/ubench/pk_mfma_repro.hip)."""
+    from pna_amd import Graph, degree_groups as DG
+    from pna_amd.dgl.pna_layer import PNASimpleLayer
+    from pna_amd.synth import powerlaw_graph
+    V, E, F = 1_000_000, 10_000_000, 75
+    src, dst = powerlaw_graph(V, E, seed=1234, device=cuda_device)
+    g = Graph(src, dst, V)
+    torch.manual_seed(5)
+    layer = PNASimpleLayer(F, F, "mean max min std", "identity amplification attenuation", {"log": torch.tensor(2.3)}, 0.0, True, True).to(cuda_device).eval()
+    h = torch.randn(V, 80, device=cuda_device)[:, :F]
+    keep = (DG.ENABLED, DG.FUSED)
+    try:
+        with torch.no_grad():
+            for enabled, fused in ((False, False), (True, False), (True, True)):
+                DG.ENABLED, DG.FUSED = enabled, fused
+                y0 = layer(g, h).clone()
+                bad = sum(int(not torch.equal(layer(g, h), y0)) for _ in range(50))
+                assert bad == 0, (enabled, fused, bad)
+    finally:
+        DG.ENABLED, DG.FUSED = keep
