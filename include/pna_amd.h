@@ -26,7 +26,10 @@
 extern "C" {
 #endif
 
-#define PNA_ABI_VERSION 11 /* 11: - pna_posttrans_x3w_* (ABI 8's contraction on 32x32 tiles: parity-green, 5 % slower than the 16x16 kernel on every
+#define PNA_ABI_VERSION 13 /* 13: pna_fused_degree_args.x_dst / h_self / row_post + pna_fused_tower_{image_bytes,pack_f32}: the one-kernel layer
+                                  for PNALayer with one tower.
+                              12: pna_segreduce_args.out_row_of (the tower layers' aggregate written in degree order).
+                              11: - pna_posttrans_x3w_* (ABI 8's contraction on 32x32 tiles: parity-green, 5 % slower than the 16x16 kernel on every
                                   shape measured, never selected -- removed, round 3).
                               10: + pna_fused_degree_{image_bytes,pack_f32,f32} (gather + degree-grouped contraction in one kernel).
                               9: pna_posttrans_args.row_perm / tile_image / image_stride (degree-grouped contraction),
@@ -178,6 +181,9 @@ typedef struct pna_segreduce_args {
    * field for nothing else when there is no dst_term) this lets a caller have the aggregate written in any row order -- e.g.
    * grouped by in-degree for pna_posttrans_args.row_perm.  `out` must then have as many rows as the largest index + 1. */
   const int32_t* heavy_out_rows;
+  /* ABI 12: with dst_term (where the work list's `row` must stay the node), the row of `out` that receives node v's aggregate:
+   * out_row_of[v] for whole-row records (heavy rows: heavy_out_rows).  Nullable; hand-scheduled kernel with work_items only. */
+  const int32_t* out_row_of;
 } pna_segreduce_args;
 
 /* Launches the kernels described above on `stream`. */
@@ -441,6 +447,20 @@ int pna_fused_simple_f32(const pna_fused_simple_args* args, pna_stream_t stream)
  * statistics the contraction consumed, [mean | max | min | std] x F per virtual row (verification; a slower instantiation).
  * Rows of degrees too rare to fill a tile, and hub rows, are the caller's: pna_segreduce_fwd_f32 + pna_posttrans_x3_f32 over
  * their compact list.
+ *
+ * TOWER MODE (ABI 13; x_dst, h_self and row_post non-null together): PNALayer.forward with ONE tower, 1-layer pretrans / posttrans,
+ * no edge features (models/dgl/pna_layer.py:33-76, :130-145), inference.  The pretrans Linear of [h_u | h_v] is x_src[u] + x_dst[v]
+ * (two node-level projections, the caller's): x = x_src, and with a[v] the statistics of x_src over the in-edges as above
+ *
+ *   y[perm[v]] = residual + act(((bias + W_D . a[v] + [deg > 0] (W_D,mean + W_D,max + W_D,min) . x_dst[perm[v]] + W_self . h_self[perm[v]])
+ *                                 * row_post[v]) * col_scale + col_shift)
+ *
+ * -- mean / max / min of (a_u + b) are those of a_u plus b (max / min: the same bits, rounding is monotone), the std does not see
+ * the shift.  x_dst, h_self: (n_nodes, ld) tables in node order under x's alignment rules; row_post: [M] in VIRTUAL row order
+ * (graph norm; ones without); residual additionally 16-byte aligned with ld_res % 4 == 0.  49 <= F <= 80.  The images come from
+ * pna_fused_tower_pack_f32: w_ref (N, n_scaler * 5F) in scaler blocks [4F aggregators | F self panel (block 0 only)] -- the
+ * posttrans Linear with its h columns moved behind the first block, or posttrans . BatchNorm . mixing Linear collapsed into one
+ * weight (pna_amd/functional.py::_tower_collapsed_weights).  No agg_out in this mode.
  */
 typedef struct pna_fused_degree_args {
   const int32_t* tile_desc;
@@ -467,12 +487,20 @@ typedef struct pna_fused_degree_args {
   float act_slope;
   float* agg_out;         /* nullable (M, ld_agg) */
   int64_t ld_agg;
+  const float* x_dst;     /* tower mode (ABI 13): (n_nodes, ld_xdst) */
+  int64_t ld_xdst;
+  const float* h_self;    /* (n_nodes, ld_h) */
+  int64_t ld_h;
+  const float* row_post;  /* [M], virtual row order */
 } pna_fused_degree_args;
 
 int64_t pna_fused_degree_image_bytes(int32_t F, int32_t N);   /* 0 = unsupported shape */
 int pna_fused_degree_pack_f32(const float* w_ref, int64_t ldw_ref, int32_t N, int32_t F, int32_t n_scaler, const float* scale,
                               int32_t n_img, void* img, pna_stream_t stream);
 int pna_fused_degree_f32(const pna_fused_degree_args* args, pna_stream_t stream);
+int64_t pna_fused_tower_image_bytes(int32_t F, int32_t N);    /* 0 = unsupported shape */
+int pna_fused_tower_pack_f32(const float* w_ref, int64_t ldw_ref, int32_t N, int32_t F, int32_t n_scaler, const float* scale,
+                             int32_t n_img, void* img, pna_stream_t stream);
 
 /* ---- the tower layer of molecule-sized batches: one call, two launches (BASELINE.json configs[1]) -------------------
  *

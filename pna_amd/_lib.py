@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to the HI
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpna_amd.so")
 
-PNA_ABI_VERSION = 11
+PNA_ABI_VERSION = 13
 PNA_MAX_AGGR = 8
 PNA_MAX_SCALER = 8
 
@@ -46,7 +46,7 @@ class PnaSegreduceArgs(ctypes.Structure):
         ("work_items", ctypes.c_void_p), ("n_work_items", ctypes.c_int32), ("_pad2", ctypes.c_int32),
         ("n_edges", ctypes.c_int64),
         ("tune", PnaTuning),
-        ("heavy_out_rows", ctypes.c_void_p),
+        ("heavy_out_rows", ctypes.c_void_p), ("out_row_of", ctypes.c_void_p),
     ]
 
 
@@ -110,6 +110,7 @@ class PnaFusedDegreeArgs(ctypes.Structure):
         ("col_scale", ctypes.c_void_p), ("col_shift", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("ld_res", ctypes.c_int64),
         ("y", ctypes.c_void_p), ("ldy", ctypes.c_int64), ("relu", ctypes.c_int32), ("act_slope", ctypes.c_float),
         ("agg_out", ctypes.c_void_p), ("ld_agg", ctypes.c_int64),
+        ("x_dst", ctypes.c_void_p), ("ld_xdst", ctypes.c_int64), ("h_self", ctypes.c_void_p), ("ld_h", ctypes.c_int64), ("row_post", ctypes.c_void_p),
     ]
 
 
@@ -191,6 +192,10 @@ def lib():
         L.pna_fused_degree_pack_f32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                 ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
         L.pna_fused_degree_pack_f32.restype = ctypes.c_int
+        L.pna_fused_tower_image_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32]
+        L.pna_fused_tower_image_bytes.restype = ctypes.c_int64
+        L.pna_fused_tower_pack_f32.argtypes = L.pna_fused_degree_pack_f32.argtypes
+        L.pna_fused_tower_pack_f32.restype = ctypes.c_int
         L.pna_fused_degree_f32.argtypes = [ctypes.POINTER(PnaFusedDegreeArgs), ctypes.c_void_p]
         L.pna_fused_degree_f32.restype = ctypes.c_int
         L.pna_posttrans_packed_floats.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,

@@ -54,6 +54,8 @@ struct FDArgs {
   const int* perm; const unsigned char* w_img; long img_stride;
   const float* bias; const float* col_scale; const float* col_shift; const float* residual; float* y;
   float* agg_out; long ld_agg; // optional: the statistics as the contraction sees them, [mean | max | min | std] x F per virtual row
+  const float* xd; const float* xh; const float* row_post;   // tower layers: the rows' own projections / features, the per-row factor
+  unsigned lddb, ldhb;         // row pitch of xd / xh in bytes
   unsigned long long* dbg;     // experiments build only: per-wavefront phase timers
   unsigned ldb;                // row pitch of x in bytes
   unsigned ldyb, ldrb;         // row pitch of y / residual in bytes (ldrb = 0 without a residual: every load reads y's first row)
@@ -92,6 +94,20 @@ __device__ __forceinline__ void ld4(int& dst, const void* base, unsigned voff) {
 }
 __device__ __forceinline__ void ld4f(float& dst, const void* base, unsigned voff) {
   asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
+}
+// The same loads behind five wait states.  "VALU writes SGPR -> VMEM reads that SGPR" needs them on gfx9 / CDNA; hipcc inserts the
+// s_nop for its own memory instructions but does not look inside inline asm, and under SGPR pressure it reloads a spilled base
+// pointer with v_readlane_b32 directly in front of the statement: the load then goes out with the stale base (the two-full-block
+// tower instantiation faulted at address 0x1000 that way).  Used for the once-per-tile loads whose base pointers are not live in
+// the gather loop; tools/isa_audit.py::sgpr_hazards checks EVERY inline-asm memory instruction of the compiled kernels for this.
+__device__ __forceinline__ void ld16_ws(f4& dst, const void* base, unsigned voff) {
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ void ld16_hi_ws(f4& dst, const void* base, unsigned voff) {
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:16" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ void ld16i_ws(i4& dst, const void* base, unsigned voff) {
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
 }
 // Scalar load of a tile descriptor, waited for INSIDE the statement: an SGPR result that is still in flight when the statement
 // ends may be SPILLED by hipcc (v_writelane of the stale value) -- the 2 full + half instantiation of the verification kernel did
@@ -142,10 +158,27 @@ __device__ __forceinline__ unsigned long long now() {
 
 // RESPF: the tile's residual rows are requested during the gather's drain and ride through the multiply phase in 20 registers
 // (not in the verification instantiation DUMP, whose stores need registers of their own).
-template <int NFBF, bool HALF, bool DUMP, bool RESPF = !DUMP>
+//
+// TOWER (PNALayer with one tower, models/dgl/pna_layer.py:33-76 + :130-145).  The message of edge (u, v) is the pretrans Linear of
+// [h_u | h_v] = x_src[u] + x_dst[v] (two node-level projections): the gather runs over x_src alone and the destination's term
+// enters through the contraction -- mean / max / min of (a_u + b) are mean / max / min of a_u plus b (rounding is monotone: the
+// max / min are the same bits), the std does not see a shift -- as an extra K panel [x_dst[v]] against W_mean + W_max + W_min (not for
+// rows without in-edges: DGL leaves their aggregate at zero).  A second extra panel carries the row's own features h[v] against the
+// collapsed self weight (functional._tower_collapsed_weights).  Both are read like one more edge packet each -- the same strips,
+// of the row's own node -- but late: after step 3, into the registers the first feature block's statistics have left, three
+// steps before their first use; the residual rows follow four steps before the epilogue.  A per-row factor (graph norm) multiplies
+// the biased accumulator in the epilogue.
+template <int NFBF, bool HALF, bool DUMP, bool TOWER = false, bool RESPF = !DUMP && !TOWER>
 __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const FDArgs g) {
+  static_assert(!TOWER || (NFBF == 2 && !DUMP), "tower mode: two full feature blocks (49 <= F <= 80), production only");
   constexpr int NB = NFBF + (HALF ? 1 : 0);               // feature blocks
-  constexpr int NC = 4 * NFBF + (HALF ? 2 : 0);           // chunks of 32 k values per tile
+  constexpr int NC = 4 * NFBF + (HALF ? 2 : 0);           // chunks of 32 k values of the statistics per tile
+  constexpr int NPC = TOWER ? 2 * NFBF + (HALF ? 1 : 0) : 0;   // chunks of the two node panels (the half blocks of both share one)
+  constexpr int NCT = NC + NPC;                           // steps per tile
+  constexpr int PSTEP = 3;                                // the panels are requested at the end of this step ...
+  constexpr int PWAIT = PSTEP + kAhead;                   // ... and have landed by this step's counted wait
+  constexpr int RSTEP = NCT - kAhead;                     // tower mode: the residual rows are requested at the end of this step
+  static_assert(!TOWER || (PWAIT < NC && RSTEP > PWAIT), "panel / residual windows");
   constexpr int NL = 2 * NFBF + (HALF ? 1 : 0);           // 16-byte row loads per edge
   constexpr int LB = NL + 1;                              // loads of one edge packet (the strips + the slot's next id)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -190,6 +223,8 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
   const unsigned lib = (unsigned)li * 4u;
   int idr[kRing];
   i4 pr;                                                  // rows of y / residual of the lane's four C rows 4 lg + r (-1: padding)
+  int pn = 0;                                             // tower mode: the node of tile row li (-1: padding)
+  f4 rp;                                                  // tower mode: the per-row factor of the lane's four C rows
   f4 res[kNRes];                                          // residual, TRANSPOSED layout: row 4 lg + (li & 3), columns 16 n + 4 (li >> 2) .. + 4
 
   // ---- the gather: running statistics of the wavefront's 16 rows ----------------------------------------------------------
@@ -219,7 +254,9 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     const int D = td_cur.y;
     const unsigned rb = (unsigned)td_cur.x * 64u, rbn = (unsigned)td_nxt.x * 64u;       // byte offsets of this / the next tile's records
     deg = D;
-    ld16i(pr, g.perm, (unsigned)((t * kWaves + wave) * 16 + 4 * lg) * 4u);
+    // (tower mode: the rows of y and their factors are needed from step RSTEP on only: requested with the panels)
+    if constexpr (TOWER) ld4(pn, g.perm, (unsigned)((t * kWaves + wave) * 16 + li) * 4u);
+    else ld16i(pr, g.perm, (unsigned)((t * kWaves + wave) * 16 + 4 * lg) * 4u);
 #pragma unroll
     for (int fb = 0; fb < NB; ++fb)
 #pragma unroll
@@ -269,7 +306,8 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     // slot 0 -- perm (requested before every packet) has landed by then -- and stay in flight into the multiply phase.
     const int e0 = 4 * (ng - 1);
     wait_slot<3 * LB, NL>(sl[0], idr[0]);
-    asm volatile("" : "+v"(pr));
+    if constexpr (TOWER) asm volatile("" : "+v"(pn));
+    else asm volatile("" : "+v"(pr));
     fold(J0{}, e0 < D);
     constexpr int NR = RESPF ? kNRes : 0;
     if constexpr (RESPF) {
@@ -304,9 +342,41 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     if (f >= g.F) r = 0.f;                                // padding features of the last block (their weights are 0; the table's
     return r;                                             // padding columns may hold anything)
   };
+  f4 pk[2][NL];                                           // tower mode: strips of x_dst (0) and h (1) of the row's own node
+  constexpr int NPL = 2 * NL + 2;                         // loads of the panel request: the strips, the rows of y, their factors
+  auto issue_panels = [&]() __attribute__((always_inline)) {
+    const unsigned r0 = (unsigned)max(pn, 0);
+    ld16i_ws(pr, g.perm, (unsigned)((t * kWaves + wave) * 16 + 4 * lg) * 4u);
+    ld16_ws(rp, g.row_post, (unsigned)((t * kWaves + wave) * 16 + 4 * lg) * 4u);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const void* const base = p == 0 ? (const void*)g.xd : (const void*)g.xh;
+      const unsigned rowb = __umul24(r0, p == 0 ? g.lddb : g.ldhb);
+#pragma unroll
+      for (int fb = 0; fb < NB; ++fb) {
+        ld16_ws(pk[p][2 * fb], base, rowb + f0b[fb]);
+        if (!(HALF && fb == NFBF)) ld16_hi_ws(pk[p][2 * fb + 1], base, rowb + f0b[fb]);
+      }
+    }
+  };
   auto frag = [&](auto c_c) __attribute__((always_inline)) {
     constexpr int c = decltype(c_c)::value;
     if (c > 0 && FD_ABL(1)) { asm volatile("" : "+v"(A[0])); return; }
+    if constexpr (c >= NC) {                              // a node panel: the strips are the A operand as they come
+      constexpr int pc = c - NC;
+      constexpr bool halfc = pc >= 2 * NFBF;
+      constexpr int p = halfc ? 0 : pc / NFBF, fb = halfc ? NFBF : pc % NFBF;
+      f4 lo4 = pk[p][2 * fb], hi4 = halfc ? pk[1][2 * fb] : pk[p][2 * fb + 1];
+      const int fl = halfc ? fb * 32 + lg * 4 : fb * 32 + lg * 8, fh = halfc ? fl : fl + 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (fl + j >= g.F || ((halfc || p == 0) && deg <= 0)) lo4[j] = 0.f;     // (the x_dst panel: not for rows without in-edges)
+        if (fh + j >= g.F || (!halfc && p == 0 && deg <= 0)) hi4[j] = 0.f;
+      }
+      if (__builtin_amdgcn_ballot_w64(absmax8(lo4, hi4) == INFINITY) != 0) split8_inf(lo4, hi4, A[0], A[1], A[2]);
+      else split8(lo4, hi4, A[0], A[1], A[2]);
+      return;
+    }
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -341,7 +411,10 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
                  : "+v"(cb[0]), "+v"(cb[1]), "+v"(cb[2]), "+v"(cb[3]), "+v"(cb[4]), "+v"(cs[0]), "+v"(cs[1]), "+v"(cs[2]), "+v"(cs[3]), "+v"(cs[4]),
                    "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]), "+v"(ct[4]) : : "memory");
     const int row = prow();
-    if constexpr (!RESPF) {
+    if constexpr (TOWER) {
+      // the residual rows were requested at the end of step RSTEP; younger than them: the weight copies of the three steps since
+      asm volatile("s_waitcnt vmcnt(%5)" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]) : "n"((kAhead - 1) * kNI) : "memory");
+    } else if constexpr (!RESPF) {
       const char* rbase = reinterpret_cast<const char*>(resb) + (size_t)((unsigned)max(row, 0) * g.ldrb);
 #pragma unroll
       for (int n = 0; n < kNT; ++n) res[n] = reinterpret_cast<const f4u*>(rbase + res_col(n))->v;
@@ -354,6 +427,7 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = acc[n][r] + cb[n];
+        if constexpr (TOWER) v = v * rp[r];
         v = __builtin_fmaf(v, cs[n], ct[n]);
         x[r] = v < lo ? (leaky ? v * g.slope : 0.f) : v;  // ReLU / LeakyReLU / none (lo = -inf); NaN < lo is false: NaN is kept
       }
@@ -454,10 +528,22 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     FD_WAIT_B();
     // (the images of a tile's first kAhead - 1 steps were requested before its gather, whose waits retired them; waiting here
     // would only wait for the residual rows requested at the end of the gather -- a full memory round trip per tile)
-    if constexpr (c >= kAhead - 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"((kAhead - 2) * kNI) : "memory");
+    // tower mode: the panel strips (requested at the end of step PSTEP) may stay in flight for three steps, the residual rows
+    // (end of step RSTEP) into the epilogue: they are younger than the image this wait is for
+    constexpr int young = !TOWER ? 0 : (c > PSTEP && c < PWAIT) ? NPL : c > RSTEP ? kNRes : 0;
+    if constexpr (c >= kAhead - 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"((kAhead - 2) * kNI + young) : "memory");
     else asm volatile("s_barrier" ::: "memory");
-    if (c + kAhead < NC) stage(c + kAhead, buf2, ib_cur);
-    else stage(c + kAhead - NC, buf2, ib_next);
+    if constexpr (TOWER && c == PWAIT) {                  // (the wait above left only the two youngest images in flight)
+      static_assert(NL == 4 || NL == 5, "tower shapes");
+      asm volatile("" : "+v"(pr), "+v"(rp));
+      if constexpr (NL == 4)
+        asm volatile("" : "+v"(pk[0][0]), "+v"(pk[0][1]), "+v"(pk[0][2]), "+v"(pk[0][3]), "+v"(pk[1][0]), "+v"(pk[1][1]), "+v"(pk[1][2]), "+v"(pk[1][3]));
+      else
+        asm volatile("" : "+v"(pk[0][0]), "+v"(pk[0][1]), "+v"(pk[0][2]), "+v"(pk[0][3]), "+v"(pk[0][NL - 1]), "+v"(pk[1][0]), "+v"(pk[1][1]), "+v"(pk[1][2]),
+                     "+v"(pk[1][3]), "+v"(pk[1][NL - 1]));
+    }
+    if (c + kAhead < NCT) stage(c + kAhead, buf2, ib_cur);
+    else stage(c + kAhead - NCT, buf2, ib_next);
     if (!FD_ABL(0))
 #pragma unroll
     for (int pp = 0; pp < 6; ++pp) {
@@ -475,16 +561,20 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
 #undef FD_WAIT_B
 #undef FD_FENCE
     buf = buf == kNBuf - 1 ? 0 : buf + 1;
-    if constexpr (c + 1 < NC) frag(std::integral_constant<int, c + 1>{});
+    if constexpr (c + 1 < NCT) frag(std::integral_constant<int, c + 1>{});
+    if constexpr (TOWER && c == PSTEP) issue_panels();
+    if constexpr (TOWER && c == RSTEP) {
+      const unsigned rrow = (unsigned)max(prow(), 0) * g.ldrb;
+#pragma unroll
+      for (int n = 0; n < kNT; ++n) ld16_ws(res[n], resb, rrow + res_col(n));
+    }
   };
   auto steps4 = [&](auto b_c) __attribute__((always_inline)) {
     constexpr int b = decltype(b_c)::value;
     step(std::integral_constant<int, b>{});
-    step(std::integral_constant<int, b + 1>{});
-    if constexpr (b + 2 < NC) {
-      step(std::integral_constant<int, (b + 2 < NC) ? b + 2 : 0>{});
-      step(std::integral_constant<int, (b + 3 < NC) ? b + 3 : 0>{});
-    }
+    if constexpr (b + 1 < NCT) step(std::integral_constant<int, (b + 1 < NCT) ? b + 1 : 0>{});
+    if constexpr (b + 2 < NCT) step(std::integral_constant<int, (b + 2 < NCT) ? b + 2 : 0>{});
+    if constexpr (b + 3 < NCT) step(std::integral_constant<int, (b + 3 < NCT) ? b + 3 : 0>{});
   };
   while (true) {
     const unsigned long long t0 = now();
@@ -494,8 +584,10 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     // the experiments build on the C3 layer: 0.873 -> 0.790 ms.
     if (!FD_ABL(6)) __builtin_amdgcn_s_setprio(1);
     steps4(std::integral_constant<int, 0>{});
-    if constexpr (NC > 4) steps4(std::integral_constant<int, ((NC > 4) ? 4 : 0)>{});
-    if constexpr (NC > 8) steps4(std::integral_constant<int, ((NC > 8) ? 8 : 0)>{});
+    if constexpr (NCT > 4) steps4(std::integral_constant<int, ((NCT > 4) ? 4 : 0)>{});
+    if constexpr (NCT > 8) steps4(std::integral_constant<int, ((NCT > 8) ? 8 : 0)>{});
+    if constexpr (NCT > 12) steps4(std::integral_constant<int, ((NCT > 12) ? 12 : 0)>{});
+    static_assert(NCT <= 16, "steps4 calls");
     // the residual rows landed by the last step's counted wait (they are older than all but the first copies of the tile, and
     // every shape has at least 4 steps); from here on the compiler may read them
     if constexpr (RESPF) asm volatile("" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]));
@@ -524,8 +616,11 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
 
 // ---- weight images: W_D = sum_s scale[i][s] W_s in fp32 (scaler order), K reordered into the kernel's chunks, cut into three
 //      bf16 terms, laid out as the LDS image of every chunk: [chunk][term][lane group][80 cols][8 k] ---------------------------
-__global__ void k_pack_fused_degree(const float* w_ref, long ldw, int N, int F, int S, const float* scale, int n_img, unsigned short* img) {
-  const int nfull = shape_full(F), NC = shape_chunks(F), K = 4 * F;
+//      Tower images (tower != 0): scaler blocks of K = 5 F columns [4 F aggregators | F self panel (block 0 only)], followed by
+//      the chunks of the two node panels: x_dst against W_D,mean + W_D,max + W_D,min, h against the self panel.
+__global__ void k_pack_fused_degree(const float* w_ref, long ldw, int N, int F, int S, const float* scale, int n_img, unsigned short* img, int tower) {
+  const int nfull = shape_full(F), NCS = shape_chunks(F), K = tower ? 5 * F : 4 * F;
+  const int NC = NCS + (tower ? 2 * nfull + (shape_half(F) ? 1 : 0) : 0);
   const long per = (long)NC * 3 * 4 * kNW * 8;
   const long total = per * n_img;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -536,30 +631,37 @@ __global__ void k_pack_fused_degree(const float* w_ref, long ldw, int N, int F, 
     const int term = r % 3; r /= 3;
     const int c = r % NC; r /= NC;
     const int im = (int)r;
-    int a, f;
+    int a, f;                                             // a: aggregator 0..3; 4: the self panel; 5: the x_dst panel
     if (c < 4 * nfull) { a = c % 4; f = (c / 4) * 32 + lgp * 8 + e; }
-    else { a = 2 * (c - 4 * nfull) + (e >> 2); f = nfull * 32 + lgp * 4 + (e & 3); }
-    float w = 0.f;
-    if (n < N && f < F) {
-      const float* row = w_ref + (long)n * ldw + (long)a * F + f;
-      w = scale ? scale[(long)im * S] * row[0] : row[0];
+    else if (c < NCS) { a = 2 * (c - 4 * nfull) + (e >> 2); f = nfull * 32 + lgp * 4 + (e & 3); }
+    else if (c - NCS < 2 * nfull) { a = (c - NCS) / nfull == 0 ? 5 : 4; f = ((c - NCS) % nfull) * 32 + lgp * 8 + e; }
+    else { a = (e >> 2) == 0 ? 5 : 4; f = nfull * 32 + lgp * 4 + (e & 3); }
+    auto combined = [&](int col) -> float {               // W_D[n][col] = sum_s scale_s(D) W_s[n][col], scaler order
+      const float* row = w_ref + (long)n * ldw + col;
+      float w = scale ? scale[(long)im * S] * row[0] : row[0];
       for (int s = 1; s < S; ++s) w = w + (scale ? scale[(long)im * S + s] * row[(long)s * K] : row[(long)s * K]);
-    }
+      return w;
+    };
+    float w = 0.f;
+    if (n < N && f < F) w = a < 5 ? combined(a * F + f) : (combined(f) + combined(F + f)) + combined(2 * F + f);
     img[i] = weight_term(w, term);
   }
 }
 
-template <int NFBF, bool HALF, bool DUMP>
+template <int NFBF, bool HALF, bool DUMP, bool TOWER = false>
 int launch(const FDArgs& g, int wgs, hipStream_t st) {
   const size_t lds = (size_t)kNBuf * kChunkV * 16 + (size_t)(3 * kNW) * sizeof(float);
-  if (hipFuncSetAttribute((const void*)k_fused_degree<NFBF, HALF, DUMP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-  hipLaunchKernelGGL((k_fused_degree<NFBF, HALF, DUMP>), dim3((unsigned)wgs), dim3(kThreads), lds, st, g);
+  if (hipFuncSetAttribute((const void*)k_fused_degree<NFBF, HALF, DUMP, TOWER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+  hipLaunchKernelGGL((k_fused_degree<NFBF, HALF, DUMP, TOWER>), dim3((unsigned)wgs), dim3(kThreads), lds, st, g);
   return 0;
 }
 template <bool DUMP>
 int launch_shape(const FDArgs& g, int wgs, hipStream_t st) {
   const int nf = shape_full(g.F);
   const bool half = shape_half(g.F);
+  if constexpr (!DUMP) {
+    if (g.xd) return nf != 2 ? -2 : half ? launch<2, true, false, true>(g, wgs, st) : launch<2, false, false, true>(g, wgs, st);
+  }
   if (nf == 1 && !half) return launch<1, false, DUMP>(g, wgs, st);
   if (nf == 1 && half) return launch<1, true, DUMP>(g, wgs, st);
   if (nf == 2 && !half) return launch<2, false, DUMP>(g, wgs, st);
@@ -574,6 +676,26 @@ extern "C" int64_t pna_fused_degree_image_bytes(int32_t F, int32_t N) {
   return (int64_t)shape_chunks(F) * kChunkV * 16;
 }
 
+static int64_t tower_image_bytes(int F, int N) {
+  if (pna_fused_degree_image_bytes(F, N) == 0 || shape_full(F) != 2) return 0;
+  return (int64_t)(shape_chunks(F) + 2 * shape_full(F) + (shape_half(F) ? 1 : 0)) * kChunkV * 16;
+}
+extern "C" int64_t pna_fused_tower_image_bytes(int32_t F, int32_t N) { return tower_image_bytes(F, N); }
+
+extern "C" int pna_fused_tower_pack_f32(const float* w_ref, int64_t ldw, int32_t N, int32_t F, int32_t n_scaler, const float* scale,
+                                        int32_t n_img, void* img, pna_stream_t stream) {
+  if (!w_ref || !img || n_img < 1 || n_scaler < 1 || n_scaler > PNA_MAX_SCALER || tower_image_bytes(F, N) == 0 ||
+      ldw < (int64_t)n_scaler * 5 * F || (n_scaler > 1 && !scale))
+    return pna_set_error(PNA_E_INVALID, "pna_fused_tower_pack_f32: bad arguments (49 <= F <= 80, 4 <= N <= 80, ldw >= n_scaler * 5 F, scale required for n_scaler > 1)");
+  const int64_t elems = tower_image_bytes(F, N) / 2 * n_img;
+  const int blocks = (int)((elems + 255) / 256 > 8192 ? 8192 : (elems + 255) / 256);
+  hipLaunchKernelGGL(k_pack_fused_degree, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ref, (long)ldw, N, F, n_scaler, scale, n_img,
+                     (unsigned short*)img, 1);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
+  return PNA_OK;
+}
+
 extern "C" int pna_fused_degree_pack_f32(const float* w_ref, int64_t ldw, int32_t N, int32_t F, int32_t n_scaler, const float* scale,
                                          int32_t n_img, void* img, pna_stream_t stream) {
   if (!w_ref || !img || n_img < 1 || n_scaler < 1 || n_scaler > PNA_MAX_SCALER || pna_fused_degree_image_bytes(F, N) == 0 ||
@@ -582,7 +704,7 @@ extern "C" int pna_fused_degree_pack_f32(const float* w_ref, int64_t ldw, int32_
   const int64_t elems = pna_fused_degree_image_bytes(F, N) / 2 * n_img;
   const int blocks = (int)((elems + 255) / 256 > 8192 ? 8192 : (elems + 255) / 256);
   hipLaunchKernelGGL(k_pack_fused_degree, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ref, (long)ldw, N, F, n_scaler, scale, n_img,
-                     (unsigned short*)img);
+                     (unsigned short*)img, 0);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
   return PNA_OK;
@@ -611,6 +733,16 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
   if ((p->col_scale == nullptr) != (p->col_shift == nullptr))
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: col_scale and col_shift come together");
   if (p->agg_out && p->ld_agg < 4 * (int64_t)p->F) return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: ld_agg < 4 F");
+  const bool tower = p->x_dst || p->h_self || p->row_post;
+  if (tower) {
+    if (!p->x_dst || !p->h_self || !p->row_post || p->agg_out || tower_image_bytes(p->F, p->N) == 0)
+      return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: tower mode takes x_dst, h_self and row_post together, 49 <= F <= 80, no agg_out");
+    if (p->ld_xdst < need || p->ld_xdst % 4 != 0 || ((uintptr_t)p->x_dst & 15) != 0 || p->ld_h < need || p->ld_h % 4 != 0 || ((uintptr_t)p->h_self & 15) != 0 ||
+        p->n_nodes >= (1 << 24) || p->n_nodes * p->ld_xdst * 4 >= (1ll << 32) || p->n_nodes * p->ld_h * 4 >= (1ll << 32))
+      return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: x_dst / h_self must be 16-byte aligned (n_nodes, F) tables below 4 GiB with a row pitch like x's");
+    if (p->residual && (((uintptr_t)p->residual & 15) != 0 || p->ld_res % 4 != 0))
+      return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: tower mode reads the residual in 16-byte pieces: 16-byte aligned, ld_res a multiple of 4");
+  }
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
     return pna_set_error(PNA_E_NODEVICE, "pna_fused_degree_f32: no device");
@@ -622,6 +754,7 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
   g.ldyb = (unsigned)(p->ldy * 4); g.ldrb = p->residual ? (unsigned)(p->ld_res * 4) : 0u;
   g.M = (int)p->M; g.N = p->N; g.relu = p->relu; g.slope = p->relu == 2 ? p->act_slope : 0.f;
   g.agg_out = p->agg_out; g.ld_agg = p->ld_agg;
+  g.xd = p->x_dst; g.xh = p->h_self; g.row_post = p->row_post; g.lddb = (unsigned)(p->ld_xdst * 4); g.ldhb = (unsigned)(p->ld_h * 4);
 #ifdef PNA_AMD_EXPERIMENTS
   if (const char* e = getenv("PNA_FD_DBG_PTR")) g.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // device buffer: 4 counters per wavefront
   if (const char* e = getenv("PNA_FD_ABL")) g.abl = atoi(e);

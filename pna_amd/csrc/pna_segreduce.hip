@@ -452,6 +452,7 @@ struct FArgs {
                           //                 slot >= 0 -> heavy segment: raw partials to partials[slot]
   const int32_t* col; const float* x; float* out; float* partials;
   const float* dst;       // per-destination additive term (the h_dst half of a factorised pretrans), DST kernels only
+  const int32_t* orow;    // OROW kernels: output row of node v's aggregate (pna_segreduce_args.out_row_of)
   long ldo, ts_out;
   unsigned ldb, ts_in_b;  // x row pitch / tower stride in bytes
   unsigned ldd_b;         // dst_term row pitch in bytes
@@ -506,7 +507,9 @@ __device__ __forceinline__ void fast_batch(const float* x, AccF& acc, int idx, i
 // item r's gathers; VMEM returns in order, so once the wave has waited for any gather of item r they have landed.
 // DST: message = x[src] + dst_term[row] (the tower layers: models/dgl/pna_layer.py:35-40 with the 1-layer pretrans
 // factorised to node level).  The row's term is one more dwordx4 per lane, fetched one item ahead like the source ids.
-template <int U, bool DST>
+// OROW (with DST): a whole-row record's aggregate goes to row out_row_of[row] of `out` (the record's `row` stays the node: the
+// dst_term needs it) -- the tower layers' aggregate written in degree order (ABI 12).  Fetched one item ahead like the ids.
+template <int U, bool DST, bool OROW = false>
 __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -555,9 +558,12 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
   ids_of(idx_c, cur);
   f4 dt_c = (f4){0.f, 0.f, 0.f, 0.f};
   if constexpr (DST) dst_of(dt_c, cur);
+  int orow_c = 0;
+  if constexpr (OROW) aload32(orow_c, a.orow, (unsigned)cur.x * 4u);
   i4 nxt;
   issue_item(nxt, min(base + NG, last));
-  if constexpr (DST) asm volatile("s_waitcnt vmcnt(0)" : "+v"(idx_c), "+v"(nxt), "+v"(dt_c) : : "memory");
+  if constexpr (OROW) asm volatile("s_waitcnt vmcnt(0)" : "+v"(idx_c), "+v"(nxt), "+v"(dt_c), "+v"(orow_c) : : "memory");
+  else if constexpr (DST) asm volatile("s_waitcnt vmcnt(0)" : "+v"(idx_c), "+v"(nxt), "+v"(dt_c) : : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" : "+v"(idx_c), "+v"(nxt) : : "memory");
 
   AccF acc;
@@ -570,6 +576,8 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
     f4 dt_n = (f4){0.f, 0.f, 0.f, 0.f};
     ids_of(idx_n, nxt);
     if constexpr (DST) dst_of(dt_n, nxt);
+    int orow_n = 0;
+    if constexpr (OROW) aload32(orow_n, a.orow, (unsigned)nxt.x * 4u);
     issue_item(nn, min(item + 2 * NG, last));
     // ---- this item
     const int row = cur.x, beg = cur.y, end = cur.z, slot = cur.w;
@@ -587,7 +595,7 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
     }
     if (lane_ok && PNA_STORES_ON(a, acc.s.x)) {
       if (slot < 0) {
-        fast_finalize_store(a, acc, row, end - beg, offo);
+        fast_finalize_store(a, acc, OROW ? orow_c : row, end - beg, offo);
       } else {                                               // heavy segment: raw (s, q, max, min) to the workspace
         typedef f4 f4a4 __attribute__((aligned(4)));
         float* p = a.partials + ((size_t)slot * a.T + tower) * kNQ * a.pstride + off;
@@ -602,6 +610,7 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
     if (__builtin_amdgcn_ballot_w64(end > beg) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("" : "+v"(idx_n), "+v"(nn));                 // anchor: consumers cannot move above this point
     if constexpr (DST) { asm volatile("" : "+v"(dt_n)); dt_c = dt_n; }
+    if constexpr (OROW) { asm volatile("" : "+v"(orow_n)); orow_c = orow_n; }
     idx_c = idx_n; cur = nxt; nxt = nn;
   }
 }
@@ -840,10 +849,15 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
     f.n_items = p->n_work_items; f.n_edges = (int)p->n_edges; f.F = p->F; f.L = k.L; f.G = k.G; f.R = k.R; f.T = T; f.tiles = tiles;
     f.pstride = k.pstride; f.block_stride = p->block_stride; f.nt = k.nt; f.dbg = k.dbg;
     f.dst = p->dst_term; f.ldd_b = (unsigned)(p->ld_dst * 4);
+    f.orow = p->out_row_of;
+    if (p->out_row_of && !(p->dst_term && U == 4))
+      return pna_set_error(PNA_E_INVALID, "pna_segreduce_fwd_f32: out_row_of is honoured with dst_term and the default unroll only (without dst_term the work list's row field is the output row)");
     const long fb = (p->n_work_items + rows_per_block - 1) / rows_per_block;
     dim3 fgrid((unsigned)fb, (unsigned)(tiles * T));
     const unsigned dyn_lds = (unsigned)(k.dbg >> 8) * 1024u;   // 0 in the shipped build
-    if (p->dst_term) {
+    if (p->dst_term && p->out_row_of) {
+      hipLaunchKernelGGL((k_segreduce_fast<4, true, true>), fgrid, dim3(kBlock), dyn_lds, st, f);
+    } else if (p->dst_term) {
       switch (U) {
         case 2: hipLaunchKernelGGL((k_segreduce_fast<2, true>), fgrid, dim3(kBlock), dyn_lds, st, f); break;
         case 3: hipLaunchKernelGGL((k_segreduce_fast<3, true>), fgrid, dim3(kBlock), dyn_lds, st, f); break;

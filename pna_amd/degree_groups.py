@@ -87,7 +87,7 @@ class DegreePlan:
         self.heavy_out = vmap[hs.heavy_rows.long()].to(torch.int32).contiguous() if hs.n_heavy > 0 else None
         self.rows = self.NV + self.NRp
         self._rest_scales = {}
-        self._fused, self._rest_items = None, None
+        self._fused, self._rest_items, self._vmap32, self._perm_all, self._rest_items_node, self._ones_rows = None, None, None, None, None, None
         self._deg, self._csr = deg, csr
 
     def fused_tables(self):
@@ -126,6 +126,18 @@ class DegreePlan:
             self._fused = (desc, ids, total)
         return self._fused
 
+    def vmap32(self):
+        """int32 [V]: row of the plan-ordered aggregate buffer that holds node v (pna_segreduce_args.out_row_of)."""
+        if self._vmap32 is None:
+            self._vmap32 = self._vmap.to(torch.int32).contiguous()
+        return self._vmap32
+
+    def perm_all(self):
+        """int32 [rows]: node of every row of the plan-ordered buffer (degree tiles, then the rest), padding rows -> node 0."""
+        if self._perm_all is None:
+            self._perm_all = torch.cat([self.perm, self.perm_rest]).clamp(min=0).contiguous()
+        return self._perm_all
+
     def rest_items(self, graph):
         """(work list, heavy_out, heavy schedule) of the rows no degree group holds, output rows counted from the start of the rest
         region: the gather of the one-kernel layer's leftover rows (pna_fused_degree_f32 takes the group rows).  The hub rows are
@@ -143,6 +155,26 @@ class DegreePlan:
             hout = (self._vmap[hs.heavy_rows.long()] - self.NV).to(torch.int32).contiguous() if hs.n_heavy > 0 else None
             self._rest_items = (items, hout, hs)
         return self._rest_items
+
+    def ones_rows(self):
+        """float32 [NV] of ones: the per-row factor of a layer without graph norm."""
+        if self._ones_rows is None:
+            self._ones_rows = torch.ones(self.NV, dtype=torch.float32, device=self.perm.device)
+        return self._ones_rows
+
+    def rest_items_by_node(self, graph):
+        """rest_items() for a gather that needs the NODE of every row (the tower layers' destination term): the work list keeps
+        the node in column 0 and the output row comes from a per-node table (pna_segreduce_args.out_row_of), counted from the start
+        of the rest region."""
+        if self._rest_items_node is None:
+            _, hout, hs = self.rest_items(graph)
+            it = graph.work_items(seg_len=REST_SEG_LEN)
+            n_seg = hs.n_seg if hs.n_heavy > 0 else 0
+            rows = it[n_seg:]
+            light = rows[self._vmap[rows[:, 0].long()] >= self.NV]
+            items = torch.cat([it[:n_seg], light], dim=0).contiguous() if n_seg else light.contiguous()
+            self._rest_items_node = (items, (self._vmap - self.NV).to(torch.int32).contiguous(), hout, hs)
+        return self._rest_items_node
 
     def split_items(self, graph):
         """(interior, boundary) work lists of a sharded graph (HaloGraph.split_work_lists: the rows that read only local
@@ -232,18 +264,25 @@ def combined_images(weight, K, row_scales, plan):
     return img, stride
 
 
-def fused_images(weight, F, row_scales, plan):
+def fused_tower_images(weight, F, row_scales, plan):
+    """fused_images() for the tower mode of pna_fused_degree_f32: `weight` (N, S * 5F) in scaler blocks [4F aggregators | F self
+    panel (block 0)] (functional._tower_collapsed_weights with one tower); the pack kernel appends the chunks of the two node
+    panels (pna_fused_tower_pack_f32)."""
+    return fused_images(weight, F, row_scales, plan, tower=True)
+
+
+def fused_images(weight, F, row_scales, plan, tower=False):
     """Packed images of W_D = sum_s s_s(D) W_s for pna_fused_degree_f32 (K in the kernel's chunk order), one per degree group,
     cached on the weight like combined_images.  The combination and the bf16x3 split happen in the pack kernel
     (pna_fused_degree_pack_f32) from the (G, S) matrix of the groups' scaler values."""
     N, G, S = weight.shape[0], plan.G, len(row_scales)
-    key = ("fused", weight._version, weight.data_ptr(), str(weight.device), tuple(weight.shape), F, plan.serial, G,
+    key = ("fused", tower, weight._version, weight.data_ptr(), str(weight.device), tuple(weight.shape), F, plan.serial, G,
            tuple(None if rs is None else (rs.data_ptr(), rs._version) for rs in row_scales))
     hit = getattr(weight, "_pna_amd_fused_img", None)
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
     L = _lib.lib()
-    stride = L.pna_fused_degree_image_bytes(F, N)
+    stride = L.pna_fused_tower_image_bytes(F, N) if tower else L.pna_fused_degree_image_bytes(F, N)
     if stride <= 0:
         raise RuntimeError(f"pna_fused_degree: unsupported shape F={F}, N={N}")
     with torch.no_grad():
@@ -254,9 +293,10 @@ def fused_images(weight, F, row_scales, plan):
         scale = scale.contiguous()
     img = torch.empty(G * stride // 4, dtype=torch.float32, device=weight.device)
     w = weight.detach()
-    rc = L.pna_fused_degree_pack_f32(_lib.dev_ptr(w, torch.float32, "weight"), w.stride(0), N, F, S, _lib.dev_ptr(scale, torch.float32, "scale"),
-                                     G, _lib.dev_ptr(img, torch.float32, "w_img"), _lib.stream_ptr(weight.device))
-    _lib.check(rc, "pna_fused_degree_pack_f32")
+    pack = L.pna_fused_tower_pack_f32 if tower else L.pna_fused_degree_pack_f32
+    rc = pack(_lib.dev_ptr(w, torch.float32, "weight"), w.stride(0), N, F, S, _lib.dev_ptr(scale, torch.float32, "scale"),
+              G, _lib.dev_ptr(img, torch.float32, "w_img"), _lib.stream_ptr(weight.device))
+    _lib.check(rc, "pna_fused_tower_pack_f32" if tower else "pna_fused_degree_pack_f32")
     try:
         weight._pna_amd_fused_img = (key, img, stride)
     except AttributeError:
@@ -266,6 +306,7 @@ def fused_images(weight, F, row_scales, plan):
 
 REST_SEG_LEN = 128         # edges per hub-row segment in the rest launch of the one-kernel layer (see DegreePlan.rest_items)
 REST_ROWS_PER_GROUP = 1    # work items per lane group in that launch (the full-graph gather: 4): a few thousand items must spread over 256 CUs
+TOWERS = True              # the tower layers (PNALayer) through the degree-grouped contraction with collapsed posttrans / mixing weights
 FUSED = True               # gather + contraction in ONE kernel (pna_fused_degree_f32) where it applies; False: the two-kernel grouped path
 MAX_REST_FRACTION = 0.5    # more rest rows than this: the grouping is overhead, the ordinary path takes the graph
 

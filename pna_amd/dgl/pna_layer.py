@@ -139,6 +139,22 @@ def _projection_cache(towers, Fi):
     return hit[1], hit[2]
 
 
+def _projection_cache_padded(tower, Fi, P):
+    """_projection_cache for ONE tower with each half padded to P columns (zero weight rows): x_cat = [x_src | 0 | x_dst | 0],
+    rows and halves 16-byte aligned -- the table the one-kernel tower layer reads in 16-byte strips."""
+    lin = tower.pretrans.fully_connected[0].linear
+    key = tuple((p._version, p.data_ptr(), str(p.device)) for p in (lin.weight, lin.bias)) + (P,)
+    hit = tower.__dict__.get("_pna_amd_proj_pad")
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            W = torch.zeros(2 * P, Fi, dtype=lin.weight.dtype, device=lin.weight.device)
+            b = torch.zeros(2 * P, dtype=lin.weight.dtype, device=lin.weight.device)
+            W[:Fi], W[P:P + Fi], b[P:P + Fi] = lin.weight[:, :Fi], lin.weight[:, Fi:2 * Fi], lin.bias
+        hit = (key, W.contiguous(), b.contiguous())
+        tower.__dict__["_pna_amd_proj_pad"] = hit
+    return hit[1], hit[2]
+
+
 def _towers_forward(towers, graph, h, e, snorm_n, divide_input):
     """Shared body of PNATower.forward / PNALayer.forward: all towers through one gather kernel."""
     t0 = towers[0]
@@ -289,6 +305,26 @@ class PNALayer(nn.Module):
             t0 = self.towers[0]
             return PF.tower_layer_small(self, list(self.towers), self.mixing_network, graph, h, snorm_n,
                                         _row_scales(graph, t0.scalers, t0.avg_d, h.device), self.divide_input, self.residual)
+        if PF.tower_layer_degree_grouped_applies(self, graph, h):
+            # large whole graphs, inference: node-level projections, gather in degree order, ONE grouped contraction for posttrans,
+            # graph norm, BatchNorm and the mixing network (functional.tower_layer_degree_grouped)
+            towers = list(self.towers)
+            T, Fi = len(towers), towers[0].in_dim
+            if PF.tower_layer_degree_fused_applies(self, graph, h):
+                # one tower: everything after the projection in ONE kernel (functional.tower_layer_degree_fused)
+                Wpad, bpad = _projection_cache_padded(towers[0], Fi, PF.tower_projection_pitch(Fi))
+                return PF.tower_layer_degree_fused(self, graph, h, snorm_n, PF.linear_act(h, Wpad, bpad))
+            if self.divide_input:
+                W = torch.stack([t.pretrans.fully_connected[0].linear.weight for t in towers])
+                b = torch.stack([t.pretrans.fully_connected[0].linear.bias for t in towers])
+                hv = h.reshape(h.shape[0], T, Fi)
+                x_src = torch.einsum("vti,tfi->vtf", hv, W[:, :, :Fi]).reshape(h.shape[0], T * Fi)
+                x_dst = (torch.einsum("vti,tfi->vtf", hv, W[:, :, Fi:2 * Fi]) + b).reshape(h.shape[0], T * Fi)
+            else:
+                Wcat, bcat = _projection_cache(towers, Fi)
+                x_cat = PF.linear_act(h, Wcat, bcat)
+                x_src, x_dst = x_cat[:, :T * Fi], x_cat[:, T * Fi:]
+            return PF.tower_layer_degree_grouped(self, graph, h, snorm_n, x_src, x_dst)
         h_cat = _towers_forward(list(self.towers), graph, h, e, snorm_n, self.divide_input)
         mix = self.mixing_network
         if (h_cat.shape[1] >= 4 and isinstance(mix.activation, nn.LeakyReLU) and mix.b_norm is None and (mix.dropout is None or not self.training)

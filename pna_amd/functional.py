@@ -366,6 +366,230 @@ def degree_grouped_posttrans(layer, graph, h, agg, plan, out=None):
     return y
 
 
+def _tower_collapsed_weights(owner, towers, mix, divide_input):
+    """The tower layers' posttrans Linear, graph norm, eval BatchNorm and the mixing Linear have NO non-linearity between them
+    (models/dgl/pna_layer.py:65-75, :141): for all towers t with z_t = [h_t | S a_t],
+        W_m concat_t BN_t(snorm (W_t z_t + b_t)) + b_m  =  snorm (sum_t C_t z_t + d) + c,
+        C_t = W_m[:, t] P_t W_t,   d = sum_t W_m[:, t] P_t b_t,   c = sum_t W_m[:, t] q_t + b_m        (BN_t(u) = P_t u + q_t)
+    -- one contraction of [a_1 .. a_T | h] against the collapsed weight instead of T posttrans contractions, a (V, T Fo)
+    intermediate and a mixing GEMM.  Returned as a virtual nn.Linear weight (out, S * K) in scaler blocks of
+    K = T * 4 Fi + in_dim columns [C_1,s | .. | C_T,s | h panel (block 0 only)], so that the degree-grouped machinery of the simple
+    layer (combined images W_D, three-block rest) applies unchanged; formed in float64, rounded once.  Cached on `owner`."""
+    t0 = towers[0]
+    T, Fi, Fo, S = len(towers), t0.in_dim, t0.out_dim, len(t0.scalers)
+    lins = [t.posttrans.fully_connected[0].linear for t in towers]
+    ts = [p for l in lins for p in (l.weight, l.bias)] + [mix.linear.weight, mix.linear.bias]
+    if t0.batch_norm:
+        ts += [x for t in towers for x in (t.batchnorm_h.weight, t.batchnorm_h.bias, t.batchnorm_h.running_mean, t.batchnorm_h.running_var)]
+    key = tuple((x._version, x.data_ptr(), str(x.device)) for x in ts if x is not None) + (divide_input,)
+    hit = owner.__dict__.get("_pna_amd_collapsed")
+    if hit is not None and hit[0] == key:
+        return hit[1:]
+    with torch.no_grad():
+        Wm = mix.linear.weight.double()
+        out = Wm.shape[0]
+        in_dim = T * Fi if divide_input else Fi
+        K = T * 4 * Fi + in_dim
+        Wv = torch.zeros(out, S * K, dtype=torch.float64, device=Wm.device)
+        d = torch.zeros(out, dtype=torch.float64, device=Wm.device)
+        c = mix.linear.bias.double().clone() if mix.linear.bias is not None else torch.zeros(out, dtype=torch.float64, device=Wm.device)
+        for t, (tower, lin) in enumerate(zip(towers, lins)):
+            if tower.batch_norm:
+                bn = tower.batchnorm_h
+                p = (bn.weight.double() if bn.weight is not None else 1.0) / torch.sqrt(bn.running_var.double() + bn.eps)
+                q = (bn.bias.double() if bn.bias is not None else 0.0) - bn.running_mean.double() * p
+            else:
+                p, q = torch.ones(Fo, dtype=torch.float64, device=Wm.device), torch.zeros(Fo, dtype=torch.float64, device=Wm.device)
+            WmP = Wm[:, t * Fo:(t + 1) * Fo] * p[None, :]
+            C = WmP @ lin.weight.double()                                        # (out, Fi + S * 4 Fi): [h | scaler blocks]
+            if lin.bias is not None:
+                d += WmP @ lin.bias.double()
+            c += Wm[:, t * Fo:(t + 1) * Fo] @ q
+            for s_ in range(S):
+                Wv[:, s_ * K + t * 4 * Fi:s_ * K + (t + 1) * 4 * Fi] = C[:, Fi + s_ * 4 * Fi:Fi + (s_ + 1) * 4 * Fi]
+            hcol = T * 4 * Fi + (t * Fi if divide_input else 0)
+            Wv[:, hcol:hcol + Fi] += C[:, :Fi]                                   # block 0 (the identity scaler's) carries the h panel
+        res = (Wv.float().contiguous(), d.float().contiguous(), c.float().contiguous(), torch.ones(out, dtype=torch.float32, device=Wm.device), K)
+    owner.__dict__["_pna_amd_collapsed"] = (key,) + res
+    return res
+
+
+def tower_layer_degree_grouped_applies(layer, graph, h):
+    """Whether PNALayer.forward (eval) takes the degree-grouped path below: a large whole graph, 1-layer pretrans / posttrans, no
+    edge features, the four standard aggregators, 3 scalers led by `identity`, a LeakyReLU mixing network without batch norm."""
+    from . import degree_groups as DG
+    from .graph import Graph
+    towers = list(layer.towers)
+    t0, mix = towers[0], layer.mixing_network
+    if layer.training or not h.is_cuda or h.dtype != torch.float32 or type(graph) is not Graph or layer.edge_features:
+        return False
+    if not (DG.ENABLED and DG.TOWERS and h.shape[0] >= DG.MIN_ROWS and DG.MIN_OUT <= layer.out_dim <= 128 and t0.in_dim >= 4 and ops.POSTTRANS_ARITH != "f32"):
+        return False
+    if not (tuple(t0.aggregators) == ("mean", "max", "min", "std") and len(t0.scalers) == 3 and t0.scalers[0] == "identity"
+            and isinstance(mix.activation, torch.nn.LeakyReLU) and mix.b_norm is None and mix.linear.bias is not None
+            and all(t.pretrans.is_affine and t.posttrans.is_affine and t.scalers == t0.scalers and t.aggregators == t0.aggregators
+                    and t.graph_norm == t0.graph_norm and t.batch_norm == t0.batch_norm and not t.training for t in towers)):
+        return False
+    if torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in layer.parameters())):
+        return False
+    n_edges = graph.csr.col.numel()
+    if not (0 < n_edges < (1 << 30)) or h.shape[0] >= (1 << 24):
+        return False
+    plan = DG.plan_of(graph)
+    K = len(towers) * 4 * t0.in_dim + layer.in_dim
+    return plan.G > 0 and plan.NR <= DG.MAX_REST_FRACTION * h.shape[0] and plan.rows * DG.agg_pitch(K) * 4 < (1 << 34)
+
+
+def tower_layer_degree_grouped(layer, graph, h, snorm_n, x_src, x_dst):
+    """PNALayer.forward (eval; models/dgl/pna_layer.py:130-145 over :55-76) after the node-level projections: the gather writes
+    every tower's aggregate in DEGREE order (pna_segreduce_args.out_row_of), the rows' own features are copied behind it, and ONE
+    degree-grouped contraction per row class (combined block W_D over the degree tiles, three scaler blocks over the rest) applies
+    the collapsed posttrans . graph norm . BatchNorm . mixing weight (see _tower_collapsed_weights) with LeakyReLU and the
+    residual in its epilogue."""
+    from . import degree_groups as DG
+    from .dgl.pna_layer import _row_scales
+    towers, mix = list(layer.towers), layer.mixing_network
+    t0 = towers[0]
+    T, Fi = len(towers), t0.in_dim
+    V, dev = h.shape[0], h.device
+    plan = DG.plan_of(graph)
+    Wv, d, c, ones, K = _tower_collapsed_weights(layer, towers, mix, layer.divide_input)
+    N = Wv.shape[0]
+    Ka = T * 4 * Fi
+    buf = torch.empty(plan.rows, DG.agg_pitch(K), dtype=torch.float32, device=dev)
+    csr = graph.csr
+    ops.segreduce(csr.rowptr, csr.col, _unit_stride(x_src), Fi, t0.aggregators, (None,), n_tower=T, tower_stride_in=Fi, dst_term=_unit_stride(x_dst),
+                  out=buf, tower_stride_out=4 * Fi, heavy=graph.heavy_schedule(), workspace=graph.workspace, items=graph.work_items(),
+                  out_row_of=plan.vmap32(), heavy_out=plan.heavy_out, tune=dict(generic=2))
+    hc = _unit_stride(h)
+    ops.pack_rows(hc, plan.perm_all(), out=buf[:, Ka:Ka + hc.shape[1]])
+    scales = _row_scales(graph, t0.scalers, t0.avg_d, dev)
+    y = torch.empty(V, N, dtype=torch.float32, device=dev)
+    res = hc if layer.residual else None
+    slope = float(mix.activation.negative_slope)
+    post_g = post_r = None
+    if t0.graph_norm and snorm_n is not None:
+        sn = snorm_n.reshape(-1).to(torch.float32)
+        idx = plan.perm_all().long()
+        post = sn[idx]
+        post_g, post_r = post[:plan.NV].contiguous(), post[plan.NV:].contiguous()
+    if plan.G:
+        img, stride = DG.combined_images(Wv, K, scales, plan)
+        ops.posttrans(buf[:plan.NV, :K], K, Wv, [None], d, out=y, row_post=post_g, col_scale=ones, col_shift=c, leaky_slope=slope, residual=res,
+                      row_perm=plan.perm, tile_image=plan.tile_image, w_img=img, image_stride=stride, n_out=N)
+    if plan.NR:
+        from .dgl.pna_layer import _avg_log_value
+        rest_scales = plan.rest_scales(tuple(t0.scalers) + (_avg_log_value(t0.avg_d),), scales)
+        if N <= 80:
+            ops.posttrans(buf[plan.NV:, :K], K, Wv, rest_scales, d, out=y, row_post=post_r, col_scale=ones, col_shift=c, leaky_slope=slope,
+                          residual=res, row_perm=plan.perm_rest, n_out=N)
+        else:
+            rr = plan.rest_rows
+            y_r = ops.posttrans(buf[plan.NV:plan.NV + plan.NR, :K], K, Wv, [None if r is None else r[:plan.NR] for r in rest_scales], d,
+                                row_post=None if post_r is None else post_r[:plan.NR], col_scale=ones, col_shift=c, leaky_slope=slope,
+                                residual=None if res is None else res.index_select(0, rr), arith="bf16x3")
+            y.index_copy_(0, rr, y_r)
+    return y
+
+
+def tower_projection_pitch(Fi):
+    """Column pitch of one half of the [x_src | x_dst] table the one-kernel tower layer gathers from: rows 16-byte aligned, the
+    last strip inside the half."""
+    return (Fi + 7) // 8 * 8
+
+
+def tower_layer_degree_fused_applies(layer, graph, h):
+    """Whether the grouped tower path runs its group rows through pna_fused_degree_f32's tower mode: ONE tower of 49..80
+    features, at most 80 outputs, features the kernel can read in 16-byte pieces."""
+    from . import degree_groups as DG
+    towers = list(layer.towers)
+    Fi = towers[0].in_dim
+    if not (DG.FUSED and len(towers) == 1 and 49 <= Fi <= 80 and layer.in_dim == Fi and 4 <= layer.out_dim <= 80):
+        return False
+    if not DG.fused_applies(graph, h, Fi, layer.out_dim):
+        return False
+    return h.shape[0] * 2 * tower_projection_pitch(Fi) * 4 < (1 << 32)
+
+
+class FusedTowerCall:
+    """One PNALayer forward (ONE tower; eval) on the one-kernel path after the node-level projection, cut into its launches like
+    FusedDegreeCall: `group_rows()` = pna_fused_degree_f32 in tower mode, `rest_rows()` = gather with the destination term + the
+    rows' own features + three-block contraction over the compact list of the rows no degree group holds."""
+
+    def __init__(self, layer, graph, h, snorm_n, x_cat):
+        from . import _lib, degree_groups as DG
+        from .dgl.pna_layer import _row_scales
+        import ctypes
+        towers, mix = list(layer.towers), layer.mixing_network
+        t0 = towers[0]
+        Fi, V, dev = t0.in_dim, h.shape[0], h.device
+        P = x_cat.shape[1] // 2
+        self.layer, self.graph, self.plan, self.t0 = layer, graph, DG.plan_of(graph), t0
+        plan = self.plan
+        self.Wv, self.d, self.c, self.ones, self.K = Wv, d, c, ones, K = _tower_collapsed_weights(layer, towers, mix, layer.divide_input)
+        N = Wv.shape[0]
+        self.x_src, self.x_dst, self.h = x_cat[:, :Fi], x_cat[:, P:P + Fi], h
+        self.scales = scales = _row_scales(graph, t0.scalers, t0.avg_d, dev)
+        self.y = y = torch.empty(V, (N + 3) // 4 * 4, dtype=torch.float32, device=dev)[:, :N]
+        self.res = res = h if layer.residual else None
+        self.slope = float(mix.activation.negative_slope)
+        if t0.graph_norm and snorm_n is not None:
+            post = snorm_n.reshape(-1).to(torch.float32)[plan.perm_all().long()]
+            self.post_g, self.post_r = post[:plan.NV].contiguous(), post[plan.NV:].contiguous()
+        else:
+            self.post_g, self.post_r = plan.ones_rows(), None
+        desc, ids, n_rec = plan.fused_tables()
+        img, stride = DG.fused_tower_images(Wv, Fi, scales, plan)
+        self.keep = (desc, ids, img, x_cat)
+        a = _lib.PnaFusedDegreeArgs()
+        a.tile_desc, a.tile_ids, a.n_records = _lib.dev_ptr(desc, torch.int32, "tile_desc"), _lib.dev_ptr(ids, torch.int32, "tile_ids"), n_rec
+        a.x, a.ldx, a.x_rows, a.F, a.N = _lib.dev_ptr(self.x_src, torch.float32, "x_src"), x_cat.stride(0), V, Fi, N
+        a.x_dst, a.ld_xdst = _lib.dev_ptr(self.x_dst, torch.float32, "x_dst"), x_cat.stride(0)
+        a.h_self, a.ld_h = _lib.dev_ptr(h, torch.float32, "h"), h.stride(0)
+        a.row_post = _lib.dev_ptr(self.post_g, torch.float32, "row_post")
+        a.row_perm, a.M, a.n_nodes = _lib.dev_ptr(plan.perm, torch.int32, "row_perm"), plan.NV, V
+        a.w_img, a.image_stride = _lib.dev_ptr(img, torch.float32, "w_img"), stride
+        a.bias = _lib.dev_ptr(d, torch.float32, "bias")
+        a.col_scale, a.col_shift = _lib.dev_ptr(ones, torch.float32, "col_scale"), _lib.dev_ptr(c, torch.float32, "col_shift")
+        if res is not None:
+            a.residual, a.ld_res = _lib.dev_ptr(res, torch.float32, "residual"), res.stride(0)
+        a.y, a.ldy, a.relu, a.act_slope = _lib.dev_ptr(y, torch.float32, "y"), y.stride(0), 2, self.slope
+        self.args, self.ref = a, ctypes.byref(a)
+        self.fn, self.check, self.stream = _lib.lib().pna_fused_degree_f32, _lib.check, _lib.stream_ptr(dev)
+
+    def group_rows(self):
+        self.check(self.fn(self.ref, self.stream), "pna_fused_degree_f32")
+        return self.y
+
+    def rest_rows(self):
+        plan, graph, t0 = self.plan, self.graph, self.t0
+        if plan.NR:
+            from . import degree_groups as DG
+            from .dgl.pna_layer import _avg_log_value
+            Fi, K, N = t0.in_dim, self.K, self.Wv.shape[0]
+            items, orow, hout, hs = plan.rest_items_by_node(graph)
+            agg = torch.empty(plan.NRp, DG.agg_pitch(K), dtype=torch.float32, device=self.y.device)
+            csr = graph.csr
+            ops.segreduce(csr.rowptr, csr.col, self.x_src, Fi, t0.aggregators, (None,), n_tower=1, tower_stride_in=Fi, dst_term=self.x_dst,
+                          out=agg, tower_stride_out=4 * Fi, heavy=hs, workspace=graph.workspace, items=items, out_row_of=orow, heavy_out=hout,
+                          tune=dict(generic=2, rows_per_group=DG.REST_ROWS_PER_GROUP))
+            ops.pack_rows(_unit_stride(self.h), plan.perm_all()[plan.NV:], out=agg[:, 4 * Fi:5 * Fi])
+            rest_scales = plan.rest_scales(tuple(t0.scalers) + (_avg_log_value(t0.avg_d),), self.scales)
+            ops.posttrans(agg[:, :K], K, self.Wv, rest_scales, self.d, out=self.y, row_post=self.post_r, col_scale=self.ones, col_shift=self.c,
+                          leaky_slope=self.slope, residual=self.res, row_perm=plan.perm_rest, n_out=N)
+        return self.y
+
+
+def tower_layer_degree_fused(layer, graph, h, snorm_n, x_cat):
+    """PNALayer.forward (eval, ONE tower; models/dgl/pna_layer.py:130-145 over :33-76) after the node-level projection
+    x_cat = [x_src | x_dst] (halves of tower_projection_pitch columns): gather over x_src, the destination term, the row's own
+    features, the collapsed posttrans . graph norm . BatchNorm . mixing weight, LeakyReLU and the residual in ONE kernel for the
+    rows of the degree groups; the aggregate never reaches HBM."""
+    call = FusedTowerCall(layer, graph, h, snorm_n, x_cat)
+    call.group_rows()
+    return call.rest_rows()
+
+
 class FusedDegreeCall:
     """One PNASimpleLayer forward on the one-kernel path, cut into its two launches so that bench.py can time them apart:
     `group_rows()` = pna_fused_degree_f32 (99.6 % of the benchmark graph's rows), `rest_rows()` = gather + three-block contraction

@@ -42,7 +42,7 @@ def segreduce(rowptr: torch.Tensor, col: Optional[torch.Tensor], x: torch.Tensor
               out: Optional[torch.Tensor] = None, block_stride: Optional[int] = None,
               tower_stride_out: Optional[int] = None, want_arg: bool = False,
               heavy: Optional[HeavySchedule] = None, workspace=None, tune: Optional[dict] = None,
-              items: Optional[torch.Tensor] = None, heavy_out: Optional[torch.Tensor] = None):
+              items: Optional[torch.Tensor] = None, heavy_out: Optional[torch.Tensor] = None, out_row_of: Optional[torch.Tensor] = None):
     """out[v, t*tso + (s*A + a)*bs + f] = aggregators[a]({m_k}) [f] * row_scales[s][v]   (see pna_amd.h).
 
     rowptr:int32[V+1]; col:int32[E] or None (x edge-resident); x:(rows, >= T*F) fp32.
@@ -85,6 +85,8 @@ def segreduce(rowptr: torch.Tensor, col: Optional[torch.Tensor], x: torch.Tensor
         a.argmax, a.argmin, a.ld_arg = (_lib.dev_ptr(argmax, torch.int32, "argmax"),
                                         _lib.dev_ptr(argmin, torch.int32, "argmin"), _ld(argmax))
     keep = None
+    if out_row_of is not None:                     # with dst_term: output row of every node (ABI 12)
+        a.out_row_of = _lib.dev_ptr(out_row_of, torch.int32, "out_row_of")
     if heavy is not None and heavy.n_heavy > 0:
         a.heavy_threshold, a.seg_len, a.n_heavy, a.n_seg = heavy.threshold, heavy.seg_len, heavy.n_heavy, heavy.n_seg
         a.heavy_rows = _lib.dev_ptr(heavy.heavy_rows, torch.int32, "heavy_rows")

@@ -19,6 +19,7 @@ CSRC = os.path.join(ROOT, "pna_amd", "csrc")
                                                                     "k_posttrans_x3ILi3ELb0ELi80ELi5ELi1ELi12ELi3ELb0ELb1EEE": 168}), ("pna_segreduce.hip", {"k_segreduce_fastILi4E": 80}),
                                           ("pna_posttrans.hip", {}), ("pna_pack.hip", {}),
                                           # the one-kernel layer: two 4-wavefront workgroups per CU (the production instantiations: DUMP = false)
+                                          # (incl. the tower instantiations ...ELb0ELb1ELb0EEE of the two-full-block shapes)
                                           ("pna_fused_degree.hip", {"k_fused_degreeILi1ELb0ELb0E": 256, "k_fused_degreeILi1ELb1ELb0E": 256,
                                                                     "k_fused_degreeILi2ELb0ELb0E": 256, "k_fused_degreeILi2ELb1ELb0E": 256})])
 def test_no_kernel_uses_scratch(src, max_vgpr, tmp_path):
@@ -43,6 +44,14 @@ def test_no_kernel_uses_scratch(src, max_vgpr, tmp_path):
     for key, lim in max_vgpr.items():
         over = [(n, v) for n, v in zip(names, vgprs) if key in n and v > lim]
         assert not over, over[:5]
+    # every inline-asm memory instruction of every kernel: no SGPR operand written by a VALU instruction (an SGPR-spill reload)
+    # fewer than five wait states before it (tools/isa_audit.py::sgpr_hazards; hipcc does not check inside inline asm)
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_audit
+    for n in names:
+        haz = isa_audit.sgpr_hazards(isa_audit.kernel_lines(str(tmp_path / "out.s"), n))
+        assert not haz, (n, haz[:5])
 
 
 def test_one_kernel_layer_never_touches_a_register_in_flight(tmp_path):
@@ -60,7 +69,12 @@ def test_one_kernel_layer_never_touches_a_register_in_flight(tmp_path):
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
                     "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "pna_fused_degree.hip")], check=True, capture_output=True)
     names = sorted(set(re.findall(r"^(_ZN\S*k_fused_degreeI\S+?):", open(out).read(), flags=re.M)))
-    assert len(names) == 8, names
+    assert len(names) == 10, names                         # 4 shapes x (production, verification) + 2 tower shapes
     for n in names:
-        probs = isa_audit.audit(isa_audit.kernel_lines(out, n))
+        kl = isa_audit.kernel_lines(out, n)
+        probs = isa_audit.audit(kl)
         assert not probs, (n, probs[:5])
+        # ... nor hands an inline-asm memory instruction an SGPR (a base pointer) that a VALU instruction -- the v_readlane_b32 of
+        # an SGPR-spill reload -- wrote fewer than five wait states before: hipcc's hazard recognizer does not look inside inline asm
+        haz = isa_audit.sgpr_hazards(kl)
+        assert not haz, (n, haz[:5])

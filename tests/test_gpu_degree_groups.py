@@ -207,3 +207,142 @@ def test_grouped_path_on_a_graph_without_any_group(cuda_device):
         DG.ENABLED, DG.MIN_ROWS = keep
         PF.SMALL_SIMPLE_ROWS = keep_small
     assert (y_grouped - y_plain).abs().max().item() <= 2e-6 * y_plain.abs().max().item()
+
+
+def _pitched(x, mult=4):
+    """The same values in rows of a pitch that is a multiple of `mult` floats (what the one-kernel paths read in 16-byte strips)."""
+    P = (x.shape[1] + mult - 1) // mult * mult
+    buf = torch.full((x.shape[0], P), float("nan"), dtype=x.dtype, device=x.device)
+    buf[:, :x.shape[1]] = x
+    return buf[:, :x.shape[1]]
+
+
+@pytest.mark.parametrize("path", ["one-kernel", "degree-grouped", "ordinary"])
+@pytest.mark.parametrize("name", __import__("conftest").golden_names("dgl_tower_groups"))
+def test_grouped_tower_layer_vs_reference_golden(cuda_device, name, path):
+    """The REFERENCE's own PNALayer output (towers, graph norm, BatchNorm, mixing network; oracle/make_golden_degree_groups.py) on
+    graphs with degree tiles: through the degree-grouped tower path -- gather in degree order, ONE contraction with the collapsed
+    posttrans . BatchNorm . mixing weight (functional.tower_layer_degree_grouped) -- and through the ordinary kernels."""
+    from conftest import load_golden
+    from pna_amd import Graph, degree_groups as DG, functional as PF
+    from pna_amd.dgl.pna_layer import PNALayer
+    meta, a, sd = load_golden(name)
+    layer = PNALayer(meta["in_dim"], meta["out_dim"], meta["aggregators"], meta["scalers"], {"log": a["avg_log"]}, 0.0, meta["graph_norm"],
+                     meta["batch_norm"], towers=meta["towers"], pretrans_layers=1, posttrans_layers=1, divide_input=meta["divide_input"],
+                     residual=meta["residual"], edge_features=False, edge_dim=0)
+    layer.load_state_dict(sd)
+    layer = layer.to(cuda_device).eval()
+    g = Graph(a["src"].long(), a["dst"].long(), meta["N"], meta["sizes"]).to(cuda_device)
+    h, snorm = a["h"].to(cuda_device), a["snorm_n"].to(cuda_device)
+    one = path == "one-kernel"
+    if one and not (meta["towers"] == 1 and 49 <= meta["in_dim"] <= 80 and meta["out_dim"] <= 80):
+        pytest.skip("the one-kernel tower layer takes ONE tower of 49..80 features")
+    if one:
+        h = _pitched(h)                                   # (pitch 75 rows are not 16-byte aligned: the path would decline)
+    keep = (DG.ENABLED, DG.MIN_ROWS, DG.MIN_OUT, PF.SMALL_TOWER_ROWS, DG.FUSED)
+    DG.ENABLED, DG.MIN_ROWS, DG.MIN_OUT, PF.SMALL_TOWER_ROWS, DG.FUSED = path != "ordinary", 1, 1, 0, one
+    try:
+        with torch.no_grad():
+            assert PF.tower_layer_degree_grouped_applies(layer, g, h) == (path != "ordinary")
+            if path != "ordinary":
+                assert PF.tower_layer_degree_fused_applies(layer, g, h) == one
+            out = layer(g, h, None, snorm).cpu()
+        if path != "ordinary":
+            plan = DG.plan_of(g)
+            assert plan.G > 0 and plan.NR > 0
+    finally:
+        DG.ENABLED, DG.MIN_ROWS, DG.MIN_OUT, PF.SMALL_TOWER_ROWS, DG.FUSED = keep
+    # 1e-5 relative + 1e-5 absolute, plus -- for the few elements where a row's terms cancel -- 4 x the REFERENCE's own fp32 error on
+    # that row (its fp32 output against the oracle's float64 evaluation of the same formulas): the collapsed weight rounds the two
+    # Linears' product once where the reference rounds twice, neither is closer to the exact value
+    from oracle import torch_oracle as O
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    ref64 = O.dgl_layer_forward(sd64, a["src"].long(), a["dst"].long(), meta["N"], a["h"].double(), torch.zeros(a["src"].numel(), 0, dtype=torch.float64),
+                                a["snorm_n"].double(), meta["aggregators"].split(), meta["scalers"].split(), a["avg_log"].double(), meta["towers"],
+                                meta["divide_input"], meta["graph_norm"], meta["batch_norm"], meta["residual"], False)
+    floor = 4.0 * (a["out"].double() - ref64).abs().max(dim=1, keepdim=True).values
+    err = (out.double() - a["out"].double()).abs()
+    plain = 1e-5 * a["out"].double().abs() + 1e-5
+    assert bool((err <= plain + floor).all()), float((err - plain - floor).max())
+    assert (err <= plain).double().mean().item() >= 0.999
+
+
+@pytest.mark.parametrize("T,Fi,out,divide", [(1, 75, 75, False), (5, 75, 75, False), (4, 16, 64, True)])
+def test_grouped_tower_layer_equals_ordinary_kernels(cuda_device, T, Fi, out, divide):
+    from pna_amd import Graph, degree_groups as DG, functional as PF
+    from pna_amd.dgl.pna_layer import PNALayer
+    from pna_amd.synth import powerlaw_graph
+    V, E = 150_000, 1_200_000
+    src, dst = powerlaw_graph(V, E, seed=T + Fi, device=cuda_device)
+    sizes = [V // 2, V - V // 2]
+    g = Graph(src, dst, V, sizes)
+    in_dim = T * Fi if divide else Fi
+    torch.manual_seed(T)
+    layer = PNALayer(in_dim, out, "mean max min std", "identity amplification attenuation", {"log": torch.tensor(2.2)}, 0.0, True, True,
+                     towers=T, divide_input=divide, residual=in_dim == out).to(cuda_device).eval()
+    with torch.no_grad():
+        for t in layer.towers:
+            t.batchnorm_h.running_mean.normal_()
+            t.batchnorm_h.running_var.uniform_(0.5, 2.0)
+    h = torch.randn(V, in_dim, device=cuda_device)
+    snorm = g.snorm_n()
+    keep = (DG.ENABLED, DG.MIN_ROWS, DG.MIN_OUT, PF.SMALL_TOWER_ROWS)
+    DG.MIN_ROWS, DG.MIN_OUT, PF.SMALL_TOWER_ROWS = 1, 1, 0
+    try:
+        with torch.no_grad():
+            DG.ENABLED = True
+            assert PF.tower_layer_degree_grouped_applies(layer, g, h)
+            y_g = layer(g, h, None, snorm)
+            assert torch.equal(layer(g, h, None, snorm), y_g)
+            DG.ENABLED = False
+            y_p = layer(g, h, None, snorm)
+    finally:
+        DG.ENABLED, DG.MIN_ROWS, DG.MIN_OUT, PF.SMALL_TOWER_ROWS = keep
+    assert torch.isfinite(y_g).all()
+    assert (y_g - y_p).abs().max().item() <= 1e-5 * y_p.abs().max().item()       # (two Linears collapsed into one: rounded differently)
+
+
+@pytest.mark.parametrize("Fi,out,gn,bn,res", [(75, 75, True, True, True), (64, 64, False, True, True), (80, 48, True, False, False),
+                                              (49, 80, True, True, False), (56, 20, False, False, False), (72, 72, True, True, True)])
+def test_one_kernel_tower_layer_equals_two_kernel_grouped_path(cuda_device, Fi, out, gn, bn, res):
+    """pna_fused_degree_f32 in tower mode (gather over x_src, destination term and self features as extra K panels) against the
+    two-kernel grouped path (gather with the destination term added per edge -> aggregate in HBM -> grouped contraction), which
+    the reference goldens pin: same collapsed weight, bf16x3 arithmetic in both; they differ in WHERE x_dst is added (after the
+    statistics instead of per edge) and in the summation order over K.  Every shape class: half block or not, partial column
+    windows, with / without graph norm, BatchNorm, residual; isolated nodes and hub rows are in the graph."""
+    from pna_amd import Graph, degree_groups as DG, functional as PF
+    from pna_amd.dgl.pna_layer import PNALayer
+    from pna_amd.synth import powerlaw_graph
+    V, E = 120_000, 900_000
+    src, dst = powerlaw_graph(V, E, seed=Fi + out, device=cuda_device)
+    keep_e = dst >= 500                                    # nodes 0..499 lose their in-edges: rows without any message
+    g = Graph(src[keep_e], dst[keep_e], V, [V // 2, V - V // 2])
+    torch.manual_seed(Fi)
+    layer = PNALayer(Fi, out, "mean max min std", "identity amplification attenuation", {"log": torch.tensor(2.2)}, 0.0, gn, bn,
+                     towers=1, divide_input=False, residual=res and Fi == out).to(cuda_device).eval()
+    with torch.no_grad():
+        if bn:
+            layer.towers[0].batchnorm_h.running_mean.normal_()
+            layer.towers[0].batchnorm_h.running_var.uniform_(0.5, 2.0)
+    h = _pitched(torch.randn(V, Fi, device=cuda_device), 8)      # (a full last block is read in 32-byte strips: pitch >= round_up(F, 8))
+    snorm = g.snorm_n()
+    keep = (DG.ENABLED, DG.MIN_ROWS, DG.MIN_OUT, PF.SMALL_TOWER_ROWS, DG.FUSED)
+    DG.ENABLED, DG.MIN_ROWS, DG.MIN_OUT, PF.SMALL_TOWER_ROWS = True, 1, 1, 0
+    try:
+        with torch.no_grad():
+            DG.FUSED = True
+            assert PF.tower_layer_degree_fused_applies(layer, g, h)
+            y_f = layer(g, h, None, snorm)
+            assert torch.equal(layer(g, h, None, snorm), y_f)
+            DG.FUSED = False
+            assert not PF.tower_layer_degree_fused_applies(layer, g, h) and PF.tower_layer_degree_grouped_applies(layer, g, h)
+            y_g = layer(g, h, None, snorm)
+    finally:
+        DG.ENABLED, DG.MIN_ROWS, DG.MIN_OUT, PF.SMALL_TOWER_ROWS, DG.FUSED = keep
+    plan = DG.plan_of(g)
+    assert plan.G > 0 and plan.NR > 0 and int((g.in_degrees() == 0).sum()) >= 500
+    assert torch.isfinite(y_f).all()
+    # per element: 1e-5 relative + 2e-6 of the row's largest output (cancelling terms)
+    tol = 1e-5 * y_g.abs() + 2e-6 * y_g.abs().max(dim=1, keepdim=True).values + 1e-6
+    bad = (y_f - y_g).abs() > tol
+    assert not bool(bad.any()), (int(bad.sum()), float(((y_f - y_g).abs() / tol).max()))

@@ -159,8 +159,67 @@ def audit(lines, verbose=False):
     return problems
 
 
+def _valu_sgpr_writes(mn, ops):
+    """SGPRs (1000..) a VALU instruction writes: lane reads, compares (e64 destination), carry-outs."""
+    if not mn.startswith("v_"):
+        return set()
+    parts = [x.strip() for x in ops.split(",")]
+    if mn.startswith(("v_readlane", "v_readfirstlane", "v_cmp")):
+        return _regs(_SREG, parts[0], 1000)
+    if "_co_" in mn or mn.startswith(("v_div_scale", "v_mad_u64_u32", "v_mad_i64_i32")):
+        return _regs(_SREG, parts[1], 1000) if len(parts) > 1 else set()
+    return set()
+
+
+def sgpr_hazards(lines, wait_states=5):
+    """"VALU writes SGPR -> VMEM reads that SGPR" needs 5 wait states on gfx9 / CDNA (ISA guide, manually inserted wait states).
+    hipcc's hazard recognizer inserts the s_nop for its OWN memory instructions but does not look inside inline asm: an SGPR
+    spill reloaded by v_readlane_b32 right in front of an asm `global_load ... s[a:b]` hands the load a stale base (round 3: the
+    two-full-block tower instantiation of pna_fused_degree.hip faulted at address 0x1000 that way).  Reports every inline-asm
+    VMEM instruction with fewer than `wait_states` instructions (s_nop N counts N + 1) between it and a VALU write of one of its
+    SGPR operands, following the control-flow graph backwards.  Returns [(line, mnemonic, operands, writer line)]."""
+    ins = parse(lines)
+    labels = {name: k for k, (_, a, mn, name) in enumerate(ins) if mn == "label"}
+    preds = {k: [] for k in range(len(ins))}
+    for k, (_, _, mn, ops) in enumerate(ins):
+        if mn in ("s_branch",) or mn.startswith("s_cbranch"):
+            preds[labels[ops.strip()]].append(k)
+        if k + 1 < len(ins) and mn not in ("s_branch", "s_endpgm"):
+            preds[k + 1].append(k)
+    out = []
+    for k, (ln, in_asm, mn, ops) in enumerate(ins):
+        if not (in_asm and is_vmem(mn)):
+            continue
+        uses = _regs(_SREG, ops, 1000)
+        if not uses:
+            continue
+        # wait states already provided inside the same asm statement (an `s_nop` in front of the load) are instructions too
+        stack, seen = [(p, wait_states) for p in preds[k]], set()
+        while stack:
+            p, need = stack.pop()
+            if need <= 0 or (p, need) in seen:
+                continue
+            seen.add((p, need))
+            _, _, pmn, pops = ins[p]
+            if pmn == "label":
+                stack.extend((q, need) for q in preds[p])
+                continue
+            if _valu_sgpr_writes(pmn, pops) & uses:
+                out.append((ln, mn, ops, ins[p][0]))
+                break
+            cost = 1
+            if pmn == "s_nop":
+                cost = int(pops.strip() or 0) + 1
+            stack.extend((q, need - cost) for q in preds[p])
+    return out
+
+
 if __name__ == "__main__":
-    probs = audit(kernel_lines(sys.argv[1], sys.argv[2]), verbose=True)
+    kl = kernel_lines(sys.argv[1], sys.argv[2])
+    probs = audit(kl, verbose=True)
     for ln, mn, ops, bad in probs:
         print(f"  line {ln}: {mn} {ops}   touches in-flight v{bad}")
-    sys.exit(1 if probs else 0)
+    haz = sgpr_hazards(kl)
+    for ln, mn, ops, w in haz:
+        print(f"  line {ln}: {mn} {ops}   SGPR operand written by a VALU instruction at line {w}, fewer than 5 wait states before")
+    sys.exit(1 if probs or haz else 0)
