@@ -216,6 +216,23 @@ def _column_sums(t):
     return out + t[main:].sum(0) if main < M else out
 
 
+def _tall_tn(p, q, chunks=256):
+    """p^T q for tall (M, a), (M, b) operands: the reduction runs over M.  As ONE library GEMM the 1e6-long reduction of the C3
+    weight gradient ((225 x 1e6)(1e6 x 300)) runs at 44 TF/s -- the output has only 24 tiles; cut into 256 row slabs as a batched
+    GEMM + a sum over the slabs it takes 1.27 instead of 3.06 ms (tools/exp_dw_gemm.py), and the slab-wise summation is the more
+    accurate order."""
+    M = p.shape[0]
+    if not p.is_cuda or M < 64 * chunks:
+        return p.t() @ q
+    Mc = M // chunks * chunks
+    pc = p if p.is_contiguous() else p.contiguous()
+    qc = q if q.is_contiguous() else q.contiguous()
+    out = torch.bmm(pc[:Mc].view(chunks, Mc // chunks, -1).transpose(1, 2), qc[:Mc].view(chunks, Mc // chunks, -1)).sum(0)
+    if Mc < M:
+        out = out + pc[Mc:].t() @ qc[Mc:]
+    return out
+
+
 def _backward_pull(graph, x, dst_term, ident, amx, amn, gagg, aggs, all_aggs, T, F, need_x, need_d):
     """Gradient of the aggregation w.r.t. the source table / destination term WITHOUT one atomic per edge and feature
     (the scatter kernel: 750 M atomics = 11.4 ms on the roofline workload).  With messages m_k = x[u_k] + dst_term[v]:
@@ -304,8 +321,17 @@ class PosttransFn(torch.autograd.Function):
         a = agg[:, :K]
         # G = [scale_0 (.) gy | scale_1 (.) gy | ...]  (M, S*N): one operand for both big products, so that each is ONE
         # library GEMM (three (N x M)(M x K) products with M = 1e6 ran at 20 TF/s; the fused (S*N x M)(M x K) one tiles better)
-        G = gy if S == 1 and scales[0] is None else torch.cat([gy if rs is None else gy * rs.unsqueeze(1) for rs in scales], dim=1)
         N = gy.shape[1]
+        if S == 1 and scales[0] is None:
+            G = gy
+        else:                                             # written block by block into place (mul + cat cost a second pass: 0.65 ms at C3)
+            G3 = gy.new_empty(gy.shape[0], S, N)
+            for s, rs in enumerate(scales):
+                if rs is None:
+                    G3[:, s].copy_(gy)
+                else:
+                    torch.mul(gy, rs.unsqueeze(1), out=G3[:, s])
+            G = G3.view(gy.shape[0], S * N)
         g_agg = g_w = g_b = g_h = None
         if ctx.needs_input_grad[0]:
             # d agg = sum_s scale_s (.) (gy W_s) is the forward contraction with the roles of K and N swapped: input gy (M, N),
@@ -321,8 +347,8 @@ class PosttransFn(torch.autograd.Function):
                 full[:, :K] = g_agg
                 g_agg = full
         if ctx.needs_input_grad[2]:
-            gw = G.t() @ a                                                         # (S*N, K): block s = (scale_s gy)^T a
-            parts = ([gy.t() @ h_self] if Kh else []) + [gw[s * N:(s + 1) * N] for s in range(S)]
+            gw = _tall_tn(G, a)                                                    # (S*N, K): block s = (scale_s gy)^T a
+            parts = ([_tall_tn(gy, h_self)] if Kh else []) + [gw[s * N:(s + 1) * N] for s in range(S)]
             g_w = torch.cat(parts, dim=1)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             g_b = _column_sums(gy)

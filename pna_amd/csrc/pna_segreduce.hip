@@ -400,6 +400,18 @@ __device__ __forceinline__ void aload64(i2& dst, const void* base, unsigned voff
 __device__ __forceinline__ void aload128(f4& dst, const void* base, unsigned voff) {
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
 }
+// The same behind five wait states ("VALU writes SGPR -> VMEM reads that SGPR": hipcc reloads a spilled base pointer with
+// v_readlane_b32 directly in front of an inline-asm load and does not insert the s_nop itself -- pna_fused_degree.hip has the
+// story; tools/isa_audit.py::sgpr_hazards checks every kernel).  For the once-per-item loads of the instantiations whose
+// argument block no longer fits the scalar registers (ARG).
+template <bool WS> __device__ __forceinline__ void aload32w(int& dst, const void* base, unsigned voff) {
+  if constexpr (WS) asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
+  else aload32(dst, base, voff);
+}
+template <bool WS> __device__ __forceinline__ void aload128w(f4& dst, const void* base, unsigned voff) {
+  if constexpr (WS) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
+  else aload128(dst, base, voff);
+}
 template <int N> __device__ __forceinline__ void await(f4& v) {
   asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N) : "memory");
 }
@@ -430,16 +442,42 @@ struct AccF {   // fast-path accumulators of one lane: 4 features
   }
 };
 
-template <int I, int U, bool DST> struct Drain {   // wait for gather I of U (U-1-I younger ones may stay in flight), fold it
-  static __device__ __forceinline__ void run(AccF& acc, f4 (&v)[U], int nvalid, bool partial, const f4 dt) {
+// ARG kernels (training: the backward routes the max / min gradients through these): the CSR position of the edge that set the
+// running max / min, with k_segreduce's fold -- strict comparison, so the FIRST extremal edge in edge order wins and a copy of an
+// already folded edge never does; NaN is sticky in value and position (torch.max / min semantics).
+struct ArgF {
+  i4 amx, amn;
+  __device__ __forceinline__ void init() { amx = (i4){-1, -1, -1, -1}; amn = amx; }
+};
+#define PNA_FOLD_ARG1(mx, mn, amx, amn, v, e)                          \
+  {                                                                   \
+    const bool gx_ = (v) > (mx) || ((v) != (v) && (mx) == (mx));     \
+    const bool gn_ = (v) < (mn) || ((v) != (v) && (mn) == (mn));     \
+    mx = gx_ ? (v) : (mx); amx = gx_ ? (e) : (amx);                   \
+    mn = gn_ ? (v) : (mn); amn = gn_ ? (e) : (amn);                   \
+  }
+__device__ __forceinline__ void fold_arg(AccF& acc, ArgF& ag, const f4 v, bool on, int e) {
+  const f4 z = (f4){0.f, 0.f, 0.f, 0.f};
+  const f4 vm = on ? v : z;
+  acc.s = acc.s + vm;
+  acc.q = acc.q + vm * vm;
+  if (on) {                                                  // (wave-divergent only in a row's last, partial batch)
+    PNA_FOLD_ARG1(acc.mx.x, acc.mn.x, ag.amx.x, ag.amn.x, v.x, e) PNA_FOLD_ARG1(acc.mx.y, acc.mn.y, ag.amx.y, ag.amn.y, v.y, e)
+    PNA_FOLD_ARG1(acc.mx.z, acc.mn.z, ag.amx.z, ag.amn.z, v.z, e) PNA_FOLD_ARG1(acc.mx.w, acc.mn.w, ag.amx.w, ag.amn.w, v.w, e)
+  }
+}
+
+template <int I, int U, bool DST, bool ARG> struct Drain {   // wait for gather I of U (U-1-I younger ones may stay in flight), fold it
+  static __device__ __forceinline__ void run(AccF& acc, ArgF& ag, f4 (&v)[U], int nvalid, bool partial, const f4 dt, int e0) {
     await<U - 1 - I>(v[I]);
     const f4 m = DST ? v[I] + dt : v[I];                     // message = x[src] (+ dst_term[row]), as k_segreduce forms it
-    if (partial) acc.fold_masked(m, I < nvalid); else acc.fold(m);
-    Drain<I + 1, U, DST>::run(acc, v, nvalid, partial, dt);
+    if constexpr (ARG) fold_arg(acc, ag, m, !partial || I < nvalid, e0 + I);
+    else if (partial) acc.fold_masked(m, I < nvalid); else acc.fold(m);
+    Drain<I + 1, U, DST, ARG>::run(acc, ag, v, nvalid, partial, dt, e0);
   }
 };
-template <int U, bool DST> struct Drain<U, U, DST> {
-  static __device__ __forceinline__ void run(AccF&, f4 (&)[U], int, bool, const f4) {}
+template <int U, bool DST, bool ARG> struct Drain<U, U, DST, ARG> {
+  static __device__ __forceinline__ void run(AccF&, ArgF&, f4 (&)[U], int, bool, const f4, int) {}
 };
 
 // Slim argument block of the hand-scheduled kernel.  Everything the row loop touches fits in ~40 SGPRs; the full
@@ -453,6 +491,7 @@ struct FArgs {
   const int32_t* col; const float* x; float* out; float* partials;
   const float* dst;       // per-destination additive term (the h_dst half of a factorised pretrans), DST kernels only
   const int32_t* orow;    // OROW kernels: output row of node v's aggregate (pna_segreduce_args.out_row_of)
+  int32_t* argmax; int32_t* argmin; long ld_arg, ts_arg;     // ARG kernels: CSR position of the extremal edge per (row, feature)
   long ldo, ts_out;
   unsigned ldb, ts_in_b;  // x row pitch / tower stride in bytes
   unsigned ldd_b;         // dst_term row pitch in bytes
@@ -491,16 +530,16 @@ __device__ __forceinline__ void fast_finalize_store(const FArgs& a, const AccF& 
 }
 
 // U gathers of one row issued back to back from the ids held by the group's lanes, then folded in order.
-template <int U, bool PARTIAL, bool DST>
-__device__ __forceinline__ void fast_batch(const float* x, AccF& acc, int idx, int src_lane0, unsigned ldb,
-                                           unsigned offb, int nvalid, const f4 dt) {
+template <int U, bool PARTIAL, bool DST, bool ARG>
+__device__ __forceinline__ void fast_batch(const float* x, AccF& acc, ArgF& ag, int idx, int src_lane0, unsigned ldb,
+                                           unsigned offb, int nvalid, const f4 dt, int e0) {
   int id[U];
   f4 v[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) id[u] = __shfl(idx, src_lane0 + (PARTIAL ? min(u, nvalid - 1) : u));
 #pragma unroll
   for (int u = 0; u < U; ++u) aload128(v[u], x, __umul24((unsigned)id[u], ldb) + offb);
-  Drain<0, U, DST>::run(acc, v, nvalid, PARTIAL, dt);
+  Drain<0, U, DST, ARG>::run(acc, ag, v, nvalid, PARTIAL, dt, e0);
 }
 
 // The prefetch invariants: the first L source ids of item r+1 and the record of item r+2 are requested BEFORE
@@ -509,7 +548,9 @@ __device__ __forceinline__ void fast_batch(const float* x, AccF& acc, int idx, i
 // factorised to node level).  The row's term is one more dwordx4 per lane, fetched one item ahead like the source ids.
 // OROW (with DST): a whole-row record's aggregate goes to row out_row_of[row] of `out` (the record's `row` stays the node: the
 // dst_term needs it) -- the tower layers' aggregate written in degree order (ABI 12).  Fetched one item ahead like the ids.
-template <int U, bool DST, bool OROW = false>
+// ARG: also writes argmax / argmin (see ArgF); heavy segments then write k_segreduce's seven-quantity partials and are finished by
+// k_heavy_finalize<4, true>.
+template <int U, bool DST, bool OROW = false, bool ARG = false>
 __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -531,7 +572,8 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
   const unsigned ldb = a.ldb;
   const unsigned offb = (unsigned)tower * a.ts_in_b + (unsigned)off * 4u;
   auto issue_item = [&](i4& dst, long k) {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"((unsigned)k * 16u), "s"(a.items) : "memory");
+    if constexpr (ARG) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"((unsigned)k * 16u), "s"(a.items) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"((unsigned)k * 16u), "s"(a.items) : "memory");
   };
 
   // Every asm-loaded register below is written by an asm load on EVERY path (addresses are clamped instead of
@@ -542,12 +584,12 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
   auto ids_of = [&](int& dst, const i4 rec) {                // lane c <- col[beg + min(c, deg-1)], clamped into col[]
     const int d = rec.z - rec.y;
     const unsigned pos = (unsigned)rec.y + (unsigned)min(c, max(d - 1, 0));
-    aload32(dst, a.col, min(pos, e_last) * 4u);
+    aload32w<ARG>(dst, a.col, min(pos, e_last) * 4u);
   };
 
   const unsigned ldd_b = a.ldd_b;
   auto dst_of = [&](f4& dst, const i4 rec) {                 // lane c <- dst_term[row][its 4 features] (row < V always)
-    aload128(dst, a.dst, __umul24((unsigned)rec.x, ldd_b) + offb);
+    aload128w<ARG>(dst, a.dst, __umul24((unsigned)rec.x, ldd_b) + offb);
   };
 
   // prologue: record of item 0 -> its first ids and the record of item 1
@@ -567,6 +609,8 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
   else asm volatile("s_waitcnt vmcnt(0)" : "+v"(idx_c), "+v"(nxt) : : "memory");
 
   AccF acc;
+  ArgF ag;
+  ag.init();
   for (int r = 0; r < a.R; ++r) {
     const long item = base + (long)r * NG;
     if (item >= NI) break;
@@ -582,20 +626,27 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
     // ---- this item
     const int row = cur.x, beg = cur.y, end = cur.z, slot = cur.w;
     acc.init();
+    if constexpr (ARG) ag.init();
     int idx = idx_c;
     for (int cb = beg; cb < end; cb += L) {
       const int nidx = min(L, end - cb);
       if (cb != beg) {                                       // longer than one id chunk (rare): fetch + wait
-        aload32(idx, a.col, (unsigned)(cb + min(c, nidx - 1)) * 4u);
+        aload32w<ARG>(idx, a.col, (unsigned)(cb + min(c, nidx - 1)) * 4u);
         await<0>(idx);
       }
       int j = 0;
-      for (; j + U <= nidx; j += U) fast_batch<U, false, DST>(a.x, acc, idx, grp_lane0 + j, ldb, offb, U, dt_c);
-      if (j < nidx) fast_batch<U, true, DST>(a.x, acc, idx, grp_lane0 + j, ldb, offb, nidx - j, dt_c);
+      for (; j + U <= nidx; j += U) fast_batch<U, false, DST, ARG>(a.x, acc, ag, idx, grp_lane0 + j, ldb, offb, U, dt_c, cb + j);
+      if (j < nidx) fast_batch<U, true, DST, ARG>(a.x, acc, ag, idx, grp_lane0 + j, ldb, offb, nidx - j, dt_c, cb + j);
     }
     if (lane_ok && PNA_STORES_ON(a, acc.s.x)) {
       if (slot < 0) {
         fast_finalize_store(a, acc, OROW ? orow_c : row, end - beg, offo);
+        if constexpr (ARG) {
+          typedef i4 i4a4 __attribute__((aligned(4)));
+          const size_t oa = (size_t)row * a.ld_arg + (size_t)tower * a.ts_arg + off;
+          if (a.argmax) *reinterpret_cast<i4a4*>(a.argmax + oa) = ag.amx;
+          if (a.argmin) *reinterpret_cast<i4a4*>(a.argmin + oa) = ag.amn;
+        }
       } else {                                               // heavy segment: raw (s, q, max, min) to the workspace
         typedef f4 f4a4 __attribute__((aligned(4)));
         float* p = a.partials + ((size_t)slot * a.T + tower) * kNQ * a.pstride + off;
@@ -603,6 +654,12 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
         *reinterpret_cast<f4a4*>(p + a.pstride) = acc.q;
         *reinterpret_cast<f4a4*>(p + 2 * a.pstride) = acc.mx;
         *reinterpret_cast<f4a4*>(p + 3 * a.pstride) = acc.mn;
+        if constexpr (ARG) {                                 // k_segreduce's partial record: + argmax, argmin (as bits), edge count
+          typedef i4 i4a4 __attribute__((aligned(4)));
+          *reinterpret_cast<i4a4*>(p + 4 * a.pstride) = ag.amx;
+          *reinterpret_cast<i4a4*>(p + 5 * a.pstride) = ag.amn;
+          if (chunk == 0) p[6 * a.pstride - off] = (float)(end - beg);
+        }
       }
     }
     // The prefetches were issued before this item's gathers and VMEM returns in order, so once the wave has waited
@@ -823,7 +880,9 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
   const long light_blocks = (p->V + rows_per_block - 1) / rows_per_block;
   if (light_blocks + k.n_heavy_blocks > 0x7fffffffL) return pna_set_error(PNA_E_INVALID, "pna_segreduce_fwd_f32: grid too large");
   const bool extra = p->dst_term || p->edge_term || p->edge_weight || p->argmax || p->argmin;
-  const bool extra_fast = p->edge_term || p->edge_weight || p->argmax || p->argmin;   // what the hand-scheduled kernel lacks
+  const bool want_arg = p->argmax || p->argmin;
+  // what the hand-scheduled kernel lacks (argmax / argmin: built for the default unroll, together)
+  const bool extra_fast = p->edge_term || p->edge_weight || (want_arg && !(U == 4 && p->argmax && p->argmin && !p->out_row_of));
   dim3 grid((unsigned)(light_blocks + k.n_heavy_blocks), (unsigned)(tiles * T));
   hipStream_t st = (hipStream_t)stream;
   // 32-bit gather offsets when the whole feature table is addressable with them
@@ -850,12 +909,16 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
     f.pstride = k.pstride; f.block_stride = p->block_stride; f.nt = k.nt; f.dbg = k.dbg;
     f.dst = p->dst_term; f.ldd_b = (unsigned)(p->ld_dst * 4);
     f.orow = p->out_row_of;
+    f.argmax = p->argmax; f.argmin = p->argmin; f.ld_arg = p->ld_arg; f.ts_arg = ts_in;
     if (p->out_row_of && !(p->dst_term && U == 4))
       return pna_set_error(PNA_E_INVALID, "pna_segreduce_fwd_f32: out_row_of is honoured with dst_term and the default unroll only (without dst_term the work list's row field is the output row)");
     const long fb = (p->n_work_items + rows_per_block - 1) / rows_per_block;
     dim3 fgrid((unsigned)fb, (unsigned)(tiles * T));
     const unsigned dyn_lds = (unsigned)(k.dbg >> 8) * 1024u;   // 0 in the shipped build
-    if (p->dst_term && p->out_row_of) {
+    if (want_arg) {
+      if (p->dst_term) hipLaunchKernelGGL((k_segreduce_fast<4, true, false, true>), fgrid, dim3(kBlock), dyn_lds, st, f);
+      else hipLaunchKernelGGL((k_segreduce_fast<4, false, false, true>), fgrid, dim3(kBlock), dyn_lds, st, f);
+    } else if (p->dst_term && p->out_row_of) {
       hipLaunchKernelGGL((k_segreduce_fast<4, true, true>), fgrid, dim3(kBlock), dyn_lds, st, f);
     } else if (p->dst_term) {
       switch (U) {
@@ -886,7 +949,9 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
     dim3 g2((unsigned)((k.n_heavy + kWaves - 1) / kWaves), (unsigned)(tiles * T));
     // the hand-scheduled kernel writes (s, q, max, min) partials with NaN-dropping max/min: finish them with the
     // plain finalize (NaN restored from q), also when a dst_term was added to the messages
-    const bool extra = !fast_ok && (p->dst_term || p->edge_term || p->edge_weight || p->argmax || p->argmin);
+    // (its ARG instantiation writes k_segreduce's full partial records -- NaN-sticky max / min with their positions -- and is
+    // finished by the EXTRA finalize, which also stores argmax / argmin; the dst_term is already inside the partials)
+    const bool extra = fast_ok ? want_arg : (p->dst_term || p->edge_term || p->edge_weight || p->argmax || p->argmin);
     if (vec == 4) {
       if (extra) hipLaunchKernelGGL((k_heavy_finalize<4, true>), g2, dim3(kBlock), 0, st, k);
       else hipLaunchKernelGGL((k_heavy_finalize<4, false>), g2, dim3(kBlock), 0, st, k);

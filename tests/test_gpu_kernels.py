@@ -131,6 +131,34 @@ def test_segreduce_towers_terms_weights_args(cuda_device, T, F):
             assert ((ax[rows, cols] >= rp[rows]) & (ax[rows, cols] < rp[rows + 1])).all()
 
 
+@pytest.mark.parametrize("F,with_dst", [(75, False), (75, True), (16, False), (130, True)])
+def test_hand_scheduled_gather_with_arg_tracking_equals_the_generic_kernel(cuda_device, F, with_dst):
+    """The training forward's gather (argmax / argmin recorded for the backward) on the hand-scheduled kernel against the
+    compiler-scheduled one it replaces there: every output block and both position arrays identical -- hub rows (partials +
+    finalize), isolated rows, TIES (small-integer features: the FIRST extremal edge must win) and NaN messages included."""
+    rng = np.random.default_rng(F)
+    V, E = 3000, 40000
+    src, dst = _rand_graph(rng, V, E, hub=1500)
+    keep_e = (dst < 20) | (dst >= 40)                       # rows 20..39 without in-edges (0..2 are the hubs)
+    g = Graph(src[keep_e], dst[keep_e], V).to(cuda_device)
+    c = g.csr
+    gen = torch.Generator().manual_seed(F)
+    x = torch.randint(-3, 4, (V, F), generator=gen).float()               # many exact ties
+    x[::7] += torch.randn(V, F, generator=gen)[::7]
+    x[5, 3], x[77, 0] = float("nan"), float("inf")
+    x = x.to(cuda_device)
+    dt = torch.randint(-2, 3, (V, F), generator=gen).float().to(cuda_device) if with_dst else None
+    res = {}
+    for name, tune, items in (("fast", dict(generic=2), g.work_items()), ("generic", dict(generic=1), None)):
+        out, amx, amn = ops.segreduce(c.rowptr, c.col, x, F, ["mean", "max", "min", "std"], (None,), tower_stride_in=F, dst_term=dt, want_arg=True,
+                                      heavy=g.heavy_schedule(), workspace=g.workspace, items=items, tune=tune)
+        res[name] = (out.cpu(), amx.cpu(), amn.cpu())
+    (o1, x1, n1), (o2, x2, n2) = res["fast"], res["generic"]
+    assert torch.equal(x1, x2) and torch.equal(n1, n2)
+    assert torch.equal(torch.isnan(o1), torch.isnan(o2)) and torch.equal(torch.nan_to_num(o1, nan=0.0), torch.nan_to_num(o2, nan=0.0))
+    assert int((x1 < 0).sum()) >= 20 * F and int((c.rowptr[1:] - c.rowptr[:-1]).max()) > 128
+
+
 def test_segreduce_edge_resident_messages(cuda_device):
     rng = np.random.default_rng(5)
     V, E, F = 400, 3000, 20
