@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define PNA_ABI_VERSION 13 /* 13: pna_fused_degree_args.x_dst / h_self / row_post + pna_fused_tower_{image_bytes,pack_f32}: the one-kernel layer
+#define PNA_ABI_VERSION 14 /* 14: pna_segreduce_args.edge_type / n_edge_types (edge terms from a table of edge types); the hand-scheduled gather takes
+                                  edge terms (per edge or per type).
+                              13: pna_fused_degree_args.x_dst / h_self / row_post + pna_fused_tower_{image_bytes,pack_f32}: the one-kernel layer
                                   for PNALayer with one tower.
                               12: pna_segreduce_args.out_row_of (the tower layers' aggregate written in degree order).
                               11: - pna_posttrans_x3w_* (ABI 8's contraction on 32x32 tiles: parity-green, 5 % slower than the 16x16 kernel on every
@@ -164,7 +166,7 @@ typedef struct pna_segreduce_args {
 
   /* Optional work list for the hand-scheduled kernel (used when the call is the 4-aggregator gather
    * mean|max|min|std with the identity scaler, messages x[col[k]] or x[col[k]] + dst_term[v] -- i.e. what
-   * PNASimpleLayer and the PNATower layers without edge features issue): n_work_items records {row, beg, end, slot} (int32 x 4).  slot < 0:
+   * PNASimpleLayer and the PNATower layers issue; ABI 14: also with edge_term, per edge or per edge type): n_work_items records {row, beg, end, slot} (int32 x 4).  slot < 0:
    * the record is a whole row [beg,end) = [rowptr[row], rowptr[row+1]) whose result is finalised and stored;
    * slot >= 0: the record is heavy segment number `slot` (its partials go to partials[slot]; the segments of a
    * heavy row must be the ones heavy_segptr describes).  Every row must be covered exactly once, either by one
@@ -184,6 +186,13 @@ typedef struct pna_segreduce_args {
   /* ABI 12: with dst_term (where the work list's `row` must stay the node), the row of `out` that receives node v's aggregate:
    * out_row_of[v] for whole-row records (heavy rows: heavy_out_rows).  Nullable; hand-scheduled kernel with work_items only. */
   const int32_t* out_row_of;
+  /* ABI 14: edge terms from a table.  When the edge features are an embedding of an edge TYPE (the molecule nets: bond type,
+   * realworld_benchmark/nets/molecules_graph_regression/pna_net.py with --edge_feat True), W_e . ef has one distinct row per type:
+   * edge_term is then (n_edge_types, ld_edge) and the term of CSR edge k is row edge_type[k] (int32 [E], CSR order).  NULL: edge_term
+   * has one row per edge.  n_edge_types <= 4 keeps the table in registers of the hand-scheduled kernel. */
+  const int32_t* edge_type;
+  int32_t n_edge_types;
+  int32_t _pad3;
 } pna_segreduce_args;
 
 /* Launches the kernels described above on `stream`. */

@@ -121,7 +121,7 @@ def golden_simple(name, seed, N, E, F, out_dim, aggregators=AGG4, scalers=SCA3, 
 
 def golden_tower(name, seed, in_dim, out_dim, towers, divide_input, edge_dim=0, pretrans_layers=1,
                  posttrans_layers=1, n_graphs=6, graph_norm=True, batch_norm=True, residual=True,
-                 aggregators=AGG4, scalers=SCA3):
+                 aggregators=AGG4, scalers=SCA3, edge_types=0):
     rng = np.random.default_rng(seed)
     gen = torch.Generator().manual_seed(seed)
     src, dst, sizes = molecule_batch(rng, n_graphs)
@@ -135,6 +135,11 @@ def golden_tower(name, seed, in_dim, out_dim, towers, divide_input, edge_dim=0, 
     randomise(layer, gen)
     h = torch.randn(N, in_dim, generator=gen)
     e = torch.randn(src.size, edge_dim, generator=gen) if edge_dim > 0 else torch.zeros(src.size, 0)
+    if edge_types > 0:        # the molecule nets' edge features: an embedding of the bond type (nets/molecules_graph_regression/pna_net.py)
+        emb = torch.nn.Embedding(edge_types, edge_dim)
+        with torch.no_grad():
+            emb.weight.copy_(torch.randn(edge_types, edge_dim, generator=gen))
+            e = emb(torch.randint(0, edge_types, (src.size,), generator=gen))
     snorm_n = torch.cat([torch.full((s, 1), 1.0 / s) for s in sizes]).sqrt()   # data/molecules.py:157-159
     g = dgl_standin.StandinGraph(src, dst, N)
     with torch.no_grad():
@@ -244,6 +249,8 @@ def main():
     golden_tower("tower_zinc_first", 41, in_dim=30, out_dim=30, towers=5, divide_input=False)
     golden_tower("tower_zinc_last", 43, in_dim=30, out_dim=25, towers=5, divide_input=True)
     golden_tower("tower_edgefeat", 44, in_dim=24, out_dim=24, towers=4, divide_input=True, edge_dim=6)
+    golden_tower("tower_edgetype", 47, in_dim=30, out_dim=30, towers=5, divide_input=False, edge_dim=8, edge_types=4, n_graphs=8)
+    golden_tower("tower_edgetype_div", 48, in_dim=32, out_dim=32, towers=4, divide_input=True, edge_dim=5, edge_types=3)
     golden_tower("tower_deep_mlps", 45, in_dim=16, out_dim=16, towers=2, divide_input=False, pretrans_layers=2,
                  posttrans_layers=2, graph_norm=False)
     golden_tower("tower_f75", 46, in_dim=75, out_dim=70, towers=5, divide_input=False, n_graphs=3)

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to the HI
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpna_amd.so")
 
-PNA_ABI_VERSION = 13
+PNA_ABI_VERSION = 14
 PNA_MAX_AGGR = 8
 PNA_MAX_SCALER = 8
 
@@ -47,6 +47,7 @@ class PnaSegreduceArgs(ctypes.Structure):
         ("n_edges", ctypes.c_int64),
         ("tune", PnaTuning),
         ("heavy_out_rows", ctypes.c_void_p), ("out_row_of", ctypes.c_void_p),
+        ("edge_type", ctypes.c_void_p), ("n_edge_types", ctypes.c_int32), ("_pad3", ctypes.c_int32),
     ]
 
 

@@ -54,6 +54,7 @@ constexpr int kNQ = 7;   // partial quantities per heavy segment: s, q, mx, mn, 
 struct KArgs {
   const int32_t* rowptr; const int32_t* col;
   const float* x; const float* dst_term; const float* edge_term; const float* ew;
+  const int32_t* etype;       // nullable: edge_term has one row per edge TYPE, the term of CSR edge k is row etype[k]
   const float* row_scale[PNA_MAX_SCALER];
   float* out; int32_t* argmax; int32_t* argmin;
   const int32_t* heavy_rows; const int32_t* heavy_segptr; const int32_t* seg_heavy; float* partials;
@@ -194,7 +195,7 @@ __device__ __forceinline__ void batch(const KArgs& a, Acc<VEC, EXTRA>& acc, int 
     float w[B];
     if (a.edge_term) {
 #pragma unroll
-      for (int u = 0; u < B; ++u) Ld<VEC>::load(a.edge_term + (size_t)ee[u] * a.ld_edge + off, et[u]);
+      for (int u = 0; u < B; ++u) Ld<VEC>::load(a.edge_term + (size_t)(a.etype ? a.etype[ee[u]] : ee[u]) * a.ld_edge + off, et[u]);
     }
     if (a.ew) {
 #pragma unroll
@@ -467,17 +468,37 @@ __device__ __forceinline__ void fold_arg(AccF& acc, ArgF& ag, const f4 v, bool o
   }
 }
 
-template <int I, int U, bool DST, bool ARG> struct Drain {   // wait for gather I of U (U-1-I younger ones may stay in flight), fold it
-  static __device__ __forceinline__ void run(AccF& acc, ArgF& ag, f4 (&v)[U], int nvalid, bool partial, const f4 dt, int e0) {
-    await<U - 1 - I>(v[I]);
-    const f4 m = DST ? v[I] + dt : v[I];                     // message = x[src] (+ dst_term[row]), as k_segreduce forms it
+// ET (the tower layers WITH edge features, models/dgl/pna_layer.py:35-40: the W_e . ef part of the factorised pretrans):
+//   1: one more 16-byte load per edge and lane from the per-edge term (rows in CSR order: a stream), issued right behind the
+//      edge's gather, so edge I is complete once 2 (U - 1 - I) younger loads remain;
+//   2: the term is a row of a table of <= 4 edge TYPES (bond types: the term of an embedding) held in 16 registers per lane; the
+//      types of a row's edges are fetched like its source ids.
+// The message is formed in k_segreduce's order, (x[src] + dst_term[row]) + edge_term[k]: the same bits.
+struct EtF {
+  f4 tab[4];                                                 // ET == 2: the lane's 4 features of every type's term
+};
+__device__ __forceinline__ f4 et_select(const EtF& t, int ty) {
+  return ty == 0 ? t.tab[0] : ty == 1 ? t.tab[1] : ty == 2 ? t.tab[2] : t.tab[3];
+}
+template <int N> __device__ __forceinline__ void await2(f4& v, f4& w) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(v), "+v"(w) : "n"(N) : "memory");
+}
+
+template <int I, int U, bool DST, bool ARG, int ET> struct Drain {   // wait for gather I of U (U-1-I younger ones may stay in flight), fold it
+  static __device__ __forceinline__ void run(AccF& acc, ArgF& ag, f4 (&v)[U], f4 (&w)[U], const int (&ty)[U], const EtF& tb,
+                                             int nvalid, bool partial, const f4 dt, int e0) {
+    if constexpr (ET == 1) await2<2 * (U - 1 - I)>(v[I], w[I]);
+    else await<U - 1 - I>(v[I]);
+    f4 m = DST ? v[I] + dt : v[I];                           // message = x[src] (+ dst_term[row]), as k_segreduce forms it
+    if constexpr (ET == 1) m = m + w[I];
+    if constexpr (ET == 2) m = m + et_select(tb, ty[I]);
     if constexpr (ARG) fold_arg(acc, ag, m, !partial || I < nvalid, e0 + I);
     else if (partial) acc.fold_masked(m, I < nvalid); else acc.fold(m);
-    Drain<I + 1, U, DST, ARG>::run(acc, ag, v, nvalid, partial, dt, e0);
+    Drain<I + 1, U, DST, ARG, ET>::run(acc, ag, v, w, ty, tb, nvalid, partial, dt, e0);
   }
 };
-template <int U, bool DST, bool ARG> struct Drain<U, U, DST, ARG> {
-  static __device__ __forceinline__ void run(AccF&, ArgF&, f4 (&)[U], int, bool, const f4, int) {}
+template <int U, bool DST, bool ARG, int ET> struct Drain<U, U, DST, ARG, ET> {
+  static __device__ __forceinline__ void run(AccF&, ArgF&, f4 (&)[U], f4 (&)[U], const int (&)[U], const EtF&, int, bool, const f4, int) {}
 };
 
 // Slim argument block of the hand-scheduled kernel.  Everything the row loop touches fits in ~40 SGPRs; the full
@@ -492,6 +513,7 @@ struct FArgs {
   const float* dst;       // per-destination additive term (the h_dst half of a factorised pretrans), DST kernels only
   const int32_t* orow;    // OROW kernels: output row of node v's aggregate (pna_segreduce_args.out_row_of)
   int32_t* argmax; int32_t* argmin; long ld_arg, ts_arg;     // ARG kernels: CSR position of the extremal edge per (row, feature)
+  const float* et; const int32_t* etype; unsigned lde_b; int n_types;   // ET kernels: per-edge term (1) / per-type table + types (2)
   long ldo, ts_out;
   unsigned ldb, ts_in_b;  // x row pitch / tower stride in bytes
   unsigned ldd_b;         // dst_term row pitch in bytes
@@ -530,16 +552,23 @@ __device__ __forceinline__ void fast_finalize_store(const FArgs& a, const AccF& 
 }
 
 // U gathers of one row issued back to back from the ids held by the group's lanes, then folded in order.
-template <int U, bool PARTIAL, bool DST, bool ARG>
+template <int U, bool PARTIAL, bool DST, bool ARG, int ET>
 __device__ __forceinline__ void fast_batch(const float* x, AccF& acc, ArgF& ag, int idx, int src_lane0, unsigned ldb,
-                                           unsigned offb, int nvalid, const f4 dt, int e0) {
-  int id[U];
-  f4 v[U];
+                                           unsigned offb, int nvalid, const f4 dt, int e0, const float* et, unsigned lde_b,
+                                           int ety, const EtF& tb) {
+  int id[U], ty[U];
+  f4 v[U], w[U];
 #pragma unroll
-  for (int u = 0; u < U; ++u) id[u] = __shfl(idx, src_lane0 + (PARTIAL ? min(u, nvalid - 1) : u));
+  for (int u = 0; u < U; ++u) {
+    id[u] = __shfl(idx, src_lane0 + (PARTIAL ? min(u, nvalid - 1) : u));
+    ty[u] = ET == 2 ? __shfl(ety, src_lane0 + (PARTIAL ? min(u, nvalid - 1) : u)) : 0;
+  }
 #pragma unroll
-  for (int u = 0; u < U; ++u) aload128(v[u], x, __umul24((unsigned)id[u], ldb) + offb);
-  Drain<0, U, DST, ARG>::run(acc, ag, v, nvalid, PARTIAL, dt, e0);
+  for (int u = 0; u < U; ++u) {
+    aload128(v[u], x, __umul24((unsigned)id[u], ldb) + offb);
+    if constexpr (ET == 1) aload128(w[u], et, (unsigned)(e0 + (PARTIAL ? min(u, nvalid - 1) : u)) * lde_b + offb);
+  }
+  Drain<0, U, DST, ARG, ET>::run(acc, ag, v, w, ty, tb, nvalid, PARTIAL, dt, e0);
 }
 
 // The prefetch invariants: the first L source ids of item r+1 and the record of item r+2 are requested BEFORE
@@ -550,7 +579,7 @@ __device__ __forceinline__ void fast_batch(const float* x, AccF& acc, ArgF& ag, 
 // dst_term needs it) -- the tower layers' aggregate written in degree order (ABI 12).  Fetched one item ahead like the ids.
 // ARG: also writes argmax / argmin (see ArgF); heavy segments then write k_segreduce's seven-quantity partials and are finished by
 // k_heavy_finalize<4, true>.
-template <int U, bool DST, bool OROW = false, bool ARG = false>
+template <int U, bool DST, bool OROW = false, bool ARG = false, int ET = 0>
 __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -591,6 +620,19 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
   auto dst_of = [&](f4& dst, const i4 rec) {                 // lane c <- dst_term[row][its 4 features] (row < V always)
     aload128w<ARG>(dst, a.dst, __umul24((unsigned)rec.x, ldd_b) + offb);
   };
+  auto types_of = [&](int& dst, const i4 rec) {              // lane c <- etype[beg + min(c, deg-1)] (ET == 2), like ids_of
+    const int d = rec.z - rec.y;
+    const unsigned pos = (unsigned)rec.y + (unsigned)min(c, max(d - 1, 0));
+    aload32w<true>(dst, a.etype, min(pos, e_last) * 4u);
+  };
+  EtF tb;
+  if constexpr (ET == 2) {                                   // the lane's slice of the type table: ordinary loads, before any asm load
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty) {
+      const float* r = a.et + (size_t)min(ty, a.n_types - 1) * (a.lde_b / 4u) + (size_t)tower * (a.ts_in_b / 4u) + off;
+      tb.tab[ty] = (f4){r[0], r[1], r[2], r[3]};
+    }
+  }
 
   // prologue: record of item 0 -> its first ids and the record of item 1
   i4 cur;
@@ -602,6 +644,8 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
   if constexpr (DST) dst_of(dt_c, cur);
   int orow_c = 0;
   if constexpr (OROW) aload32(orow_c, a.orow, (unsigned)cur.x * 4u);
+  int ety_c = 0;
+  if constexpr (ET == 2) { types_of(ety_c, cur); asm volatile("s_waitcnt vmcnt(0)" : "+v"(ety_c) : : "memory"); }
   i4 nxt;
   issue_item(nxt, min(base + NG, last));
   if constexpr (OROW) asm volatile("s_waitcnt vmcnt(0)" : "+v"(idx_c), "+v"(nxt), "+v"(dt_c), "+v"(orow_c) : : "memory");
@@ -622,21 +666,26 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
     if constexpr (DST) dst_of(dt_n, nxt);
     int orow_n = 0;
     if constexpr (OROW) aload32(orow_n, a.orow, (unsigned)nxt.x * 4u);
+    int ety_n = 0;
+    if constexpr (ET == 2) types_of(ety_n, nxt);
     issue_item(nn, min(item + 2 * NG, last));
     // ---- this item
     const int row = cur.x, beg = cur.y, end = cur.z, slot = cur.w;
     acc.init();
     if constexpr (ARG) ag.init();
-    int idx = idx_c;
+    int idx = idx_c, ety = ety_c;
     for (int cb = beg; cb < end; cb += L) {
       const int nidx = min(L, end - cb);
       if (cb != beg) {                                       // longer than one id chunk (rare): fetch + wait
         aload32w<ARG>(idx, a.col, (unsigned)(cb + min(c, nidx - 1)) * 4u);
+        if constexpr (ET == 2) { aload32w<true>(ety, a.etype, (unsigned)(cb + min(c, nidx - 1)) * 4u); await<0>(ety); }
         await<0>(idx);
       }
       int j = 0;
-      for (; j + U <= nidx; j += U) fast_batch<U, false, DST, ARG>(a.x, acc, ag, idx, grp_lane0 + j, ldb, offb, U, dt_c, cb + j);
-      if (j < nidx) fast_batch<U, true, DST, ARG>(a.x, acc, ag, idx, grp_lane0 + j, ldb, offb, nidx - j, dt_c, cb + j);
+      for (; j + U <= nidx; j += U)
+        fast_batch<U, false, DST, ARG, ET>(a.x, acc, ag, idx, grp_lane0 + j, ldb, offb, U, dt_c, cb + j, a.et, a.lde_b, ety, tb);
+      if (j < nidx)
+        fast_batch<U, true, DST, ARG, ET>(a.x, acc, ag, idx, grp_lane0 + j, ldb, offb, nidx - j, dt_c, cb + j, a.et, a.lde_b, ety, tb);
     }
     if (lane_ok && PNA_STORES_ON(a, acc.s.x)) {
       if (slot < 0) {
@@ -668,6 +717,7 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
     asm volatile("" : "+v"(idx_n), "+v"(nn));                 // anchor: consumers cannot move above this point
     if constexpr (DST) { asm volatile("" : "+v"(dt_n)); dt_c = dt_n; }
     if constexpr (OROW) { asm volatile("" : "+v"(orow_n)); orow_c = orow_n; }
+    if constexpr (ET == 2) { asm volatile("" : "+v"(ety_n)); ety_c = ety_n; }
     idx_c = idx_n; cur = nxt; nxt = nn;
   }
 }
@@ -832,6 +882,8 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
   if ((p->dst_term && p->ld_dst < in_w) || (p->edge_term && p->ld_edge < in_w) ||
       ((p->argmax || p->argmin) && p->ld_arg < in_w))
     return pna_set_error(PNA_E_INVALID, "pna_segreduce_fwd_f32: leading dimensions too small");
+  if (p->edge_type && (!p->edge_term || p->n_edge_types < 1))
+    return pna_set_error(PNA_E_INVALID, "pna_segreduce_fwd_f32: edge_type needs edge_term (the table) and n_edge_types >= 1");
   const bool heavy = p->heavy_threshold > 0 && p->n_heavy > 0;
   if (heavy && (!p->heavy_rows || !p->heavy_segptr || !p->seg_heavy || !p->partials || p->seg_len <= 0 || p->n_seg <= 0))
     return pna_set_error(PNA_E_INVALID, "pna_segreduce_fwd_f32: incomplete heavy-row schedule");
@@ -839,7 +891,7 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
   KArgs k;
   memset(&k, 0, sizeof(k));
   k.rowptr = p->rowptr; k.col = p->col; k.x = p->x; k.dst_term = p->dst_term; k.edge_term = p->edge_term;
-  k.ew = p->edge_weight;
+  k.ew = p->edge_weight; k.etype = p->edge_type;
   for (int s = 0; s < p->n_scaler; ++s) k.row_scale[s] = p->row_scale[s];
   k.out = p->out; k.argmax = p->argmax; k.argmin = p->argmin;
   k.heavy_rows = p->heavy_rows; k.heavy_segptr = p->heavy_segptr; k.seg_heavy = p->seg_heavy; k.partials = p->partials;
@@ -881,8 +933,14 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
   if (light_blocks + k.n_heavy_blocks > 0x7fffffffL) return pna_set_error(PNA_E_INVALID, "pna_segreduce_fwd_f32: grid too large");
   const bool extra = p->dst_term || p->edge_term || p->edge_weight || p->argmax || p->argmin;
   const bool want_arg = p->argmax || p->argmin;
+  // edge terms on the hand-scheduled kernel (ABI 14): with dst_term, default unroll, no position tracking / row map; per edge (32-bit
+  // offsets into the term) or per edge type (<= 4 types: the table rides in registers)
+  const int et_mode = !p->edge_term ? 0 : p->edge_type ? 2 : 1;
+  const bool et_fast = et_mode == 0 || (p->dst_term && U == 4 && !want_arg && !p->out_row_of && p->ld_edge * 4 < (1ll << 24) &&
+                                        (et_mode == 2 ? p->n_edge_types <= 4
+                                                      : (double)p->n_edges * (double)p->ld_edge * 4.0 < 4294967296.0));
   // what the hand-scheduled kernel lacks (argmax / argmin: built for the default unroll, together)
-  const bool extra_fast = p->edge_term || p->edge_weight || (want_arg && !(U == 4 && p->argmax && p->argmin && !p->out_row_of));
+  const bool extra_fast = !et_fast || p->edge_weight || (want_arg && !(U == 4 && p->argmax && p->argmin && !p->out_row_of));
   dim3 grid((unsigned)(light_blocks + k.n_heavy_blocks), (unsigned)(tiles * T));
   hipStream_t st = (hipStream_t)stream;
   // 32-bit gather offsets when the whole feature table is addressable with them
@@ -910,12 +968,17 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
     f.dst = p->dst_term; f.ldd_b = (unsigned)(p->ld_dst * 4);
     f.orow = p->out_row_of;
     f.argmax = p->argmax; f.argmin = p->argmin; f.ld_arg = p->ld_arg; f.ts_arg = ts_in;
+    f.et = p->edge_term; f.etype = p->edge_type; f.lde_b = (unsigned)(p->ld_edge * 4); f.n_types = p->n_edge_types;
     if (p->out_row_of && !(p->dst_term && U == 4))
       return pna_set_error(PNA_E_INVALID, "pna_segreduce_fwd_f32: out_row_of is honoured with dst_term and the default unroll only (without dst_term the work list's row field is the output row)");
     const long fb = (p->n_work_items + rows_per_block - 1) / rows_per_block;
     dim3 fgrid((unsigned)fb, (unsigned)(tiles * T));
     const unsigned dyn_lds = (unsigned)(k.dbg >> 8) * 1024u;   // 0 in the shipped build
-    if (want_arg) {
+    if (et_mode == 1) {
+      hipLaunchKernelGGL((k_segreduce_fast<4, true, false, false, 1>), fgrid, dim3(kBlock), dyn_lds, st, f);
+    } else if (et_mode == 2) {
+      hipLaunchKernelGGL((k_segreduce_fast<4, true, false, false, 2>), fgrid, dim3(kBlock), dyn_lds, st, f);
+    } else if (want_arg) {
       if (p->dst_term) hipLaunchKernelGGL((k_segreduce_fast<4, true, false, true>), fgrid, dim3(kBlock), dyn_lds, st, f);
       else hipLaunchKernelGGL((k_segreduce_fast<4, false, false, true>), fgrid, dim3(kBlock), dyn_lds, st, f);
     } else if (p->dst_term && p->out_row_of) {

@@ -162,10 +162,14 @@ def _towers_forward(towers, graph, h, e, snorm_n, divide_input):
     A, S = len(t0.aggregators), len(t0.scalers)
     V = h.shape[0]
     csr = graph.csr
+    etab = None
     if t0.edge_features:
         if e is None:
             raise ValueError("edge_features=True but no edge features were given")
-        e_csr = e[csr.eid]                                    # per-edge features in CSR (dst-sorted) order
+        no_grad = not torch.is_grad_enabled() or not (h.requires_grad or e.requires_grad or any(p.requires_grad for t in towers for p in t.parameters()))
+        if no_grad and e.is_cuda and type(graph) is Graph and all(t.pretrans.is_affine for t in towers):
+            etab = graph.edge_type_table(e)                   # edge features that are an embedding of <= 4 edge types: a table
+        e_csr = e[csr.eid] if etab is None else None          # per-edge features in CSR (dst-sorted) order
     hs = [h[:, t * Fi:(t + 1) * Fi] if divide_input else h for t in range(T)]
 
     if all(t.pretrans.is_affine for t in towers):
@@ -193,9 +197,13 @@ def _towers_forward(towers, graph, h, e, snorm_n, divide_input):
         else:
             x_src = h @ Wa.reshape(T * Fi, Fi).t()
             x_dst = torch.addmm(b.reshape(-1), h, Wb.reshape(T * Fi, Fi).t())
-        x_edge = e_csr @ We.reshape(T * Fi, ed).t() if t0.edge_features else None
+        x_edge = edge_type = None
+        if t0.edge_features and etab is not None:             # W_e . ef of the <= 4 distinct feature rows; the gather indexes it by type
+            edge_type, x_edge = etab[0], etab[1] @ We.reshape(T * Fi, ed).t()
+        elif t0.edge_features:
+            x_edge = e_csr @ We.reshape(T * Fi, ed).t()
         x_src = graph.source_features(x_src, defer=True)      # multi-GPU: halo exchange of the PROJECTED rows, overlapped
-        agg = PF.aggregate(graph, x_src, Fi, t0.aggregators, n_tower=T, dst_term=x_dst, edge_term=x_edge)   # (waits for it)
+        agg = PF.aggregate(graph, x_src, Fi, t0.aggregators, n_tower=T, dst_term=x_dst, edge_term=x_edge, edge_type=edge_type)   # (waits for it)
     else:
         # general pretrans (MLP with hidden layers): per-edge messages are materialised in CSR order
         src, dst = csr.col.long(), csr.row.long()

@@ -17,7 +17,7 @@ def _unit_stride(t):
 
 
 def aggregate(graph, x, F, aggregators, *, n_tower=1, dst_term=None, edge_term=None, row_scales=(None,),
-              edge_resident=False, edge_weight=None, col_override=None):
+              edge_resident=False, edge_weight=None, col_override=None, edge_type=None):
     """(V, n_tower * S * A * F) aggregate of the messages flowing into every node of `graph`.
 
     message(u->v) = x[u] (+ dst_term[v]) (+ edge_term[k]);  with edge_resident=True, x already holds
@@ -25,7 +25,7 @@ def aggregate(graph, x, F, aggregators, *, n_tower=1, dst_term=None, edge_term=N
     result: tower-major, then scaler-major, then aggregator-major (the reference's cat order).
     edge_weight: fp32 [E] in CSR order (dense-variant adjacency weights).  col_override: int32 [E] row of
     `x` to gather for each CSR edge instead of the edge's source node (x then holds per-edge messages in
-    some other edge order).
+    some other edge order).  edge_type: int32 [E] in CSR order -- edge_term then has one row per edge TYPE (inference only).
     """
     x, dst_term, edge_term = _unit_stride(x), _unit_stride(dst_term), _unit_stride(edge_term)
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, dst_term, edge_term)):
@@ -63,7 +63,7 @@ def aggregate(graph, x, F, aggregators, *, n_tower=1, dst_term=None, edge_term=N
     return ops.segreduce(csr.rowptr, col, x, F, aggregators, row_scales,
                          n_tower=n_tower, tower_stride_in=F, dst_term=dst_term, edge_term=edge_term,
                          edge_weight=edge_weight, heavy=graph.heavy_schedule(), workspace=graph.workspace,
-                         items=graph.work_items())
+                         items=graph.work_items(), edge_type=edge_type)
 
 
 def _fold_batchnorm(bn):

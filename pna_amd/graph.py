@@ -312,6 +312,33 @@ class Graph:
             self._scalers[key] = (amp, att)
         return self._scalers[key]
 
+    MAX_EDGE_TYPES = 4        # what the hand-scheduled gather keeps in registers (pna_segreduce_args.edge_type, ABI 14)
+
+    def edge_type_table(self, e):
+        """(types int32 [E] in CSR order, rows (n_types, edge_dim)) when the per-edge feature rows `e` take at most
+        MAX_EDGE_TYPES distinct values -- the molecule nets' edge features are an EMBEDDING of the bond type
+        (realworld_benchmark/nets/molecules_graph_regression/pna_net.py: `e = self.embedding_e(e)`), so the W_e . ef part of a
+        factorised pretrans is a table with one row per type -- else None.  Found by hashing the rows (one sort of E scalars) and
+        VERIFIED against e (a hash collision makes it None, never a wrong table); cached per (tensor, version)."""
+        key = (e.data_ptr(), e._version, tuple(e.shape), str(e.device))
+        hit = self.__dict__.get("_edge_types")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        res = None
+        with torch.no_grad():
+            if e.dim() == 2 and e.shape[0] == self.csr.col.numel() and e.shape[0] > 0:
+                gen = torch.Generator(device="cpu").manual_seed(0x5eed)
+                w = torch.randn(e.shape[1], dtype=torch.float64, generator=gen).to(e.device)
+                uniq, inv = torch.unique(e.double() @ w, return_inverse=True)
+                if uniq.numel() <= self.MAX_EDGE_TYPES:
+                    rep = torch.zeros(uniq.numel(), dtype=torch.long, device=e.device)
+                    rep.scatter_(0, inv, torch.arange(e.shape[0], device=e.device))      # any edge of each type
+                    rows = e[rep].contiguous()
+                    if torch.equal(rows[inv], e):
+                        res = (inv[self.csr.eid].to(torch.int32).contiguous(), rows)
+        self.__dict__["_edge_types"] = (key, res, e)          # (`e` kept alive: the key holds its address)
+        return res
+
     def snorm_n(self):
         """Graph-size normalisation 1/sqrt(nodes in the node's graph), (V,1) -- data/molecules.py:157-159."""
         if self._snorm_n is None:

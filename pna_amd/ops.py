@@ -42,8 +42,10 @@ def segreduce(rowptr: torch.Tensor, col: Optional[torch.Tensor], x: torch.Tensor
               out: Optional[torch.Tensor] = None, block_stride: Optional[int] = None,
               tower_stride_out: Optional[int] = None, want_arg: bool = False,
               heavy: Optional[HeavySchedule] = None, workspace=None, tune: Optional[dict] = None,
-              items: Optional[torch.Tensor] = None, heavy_out: Optional[torch.Tensor] = None, out_row_of: Optional[torch.Tensor] = None):
+              items: Optional[torch.Tensor] = None, heavy_out: Optional[torch.Tensor] = None, out_row_of: Optional[torch.Tensor] = None,
+              edge_type: Optional[torch.Tensor] = None):
     """out[v, t*tso + (s*A + a)*bs + f] = aggregators[a]({m_k}) [f] * row_scales[s][v]   (see pna_amd.h).
+    edge_type (int32 [E], CSR order): edge_term then holds one row per edge TYPE (ABI 14).
 
     rowptr:int32[V+1]; col:int32[E] or None (x edge-resident); x:(rows, >= T*F) fp32.
     Returns out, or (out, argmax, argmin) when want_arg.
@@ -65,6 +67,8 @@ def segreduce(rowptr: torch.Tensor, col: Optional[torch.Tensor], x: torch.Tensor
         a.dst_term, a.ld_dst = _lib.dev_ptr(dst_term, torch.float32, "dst_term"), _ld(dst_term)
     if edge_term is not None:
         a.edge_term, a.ld_edge = _lib.dev_ptr(edge_term, torch.float32, "edge_term"), _ld(edge_term)
+        if edge_type is not None:
+            a.edge_type, a.n_edge_types = _lib.dev_ptr(edge_type, torch.int32, "edge_type"), edge_term.shape[0]
     if edge_weight is not None:
         a.edge_weight = _lib.dev_ptr(edge_weight, torch.float32, "edge_weight")
     a.n_tower, a.tower_stride_in, a.tower_stride_out = T, tsi, tso

@@ -159,6 +159,39 @@ def test_hand_scheduled_gather_with_arg_tracking_equals_the_generic_kernel(cuda_
     assert int((x1 < 0).sum()) >= 20 * F and int((c.rowptr[1:] - c.rowptr[:-1]).max()) > 128
 
 
+@pytest.mark.parametrize("T,F", [(1, 75), (5, 15), (4, 16), (1, 130)])
+def test_hand_scheduled_gather_with_edge_terms_equals_the_generic_kernel(cuda_device, T, F):
+    """The tower layers WITH edge features (models/dgl/pna_layer.py:35-40): message = x[src] + dst_term[v] + edge_term, on the
+    hand-scheduled kernel -- per-edge term, and the term as a table of <= 4 edge types (ABI 14) -- against the compiler-scheduled
+    kernel with the per-edge term: identical bits (the message is formed in the same order), hub rows and isolated rows included;
+    and the type table through the compiler-scheduled kernel too."""
+    rng = np.random.default_rng(T * 1000 + F)
+    V, E = 3000, 40000
+    src, dst = _rand_graph(rng, V, E, hub=1500)
+    keep_e = (dst < 20) | (dst >= 40)
+    g = Graph(src[keep_e], dst[keep_e], V).to(cuda_device)
+    c = g.csr
+    Ecsr = c.col.numel()
+    gen = torch.Generator().manual_seed(F)
+    x, dt = torch.randn(V, T * F, generator=gen).to(cuda_device), torch.randn(V, T * F, generator=gen).to(cuda_device)
+    table = torch.randn(4, T * F, generator=gen).to(cuda_device)
+    types = torch.randint(0, 4, (Ecsr,), generator=gen).to(torch.int32).to(cuda_device)
+    per_edge = table[types.long()].contiguous()
+    aggs = ["mean", "max", "min", "std"]
+    kw = dict(n_tower=T, tower_stride_in=F, dst_term=dt, heavy=g.heavy_schedule(), workspace=g.workspace)
+    ref = ops.segreduce(c.rowptr, c.col, x, F, aggs, (None,), edge_term=per_edge, tune=dict(generic=1), **kw).clone()
+    fast_e = ops.segreduce(c.rowptr, c.col, x, F, aggs, (None,), edge_term=per_edge, items=g.work_items(), tune=dict(generic=2), **kw).clone()
+    fast_t = ops.segreduce(c.rowptr, c.col, x, F, aggs, (None,), edge_term=table, edge_type=types, items=g.work_items(), tune=dict(generic=2), **kw).clone()
+    gen_t = ops.segreduce(c.rowptr, c.col, x, F, aggs, (None,), edge_term=table, edge_type=types, tune=dict(generic=1), **kw).clone()
+    assert torch.equal(fast_e, ref) and torch.equal(fast_t, ref) and torch.equal(gen_t, ref)
+    # ... and a random per-edge term (no table) against the oracle-checked generic kernel
+    et = torch.randn(Ecsr, T * F, generator=gen).to(cuda_device)
+    a = ops.segreduce(c.rowptr, c.col, x, F, aggs, (None,), edge_term=et, tune=dict(generic=1), **kw).clone()
+    b = ops.segreduce(c.rowptr, c.col, x, F, aggs, (None,), edge_term=et, items=g.work_items(), tune=dict(generic=2), **kw)
+    assert torch.equal(a, b)
+    assert int((c.rowptr[1:] - c.rowptr[:-1]).max()) > 128
+
+
 def test_segreduce_edge_resident_messages(cuda_device):
     rng = np.random.default_rng(5)
     V, E, F = 400, 3000, 20

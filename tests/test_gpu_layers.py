@@ -77,6 +77,28 @@ def test_tower_layer_golden(cuda_device, monkeypatch, name, path):
     torch.testing.assert_close(out, a["out"], **TOL)
 
 
+@pytest.mark.parametrize("name", ["tower_edgefeat", "tower_edgetype", "tower_edgetype_div"])
+def test_edge_feature_tower_layer_runs_on_the_hand_scheduled_gather(cuda_device, monkeypatch, name):
+    """PNALayer with edge features (models/dgl/pna_layer.py:35-40) against the reference's outputs with the hand-scheduled gather
+    REQUIRED (tune.generic = 2: the call fails if it does not qualify): arbitrary per-edge features take its per-edge term loads,
+    features that are an embedding of <= 4 edge types (the molecule nets' bond types) its register-resident type table."""
+    from pna_amd import functional as PF, ops
+    monkeypatch.setattr(PF, "SMALL_TOWER_ROWS", 0)
+    monkeypatch.setitem(ops._TUNE, "generic", 2)
+    meta, a, sd = load_golden(name)
+    layer = PNALayer(meta["in_dim"], meta["out_dim"], meta["aggregators"], meta["scalers"], {"log": a["avg_log"]}, 0.0,
+                     meta["graph_norm"], meta["batch_norm"], towers=meta["towers"], pretrans_layers=1, posttrans_layers=1,
+                     divide_input=meta["divide_input"], residual=meta["residual"], edge_features=True, edge_dim=meta["edge_dim"])
+    layer.load_state_dict(sd)
+    layer = layer.to(cuda_device).eval()
+    g = Graph(a["src"], a["dst"], meta["N"], meta["sizes"]).to(cuda_device)
+    e = a["e"].to(cuda_device)
+    assert (g.edge_type_table(e) is not None) == name.startswith("tower_edgetype")
+    with torch.no_grad():
+        out = layer(g, a["h"].to(cuda_device), e, a["snorm_n"].to(cuda_device)).cpu()
+    torch.testing.assert_close(out, a["out"], **TOL)
+
+
 @pytest.mark.parametrize("name", golden_names("dense"))
 def test_dense_layer_golden(cuda_device, name):
     meta, a, sd = load_golden(name)

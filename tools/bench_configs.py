@@ -15,7 +15,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import torch_oracle as O  # noqa: E402  (reported CPU baseline only)
-from pna_amd import Graph  # noqa: E402
+from pna_amd import Graph, functional as PF  # noqa: E402
 from pna_amd.capture import GraphedForward  # noqa: E402
 from pna_amd.dgl.pna_layer import PNALayer, PNASimpleLayer  # noqa: E402
 from pna_amd.pytorch.pna.layer import PNALayer as DensePNALayer  # noqa: E402
@@ -114,6 +114,30 @@ with torch.no_grad():
     t_build_first = gpu_ms(lambda: lay(build_batch(ss, dd, sizes, float(avg["log"])), hd, None, snorm), iters=20)
 out["zinc_tower_layer"] = dict(batch_build_ms=t_build, batch_build_flat_ms=t_build_flat, batch_build_plus_first_layer_ms=t_build_first, graphs=128, V=V, E=E, hidden=75, towers=5, eager_ms=eager, hipgraph_ms=graphed,
                                edges_per_s_hipgraph=E / graphed * 1e3, cpu_oracle_ms=cpu, max_abs_err_vs_oracle=err, max_rel_err_vs_oracle=err / ref.abs().max().item())
+
+# ---- the same ZINC-shaped batch with --edge_feat True: edge features = an embedding (edge_dim 50) of 4 bond types
+#      (nets/molecules_graph_regression/pna_net.py); the W_e . ef part of the factorised pretrans is a 4-row table the gather
+#      indexes by type (ABI 14).  Edge-feature layers are not on the one-call small-batch kernel: four launches. ----
+small_rows = PF.SMALL_TOWER_ROWS
+gen_e = torch.Generator().manual_seed(5)
+emb = torch.randn(4, 50, generator=gen_e)
+btype = torch.randint(0, 4, (E,), generator=gen_e)
+e_feat = emb[btype]
+layer_e = PNALayer(75, 75, AGG, SCA, avg, 0.0, True, True, towers=5, divide_input=False, residual=True, edge_features=True, edge_dim=50).eval()
+randomise(layer_e)
+sd_e = {k: v.clone() for k, v in layer_e.state_dict().items()}
+lay_e, ed = layer_e.to(dev), e_feat.to(dev)
+with torch.no_grad():
+    assert g.edge_type_table(ed) is not None
+    eager_e = gpu_ms(lambda: lay_e(g, hd, ed, snorm))
+    gf_e = GraphedForward(lambda x: lay_e(g, x, ed, snorm), hd)
+    graphed_e = gpu_ms(lambda: gf_e(hd))
+    ref_e = O.dgl_layer_forward(sd_e, src, dst, V, h, e_feat, snorm.cpu(), AGG.split(), SCA.split(), avg["log"], 5, False, True, True, True, True)
+    err_e = (gf_e(hd).cpu() - ref_e).abs().max().item()
+    eager_noe = gpu_ms(lambda: (setattr(PF, "SMALL_TOWER_ROWS", 0), lay(g, hd, None, snorm), setattr(PF, "SMALL_TOWER_ROWS", small_rows))[1])
+out["zinc_tower_layer_edge_feat"] = dict(graphs=128, V=V, E=E, hidden=75, towers=5, edge_dim=50, edge_types=4, eager_ms=eager_e, hipgraph_ms=graphed_e,
+                                         same_path_without_edge_features_eager_ms=eager_noe, max_abs_err_vs_oracle=err_e,
+                                         max_rel_err_vs_oracle=err_e / ref_e.abs().max().item())
 
 # ---- configs[3]: MolHIV-shaped batch, PNASimpleLayer hidden 80, 2048 graphs ----
 src, dst, sizes = molecule_batch(2048, mean_nodes=25.5, sd_nodes=12, lo=6, hi=222, seed=41, lognormal=True)
