@@ -60,6 +60,9 @@ def parse():
     p.add_argument("--no-power-probe", action="store_true", help="skip the rocm-smi power / clock samples (2 x ~1.5 s)")
     p.add_argument("--no-cold", action="store_true", help="skip the cold-cache leg (3 rotating copies of the inputs)")
     p.add_argument("--check-rows", type=int, default=96, help="rows re-computed on the host after the timed loop")
+    p.add_argument("--layers", type=int, default=1, help="> 1: a step = this many stacked layers (N > 1: inter-layer halo exchange cut into row "
+                   "blocks, pna_amd.shard.BlockPipeline); a reduced JSON line, the default line describes ONE layer")
+    p.add_argument("--blocks", type=int, default=4, help="--layers > 1, N > 1: row blocks per layer of the pipelined exchange")
     return p.parse_args()
 
 
@@ -310,6 +313,57 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.layers > 1:
+        # ---- a stack of layers per step.  N = 1: the layers back to back on the one-kernel path, activations
+        #      kept at the 16-byte pitch; N > 1: BlockPipeline -- block b of layer L is packed and sent while blocks b+1.. are still
+        #      being computed; per-layer kernels = gather over the block's work list + three-block contraction over its rows
+        import copy
+        from pna_amd.shard import BlockPipeline
+        L = args.layers
+        layers = [layer] + [copy.deepcopy(layer) for _ in range(L - 1)]
+        P = max(args.x_pitch, (F + 3) // 4 * 4)
+        if world > 1:
+            pipe = BlockPipeline(g, args.blocks)
+            ta = torch.zeros(n_local + g.n_halo, P, device=dev)
+            tb = torch.zeros_like(ta)
+            ta[:n_local, :F] = h
+            rows_fn = PF.SimpleLayerRows(layers, g, args.blocks)
+
+            def step_l():
+                with torch.no_grad():
+                    return pipe.run(rows_fn, L, ta, tb)
+        else:
+            def step_l():
+                with torch.no_grad():
+                    x = h
+                    for i, lay in enumerate(layers):
+                        x = lay(g, x)                    # (the one-kernel path writes rows at an aligned pitch: the next layer stays on it)
+                    return x
+        for _ in range(args.warmup):
+            step_l()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_l()
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        if rank == 0:
+            print(json.dumps({"metric": "PNA-layer fwd edges/sec (F=%d, 4 aggr x 3 scalers), %d stacked layers per step" % (F, L),
+                              "value": E * L / (dt / args.steps), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": dt / args.steps * 1e3, "ms_per_layer": dt / args.steps * 1e3 / L, "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": "%d x PNASimpleLayer(F=%d) stacked, |V|=%d |E|=%d per GPU" % (L, F, args.nodes_per_gpu, args.edges_per_gpu),
+                                         "layers": L, "row_blocks": args.blocks if world > 1 else None,
+                                         "exchange": "block-pipelined point-to-point (pna_amd.shard.BlockPipeline)" if world > 1 else None,
+                                         "halo_rows_rank0": int(getattr(g, "n_halo", 0))}}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     for _ in range(args.warmup):
         step()

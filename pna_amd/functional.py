@@ -606,7 +606,8 @@ class FusedDegreeCall:
         lin = layer.posttrans.fully_connected[0].linear
         self.scales = scales = _row_scales(graph, layer.scalers, layer.avg_d, h.device)
         V = h.shape[0]
-        self.y = y = torch.empty(V, N, dtype=torch.float32, device=h.device) if out is None else out
+        # (rows at a 16-byte aligned pitch: the next layer of a stack can read them in 16-byte strips, i.e. stay on this path)
+        self.y = y = torch.empty(V, (N + 3) // 4 * 4, dtype=torch.float32, device=h.device)[:, :N] if out is None else out
         self.cs, self.ct, self.res = cs, ct, res = _layer_tail_operands(layer, h)
         desc, ids, n_rec = plan.fused_tables()
         img, stride = DG.fused_images(lin.weight, F, scales, plan)
@@ -739,3 +740,46 @@ def tower_layer_small(owner, towers, mix, graph, h, snorm_n, row_scales, divide_
         plan = _SmallTowerPlan(towers, mix, divide_input)
         owner.__dict__["_pna_amd_small"] = plan
     return plan.run(graph, h, snorm_n, row_scales, residual)
+
+
+class SimpleLayerRows:
+    """layer_rows callback of shard.BlockPipeline for a stack of PNASimpleLayer (eval): rows [r0, r1) of layer l from the complete
+    [local | halo] table into the next table -- the gather over the block's work list (hub rows ride with block 0: their
+    finalize writes wherever they live) and the three-block contraction over the block's slice of the aggregate.  Every row is
+    computed by the same kernels in the same order as on one GPU: bit-identical to the unsharded ordinary path."""
+
+    def __init__(self, layers, graph, n_blocks):
+        from . import degree_groups as DG
+        self.layers, self.g = list(layers), graph
+        l0 = self.layers[0]
+        self.F = l0.in_dim
+        if any(l.in_dim != self.F or l.out_dim != self.F or tuple(l.aggregators) != ("mean", "max", "min", "std") or l.training for l in self.layers):
+            raise ValueError("SimpleLayerRows: a stack of eval-mode PNASimpleLayer(F -> F) with the four standard aggregators")
+        V = graph.num_nodes
+        self.agg = torch.empty(V, DG.agg_pitch(4 * self.F), dtype=torch.float32, device=graph.device)
+        hs = graph.heavy_schedule()
+        deg = graph.csr.rowptr[1:] - graph.csr.rowptr[:-1]
+        light = (deg <= hs.threshold) if hs.threshold > 0 else torch.ones_like(deg, dtype=torch.bool)
+        rows = torch.arange(V, device=graph.device)
+        self.items = []
+        for b in range(n_blocks):
+            r0, r1 = (V * b) // n_blocks, (V * (b + 1)) // n_blocks
+            self.items.append(graph.work_items_subset(light & (rows >= r0) & (rows < r1), include_heavy=(b == 0)))
+        self.hs = hs
+
+    def __call__(self, l, table, r0, r1, out, b):
+        from .dgl.pna_layer import _row_scales
+        layer, g, F = self.layers[l], self.g, self.F
+        csr = g.csr
+        K = 4 * F
+        x = table[:, :F]
+        items = self.items[b]
+        if items.shape[0]:
+            ops.segreduce(csr.rowptr, csr.col, x, F, layer.aggregators, (None,), tower_stride_in=F, out=self.agg,
+                          heavy=self.hs if b == 0 else None, workspace=g.workspace, items=items, tune=dict(generic=2))
+        if r1 > r0:
+            lin = layer.posttrans.fully_connected[0].linear
+            scales = _row_scales(g, layer.scalers, layer.avg_d, table.device)
+            cs, ct, _ = _layer_tail_operands(layer, x)
+            ops.posttrans(self.agg[r0:r1, :K], K, lin.weight, [None if r is None else r[r0:r1] for r in scales], lin.bias, out=out[:, :layer.out_dim],
+                          col_scale=cs, col_shift=ct, relu=True, residual=x[r0:r1] if layer.residual else None)

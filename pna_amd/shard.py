@@ -92,8 +92,11 @@ class HaloGraph(Graph):
     kernel whichever way the launch is split."""
 
     def __init__(self, src_ext, dst_local, n_local, n_halo, send_idx, send_splits, recv_splits, group, lo, hi,
-                 global_num_nodes, batch_num_nodes=None, any_exchange=True):
+                 global_num_nodes, batch_num_nodes=None, any_exchange=True, bounds=None, recv_ids=None, rank=None):
         super().__init__(src_ext, dst_local, n_local, batch_num_nodes)
+        self.rank = rank                          # this shard's position in `bounds` (= rank in `group`)
+        self.bounds = bounds                      # node ranges of all ranks (BlockPipeline needs the peers' row counts)
+        self.recv_ids = recv_ids                  # int64 [n_halo]: peer-local id of every halo row, grouped by peer, ascending
         self.n_halo = n_halo
         self.send_idx = send_idx                  # int64 [sum(send_splits)] local rows to pack, grouped by peer
         self.send_splits = send_splits            # rows sent to each peer
@@ -110,7 +113,8 @@ class HaloGraph(Graph):
     def to(self, device):
         g = HaloGraph(self.src.to(device), self.dst.to(device), self.num_nodes, self.n_halo, self.send_idx.to(device),
                       self.send_splits, self.recv_splits, self.group, self.lo, self.hi, self.global_num_nodes,
-                      self.batch_num_nodes, self.any_exchange)
+                      self.batch_num_nodes, self.any_exchange, self.bounds,
+                      None if self.recv_ids is None else self.recv_ids.to(device), self.rank)
         return g
 
     # -- row classes -----------------------------------------------------------------------------------
@@ -211,6 +215,32 @@ class _HaloExchange(torch.autograd.Function):
         return grad_local, None
 
 
+def shard_local(src: torch.Tensor, dst: torch.Tensor, bounds: List[int], rank: int):
+    """The part of shard_graph that needs no communication: this rank's in-edges with their sources renumbered into
+    [local rows | halo rows], and per peer the (peer-local) ids of the rows wanted from it.  ONE sort of the remote sources: the
+    owners are contiguous id ranges, so the sorted unique ids are already grouped by owner, peer by peer (round 2 ran one
+    torch.unique per peer over a masked copy: 7 sorts and 14 masked copies at 8 ranks).  At BASELINE configs[4] size (V = 16 M,
+    E = 160 M, 8 ranks) on one MI355X: tools/shard_time.py.
+    Returns (src_ext int64 [E_local], dst_local int64 [E_local], n_local, [ids wanted from peer p], [their counts])."""
+    world_size = len(bounds) - 1
+    lo, hi = bounds[rank], bounds[rank + 1]
+    n_local = hi - lo
+    mine = (dst >= lo) & (dst < hi)
+    s, d = src[mine].long(), dst[mine].long() - lo
+    del mine
+    local = (s >= lo) & (s < hi)
+    src_ext = torch.where(local, s - lo, s)                                      # (remote entries overwritten below)
+    remote = ~local
+    uniq, inv = torch.unique(s[remote], sorted=True, return_inverse=True)        # de-duplicated halo, ascending global id
+    src_ext[remote] = n_local + inv
+    bt = torch.tensor(bounds, device=s.device, dtype=torch.long)
+    cuts = torch.searchsorted(uniq, bt).tolist()                                 # peer p's ids: uniq[cuts[p]:cuts[p+1]]
+    recv_lists = [uniq[cuts[p]:cuts[p + 1]] - bounds[p] for p in range(world_size)]
+    recv_splits = [cuts[p + 1] - cuts[p] for p in range(world_size)]
+    assert recv_splits[rank] == 0
+    return src_ext, d, n_local, recv_lists, recv_splits
+
+
 def shard_graph(src: torch.Tensor, dst: torch.Tensor, num_nodes: int, rank: Optional[int] = None,
                 world_size: Optional[int] = None, group=None, balance: str = "nodes") -> HaloGraph:
     """Build this rank's shard from the GLOBAL edge list (every rank passes the same src/dst, e.g. a
@@ -222,26 +252,9 @@ def shard_graph(src: torch.Tensor, dst: torch.Tensor, num_nodes: int, rank: Opti
     dev = src.device
     bounds = partition_bounds(num_nodes, world_size, dst, balance)
     lo, hi = bounds[rank], bounds[rank + 1]
-    n_local = hi - lo
-    mine = (dst >= lo) & (dst < hi)
-    s, d = src[mine].long(), dst[mine].long() - lo
-    bt = torch.tensor(bounds, device=dev, dtype=torch.long)
-    owner = torch.searchsorted(bt, s, right=True) - 1
-    src_ext = torch.empty_like(s)
-    local = owner == rank
-    src_ext[local] = s[local] - lo
-    recv_lists, recv_splits, off = [], [], n_local
-    for p in range(world_size):
-        if p == rank:
-            recv_lists.append(s.new_empty(0))
-            recv_splits.append(0)
-            continue
-        m = owner == p
-        uniq, inv = torch.unique(s[m], sorted=True, return_inverse=True)            # de-duplicated halo of peer p
-        src_ext[m] = off + inv
-        recv_lists.append(uniq - bounds[p])                                         # peer-local row ids
-        recv_splits.append(int(uniq.numel()))
-        off += int(uniq.numel())
+    src_ext, d, n_local, recv_lists, recv_splits = shard_local(src, dst, bounds, rank)
+    s = src_ext
+    off = n_local + sum(recv_splits)
     n_halo = off - n_local
     # tell every peer which of its rows we need: counts first, then the id lists
     cnt_out = torch.tensor(recv_splits, dtype=torch.long, device=dev)
@@ -257,4 +270,128 @@ def shard_graph(src: torch.Tensor, dst: torch.Tensor, num_nodes: int, rank: Opti
     tot = torch.tensor([n_halo + sum(send_splits)], dtype=torch.long, device=dev)
     dist.all_reduce(tot, group=group)
     return HaloGraph(src_ext, d, n_local, n_halo, send_idx, send_splits, recv_splits, group, lo, hi, num_nodes,
-                     any_exchange=bool(int(tot.item()) > 0))
+                     any_exchange=bool(int(tot.item()) > 0), bounds=list(bounds), recv_ids=want, rank=rank)
+
+
+class BlockPipeline:
+    """Multi-layer inference on a sharded graph with the inter-layer halo exchange cut into ROW BLOCKS.
+
+    Per-layer exchange (HaloGraph.source_features) serialises  layer L -> pack -> all-to-all -> layer L+1 ; only the rows without
+    remote sources overlap with it, and on a locality-free graph those are 1 % of the rows.  Here every rank cuts its rows into
+    `n_blocks` contiguous blocks; as soon as layer L has produced block b, the rows of b that peers need are packed and sent,
+    and the peers' block b is received IN PLACE into the next layer's [local | halo] table -- while blocks b+1.. of layer L are
+    still being computed.  Layer L+1 starts when all blocks have arrived.  (The send lists are ascending row ids per peer, the
+    blocks contiguous id ranges: the rows of one (peer, block) pair are a contiguous piece of the send buffer and of the halo.)
+
+    layer_rows(l, table, r0, r1, out, b): compute rows [r0, r1) of layer l from the complete table `table`
+    ((n_local + n_halo, pitch): [local | halo]) into `out` (a view of the next table's rows [r0, r1)).  Point-to-point
+    isend / irecv (RCCL on GPUs, gloo on CPU); every rank must use the same n_blocks."""
+
+    def __init__(self, graph: HaloGraph, n_blocks: int):
+        if graph.bounds is None or graph.recv_ids is None or graph.rank is None:
+            raise ValueError("BlockPipeline needs a HaloGraph built by shard_graph (bounds / recv_ids / rank)")
+        self.g, self.B = graph, int(n_blocks)
+        g, B = graph, self.B
+        W = len(g.bounds) - 1
+        self.rank = g.rank
+        n = g.num_nodes
+        self.rows = [(n * b) // B for b in range(B + 1)]                          # my block bounds (local row ids)
+        dev = g.send_idx.device
+        # send side: position of every (block, peer) piece in the peer-major send list, then a block-major copy of the list
+        so = [0]
+        for v in g.send_splits:
+            so.append(so[-1] + v)
+        cut_s = []                                                                # cut_s[p][b]: first entry of block b in peer p's segment
+        mine = torch.tensor(self.rows, device=dev, dtype=g.send_idx.dtype)
+        for p in range(W):
+            seg = g.send_idx[so[p]:so[p + 1]]
+            cut_s.append((torch.searchsorted(seg, mine) + so[p]).tolist())
+        order, self.send_piece = [], []                                           # send_piece[b][p] = (offset, count) in the block-major list
+        off = 0
+        for b in range(B):
+            row = []
+            for p in range(W):
+                a, z = cut_s[p][b], cut_s[p][b + 1]
+                order.append(torch.arange(a, z, device=dev))
+                row.append((off, z - a))
+                off += z - a
+            self.send_piece.append(row)
+        perm = torch.cat(order) if order else g.send_idx.new_empty(0)
+        self.send_rows = g.send_idx[perm].contiguous()                            # block-major, peer-minor
+        self._send_rows32 = None
+        # receive side: the halo rows of peer p (ascending peer-local ids) cut by PEER p's block bounds
+        ro = [0]
+        for v in g.recv_splits:
+            ro.append(ro[-1] + v)
+        self.recv_piece = []                                                      # recv_piece[b][p] = (first halo row, count)
+        cut_r = []
+        for p in range(W):
+            n_p = g.bounds[p + 1] - g.bounds[p]
+            theirs = torch.tensor([(n_p * b) // B for b in range(B + 1)], device=g.recv_ids.device, dtype=g.recv_ids.dtype)
+            cut_r.append((torch.searchsorted(g.recv_ids[ro[p]:ro[p + 1]], theirs) + ro[p]).tolist())
+        for b in range(B):
+            self.recv_piece.append([(cut_r[p][b], cut_r[p][b + 1] - cut_r[p][b]) for p in range(W)])
+        self.W = W
+
+    def _pack(self, table, b):
+        g = self.g
+        o0, o1 = self.send_piece[b][0][0], self.send_piece[b][-1][0] + self.send_piece[b][-1][1]
+        if o1 == o0:
+            return table.new_empty(0, table.shape[1])
+        if table.is_cuda:
+            from . import ops
+            if self._send_rows32 is None or self._send_rows32.device != table.device:
+                self._send_rows32 = self.send_rows.to(device=table.device, dtype=torch.int32)
+            return ops.pack_rows(table[: g.num_nodes], self._send_rows32[o0:o1])
+        return table[: g.num_nodes].index_select(0, self.send_rows[o0:o1])
+
+    def start_block(self, table, b):
+        """Pack and post the exchange of block b of `table`'s local rows; its halo part receives the peers' block b in place.
+        Returns the handles to wait for (and the send buffer, which must outlive them)."""
+        g = self.g
+        if not g.any_exchange:
+            return [], None
+        send = self._pack(table, b)
+        if send.is_cuda and dist.get_backend(g.group) != "nccl":
+            # (the one-GPU smoke tests run this over gloo, whose point-to-point calls read device memory from the host without
+            # ordering against the stream that is still packing it; RCCL orders against the current stream itself)
+            torch.cuda.current_stream(send.device).synchronize()
+        base = self.send_piece[b][0][0]
+        ops_ = []
+        for p in range(self.W):
+            if p == self.rank:
+                continue
+            so, sc = self.send_piece[b][p]
+            ro, rc = self.recv_piece[b][p]
+            peer = p if g.group is None else dist.get_global_rank(g.group, p)
+            if sc:
+                ops_.append(dist.P2POp(dist.isend, send[so - base:so - base + sc], peer, group=g.group))
+            if rc:
+                ops_.append(dist.P2POp(dist.irecv, table[g.num_nodes + ro:g.num_nodes + ro + rc], peer, group=g.group))
+        return (dist.batch_isend_irecv(ops_) if ops_ else []), send
+
+    def exchange_all(self, table):
+        """The whole halo of `table` (all blocks back to back): the exchange in front of the first layer."""
+        pend = [self.start_block(table, b) for b in range(self.B)]
+        for works, _ in pend:
+            for w in works:
+                w.wait()
+
+    def run(self, layer_rows, n_layers, table_a, table_b):
+        """n_layers layers from table_a (local rows filled; halo NOT yet exchanged) ping-ponging with table_b; returns the table
+        that holds the last layer's local rows (its halo part is stale)."""
+        g = self.g
+        self.exchange_all(table_a)
+        cur, nxt = table_a, table_b
+        for l in range(n_layers):
+            pend = []
+            for b in range(self.B):
+                r0, r1 = self.rows[b], self.rows[b + 1]
+                layer_rows(l, cur, r0, r1, nxt[r0:r1], b)
+                if l + 1 < n_layers:
+                    pend.append(self.start_block(nxt, b))
+            for works, _ in pend:
+                for w in works:
+                    w.wait()
+            cur, nxt = nxt, cur
+        return cur

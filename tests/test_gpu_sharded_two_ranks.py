@@ -148,3 +148,49 @@ def _worker_grouped(rank, world, port, V, E, F):
 
 def test_two_rank_degree_grouped_layer_on_one_gpu():
     mp.spawn(_worker_grouped, args=(2, _free_port(), 12000, 120000, 75), nprocs=2, join=True)
+
+
+def _worker_pipeline(rank, world, port, V, E, F, L, n_blocks):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pna_amd import Graph, functional as PF, degree_groups as DG
+        PF.SMALL_SIMPLE_ROWS = 0
+        DG.ENABLED = False            # the reference below: the ordinary three-block path (what the row blocks run), bit for bit
+        from pna_amd.dgl.pna_layer import PNASimpleLayer
+        from pna_amd.shard import BlockPipeline, shard_graph
+        from pna_amd.synth import powerlaw_graph
+        src, dst = powerlaw_graph(V, E, seed=21, device=dev)
+        gs, g = shard_graph(src, dst, V), Graph(src, dst, V)
+        assert gs.n_halo > 0 and int((g.in_degrees() > 128).sum()) > 0          # hub rows ride with block 0
+        torch.manual_seed(0)
+        layers = [PNASimpleLayer(F, F, "mean max min std", "identity amplification attenuation", {"log": torch.tensor(2.0)}, 0.0, True, True).to(dev).eval()
+                  for _ in range(L)]
+        h = torch.randn(V, F, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+        with torch.no_grad():
+            want = h
+            for layer in layers:
+                want = layer(g, want)
+            pipe = BlockPipeline(gs, n_blocks)
+            P = (F + 3) // 4 * 4
+            ta = torch.zeros(gs.num_nodes + gs.n_halo, P, device=dev)
+            tb = torch.full_like(ta, float("nan"))
+            ta[: gs.num_nodes, :F] = h[gs.lo:gs.hi]
+            rows = PF.SimpleLayerRows(layers, gs, n_blocks)
+            res = pipe.run(rows, L, ta, tb)
+            torch.cuda.synchronize()
+        assert torch.equal(res[: gs.num_nodes, :F], want[gs.lo:gs.hi])
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_blocks", [1, 4])
+def test_two_rank_block_pipelined_layers_on_one_gpu(n_blocks):
+    """Three PNASimpleLayers on two shards with the inter-layer halo exchange cut into row blocks (shard.BlockPipeline: block b of
+    layer L is packed and sent while blocks b+1.. are still being computed): every rank's rows equal the unsharded three-layer
+    result bit for bit."""
+    mp.spawn(_worker_pipeline, args=(2, _free_port(), 6000, 70000, 20, 3, n_blocks), nprocs=2, join=True)
