@@ -236,3 +236,54 @@ def test_fused_entry_point_rejects_bad_arguments(cuda_device):
     assert L.pna_fused_degree_f32(ctypes.byref(a), None) == -1 and b"non-null" in L.pna_last_error()
     assert L.pna_fused_degree_image_bytes(96, 80) == 0 and L.pna_fused_degree_image_bytes(75, 81) == 0 and L.pna_fused_degree_image_bytes(16, 16) == 0
     assert L.pna_fused_degree_image_bytes(75, 75) == 10 * 15360 and L.pna_fused_degree_image_bytes(64, 80) == 8 * 15360
+
+
+def test_tower_mode_rows_vs_float64_and_100_identical_runs_at_full_size(cuda_device, c3):
+    """The tower mode of the one-kernel layer (PNALayer with one tower, models/dgl/pna_layer.py:33-76 + :130-145) at the C3 size:
+    sampled rows -- frequent degrees, rare degrees, the largest hubs, isolated rows -- against a float64 restatement of the
+    reference's formulas (per-edge pretrans Linear of [h_u | h_v], aggregators, scalers, posttrans Linear, graph norm, eval
+    BatchNorm, mixing Linear + LeakyReLU, residual), and 100 launches with identical bits."""
+    from pna_amd import degree_groups as DG, functional as PF
+    from pna_amd.dgl.pna_layer import PNALayer
+    g, _, h = c3
+    F = 75
+    torch.manual_seed(11)
+    layer = PNALayer(F, F, "mean max min std", "identity amplification attenuation", {"log": torch.tensor(2.3)}, 0.0, True, True,
+                     towers=1, divide_input=False, residual=True).to(cuda_device).eval()
+    tw = layer.towers[0]
+    with torch.no_grad():
+        tw.batchnorm_h.running_mean.normal_()
+        tw.batchnorm_h.running_var.uniform_(0.5, 2.0)
+    snorm = torch.rand(g.num_nodes, 1, device=cuda_device, generator=torch.Generator(device=cuda_device).manual_seed(2)) + 0.5
+    with torch.no_grad():
+        assert PF.tower_layer_degree_grouped_applies(layer, g, h) and PF.tower_layer_degree_fused_applies(layer, g, h)
+        y = layer(g, h, None, snorm).clone()
+        bad = sum(int(not torch.equal(layer(g, h, None, snorm), y)) for _ in range(100))
+    assert bad == 0, f"{bad} of 100 runs differ"
+    deg = g.in_degrees()
+    plan = DG.plan_of(g)
+    rows = torch.cat([torch.arange(0, 800, device=cuda_device), torch.topk(deg, 30).indices, plan.rest_rows[:150],
+                      plan.perm[plan.perm >= 0][-200:].long(), torch.nonzero(deg == 0).flatten()[:20]])
+    csr = g.csr
+    amp, att = g.degree_scalers(2.3)
+    pre, post, bn, mix = (tw.pretrans.fully_connected[0].linear, tw.posttrans.fully_connected[0].linear, tw.batchnorm_h, layer.mixing_network)
+    Wp, bp, Wo, bo = pre.weight.double(), pre.bias.double(), post.weight.double(), post.bias.double()
+    Wm, bm = mix.linear.weight.double(), mix.linear.bias.double()
+    slope = mix.activation.negative_slope
+    worst = 0.0
+    for v in rows.tolist():
+        lo, hi = int(csr.rowptr[v]), int(csr.rowptr[v + 1])
+        hv = h[v].double()
+        if hi > lo:
+            hu = h[csr.col[lo:hi].long()].double()
+            m = torch.cat([hu, hv.expand(hi - lo, F)], dim=1) @ Wp.t() + bp
+            a = torch.cat([m.mean(0), m.max(0).values, m.min(0).values, torch.sqrt(torch.relu((m * m).mean(0) - m.mean(0) ** 2) + 1e-5)])
+        else:
+            a = torch.zeros(4 * F, dtype=torch.float64, device=cuda_device)
+        z = bo + Wo @ torch.cat([hv, a, a * amp[v].double(), a * att[v].double()])
+        z = z * snorm[v].double()
+        z = (z - bn.running_mean.double()) / torch.sqrt(bn.running_var.double() + bn.eps) * bn.weight.double() + bn.bias.double()
+        z = Wm @ z + bm
+        ref = hv + torch.where(z >= 0, z, z * slope)
+        worst = max(worst, (y[v].double() - ref).abs().max().item() / max(1.0, ref.abs().max().item()))
+    assert worst <= 1e-5, worst
