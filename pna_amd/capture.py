@@ -16,8 +16,17 @@ class GraphedForward:
     bound at construction.  The static input buffers are owned by this object; call() copies into them.
     """
 
-    def __init__(self, fn, *example_args, warmup=3):
-        self.static_in = [a.clone() if torch.is_tensor(a) else a for a in example_args]
+    def __init__(self, fn, *example_args, warmup=3, alias_inputs=False):
+        # static inputs keep the example's strides (a (V, 75) view of an 80-float pitch stays one: the one-kernel layer reads
+        # 16-byte aligned rows); alias_inputs=True records the example tensors themselves (no per-call copy: the caller updates
+        # them in place)
+        def static(a):
+            if not torch.is_tensor(a) or alias_inputs:
+                return a
+            b = torch.empty_strided(a.shape, a.stride(), dtype=a.dtype, device=a.device)
+            b.copy_(a)
+            return b
+        self.static_in = [static(a) for a in example_args]
         dev = next(a.device for a in example_args if torch.is_tensor(a))
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))

@@ -134,7 +134,11 @@ with torch.no_grad():
     graphed_e = gpu_ms(lambda: gf_e(hd))
     ref_e = O.dgl_layer_forward(sd_e, src, dst, V, h, e_feat, snorm.cpu(), AGG.split(), SCA.split(), avg["log"], 5, False, True, True, True, True)
     err_e = (gf_e(hd).cpu() - ref_e).abs().max().item()
-    eager_noe = gpu_ms(lambda: (setattr(PF, "SMALL_TOWER_ROWS", 0), lay(g, hd, None, snorm), setattr(PF, "SMALL_TOWER_ROWS", small_rows))[1])
+    PF.SMALL_TOWER_ROWS = 0                                   # the same four-launch path for the layer WITHOUT edge features
+    try:
+        eager_noe = gpu_ms(lambda: lay(g, hd, None, snorm))
+    finally:
+        PF.SMALL_TOWER_ROWS = small_rows
 out["zinc_tower_layer_edge_feat"] = dict(graphs=128, V=V, E=E, hidden=75, towers=5, edge_dim=50, edge_types=4, eager_ms=eager_e, hipgraph_ms=graphed_e,
                                          same_path_without_edge_features_eager_ms=eager_noe, max_abs_err_vs_oracle=err_e,
                                          max_rel_err_vs_oracle=err_e / ref_e.abs().max().item())
