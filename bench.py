@@ -514,7 +514,8 @@ def main():
         tf = fused["ms_group_rows_kernel"] * 1e-3
         roofline_segreduce = roofline
         roofline_segreduce["note"] = "the standalone gather kernel (still shipped: rest rows, tower layers, training); not on this step's path for the group rows"
-        roofline = {"bound": "hbm", "kernel": "k_fused_degree<2 full + half feature blocks> (pna_fused_degree_f32): gather + 4 aggregators + combined scaler block + posttrans "
+        shape = "two gather passes of 2 full feature blocks, two panels of 64 output columns" if F > 96 else "2 full + half feature blocks"
+        roofline = {"bound": "hbm", "kernel": "k_fused_degree<" + shape + "> (pna_fused_degree_f32): gather + 4 aggregators + combined scaler block + posttrans "
                                               "contraction + BN / ReLU / residual; the 4F aggregate never reaches HBM",
                     "achieved": fused_bytes / tf / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": fused_bytes / tf / HBM_PEAK,
                     "traffic": None, "traffic_source": None,

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to the HI
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpna_amd.so")
 
-PNA_ABI_VERSION = 14
+PNA_ABI_VERSION = 15
 PNA_MAX_AGGR = 8
 PNA_MAX_SCALER = 8
 

@@ -168,13 +168,27 @@ __device__ __forceinline__ unsigned long long now() {
 // of the row's own node -- but late: after step 3, into the registers the first feature block's statistics have left, three
 // steps before their first use; the residual rows follow four steps before the epilogue.  A per-row factor (graph norm) multiplies
 // the biased accumulator in the epilogue.
-template <int NFBF, bool HALF, bool DUMP, bool TOWER = false, bool RESPF = !DUMP && !TOWER>
+//
+// WIDE shapes (BASELINE configs[4]: F = 128, out_dim = 128).  GP = 2: the features in TWO gather passes of NFBF full blocks each
+// (pass p: features p * 32 NFBF ..): the running statistics and the ring are re-used, the accumulators carry over -- gather 0,
+// its chunks, gather 1 (the ids of the tile's edges a second time, its source rows' second half), its chunks, epilogue.  NPAN = 2:
+// 81..128 output columns as two PANELS of 64 (4 column tiles each): a step multiplies one chunk's A fragment against one panel's
+// image (12 KB: the five-buffer pipeline still fits two workgroups per CU), the fragment is formed once per chunk.
+template <int NFBF, bool HALF, bool DUMP, bool TOWER = false, bool RESPF = !DUMP && !TOWER, int GP = 1, int NPAN = 1>
 __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const FDArgs g) {
   static_assert(!TOWER || (NFBF == 2 && !DUMP), "tower mode: two full feature blocks (49 <= F <= 80), production only");
-  constexpr int NB = NFBF + (HALF ? 1 : 0);               // feature blocks
-  constexpr int NC = 4 * NFBF + (HALF ? 2 : 0);           // chunks of 32 k values of the statistics per tile
+  static_assert((GP == 1 || (GP == 2 && !HALF && !TOWER)) && (NPAN == 1 || (NPAN == 2 && !TOWER)), "wide shapes: full blocks, no tower mode");
+  constexpr int NB = NFBF + (HALF ? 1 : 0);               // feature blocks of one gather pass
+  constexpr int NC = 4 * NFBF + (HALF ? 2 : 0);           // chunks of 32 k values of the statistics per gather pass
   constexpr int NPC = TOWER ? 2 * NFBF + (HALF ? 1 : 0) : 0;   // chunks of the two node panels (the half blocks of both share one)
-  constexpr int NCT = NC + NPC;                           // steps per tile
+  constexpr int NWP = NPAN == 1 ? kNW : 64;               // columns of one panel
+  constexpr int NT = NWP / 16, NTA = NT * NPAN;           // column tiles per panel / accumulator tiles
+  constexpr int NWA = NWP * NPAN;                         // all (padded) output columns
+  constexpr int CHV = 3 * 4 * NWP;                        // 16-byte pieces of one step's image: [term][lane group][NWP cols][8 k] bf16
+  constexpr int NI = (CHV + kThreads - 1) / kThreads;     // global_load_lds instructions per wavefront per step
+  constexpr int NSP = NC * NPAN;                          // steps of one gather pass
+  constexpr int NCT = NSP * GP + NPC;                     // steps per tile
+  static_assert(NT == 5 || NT == 4, "the column-tile pairing below");
   constexpr int PSTEP = 3;                                // the panels are requested at the end of this step ...
   constexpr int PWAIT = PSTEP + kAhead;                   // ... and have landed by this step's counted wait
   constexpr int RSTEP = NCT - kAhead;                     // tower mode: the residual rows are requested at the end of this step
@@ -188,23 +202,23 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
   const int ntiles = g.M / (kWaves * 16);
   const int G = (int)gridDim.x;
 
-  float* const colc = reinterpret_cast<float*>(lds + (size_t)kNBuf * kChunkV * 16);       // [3][80]: bias | scale | shift
-  for (int i = tid; i < kNW; i += kThreads) {
+  float* const colc = reinterpret_cast<float*>(lds + (size_t)kNBuf * CHV * 16);           // [3][NWA]: bias | scale | shift
+  for (int i = tid; i < NWA; i += kThreads) {
     colc[i] = (g.bias && i < g.N) ? g.bias[i] : 0.f;
-    colc[kNW + i] = (g.col_scale && i < g.N) ? g.col_scale[i] : 1.f;
-    colc[2 * kNW + i] = (g.col_shift && i < g.N) ? g.col_shift[i] : 0.f;
+    colc[NWA + i] = (g.col_scale && i < g.N) ? g.col_scale[i] : 1.f;
+    colc[2 * NWA + i] = (g.col_shift && i < g.N) ? g.col_shift[i] : 0.f;
   }
 
-  f4 acc[kNT];
+  f4 acc[NTA];
 
   // ---- weight chunks: global -> LDS, asynchronously (every wavefront issues exactly kNI copies per chunk) ----------------
   auto stage = [&](int c, int buf, long ib) __attribute__((always_inline)) {
-    const unsigned char* src = g.w_img + ib + (size_t)c * kChunkV * 16;
-    unsigned char* dst = lds + (size_t)buf * kChunkV * 16;
+    const unsigned char* src = g.w_img + ib + (size_t)c * CHV * 16;
+    unsigned char* dst = lds + (size_t)buf * CHV * 16;
 #pragma unroll
-    for (int i = 0; i < kNI; ++i) {
+    for (int i = 0; i < NI; ++i) {
       int w0 = (i * kWaves + wave) * 64;
-      if (w0 >= kChunkV) w0 = w0 % kChunkV;              // a slot past the image re-copies an earlier piece (same bytes, same address)
+      if (w0 >= CHV) w0 = w0 % CHV;                      // a slot past the image re-copies an earlier piece (same bytes, same address)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(w0 + lane) * 16),
                                        (__attribute__((address_space(3))) void*)(dst + (size_t)w0 * 16), 16, 0, 0);
     }
@@ -225,7 +239,7 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
   i4 pr;                                                  // rows of y / residual of the lane's four C rows 4 lg + r (-1: padding)
   int pn = 0;                                             // tower mode: the node of tile row li (-1: padding)
   f4 rp;                                                  // tower mode: the per-row factor of the lane's four C rows
-  f4 res[kNRes];                                          // residual, TRANSPOSED layout: row 4 lg + (li & 3), columns 16 n + 4 (li >> 2) .. + 4
+  f4 res[NTA];                                            // residual, TRANSPOSED layout: row 4 lg + (li & 3), columns 16 n + 4 (li >> 2) .. + 4
 
   // ---- the gather: running statistics of the wavefront's 16 rows ----------------------------------------------------------
   float S_[NB][8], Q_[NB][8], MX[NB][8], MN[NB][8];       // (a half block uses [0..3])
@@ -250,13 +264,18 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
   // byte offset of the 16-byte window of column tile n inside a row; a window past N slides back to [N - 4, N) (realigned by fix4)
   auto res_col = [&](int n) __attribute__((always_inline)) -> unsigned { return (unsigned)max(0, min(n * 16 + 4 * qq, g.N - 4)) * 4u; };
 
-  auto gather = [&](int t) __attribute__((always_inline)) {
+  // P: the gather pass (features P * 32 NFBF ..); after a pass that is not the last, the ring's ids are refilled with the SAME
+  // tile's first edges
+  auto gather = [&](int t, auto p_c) __attribute__((always_inline)) {
+    constexpr int P = decltype(p_c)::value;
     const int D = td_cur.y;
-    const unsigned rb = (unsigned)td_cur.x * 64u, rbn = (unsigned)td_nxt.x * 64u;       // byte offsets of this / the next tile's records
+    const unsigned rb = (unsigned)td_cur.x * 64u;                                        // byte offset of this tile's records ...
+    const unsigned rbn = P + 1 < GP ? rb : (unsigned)td_nxt.x * 64u;                     // ... and of the records the next gather starts with
+    const unsigned poff = (unsigned)(P * NFBF * 128);                                    // byte offset of the pass's features inside a row
     deg = D;
     // (tower mode: the rows of y and their factors are needed from step RSTEP on only: requested with the panels)
     if constexpr (TOWER) ld4(pn, g.perm, (unsigned)((t * kWaves + wave) * 16 + li) * 4u);
-    else ld16i(pr, g.perm, (unsigned)((t * kWaves + wave) * 16 + 4 * lg) * 4u);
+    else if constexpr (P == 0) ld16i(pr, g.perm, (unsigned)((t * kWaves + wave) * 16 + 4 * lg) * 4u);
 #pragma unroll
     for (int fb = 0; fb < NB; ++fb)
 #pragma unroll
@@ -270,7 +289,7 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
       constexpr int j = decltype(jc)::value;
 #pragma unroll
       for (int fb = 0; fb < NB; ++fb) {
-        const unsigned vo = __umul24((unsigned)idr[j], ldb) + f0b[fb];
+        const unsigned vo = __umul24((unsigned)idr[j], ldb) + f0b[fb] + poff;
         ld16(sl[j][2 * fb], g.x, vo);
         if (!(HALF && fb == NFBF)) ld16_hi(sl[j][2 * fb + 1], g.x, vo);
       }
@@ -293,7 +312,7 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     // the packets of edges 0..3; each refills its id with the next group's, or -- after the last group -- the NEXT tile's edge j
     const unsigned n0 = 1 < ng ? rb + 4u * 64u : rbn;
     issue(J0{}, n0); issue(J1{}, n0); issue(J2{}, n0); issue(J3{}, n0);
-    sld16(td_n2, g.tdesc, desc_off(t + 2 * G));           // (the descriptor after next: its latency sits behind the packets just issued)
+    if constexpr (P == 0) sld16(td_n2, g.tdesc, desc_off(t + 2 * G));   // (the descriptor after next: its latency sits behind the packets just issued)
     // steady state: slot j holds edge 4 gi + j; behind it in flight: the three younger packets.  Every edge here is a real one.
     for (int gi = 0; gi + 1 < ng; ++gi) {
       const unsigned nr = gi + 2 < ng ? rb + (unsigned)(4 * gi + 8) * 64u : rbn;
@@ -307,13 +326,14 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     const int e0 = 4 * (ng - 1);
     wait_slot<3 * LB, NL>(sl[0], idr[0]);
     if constexpr (TOWER) asm volatile("" : "+v"(pn));
-    else asm volatile("" : "+v"(pr));
+    else if constexpr (P == 0) asm volatile("" : "+v"(pr));
     fold(J0{}, e0 < D);
-    constexpr int NR = RESPF ? kNRes : 0;
-    if constexpr (RESPF) {
+    constexpr bool RES_NOW = RESPF && P == GP - 1;        // (the residual rows ride behind the LAST pass's drain)
+    constexpr int NR = RES_NOW ? NTA : 0;
+    if constexpr (RES_NOW) {
       const unsigned rrow = (unsigned)max(prow(), 0) * g.ldrb;
 #pragma unroll
-      for (int n = 0; n < kNT; ++n) ld16(res[n], resb, rrow + res_col(n));
+      for (int n = 0; n < NTA; ++n) ld16(res[n], resb, rrow + res_col(n));
     }
     wait_slot<2 * LB + NR, NL>(sl[1], idr[1]); fold(J1{}, e0 + 1 < D);
     wait_slot<1 * LB + NR, NL>(sl[2], idr[2]); fold(J2{}, e0 + 2 < D);
@@ -359,9 +379,10 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
       }
     }
   };
-  auto frag = [&](auto c_c) __attribute__((always_inline)) {
-    constexpr int c = decltype(c_c)::value;
-    if (c > 0 && FD_ABL(1)) { asm volatile("" : "+v"(A[0])); return; }
+  auto frag = [&](auto c_c, auto p_c) __attribute__((always_inline)) {
+    constexpr int c = decltype(c_c)::value;               // chunk within the gather pass P
+    constexpr int P = decltype(p_c)::value;
+    if ((c > 0 || P > 0) && FD_ABL(1)) { asm volatile("" : "+v"(A[0])); return; }
     if constexpr (c >= NC) {                              // a node panel: the strips are the A operand as they come
       constexpr int pc = c - NC;
       constexpr bool halfc = pc >= 2 * NFBF;
@@ -381,7 +402,7 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       int fb, sj, a, f;
-      if constexpr (c < 4 * NFBF) { fb = c / 4; sj = j; a = c % 4; f = fb * 32 + lg * 8 + j; }
+      if constexpr (c < 4 * NFBF) { fb = c / 4; sj = j; a = c % 4; f = (P * NFBF + fb) * 32 + lg * 8 + j; }
       else { fb = NFBF; sj = j & 3; a = 2 * (c - 4 * NFBF) + (j >> 2); f = fb * 32 + lg * 4 + (j & 3); }
       v[j] = stat(fb, sj, a, f);
       if constexpr (DUMP) {
@@ -394,35 +415,42 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
   };
 
   // ---- epilogue: BatchNorm / ReLU / residual, rows scattered to node order through perm -----------------------------------
-  const unsigned colc_b = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(kNBuf * kChunkV * 16) + lib;
+  const unsigned colc_b = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(kNBuf * CHV * 16) + lib;
   auto epilogue = [&]() __attribute__((always_inline)) {
     const float lo = g.relu ? 0.f : -INFINITY;
     const bool leaky = g.relu == 2;
     // the column constants, read through inline asm: an LDS read hipcc can see while a weight copy is in flight makes it
     // drain the copies (vmcnt(0)) first (DESIGN.md 4.2c point 1)
-    float cb[kNT], cs[kNT], ct[kNT];
+    float cb[NTA], cs[NTA], ct[NTA];
 #pragma unroll
-    for (int n = 0; n < kNT; ++n) {
+    for (int n = 0; n < NTA; ++n) {
       asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(cb[n]) : "v"(colc_b), "n"(n * 64) : "memory");
-      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(cs[n]) : "v"(colc_b), "n"(kNW * 4 + n * 64) : "memory");
-      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(ct[n]) : "v"(colc_b), "n"(2 * kNW * 4 + n * 64) : "memory");
+      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(cs[n]) : "v"(colc_b), "n"(NWA * 4 + n * 64) : "memory");
+      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(ct[n]) : "v"(colc_b), "n"(2 * NWA * 4 + n * 64) : "memory");
     }
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(cb[0]), "+v"(cb[1]), "+v"(cb[2]), "+v"(cb[3]), "+v"(cb[4]), "+v"(cs[0]), "+v"(cs[1]), "+v"(cs[2]), "+v"(cs[3]), "+v"(cs[4]),
-                   "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]), "+v"(ct[4]) : : "memory");
+    static_assert(NTA == 5 || NTA == 8, "operand lists of the wait below");
+    if constexpr (NTA == 5)
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(cb[0]), "+v"(cb[1]), "+v"(cb[2]), "+v"(cb[3]), "+v"(cb[4]), "+v"(cs[0]), "+v"(cs[1]), "+v"(cs[2]), "+v"(cs[3]), "+v"(cs[4]),
+                     "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]), "+v"(ct[4]) : : "memory");
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(cb[0]), "+v"(cb[1]), "+v"(cb[2]), "+v"(cb[3]), "+v"(cb[4]), "+v"(cb[5]), "+v"(cb[6]), "+v"(cb[NTA - 1]),
+                     "+v"(cs[0]), "+v"(cs[1]), "+v"(cs[2]), "+v"(cs[3]), "+v"(cs[4]), "+v"(cs[5]), "+v"(cs[6]), "+v"(cs[NTA - 1]),
+                     "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]), "+v"(ct[4]), "+v"(ct[5]), "+v"(ct[6]), "+v"(ct[NTA - 1]) : : "memory");
     const int row = prow();
     if constexpr (TOWER) {
       // the residual rows were requested at the end of step RSTEP; younger than them: the weight copies of the three steps since
-      asm volatile("s_waitcnt vmcnt(%5)" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]) : "n"((kAhead - 1) * kNI) : "memory");
+      asm volatile("s_waitcnt vmcnt(%5)" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]) : "n"((kAhead - 1) * NI) : "memory");
     } else if constexpr (!RESPF) {
       const char* rbase = reinterpret_cast<const char*>(resb) + (size_t)((unsigned)max(row, 0) * g.ldrb);
 #pragma unroll
-      for (int n = 0; n < kNT; ++n) res[n] = reinterpret_cast<const f4u*>(rbase + res_col(n))->v;
+      for (int n = 0; n < NTA; ++n) res[n] = reinterpret_cast<const f4u*>(rbase + res_col(n))->v;
     }
     char* const yrow = reinterpret_cast<char*>(g.y) + (size_t)(unsigned)max(row, 0) * g.ldyb;
     const bool odd = (sq & 1) != 0, upper = (sq & 2) != 0;
 #pragma unroll
-    for (int n = 0; n < kNT; ++n) {
+    for (int n = 0; n < NTA; ++n) {
       float x[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -476,26 +504,29 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
   long ib_cur = (long)td_cur.z * g.img_stride, ib_next = (long)td_nxt.z * g.img_stride;
   int buf = 0;
 #pragma unroll
-  for (int c = 0; c < kAhead; ++c) stage(c, c, ib_cur);   // (every shape has at least 4 chunks)
+  for (int c = 0; c < kAhead; ++c) stage(c, c, ib_cur);   // (every shape has at least 4 steps)
   // the ids of the first tile's edges 0..3 (later tiles: fetched by the previous tile's last packets)
 #pragma unroll
   for (int j = 0; j < kRing; ++j) ld4(idr[j], g.ids, (unsigned)td_cur.x * 64u + (unsigned)j * 64u + lib);
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(idr[0]), "+v"(idr[1]), "+v"(idr[2]), "+v"(idr[3]) : : "memory");
-  gather(t);
-  frag(std::integral_constant<int, 0>{});
+  gather(t, std::integral_constant<int, 0>{});
+  frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   tg += now() - t00;
 
-  auto step = [&](auto c_c) __attribute__((always_inline)) {
-    constexpr int c = decltype(c_c)::value;
-    const unsigned ba0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(buf * kChunkV + lg * kNW + li) * 16u;
+  // step s of the tile (s_c), in gather pass P: chunk c = (s - P NSP) / NPAN of the pass against column panel (s - P NSP) % NPAN
+  auto step = [&](auto s_c, auto p_c) __attribute__((always_inline)) {
+    constexpr int sg = decltype(s_c)::value, P = decltype(p_c)::value;
+    constexpr int sp = sg - P * NSP;                      // step within the pass (tower mode: the panel chunks follow, P = 0)
+    constexpr int c = sp / NPAN, pan = sp % NPAN, a0 = pan * NT;
+    const unsigned ba0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(buf * CHV + lg * NWP + li) * 16u;
     const int buf2 = buf == 0 ? kNBuf - 1 : buf - 1;     // (k + kAhead) % kNBuf
     bf8 B[2][3];                                         // B fragments of column tile n (slot n & 1): one ds_read_b128 per term
     constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
-    if constexpr (c == 0) {
+    if constexpr (sg == 0) {
 #pragma unroll
-      for (int n = 0; n < kNT; ++n) acc[n] = (f4){0.f, 0.f, 0.f, 0.f};
+      for (int n = 0; n < NTA; ++n) acc[n] = (f4){0.f, 0.f, 0.f, 0.f};
     }
     // Column tiles in PAIRS (0,1) (2,3) (4): both tiles' B fragments are read (6 x ds_read_b128, ONE wait), then their 12 MFMAs are
     // issued alternating between the two accumulators -- every accumulator sees an MFMA every other issue slot instead of six
@@ -506,7 +537,7 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     // 45 distinct addresses were hoisted out of the tile loop and spilled.
 #define FD_READ_B(slot, n)                                                                                                                  \
     _Pragma("unroll") for (int tm_ = 0; tm_ < 3; ++tm_)                                                                                     \
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(B[slot][tm_]) : "v"(ba0), "n"(tm_ * 4 * kNW * 16 + (n) * 256) : "memory")
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(B[slot][tm_]) : "v"(ba0), "n"(tm_ * 4 * NWP * 16 + (n) * 256) : "memory")
 #ifdef FD_SCHED_FENCE
 #define FD_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -514,14 +545,13 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
 #endif
 #define FD_WAIT_B()                                                                                                                         \
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(B[0][0]), "+v"(B[0][1]), "+v"(B[0][2]), "+v"(B[1][0]), "+v"(B[1][1]), "+v"(B[1][2]) : : "memory"); FD_FENCE()
-    static_assert(kNT == 5, "the pairing below is written for five column tiles");
     if (!FD_ABL(4)) { FD_READ_B(0, 0); FD_READ_B(1, 1); }
     FD_WAIT_B();
     if (!FD_ABL(0))
 #pragma unroll
     for (int pp = 0; pp < 6; ++pp) {
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[0][TB[pp]], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[1][TB[pp]], acc[1], 0, 0, 0);
+      acc[a0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[0][TB[pp]], acc[a0], 0, 0, 0);
+      acc[a0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[1][TB[pp]], acc[a0 + 1], 0, 0, 0);
     }
     FD_FENCE();
     if (!FD_ABL(4)) { FD_READ_B(0, 2); FD_READ_B(1, 3); }
@@ -530,8 +560,9 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     // would only wait for the residual rows requested at the end of the gather -- a full memory round trip per tile)
     // tower mode: the panel strips (requested at the end of step PSTEP) may stay in flight for three steps, the residual rows
     // (end of step RSTEP) into the epilogue: they are younger than the image this wait is for
-    constexpr int young = !TOWER ? 0 : (c > PSTEP && c < PWAIT) ? NPL : c > RSTEP ? kNRes : 0;
-    if constexpr (c >= kAhead - 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"((kAhead - 2) * kNI + young) : "memory");
+    // (wide shapes: the same holds for the first steps behind the second gather)
+    constexpr int young = !TOWER ? 0 : (c > PSTEP && c < PWAIT) ? NPL : c > RSTEP ? NTA : 0;
+    if constexpr (sp >= kAhead - 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"((kAhead - 2) * NI + young) : "memory");
     else asm volatile("s_barrier" ::: "memory");
     if constexpr (TOWER && c == PWAIT) {                  // (the wait above left only the two youngest images in flight)
       static_assert(NL == 4 || NL == 5, "tower shapes");
@@ -542,39 +573,50 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
         asm volatile("" : "+v"(pk[0][0]), "+v"(pk[0][1]), "+v"(pk[0][2]), "+v"(pk[0][3]), "+v"(pk[0][NL - 1]), "+v"(pk[1][0]), "+v"(pk[1][1]), "+v"(pk[1][2]),
                      "+v"(pk[1][3]), "+v"(pk[1][NL - 1]));
     }
-    if (c + kAhead < NCT) stage(c + kAhead, buf2, ib_cur);
-    else stage(c + kAhead - NCT, buf2, ib_next);
+    if (sg + kAhead < NCT) stage(sg + kAhead, buf2, ib_cur);
+    else stage(sg + kAhead - NCT, buf2, ib_next);
     if (!FD_ABL(0))
 #pragma unroll
     for (int pp = 0; pp < 6; ++pp) {
-      acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[0][TB[pp]], acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[1][TB[pp]], acc[3], 0, 0, 0);
+      acc[a0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[0][TB[pp]], acc[a0 + 2], 0, 0, 0);
+      acc[a0 + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[1][TB[pp]], acc[a0 + 3], 0, 0, 0);
     }
     FD_FENCE();
-    if (!FD_ABL(4)) { FD_READ_B(0, 4); }
-    FD_WAIT_B();
-    if (!FD_ABL(0))
+    if constexpr (NT == 5) {
+      if (!FD_ABL(4)) { FD_READ_B(0, 4); }
+      FD_WAIT_B();
+      if (!FD_ABL(0))
 #pragma unroll
-    for (int pp = 0; pp < 6; ++pp) acc[4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[0][TB[pp]], acc[4], 0, 0, 0);
-    FD_FENCE();
+      for (int pp = 0; pp < 6; ++pp) acc[a0 + 4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[0][TB[pp]], acc[a0 + 4], 0, 0, 0);
+      FD_FENCE();
+    }
 #undef FD_READ_B
 #undef FD_WAIT_B
 #undef FD_FENCE
     buf = buf == kNBuf - 1 ? 0 : buf + 1;
-    if constexpr (c + 1 < NCT) frag(std::integral_constant<int, c + 1>{});
+    // the next chunk's fragment, once the chunk's last panel is issued (tower mode: the panel chunks continue the numbering)
+    if constexpr (pan == NPAN - 1 && c + 1 < NC + NPC) frag(std::integral_constant<int, c + 1>{}, p_c);
     if constexpr (TOWER && c == PSTEP) issue_panels();
     if constexpr (TOWER && c == RSTEP) {
       const unsigned rrow = (unsigned)max(prow(), 0) * g.ldrb;
 #pragma unroll
-      for (int n = 0; n < kNT; ++n) ld16_ws(res[n], resb, rrow + res_col(n));
+      for (int n = 0; n < NTA; ++n) ld16_ws(res[n], resb, rrow + res_col(n));
     }
   };
-  auto steps4 = [&](auto b_c) __attribute__((always_inline)) {
-    constexpr int b = decltype(b_c)::value;
-    step(std::integral_constant<int, b>{});
-    if constexpr (b + 1 < NCT) step(std::integral_constant<int, (b + 1 < NCT) ? b + 1 : 0>{});
-    if constexpr (b + 2 < NCT) step(std::integral_constant<int, (b + 2 < NCT) ? b + 2 : 0>{});
-    if constexpr (b + 3 < NCT) step(std::integral_constant<int, (b + 3 < NCT) ? b + 3 : 0>{});
+  // the steps [P (NSP + NPC) + b, .. + 4) of gather pass P
+  auto steps4 = [&](auto b_c, auto p_c) __attribute__((always_inline)) {
+    constexpr int b = decltype(b_c)::value, P = decltype(p_c)::value, N1 = NSP + NPC, o = P * NSP;
+    if constexpr (b < N1) step(std::integral_constant<int, (b < N1) ? o + b : 0>{}, p_c);
+    if constexpr (b + 1 < N1) step(std::integral_constant<int, (b + 1 < N1) ? o + b + 1 : 0>{}, p_c);
+    if constexpr (b + 2 < N1) step(std::integral_constant<int, (b + 2 < N1) ? o + b + 2 : 0>{}, p_c);
+    if constexpr (b + 3 < N1) step(std::integral_constant<int, (b + 3 < N1) ? o + b + 3 : 0>{}, p_c);
+  };
+  auto pass_steps = [&](auto p_c) __attribute__((always_inline)) {
+    steps4(std::integral_constant<int, 0>{}, p_c);
+    steps4(std::integral_constant<int, 4>{}, p_c);
+    steps4(std::integral_constant<int, 8>{}, p_c);
+    steps4(std::integral_constant<int, 12>{}, p_c);
+    static_assert(NSP + NPC <= 16, "steps4 calls");
   };
   while (true) {
     const unsigned long long t0 = now();
@@ -583,14 +625,20 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     // wavefront mostly waits for memory and its fold hides behind that (skipping the fold entirely changes nothing).  Measured in
     // the experiments build on the C3 layer: 0.873 -> 0.790 ms.
     if (!FD_ABL(6)) __builtin_amdgcn_s_setprio(1);
-    steps4(std::integral_constant<int, 0>{});
-    if constexpr (NCT > 4) steps4(std::integral_constant<int, ((NCT > 4) ? 4 : 0)>{});
-    if constexpr (NCT > 8) steps4(std::integral_constant<int, ((NCT > 8) ? 8 : 0)>{});
-    if constexpr (NCT > 12) steps4(std::integral_constant<int, ((NCT > 12) ? 12 : 0)>{});
-    static_assert(NCT <= 16, "steps4 calls");
+    pass_steps(std::integral_constant<int, 0>{});
+    if constexpr (GP == 2) {                              // the second half of the features: gather again, multiply on
+      if (!FD_ABL(6)) __builtin_amdgcn_s_setprio(0);
+      gather(t, std::integral_constant<int, GP - 1>{});
+      frag(std::integral_constant<int, 0>{}, std::integral_constant<int, GP - 1>{});
+      if (!FD_ABL(6)) __builtin_amdgcn_s_setprio(1);
+      pass_steps(std::integral_constant<int, GP - 1>{});
+    }
     // the residual rows landed by the last step's counted wait (they are older than all but the first copies of the tile, and
     // every shape has at least 4 steps); from here on the compiler may read them
-    if constexpr (RESPF) asm volatile("" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]));
+    if constexpr (RESPF) {
+      asm volatile("" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]));
+      if constexpr (NTA == 8) asm volatile("" : "+v"(res[5]), "+v"(res[6]), "+v"(res[NTA - 1]));
+    }
     const unsigned long long t1 = now();
     epilogue();
     if (!FD_ABL(6)) __builtin_amdgcn_s_setprio(0);
@@ -601,8 +649,8 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     td_cur = td_nxt; td_nxt = td_n2;
     ib_cur = ib_next;
     ib_next = (long)td_nxt.z * g.img_stride;
-    gather(t);
-    frag(std::integral_constant<int, 0>{});
+    gather(t, std::integral_constant<int, 0>{});
+    frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     tg += now() - t2;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the copies issued for steps that do not exist
@@ -618,19 +666,23 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
 //      bf16 terms, laid out as the LDS image of every chunk: [chunk][term][lane group][80 cols][8 k] ---------------------------
 //      Tower images (tower != 0): scaler blocks of K = 5 F columns [4 F aggregators | F self panel (block 0 only)], followed by
 //      the chunks of the two node panels: x_dst against W_D,mean + W_D,max + W_D,min, h against the self panel.
-__global__ void k_pack_fused_degree(const float* w_ref, long ldw, int N, int F, int S, const float* scale, int n_img, unsigned short* img, int tower) {
+//      Wide shapes (npan = 2): [chunk][panel][term][lane group][64 cols][8 k], panel p = output columns 64 p .. 64 p + 64.
+__global__ void k_pack_fused_degree(const float* w_ref, long ldw, int N, int F, int S, const float* scale, int n_img, unsigned short* img, int tower,
+                                    int nwp, int npan) {
   const int nfull = shape_full(F), NCS = shape_chunks(F), K = tower ? 5 * F : 4 * F;
   const int NC = NCS + (tower ? 2 * nfull + (shape_half(F) ? 1 : 0) : 0);
-  const long per = (long)NC * 3 * 4 * kNW * 8;
+  const long per = (long)NC * npan * 3 * 4 * nwp * 8;
   const long total = per * n_img;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     long r = i;
     const int e = r % 8; r /= 8;
-    const int n = r % kNW; r /= kNW;
+    const int nn = r % nwp; r /= nwp;
     const int lgp = r % 4; r /= 4;
     const int term = r % 3; r /= 3;
+    const int pan = r % npan; r /= npan;
     const int c = r % NC; r /= NC;
     const int im = (int)r;
+    const int n = pan * nwp + nn;                         // output column
     int a, f;                                             // a: aggregator 0..3; 4: the self panel; 5: the x_dst panel
     if (c < 4 * nfull) { a = c % 4; f = (c / 4) * 32 + lgp * 8 + e; }
     else if (c < NCS) { a = 2 * (c - 4 * nfull) + (e >> 2); f = nfull * 32 + lgp * 4 + (e & 3); }
@@ -648,15 +700,22 @@ __global__ void k_pack_fused_degree(const float* w_ref, long ldw, int N, int F, 
   }
 }
 
-template <int NFBF, bool HALF, bool DUMP, bool TOWER = false>
+// wide shapes (4 full feature blocks in two gather passes, 81..128 output columns in two panels of 64)
+__host__ __device__ constexpr bool shape_wide_f(int F) { return F > 96 && F <= 128 && shape_full(F) == 4 && !shape_half(F); }
+__host__ __device__ constexpr bool shape_wide_n(int N) { return N > kNW && N <= 128; }
+
+template <int NFBF, bool HALF, bool DUMP, bool TOWER = false, int GP = 1, int NPAN = 1>
 int launch(const FDArgs& g, int wgs, hipStream_t st) {
-  const size_t lds = (size_t)kNBuf * kChunkV * 16 + (size_t)(3 * kNW) * sizeof(float);
-  if (hipFuncSetAttribute((const void*)k_fused_degree<NFBF, HALF, DUMP, TOWER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-  hipLaunchKernelGGL((k_fused_degree<NFBF, HALF, DUMP, TOWER>), dim3((unsigned)wgs), dim3(kThreads), lds, st, g);
+  constexpr int NWP = NPAN == 1 ? kNW : 64;
+  const size_t lds = (size_t)kNBuf * (3 * 4 * NWP) * 16 + (size_t)(3 * NWP * NPAN) * sizeof(float);
+  auto* fn = k_fused_degree<NFBF, HALF, DUMP, TOWER, !DUMP && !TOWER, GP, NPAN>;
+  if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+  hipLaunchKernelGGL(fn, dim3((unsigned)wgs), dim3(kThreads), lds, st, g);
   return 0;
 }
 template <bool DUMP>
 int launch_shape(const FDArgs& g, int wgs, hipStream_t st) {
+  if (shape_wide_f(g.F) && shape_wide_n(g.N)) return g.xd ? -2 : launch<2, false, DUMP, false, 2, 2>(g, wgs, st);
   const int nf = shape_full(g.F);
   const bool half = shape_half(g.F);
   if constexpr (!DUMP) {
@@ -672,12 +731,13 @@ int launch_shape(const FDArgs& g, int wgs, hipStream_t st) {
 }  // namespace
 
 extern "C" int64_t pna_fused_degree_image_bytes(int32_t F, int32_t N) {
+  if (shape_wide_f(F) && shape_wide_n(N)) return (int64_t)shape_chunks(F) * 2 * (3 * 4 * 64) * 16;   // 16 chunks x 2 panels of 64 columns
   if (F < 17 || F > 80 || N < 4 || N > kNW) return 0;   // (81..96 would need three full blocks: 96 running statistics + a 96-register ring do not fit 256 registers)
   return (int64_t)shape_chunks(F) * kChunkV * 16;
 }
 
 static int64_t tower_image_bytes(int F, int N) {
-  if (pna_fused_degree_image_bytes(F, N) == 0 || shape_full(F) != 2) return 0;
+  if (F > 80 || N > kNW || pna_fused_degree_image_bytes(F, N) == 0 || shape_full(F) != 2) return 0;
   return (int64_t)(shape_chunks(F) + 2 * shape_full(F) + (shape_half(F) ? 1 : 0)) * kChunkV * 16;
 }
 extern "C" int64_t pna_fused_tower_image_bytes(int32_t F, int32_t N) { return tower_image_bytes(F, N); }
@@ -690,7 +750,7 @@ extern "C" int pna_fused_tower_pack_f32(const float* w_ref, int64_t ldw, int32_t
   const int64_t elems = tower_image_bytes(F, N) / 2 * n_img;
   const int blocks = (int)((elems + 255) / 256 > 8192 ? 8192 : (elems + 255) / 256);
   hipLaunchKernelGGL(k_pack_fused_degree, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ref, (long)ldw, N, F, n_scaler, scale, n_img,
-                     (unsigned short*)img, 1);
+                     (unsigned short*)img, 1, kNW, 1);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
   return PNA_OK;
@@ -700,11 +760,12 @@ extern "C" int pna_fused_degree_pack_f32(const float* w_ref, int64_t ldw, int32_
                                          int32_t n_img, void* img, pna_stream_t stream) {
   if (!w_ref || !img || n_img < 1 || n_scaler < 1 || n_scaler > PNA_MAX_SCALER || pna_fused_degree_image_bytes(F, N) == 0 ||
       ldw < (int64_t)n_scaler * 4 * F || (n_scaler > 1 && !scale))
-    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_pack_f32: bad arguments (17 <= F <= 80, 4 <= N <= 80, scale required for n_scaler > 1)");
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_pack_f32: bad arguments (17 <= F <= 80 with 4 <= N <= 80, or 113 <= F <= 128 with 81 <= N <= 128; scale required for n_scaler > 1)");
   const int64_t elems = pna_fused_degree_image_bytes(F, N) / 2 * n_img;
   const int blocks = (int)((elems + 255) / 256 > 8192 ? 8192 : (elems + 255) / 256);
+  const bool wide = shape_wide_n(N);
   hipLaunchKernelGGL(k_pack_fused_degree, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ref, (long)ldw, N, F, n_scaler, scale, n_img,
-                     (unsigned short*)img, 0);
+                     (unsigned short*)img, 0, wide ? 64 : kNW, wide ? 2 : 1);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
   return PNA_OK;
@@ -716,8 +777,8 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
   if (!p->tile_desc || !p->tile_ids || !p->x || !p->row_perm || !p->w_img || !p->y)
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: tile_desc / tile_ids / x / row_perm / w_img / y must be non-null");
   if (pna_fused_degree_image_bytes(p->F, p->N) == 0)
-    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: 17 <= F <= 80 and 4 <= N <= 80");
-  const int need = shape_half(p->F) ? (p->F + 3) / 4 * 4 : (p->F + 7) / 8 * 8;
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: 17 <= F <= 80 with 4 <= N <= 80, or 113 <= F <= 128 with 81 <= N <= 128");
+  const int need = shape_wide_f(p->F) ? 128 : shape_half(p->F) ? (p->F + 3) / 4 * 4 : (p->F + 7) / 8 * 8;
   if (p->ldx < need || p->ldx % 4 != 0 || ((uintptr_t)p->x & 15) != 0)
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: x must be 16-byte aligned with a row pitch that is a multiple of 4 floats and covers the last strip (round_up(F, 8); round_up(F, 4) when F % 32 is in 1..16)");
   if (p->x_rows < 1 || p->x_rows >= (1 << 24) || (int64_t)p->x_rows * p->ldx * 4 >= (1ll << 32))

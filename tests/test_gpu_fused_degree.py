@@ -26,7 +26,8 @@ def _layer(F, N, dev, residual=True, seed=0, scalers="identity amplification att
 def _features(V, F, dev, seed=0):
     """(V, F) view of a table whose rows are 16-byte aligned (pitch = round_up(F, 8) floats): what the one-kernel path needs."""
     g = torch.Generator(device=dev).manual_seed(seed)
-    return torch.randn(V, (F + 7) // 8 * 8, device=dev, generator=g)[:, :F]
+    pitch = 128 if F > 96 else (F + 7) // 8 * 8           # (the wide shapes read every row in four 128-byte strips)
+    return torch.randn(V, pitch, device=dev, generator=g)[:, :F]
 
 
 class _Knobs:
@@ -59,6 +60,10 @@ class _Knobs:
     (140_000, 800_000, 20, 64, "amplification attenuation", False),
     (135_000, 900_000, 48, 48, "identity amplification", True),
     (135_000, 500_000, 17, 17, "identity amplification attenuation", True),
+    # the wide shapes (two gather passes x two column panels): BASELINE configs[4]'s layer, and partial last blocks / panels
+    (150_000, 1_200_000, 128, 128, "identity amplification attenuation", True),
+    (140_000, 900_000, 120, 100, "identity amplification attenuation", False),
+    (130_000, 700_000, 113, 81, "identity amplification", False),
 ])
 def test_fused_layer_equals_two_kernel_paths(cuda_device, V, E, F, N, scalers, residual):
     from pna_amd import Graph, degree_groups as DG, functional as PF
@@ -102,13 +107,14 @@ def test_fused_layer_vs_reference_golden(cuda_device, name):
     from pna_amd.dgl.pna_layer import PNASimpleLayer
     meta, a, sd = load_golden(name)
     F, N = meta["F"], meta["out_dim"]
-    if not (17 <= F <= 80 and N <= 80):
+    wide = 113 <= F <= 128 and 81 <= N <= 128              # (groups_f128: BASELINE configs[4]'s layer shape)
+    if not ((17 <= F <= 80 and N <= 80) or wide):
         pytest.skip("shape outside the one-kernel path (covered by test_gpu_degree_groups.py)")
     layer = PNASimpleLayer(F, N, meta["aggregators"], meta["scalers"], {"log": a["avg_log"]}, 0.0, True, meta["residual"])
     layer.load_state_dict(sd)
     layer = layer.to(cuda_device).eval()
     g = Graph(a["src"].long(), a["dst"].long(), meta["N"]).to(cuda_device)
-    h = torch.zeros(meta["N"], (F + 7) // 8 * 8, device=cuda_device)[:, :F]
+    h = torch.zeros(meta["N"], 128 if wide else (F + 7) // 8 * 8, device=cuda_device)[:, :F]
     h.copy_(a["h"])
     with torch.no_grad(), _Knobs(fused=True, small_graphs=True):
         assert layer._degree_grouped_path(g, h) and DG.fused_applies(g, h, F, N)
