@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PNA_ABI_VERSION 15 /* 15: pna_fused_degree_*: wide shapes (113 <= F <= 128 with 81 <= N <= 128).
+#define PNA_ABI_VERSION 15 /* 15: pna_fused_degree_*: wide shapes (F in 113..128 and / or N in 81..128).
                               14: pna_segreduce_args.edge_type / n_edge_types (edge terms from a table of edge types); the hand-scheduled gather takes
                                   edge terms (per edge or per type).
                               13: pna_fused_degree_args.x_dst / h_self / row_post + pna_fused_tower_{image_bytes,pack_f32}: the one-kernel layer
@@ -453,8 +453,9 @@ int pna_fused_simple_f32(const pna_fused_simple_args* args, pna_stream_t stream)
  *                 the weight itself); W_D is formed in fp32 in scaler order, like the reference's blocks.
  * x: (x_rows, ldx) rows, 16-byte aligned, ldx % 4 == 0, ldx >= round_up(F, 8) (round_up(F, 4) when F % 32 is in 1..16),
  * x_rows < 2^24, table < 4 GiB; y and residual: n_nodes rows, each table < 4 GiB.
- * 17 <= F <= 80 with 4 <= N <= 80; or (ABI 15) the WIDE shapes 113 <= F <= 128 with 81 <= N <= 128 (BASELINE configs[4]: 128 -> 128):
- * the features in two gather passes, the output columns in two panels of 64; ldx >= 128 there.
+ * F in 17..80, or (ABI 15) 113..128 -- the features in two gather passes (BASELINE configs[4]: 128 -> 128; ldx >= 128 there);
+ * N in 4..80, or (ABI 15) 81..128 -- the output columns in two panels of 64 (needs F in 49..64 or 113..128).  pna_fused_degree_image_bytes(F, N) > 0
+ * is the authoritative test.
  * relu: 0 none / 1 ReLU / 2 LeakyReLU(act_slope).  agg_out (nullable): (M, ld_agg) receives the
  * statistics the contraction consumed, [mean | max | min | std] x F per virtual row (verification; a slower instantiation).
  * Rows of degrees too rare to fill a tile, and hub rows, are the caller's: pna_segreduce_fwd_f32 + pna_posttrans_x3_f32 over

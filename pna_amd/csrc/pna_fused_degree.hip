@@ -616,7 +616,8 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     steps4(std::integral_constant<int, 4>{}, p_c);
     steps4(std::integral_constant<int, 8>{}, p_c);
     steps4(std::integral_constant<int, 12>{}, p_c);
-    static_assert(NSP + NPC <= 16, "steps4 calls");
+    steps4(std::integral_constant<int, 16>{}, p_c);
+    static_assert(NSP + NPC <= 20, "steps4 calls");
   };
   while (true) {
     const unsigned long long t0 = now();
@@ -715,9 +716,14 @@ int launch(const FDArgs& g, int wgs, hipStream_t st) {
 }
 template <bool DUMP>
 int launch_shape(const FDArgs& g, int wgs, hipStream_t st) {
-  if (shape_wide_f(g.F) && shape_wide_n(g.N)) return g.xd ? -2 : launch<2, false, DUMP, false, 2, 2>(g, wgs, st);
   const int nf = shape_full(g.F);
   const bool half = shape_half(g.F);
+  if (shape_wide_f(g.F) || shape_wide_n(g.N)) {
+    if (g.xd) return -2;
+    if (shape_wide_f(g.F)) return shape_wide_n(g.N) ? launch<2, false, DUMP, false, 2, 2>(g, wgs, st) : launch<2, false, DUMP, false, 2, 1>(g, wgs, st);
+    if (nf == 2 && !half) return launch<2, false, DUMP, false, 1, 2>(g, wgs, st);
+    return -2;
+  }
   if constexpr (!DUMP) {
     if (g.xd) return nf != 2 ? -2 : half ? launch<2, true, false, true>(g, wgs, st) : launch<2, false, false, true>(g, wgs, st);
   }
@@ -731,9 +737,12 @@ int launch_shape(const FDArgs& g, int wgs, hipStream_t st) {
 }  // namespace
 
 extern "C" int64_t pna_fused_degree_image_bytes(int32_t F, int32_t N) {
-  if (shape_wide_f(F) && shape_wide_n(N)) return (int64_t)shape_chunks(F) * 2 * (3 * 4 * 64) * 16;   // 16 chunks x 2 panels of 64 columns
-  if (F < 17 || F > 80 || N < 4 || N > kNW) return 0;   // (81..96 would need three full blocks: 96 running statistics + a 96-register ring do not fit 256 registers)
-  return (int64_t)shape_chunks(F) * kChunkV * 16;
+  // F: 17..80 (one gather pass) or 113..128 (two passes of two full blocks; 81..112 would need unequal passes: not built);
+  // N: 4..80 (one panel of 80 columns) or 81..128 (two panels of 64), the latter with exactly two full feature blocks per pass
+  // (49 <= F <= 64 or 113..128: with a half block on top, 80 statistics + the ring + 32 accumulators + the residual spill)
+  const bool f_ok = (F >= 17 && F <= 80) || shape_wide_f(F), n_ok = (N >= 4 && N <= kNW) || shape_wide_n(N);
+  if (!f_ok || !n_ok || (shape_wide_n(N) && !shape_wide_f(F) && !(shape_full(F) == 2 && !shape_half(F)))) return 0;
+  return (int64_t)shape_chunks(F) * (shape_wide_n(N) ? 2 * (3 * 4 * 64) : kChunkV) * 16;
 }
 
 static int64_t tower_image_bytes(int F, int N) {
@@ -760,7 +769,7 @@ extern "C" int pna_fused_degree_pack_f32(const float* w_ref, int64_t ldw, int32_
                                          int32_t n_img, void* img, pna_stream_t stream) {
   if (!w_ref || !img || n_img < 1 || n_scaler < 1 || n_scaler > PNA_MAX_SCALER || pna_fused_degree_image_bytes(F, N) == 0 ||
       ldw < (int64_t)n_scaler * 4 * F || (n_scaler > 1 && !scale))
-    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_pack_f32: bad arguments (17 <= F <= 80 with 4 <= N <= 80, or 113 <= F <= 128 with 81 <= N <= 128; scale required for n_scaler > 1)");
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_pack_f32: bad arguments (F in 17..80 or 113..128, N in 4..128, N > 80 needs F in 49..64 or 113..128; scale required for n_scaler > 1)");
   const int64_t elems = pna_fused_degree_image_bytes(F, N) / 2 * n_img;
   const int blocks = (int)((elems + 255) / 256 > 8192 ? 8192 : (elems + 255) / 256);
   const bool wide = shape_wide_n(N);
@@ -777,7 +786,7 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
   if (!p->tile_desc || !p->tile_ids || !p->x || !p->row_perm || !p->w_img || !p->y)
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: tile_desc / tile_ids / x / row_perm / w_img / y must be non-null");
   if (pna_fused_degree_image_bytes(p->F, p->N) == 0)
-    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: 17 <= F <= 80 with 4 <= N <= 80, or 113 <= F <= 128 with 81 <= N <= 128");
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: F in 17..80 or 113..128, N in 4..128 (N > 80 needs F in 49..64 or 113..128)");
   const int need = shape_wide_f(p->F) ? 128 : shape_half(p->F) ? (p->F + 3) / 4 * 4 : (p->F + 7) / 8 * 8;
   if (p->ldx < need || p->ldx % 4 != 0 || ((uintptr_t)p->x & 15) != 0)
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: x must be 16-byte aligned with a row pitch that is a multiple of 4 floats and covers the last strip (round_up(F, 8); round_up(F, 4) when F % 32 is in 1..16)");

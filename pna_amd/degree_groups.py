@@ -315,10 +315,10 @@ def fused_applies(graph, x, F, N):
     """Whether pna_fused_degree_f32 serves this call (whole-graph inference path already chosen by `applies`): shapes it is
     instantiated for, a 16-byte aligned source table whose row pitch is a multiple of 4 floats and covers the last strip, and
     tables the kernel can address with 32-bit offsets."""
-    wide = 113 <= F <= 128 and 81 <= N <= 128              # two gather passes x two column panels (BASELINE configs[4]: 128 -> 128)
-    if not FUSED or not ((17 <= F <= 80 and 4 <= N <= 80) or wide):
+    # F: one gather pass (17..80) or two (113..128; BASELINE configs[4]: 128 -> 128); N: one panel of 80 columns or two of 64
+    if not FUSED or _lib.lib().pna_fused_degree_image_bytes(F, N) <= 0:
         return False
-    need = 128 if wide else (F + 3) // 4 * 4 if 1 <= F % 32 <= 16 else (F + 7) // 8 * 8
+    need = 128 if F > 96 else (F + 3) // 4 * 4 if 1 <= F % 32 <= 16 else (F + 7) // 8 * 8
     if x.dim() != 2 or x.stride(1) != 1 or x.stride(0) % 4 != 0 or x.stride(0) < need or x.data_ptr() % 16 != 0:
         return False
     # (the last row's strip may reach past F: the storage must cover rows x pitch floats)
