@@ -286,8 +286,9 @@ def main():
     if world > 1:
         # multi-GPU: the features live in the shard's resident [local | halo] table, so the halo exchange of the
         # timed step receives the peers' rows in place (no concatenation pass)
-        # (dense rows, pitch F: exactly F floats per halo row cross xGMI; the 16-byte aligned pitch would ship 6.7 % padding)
-        h = g.alloc_features(F, pitch=F if args.x_pitch == 80 else max(args.x_pitch, F), device=dev)
+        # round 3: rows at the smallest 16-byte aligned pitch (F = 75 -> 76 floats: 1.3 % padding on the wire) -- what the
+        # one-kernel layer reads; `--x-pitch 75` restores the dense rows
+        h = g.alloc_features(F, pitch=(F + 3) // 4 * 4 if args.x_pitch == 80 else max(args.x_pitch, F), device=dev)
     else:
         h_buf = torch.zeros(hi - lo, max(args.x_pitch, F), device=dev)
         h = h_buf[:, :F]

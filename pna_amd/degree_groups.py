@@ -309,6 +309,7 @@ REST_ROWS_PER_GROUP = 1    # work items per lane group in that launch (the full-
 TOWERS = True              # the tower layers (PNALayer) through the degree-grouped contraction with collapsed posttrans / mixing weights
 FUSED = True               # gather + contraction in ONE kernel (pna_fused_degree_f32) where it applies; False: the two-kernel grouped path
 MAX_REST_FRACTION = 0.5    # more rest rows than this: the grouping is overhead, the ordinary path takes the graph
+FUSED_HALO_MAX_INTERIOR = 0.5   # shards: below this fraction of rows without remote sources, exchange first and run ONE kernel
 
 
 def fused_applies(graph, x, F, N):

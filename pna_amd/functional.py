@@ -666,10 +666,19 @@ def simple_layer_degree_grouped(layer, graph, h):
     from . import degree_groups as DG
     plan = DG.plan_of(graph)
     from .graph import Graph
-    # the one-kernel path takes whole graphs; a shard (HaloGraph) keeps the two-kernel path, whose gather is cut into the rows that
-    # read only local sources -- aggregated while the halo exchange is in flight -- and the rest
     if type(graph) is Graph and DG.fused_applies(graph, h, layer.in_dim, layer.out_dim):
         return simple_layer_degree_fused(layer, graph, h, x=h)
+    # A shard (HaloGraph).  The two-kernel path cuts its gather into the rows that read only local sources -- aggregated while
+    # the halo exchange is in flight -- and the rest; the one-kernel path needs the whole [local | halo] table first.  Which one
+    # pays depends on how many rows the overlap covers: on a graph without locality (the benchmark graph: 1 % interior rows) the
+    # overlap hides next to nothing and the one-kernel layer saves a third of the compute, so: exchange, then ONE kernel over the
+    # extended table (features in the shard's resident table at a 16-byte aligned pitch); with many interior rows, the overlap.
+    from .shard import HaloGraph
+    if (isinstance(graph, HaloGraph) and DG.FUSED and graph._resident(h) and graph._pending is None
+            and graph.interior_fraction() < DG.FUSED_HALO_MAX_INTERIOR):
+        x_ext = graph._ext[:, : h.shape[1]]
+        if DG.fused_applies(graph, x_ext, layer.in_dim, layer.out_dim):
+            return simple_layer_degree_fused(layer, graph, h, x=graph.source_features(h))
     return degree_grouped_posttrans(layer, graph, h, degree_grouped_aggregate(layer, graph, h, plan), plan)
 
 

@@ -109,6 +109,7 @@ class HaloGraph(Graph):
         self._send_idx32 = None
         self._pending = None                      # the in-flight exchange started by source_features(defer=True)
         self._split = None                        # (interior mask, interior items, boundary items)
+        self._interior_fraction = None
 
     def to(self, device):
         g = HaloGraph(self.src.to(device), self.dst.to(device), self.num_nodes, self.n_halo, self.send_idx.to(device),
@@ -121,6 +122,12 @@ class HaloGraph(Graph):
     def interior_mask(self) -> torch.Tensor:
         """bool [n_local]: rows that are not hubs and whose in-edges all have LOCAL sources (ids < n_local)."""
         return self.split_work_lists()[0]
+
+    def interior_fraction(self) -> float:
+        """Fraction of the local rows the exchange overlap covers (cached with the row classes)."""
+        if self._interior_fraction is None:
+            self._interior_fraction = float(self.interior_mask().float().mean().item()) if self.num_nodes else 0.0
+        return self._interior_fraction
 
     def split_work_lists(self):
         """(interior mask, work list of the interior rows, work list of everything else incl. all hub segments)."""

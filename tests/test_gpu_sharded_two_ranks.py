@@ -194,3 +194,54 @@ def test_two_rank_block_pipelined_layers_on_one_gpu(n_blocks):
     layer L is packed and sent while blocks b+1.. are still being computed): every rank's rows equal the unsharded three-layer
     result bit for bit."""
     mp.spawn(_worker_pipeline, args=(2, _free_port(), 6000, 70000, 20, 3, n_blocks), nprocs=2, join=True)
+
+
+def _worker_fused_shard(rank, world, port, V, E, F):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pna_amd import Graph, functional as PF, degree_groups as DG
+        PF.SMALL_SIMPLE_ROWS = 0
+        DG.MIN_ROWS = 1
+        from pna_amd.dgl.pna_layer import PNASimpleLayer
+        from pna_amd.shard import shard_graph
+        from pna_amd.synth import powerlaw_graph
+        src, dst = powerlaw_graph(V, E, seed=31, device=dev)
+        gs, g = shard_graph(src, dst, V), Graph(src, dst, V)
+        assert gs.n_halo > 0 and gs.interior_fraction() < DG.FUSED_HALO_MAX_INTERIOR
+        torch.manual_seed(0)
+        layer = PNASimpleLayer(F, F, "mean max min std", "identity amplification attenuation", {"log": torch.tensor(2.0)}, 0.0, True, True).to(dev).eval()
+        P = (F + 7) // 8 * 8
+        hg = torch.zeros(V, P, device=dev)[:, :F]
+        hg.copy_(torch.randn(V, F, device=dev, generator=torch.Generator(device=dev).manual_seed(3)))
+        hr = gs.alloc_features(F, pitch=P)
+        hr.copy_(hg[gs.lo:gs.hi])
+        with torch.no_grad():
+            assert DG.fused_applies(g, hg, F, F)
+            want = layer(g, hg)[gs.lo:gs.hi]                         # unsharded: the one-kernel path
+            calls = []
+            orig = PF.simple_layer_degree_fused
+            PF.simple_layer_degree_fused = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+            try:
+                got = layer(gs, hr)
+            finally:
+                PF.simple_layer_degree_fused = orig
+        assert calls, "the shard did not take the one-kernel path"
+        # group rows: the same statistics, the same combined weight, the same contraction -- every row's bits; the shard's plan
+        # differs from the whole graph's in WHICH rows are rest rows (a degree that fills a tile globally may not on a shard):
+        # those go through the three-block contraction instead of W_D, equal to its rounding
+        same = (got == want).all(dim=1)
+        assert same.float().mean().item() > 0.9
+        assert (got - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_shards_without_locality_take_the_one_kernel_layer():
+    """On a graph without locality the exchange overlap covers ~1 % of the rows: a shard whose features live in the resident
+    table at an aligned pitch exchanges first and runs pna_fused_degree_f32 over the extended [local | halo] table."""
+    mp.spawn(_worker_fused_shard, args=(2, _free_port(), 60000, 600000, 75), nprocs=2, join=True)
