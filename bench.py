@@ -60,6 +60,7 @@ def parse():
     p.add_argument("--no-power-probe", action="store_true", help="skip the rocm-smi power / clock samples (2 x ~1.5 s)")
     p.add_argument("--no-cold", action="store_true", help="skip the cold-cache leg (3 rotating copies of the inputs)")
     p.add_argument("--check-rows", type=int, default=96, help="rows re-computed on the host after the timed loop")
+    p.add_argument("--no-prewarm", action="store_true", help="skip the ~150 ms of untimed steps in front of the W warm-up steps")
     p.add_argument("--layers", type=int, default=1, help="> 1: a step = this many stacked layers (N > 1: inter-layer halo exchange cut into row "
                    "blocks, pna_amd.shard.BlockPipeline); a reduced JSON line, the default line describes ONE layer")
     p.add_argument("--blocks", type=int, default=4, help="--layers > 1, N > 1: row blocks per layer of the pipelined exchange")
@@ -366,6 +367,27 @@ def main():
             dist.destroy_process_group()
         return
 
+    # Pre-conditioning, untimed, BEFORE the W warm-up steps: ~150 ms of the same step.  A 0.9 ms step needs more than W = 5 of them
+    # for the device to reach its sustained clock state: measured on one box, W = 5 / K = 20 gave 0.899 ms/step, W = 50 0.838, K = 200
+    # 0.841 -- the first ~50 steps after an idle phase run 7 % slower.  The timed region below is still exactly K steps after W
+    # warm-up steps, bracketed by barrier + synchronize.
+    prewarm = 0
+    if not args.no_prewarm:
+        for _ in range(2):                                     # (first calls: degree plan, weight images, allocator)
+            step()
+        torch.cuda.synchronize()
+        prewarm, t_pre = 2, time.perf_counter()
+        while time.perf_counter() - t_pre < 0.15:
+            for _ in range(16):
+                step()
+            prewarm += 16
+            torch.cuda.synchronize()
+        if world > 1:                                          # every rank the same number of collectives
+            n = torch.tensor([prewarm], device=dev, dtype=torch.int64)
+            dist.all_reduce(n, op=dist.ReduceOp.MAX)
+            for _ in range(int(n.item()) - prewarm):
+                step()
+            prewarm = int(n.item())
     for _ in range(args.warmup):
         step()
     sync()
@@ -588,6 +610,7 @@ def main():
         "metric": f"PNA-layer fwd edges/sec (F={F}, 4 aggr x 3 scalers)", "value": value, "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "prewarm_steps_untimed": prewarm,
         "config": {"workload": wl + f"single PNA (simple) layer fwd: 4 aggregators x 3 scalers + posttrans Linear({12 * F}->{F}) + BN + ReLU + residual",
                    "V": V, "E": E, "F": F, "aggregators": AGGREGATORS, "scalers": SCALERS,
                    "parallelism": f"dst-range shard x{world}, halo all-to-all" if world > 1 else "single GPU",

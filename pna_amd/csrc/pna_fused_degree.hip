@@ -21,8 +21,9 @@
 // Contraction.  The statistics ARE the MFMA A operand: with K ordered (feature block, aggregator) -- the weight image is packed
 // to match -- chunk c = 4 fb + a multiplies the lane's eight values of aggregator a, split exactly into three bf16 terms
 // (pna_x3_split.h; six partial products per multiply, fp32 accumulation: the arithmetic of pna_posttrans_x3.hip).  One combined
-// image per degree group, streamed through three LDS buffers by global_load_lds, one barrier per chunk in the middle of the
-// chunk's MFMA stream.  Workgroups of 4 wavefronts (64 rows), two per CU: while one multiplies, the other gathers.
+// image per degree group, streamed through five LDS buffers by global_load_lds (four steps ahead, counted waits), one barrier per
+// chunk in the middle of the chunk's MFMA stream.  Workgroups of 4 wavefronts (64 rows), two per CU: while one multiplies, the
+// other gathers.  Tower mode (PNALayer with one tower) and the wide shapes (F or N up to 128) are template parameters below.
 // Rows that no degree group holds (rare degrees, hub rows) stay on the two-kernel path over their compact list (host).
 //
 // The running sums are folded by single v_add_f32 / v_mul_f32 instructions ON PURPOSE: written as plain C++, hipcc packs them into
