@@ -377,17 +377,17 @@ def main():
             step()
         torch.cuda.synchronize()
         prewarm, t_pre = 2, time.perf_counter()
-        while time.perf_counter() - t_pre < 0.15:
-            for _ in range(16):
+        if world > 1:                                          # a step holds a collective: every rank the SAME, fixed number of them
+            for _ in range(64):
                 step()
-            prewarm += 16
+            prewarm += 64
             torch.cuda.synchronize()
-        if world > 1:                                          # every rank the same number of collectives
-            n = torch.tensor([prewarm], device=dev, dtype=torch.int64)
-            dist.all_reduce(n, op=dist.ReduceOp.MAX)
-            for _ in range(int(n.item()) - prewarm):
-                step()
-            prewarm = int(n.item())
+        else:
+            while time.perf_counter() - t_pre < 0.15:
+                for _ in range(16):
+                    step()
+                prewarm += 16
+                torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     sync()
