@@ -1,11 +1,9 @@
-// pk_mfma_repro.hip -- minimal reproducer attempt for the packed-fp32 wrong-sum observation (DESIGN.md 4.7, VERDICT r2 item 2).
+// pk_mfma_repro.hip -- minimal reproducer attempt for the packed-fp32 wrong-sum observation (DESIGN.md 4.8.6, VERDICT r2 item 2).
 // Two wavefronts per SIMD (one 512-thread workgroup per CU):
 //   role M (wavefronts 0-3): a chain of v_mfma_f32_16x16x32_bf16 on four accumulators, nothing else;
-//   role F (wavefronts 4-7): the fused kernel's fold -- per iteration two 16-byte loads per lane, then for the 8 values
-//     s += m, q += m * m with the packed instructions hipcc chose in the failing kernel (v_pk_add_f32 / v_pk_mul_f32, plain and with
-//     op_sel swizzles, v_pk_mov_b32 swaps), AND the same sums again from the SAME loaded registers with single v_add_f32 /
-//     v_mul_f32 instructions (the form that was exact).  Both run in one wavefront: any difference in the final bits is an
-//     instruction-level discrepancy, whatever its cause.  Differences are counted per lane.
+//   role F (wavefronts 4-7): the fused kernel's fold -- two 16-byte loads per lane and iteration, then s += m, q += m * m for the 8
+//     values with the packed instructions hipcc chose in the failing kernel (v_pk_add_f32 / v_pk_mul_f32, plain and op_sel, behind
+//     v_pk_mov_b32 swaps) AND again from the SAME registers with single v_add_f32 / v_mul_f32: any differing bit is counted.
 // mode 0: M + F (the failing co-residence); mode 1: F on all eight wavefronts; mode 2: F alone, one wavefront per SIMD (M idle).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/ubench/pk_mfma_repro.hip -o tools/ubench/pk_mfma_repro
 //   tools/ubench/pk_mfma_repro [iterations per launch] [launches]
@@ -13,11 +11,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
-
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;                       // a 64-bit VGPR pair: (lo, hi) floats of a packed operand
 typedef short bf8 __attribute__((ext_vector_type(8)));
-
 __global__ __launch_bounds__(512, 2) void k_repro(const float* __restrict__ x, int rows, int iters, int mode, float* sink, unsigned* bad) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool fold_role = mode == 1 || wave >= 4;
@@ -105,7 +101,6 @@ __global__ __launch_bounds__(512, 2) void k_repro(const float* __restrict__ x, i
   }
   sink[blockIdx.x * 512 + threadIdx.x] = __builtin_bit_cast(float, half(P[0], 0)) + __builtin_bit_cast(float, half(PQ[3], 1));
 }
-
 int main(int argc, char** argv) {
   const int iters = argc > 1 ? atoi(argv[1]) : 4096, launches = argc > 2 ? atoi(argv[2]) : 50;
   const int rows = 1 << 22;                                // 128 MB table: the loads miss L2 like the gather's
