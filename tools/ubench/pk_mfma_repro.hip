@@ -34,8 +34,7 @@ __global__ __launch_bounds__(512, 2) void k_repro(const float* __restrict__ x, i
   }
   // packed accumulators: pair k = values (2k, 2k+1); pairs 0,1 folded with plain packed ops, pairs 2,3 with the op_sel swizzles
   // hipcc emitted in the failing kernel (lo += hi-half of the operand, hi += lo-half) behind a v_pk_mov_b32 swap
-  // (the packed operands are u64, not float2: with ext-vector asm outputs in an array hipcc read element 0 for BOTH halves after
-  //  the loop -- the first version of this file reported hi == lo for every sum, a property of that build, not of the hardware)
+  // (u64 operands, not float2: hipcc read element 0 of a float2 asm output in an array for BOTH halves -- DESIGN.md 4.8.5)
   u64 P[4], PQ[4];
   float Sr[8], Qr[8];
   auto pack = [](float lo, float hi) -> u64 { return (u64)__builtin_bit_cast(unsigned, lo) | ((u64)__builtin_bit_cast(unsigned, hi) << 32); };
