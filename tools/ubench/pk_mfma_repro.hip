@@ -32,8 +32,7 @@ __global__ __launch_bounds__(512, 2) void k_repro(const float* __restrict__ x, i
     sink[blockIdx.x * 512 + threadIdx.x] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
     return;
   }
-  // packed accumulators: pair k = values (2k, 2k+1); pairs 0,1 folded with plain packed ops, pairs 2,3 with the op_sel swizzles
-  // hipcc emitted in the failing kernel (lo += hi-half of the operand, hi += lo-half) behind a v_pk_mov_b32 swap
+  // packed accumulators: pair k = values (2k, 2k+1); pairs 0,1 plain packed ops, pairs 2,3 the failing kernel's op_sel swizzles behind a v_pk_mov_b32 swap
   // (u64 operands, not float2: hipcc read element 0 of a float2 asm output in an array for BOTH halves -- DESIGN.md 4.8.5)
   u64 P[4], PQ[4];
   float Sr[8], Qr[8];
