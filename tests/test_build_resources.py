@@ -20,7 +20,8 @@ CSRC = os.path.join(ROOT, "pna_amd", "csrc")
                                                                                         # (the arg-tracking instantiations of the training forward and the edge-term ones: four to five wavefronts per SIMD)
                                                                                         "k_segreduce_fastILi4ELb0ELb0ELb1ELi0E": 104, "k_segreduce_fastILi4ELb1ELb0ELb1ELi0E": 104,
                                                                                         "k_segreduce_fastILi4ELb1ELb0ELb0ELi1E": 104, "k_segreduce_fastILi4ELb1ELb0ELb0ELi2E": 104}),
-                                          ("pna_posttrans.hip", {}), ("pna_pack.hip", {}),
+                                          ("pna_posttrans.hip", {}), ("pna_pack.hip", {}), ("pna_tower_fused.hip", {}), ("pna_fused.hip", {}),
+                                          ("pna_segreduce_bwd.hip", {}),
                                           # the one-kernel layer: two 4-wavefront workgroups per CU (the production instantiations: DUMP = false)
                                           # (incl. the tower instantiations ...ELb0ELb1ELb0EEE of the two-full-block shapes)
                                           ("pna_fused_degree.hip", {"k_fused_degreeILi1ELb0ELb0E": 256, "k_fused_degreeILi1ELb1ELb0E": 256,
@@ -52,9 +53,17 @@ def test_no_kernel_uses_scratch(src, max_vgpr, tmp_path):
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import isa_audit
+    text = open(str(tmp_path / "out.s")).read()
     for n in names:
-        haz = isa_audit.sgpr_hazards(isa_audit.kernel_lines(str(tmp_path / "out.s"), n))
+        kl = isa_audit.kernel_lines(str(tmp_path / "out.s"), n)
+        haz = isa_audit.sgpr_hazards(kl)
         assert not haz, (n, haz[:5])
+        # ... and, in a source whose kernels issue MFMAs (wavefronts of ONE launch share SIMDs): no packed-fp32 instruction whose low
+        # lane reads src1's high half -- on gfx950 it drops its low-half result in lanes 48-63 beside an MFMA wavefront
+        # (tools/ubench/pk_opsel_mfma_repro.hip); hipcc emits the form on its own when it vectorises scalar code
+        if "v_mfma" in text:
+            pk = isa_audit.pk_src1_hi_selects(kl)
+            assert not pk, (n, pk[:5])
 
 
 def test_one_kernel_layer_never_touches_a_register_in_flight(tmp_path):

@@ -69,8 +69,9 @@ def test_full_size_50_repeats_every_large_graph_path(cuda_device):
     """BASELINE configs[2] (V = 1 M, E = 10 M, F = 75), 50 repeats each, identical bits: the three-block bf16x3 contraction over all
     rows, the degree-grouped two-kernel path (gather in plan order + one-block GRP contraction + three-block GRP rest) and the
     one-kernel path (pna_fused_degree_f32; its own 200-repeat test is tests/test_gpu_fused_degree.py).  VERDICT r2 asked for >= 50
-    full-size repeats of the x3 / GRP kernels after the packed-fp32 observation (the instruction forms are
-    exonerated, tools/ubench/pk_mfma_repro.hip)."""
+    full-size repeats of the x3 / GRP kernels after the packed-fp32 observation (root cause: DESIGN.md 4.8.6,
+    tools/ubench/pk_opsel_mfma_repro.hip -- one op_sel form of the packed-fp32 instructions beside MFMA wavefronts; the shipped
+    kernels do not contain it: tests/test_build_resources.py)."""
     from pna_amd import Graph, degree_groups as DG
     from pna_amd.dgl.pna_layer import PNASimpleLayer
     from pna_amd.synth import powerlaw_graph
