@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define PNA_ABI_VERSION 15 /* 15: pna_fused_degree_*: wide shapes (F in 113..128 and / or N in 81..128).
+#define PNA_ABI_VERSION 16 /* 16: + pna_segreduce_bwd_pull_f32 (the backward's max / min terms inside the pull: no scatter atomics).
+                              15: pna_fused_degree_*: wide shapes (F in 113..128 and / or N in 81..128).
                               14: pna_segreduce_args.edge_type / n_edge_types (edge terms from a table of edge types); the hand-scheduled gather takes
                                   edge terms (per edge or per type).
                               13: pna_fused_degree_args.x_dst / h_self / row_post + pna_fused_tower_{image_bytes,pack_f32}: the one-kernel layer
@@ -273,6 +274,29 @@ int pna_segreduce_bwd_f32(const pna_segreduce_bwd_args* args, pna_stream_t strea
  */
 int pna_segreduce_bwd_rowprep_f32(const pna_segreduce_bwd_args* args, float* table, int64_t ld_table, pna_stream_t stream);
 int pna_segreduce_bwd_argscatter_f32(const pna_segreduce_bwd_args* args, pna_stream_t stream);
+
+/* ABI 16: the same gradient with the max / min terms INSIDE the pull -- no atomics except for the segments of hub SOURCE rows.
+ * After pna_segreduce_bwd_rowprep_f32 (table = [R1 | R2]):
+ *   grad_x[u] = sum over out-edges (u -> v), the k-th in-edge of v, of  R1[v] + [k = argmax[v] - rowptr[v]] G_max[v] + [k = argmin[v] - rowptr[v]] G_min[v]
+ *               + x[u] * sum R2[v]
+ * base: rowptr (forward CSR), argmax / argmin, gagg / aggr[] (max, min and std or var among them), n_tower, F, V, x (the source
+ * table) and grad_x (n_src rows; rows of hub sources -- work-list records with slot >= 0 -- must be ZERO on entry, every other row is
+ * overwritten).  col_t / rank_t: destination v and in-list rank k of every edge of the TRANSPOSED CSR (edges sorted by source);
+ * items_t: its work list {source row, beg, end, slot} (slot < 0: whole row; slot >= 0: a segment, added atomically).  ranks:
+ * workspace (V, ld_rank >= 2 T F) of uint16 -- in-degrees up to 65534.  4 <= F <= 256. */
+typedef struct pna_segreduce_bwd_pull_args {
+  const pna_segreduce_bwd_args* base;
+  const float* table;
+  int64_t ld_table;
+  const int32_t* col_t;
+  const int32_t* rank_t;
+  const int32_t* items_t;
+  int32_t n_items_t;
+  int32_t _pad;
+  uint16_t* ranks;
+  int64_t ld_rank;
+} pna_segreduce_bwd_pull_args;
+int pna_segreduce_bwd_pull_f32(const pna_segreduce_bwd_pull_args* args, pna_stream_t stream);
 
 /*
  * Per-row degree scalers of the DGL variant -- models/dgl/scalers.py:12-19 evaluated with the

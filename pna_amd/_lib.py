@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to the HI
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpna_amd.so")
 
-PNA_ABI_VERSION = 15
+PNA_ABI_VERSION = 16
 PNA_MAX_AGGR = 8
 PNA_MAX_SCALER = 8
 
@@ -99,6 +99,13 @@ class PnaFusedSimpleArgs(ctypes.Structure):
         ("w_img", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("col_scale", ctypes.c_void_p),
         ("col_shift", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("ld_res", ctypes.c_int64),
         ("y", ctypes.c_void_p), ("ldy", ctypes.c_int64), ("relu", ctypes.c_int32), ("heavy_threshold", ctypes.c_int32),
+    ]
+
+
+class PnaSegreduceBwdPullArgs(ctypes.Structure):
+    _fields_ = [
+        ("base", ctypes.c_void_p), ("table", ctypes.c_void_p), ("ld_table", ctypes.c_int64), ("col_t", ctypes.c_void_p), ("rank_t", ctypes.c_void_p),
+        ("items_t", ctypes.c_void_p), ("n_items_t", ctypes.c_int32), ("_pad", ctypes.c_int32), ("ranks", ctypes.c_void_p), ("ld_rank", ctypes.c_int64),
     ]
 
 
@@ -193,6 +200,8 @@ def lib():
         L.pna_fused_degree_pack_f32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                 ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
         L.pna_fused_degree_pack_f32.restype = ctypes.c_int
+        L.pna_segreduce_bwd_pull_f32.argtypes = [ctypes.POINTER(PnaSegreduceBwdPullArgs), ctypes.c_void_p]
+        L.pna_segreduce_bwd_pull_f32.restype = ctypes.c_int
         L.pna_fused_tower_image_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32]
         L.pna_fused_tower_image_bytes.restype = ctypes.c_int64
         L.pna_fused_tower_pack_f32.argtypes = L.pna_fused_degree_pack_f32.argtypes

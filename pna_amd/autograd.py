@@ -284,6 +284,36 @@ def _backward_pull(graph, x, dst_term, ident, amx, amn, gagg, aggs, all_aggs, T,
         if gT is None or gT.num_nodes != x.shape[0]:
             gT = Graph(csr.row.long(), csr.col.long(), x.shape[0])        # edge (v -> u): pulls row v of the table into u
             graph._pna_amd_transposed = gT
+        if (amx is not None and has_var and "max" in aggs and "min" in aggs and 4 <= F <= 256 and csr.max_degree < 65535
+                and x.stride(1) == 1 and os.environ.get("PNA_AMD_BWD_ARGS", "pull") == "pull"):
+            # round 3: the max / min terms inside the SAME pull (pna_segreduce_bwd_pull_f32): per out-edge the rank of the edge in its
+            # destination's list is compared with the 16-bit ranks of argmax / argmin -- no scattered atomics (3.8 ms at C3)
+            tcsr = gT.csr
+            rank_t = getattr(gT, "_pna_amd_rank_t", None)
+            if rank_t is None:                                # position of every transposed edge in its destination's in-edge list
+                rank_t = (tcsr.eid.to(torch.int64) - csr.rowptr.to(torch.int64)[tcsr.col.long()]).to(torch.int32).contiguous()
+                gT._pna_amd_rank_t = rank_t
+            items = gT.work_items()
+            hs = gT.heavy_schedule()
+            gx = torch.empty(x.shape[0], TF, dtype=torch.float32, device=dev)
+            if hs.n_heavy > 0:
+                gx.index_fill_(0, hs.heavy_rows.long(), 0.0)  # hub sources: their segments add atomically
+            ranks = torch.empty(V, 2 * TF, dtype=torch.int16, device=dev)
+            b.x, b.ldx = _lib.dev_ptr(x, torch.float32, "x"), x.stride(0)
+            b.grad_x, b.ld_gx = _lib.dev_ptr(gx, torch.float32, "grad_x"), gx.stride(0)
+            q = _lib.PnaSegreduceBwdPullArgs()
+            q.base = ctypes.cast(ctypes.pointer(b), ctypes.c_void_p)
+            q.table, q.ld_table = _lib.dev_ptr(table, torch.float32, "table"), table.stride(0)
+            q.col_t, q.rank_t = _lib.dev_ptr(tcsr.col, torch.int32, "col_t"), _lib.dev_ptr(rank_t, torch.int32, "rank_t")
+            q.items_t, q.n_items_t = _lib.dev_ptr(items, torch.int32, "items_t"), items.shape[0]
+            q.ranks, q.ld_rank = _lib.dev_ptr(ranks, torch.int16, "ranks"), ranks.stride(0)
+            rc = _lib.lib().pna_segreduce_bwd_pull_f32(ctypes.byref(q), _lib.stream_ptr(dev))
+            _lib.check(rc, "pna_segreduce_bwd_pull_f32")
+            if x.shape[1] != TF:
+                full = torch.zeros_like(x)
+                full[:, :TF] = gx
+                gx = full
+            return gx, gd
         S = PF.aggregate(gT, table, F, ["sum"], n_tower=table.shape[1] // F)
         gx = (S[:, :TF] + x[:, :TF] * S[:, TF:]) if has_var else S
         gx = gx.contiguous()

@@ -105,6 +105,41 @@ def test_aggregate_backward_dst_term_only_both_paths(cuda_device, monkeypatch, m
     torch.testing.assert_close(dtg.grad.cpu().double(), dto.grad, rtol=2e-4, atol=2e-4 * scale)
 
 
+@pytest.mark.parametrize("T,F,with_dst", [(1, 75, False), (1, 20, True), (3, 16, True), (2, 130, False)])
+def test_max_min_terms_inside_the_pull_equal_the_atomic_scatter(cuda_device, monkeypatch, T, F, with_dst):
+    """pna_segreduce_bwd_pull_f32 (round 3: the max / min gradient terms routed by 16-bit ranks inside the pull over the transposed
+    graph, no scattered atomics) against the path it replaces (sums-only pull + pna_segreduce_bwd_argscatter_f32): the same
+    gradient up to the summation order -- power-law graph with hub DESTINATIONS (ranks up to thousands) and hub SOURCES (segments
+    added atomically), rows without in- or out-edges, integer-valued features (ties: the FIRST extremal edge gets the gradient in
+    both).  Both are checked against float64 autograd elsewhere in this file."""
+    from pna_amd.synth import powerlaw_graph
+    V, E = 20000, 300000
+    src, dst = powerlaw_graph(V, E, seed=T * 100 + F)
+    keep = (dst >= 50) & (src < V - 50)                     # nodes 0..49 without in-edges, the last 50 without out-edges
+    g = Graph(src[keep], dst[keep], V).to(cuda_device)
+    assert g.csr.max_degree > 500 and g.heavy_schedule().n_heavy > 0
+    gen = torch.Generator().manual_seed(F)
+    x0 = torch.randint(-3, 4, (V, T * F), generator=gen).float()
+    x0[::3] += torch.randn(V, T * F, generator=gen)[::3]
+    d0 = torch.randn(V, T * F, generator=gen) if with_dst else None
+    amp, att = g.degree_scalers(1.9)
+    R = torch.randn(V, T * 12 * F, generator=gen).to(cuda_device)
+    grads = {}
+    for mode in ("pull", "scatter"):
+        monkeypatch.setenv("PNA_AMD_BWD_ARGS", mode)
+        xg = x0.to(cuda_device).requires_grad_(True)
+        dg = d0.to(cuda_device).requires_grad_(True) if with_dst else None
+        out = PF.aggregate(g, xg, F, ["mean", "max", "min", "std"], n_tower=T, dst_term=dg, row_scales=[None, amp, att])
+        (out * R).sum().backward()
+        grads[mode] = (xg.grad.clone(), dg.grad.clone() if with_dst else None)
+    gp, gs = grads["pull"][0], grads["scatter"][0]
+    tol = 2e-5 * gs.abs().max(dim=1, keepdim=True).values + 1e-6          # per row: hub sources sum thousands of terms
+    assert bool(((gp - gs).abs() <= tol).all()), float(((gp - gs).abs() / tol).max())
+    assert torch.equal(gp[V - 50:], torch.zeros_like(gp[V - 50:]))        # no out-edges: no gradient
+    if with_dst:
+        assert torch.equal(grads["pull"][1], grads["scatter"][1])
+
+
 def test_aggregate_backward_edge_resident(cuda_device):
     V, E, F = 150, 1800, 12
     src, dst = _graph(3, V, E, 300)
