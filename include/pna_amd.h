@@ -276,7 +276,7 @@ int pna_segreduce_bwd_rowprep_f32(const pna_segreduce_bwd_args* args, float* tab
 int pna_segreduce_bwd_argscatter_f32(const pna_segreduce_bwd_args* args, pna_stream_t stream);
 
 /* ABI 16: the same gradient with the max / min terms INSIDE the pull -- no atomics except for the segments of hub SOURCE rows.
- * After pna_segreduce_bwd_rowprep_f32 (table = [R1 | R2]):
+ * After pna_segreduce_bwd_rowprep_f32 (table = [R1 | R2]) -- or with run_rowprep set, instead of it:
  *   grad_x[u] = sum over out-edges (u -> v), the k-th in-edge of v, of  R1[v] + [k = argmax[v] - rowptr[v]] G_max[v] + [k = argmin[v] - rowptr[v]] G_min[v]
  *               + x[u] * sum R2[v]
  * base: rowptr (forward CSR), argmax / argmin, gagg / aggr[] (max, min and std or var among them), n_tower, F, V, x (the source
@@ -292,7 +292,7 @@ typedef struct pna_segreduce_bwd_pull_args {
   const int32_t* rank_t;
   const int32_t* items_t;
   int32_t n_items_t;
-  int32_t _pad;
+  int32_t run_rowprep;   /* != 0: `table` is a WORKSPACE; the call runs the rowprep pass itself (table, base->grad_dst and the ranks in one sweep) */
   uint16_t* ranks;
   int64_t ld_rank;
 } pna_segreduce_bwd_pull_args;

@@ -105,7 +105,7 @@ class PnaFusedSimpleArgs(ctypes.Structure):
 class PnaSegreduceBwdPullArgs(ctypes.Structure):
     _fields_ = [
         ("base", ctypes.c_void_p), ("table", ctypes.c_void_p), ("ld_table", ctypes.c_int64), ("col_t", ctypes.c_void_p), ("rank_t", ctypes.c_void_p),
-        ("items_t", ctypes.c_void_p), ("n_items_t", ctypes.c_int32), ("_pad", ctypes.c_int32), ("ranks", ctypes.c_void_p), ("ld_rank", ctypes.c_int64),
+        ("items_t", ctypes.c_void_p), ("n_items_t", ctypes.c_int32), ("run_rowprep", ctypes.c_int32), ("ranks", ctypes.c_void_p), ("ld_rank", ctypes.c_int64),
     ]
 
 

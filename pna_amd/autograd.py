@@ -275,17 +275,19 @@ def _backward_pull(graph, x, dst_term, ident, amx, amn, gagg, aggs, all_aggs, T,
         gd = torch.empty(V, TF, dtype=torch.float32, device=dev)
         b.grad_dst, b.ld_gd = _lib.dev_ptr(gd, torch.float32, "grad_dst"), gd.stride(0)
     table = torch.empty(V, TF * (2 if has_var else 1), dtype=torch.float32, device=dev)
-    rc = _lib.lib().pna_segreduce_bwd_rowprep_f32(ctypes.byref(b), _lib.dev_ptr(table, torch.float32, "table"), table.stride(0),
-                                                  _lib.stream_ptr(dev))
-    _lib.check(rc, "pna_segreduce_bwd_rowprep_f32")
+    ranked = (need_x and amx is not None and has_var and "max" in aggs and "min" in aggs and 4 <= F <= 256 and csr.max_degree < 65535
+              and x.stride(1) == 1 and os.environ.get("PNA_AMD_BWD_ARGS", "pull") == "pull")
+    if not ranked:                                          # (the ranked pull below runs this pass itself, with the ranks)
+        rc = _lib.lib().pna_segreduce_bwd_rowprep_f32(ctypes.byref(b), _lib.dev_ptr(table, torch.float32, "table"), table.stride(0),
+                                                      _lib.stream_ptr(dev))
+        _lib.check(rc, "pna_segreduce_bwd_rowprep_f32")
     gx = None
     if need_x:
         gT = getattr(graph, "_pna_amd_transposed", None)
         if gT is None or gT.num_nodes != x.shape[0]:
             gT = Graph(csr.row.long(), csr.col.long(), x.shape[0])        # edge (v -> u): pulls row v of the table into u
             graph._pna_amd_transposed = gT
-        if (amx is not None and has_var and "max" in aggs and "min" in aggs and 4 <= F <= 256 and csr.max_degree < 65535
-                and x.stride(1) == 1 and os.environ.get("PNA_AMD_BWD_ARGS", "pull") == "pull"):
+        if ranked:
             # round 3: the max / min terms inside the SAME pull (pna_segreduce_bwd_pull_f32): per out-edge the rank of the edge in its
             # destination's list is compared with the 16-bit ranks of argmax / argmin -- no scattered atomics (3.8 ms at C3)
             tcsr = gT.csr
@@ -305,7 +307,7 @@ def _backward_pull(graph, x, dst_term, ident, amx, amn, gagg, aggs, all_aggs, T,
             q.base = ctypes.cast(ctypes.pointer(b), ctypes.c_void_p)
             q.table, q.ld_table = _lib.dev_ptr(table, torch.float32, "table"), table.stride(0)
             q.col_t, q.rank_t = _lib.dev_ptr(tcsr.col, torch.int32, "col_t"), _lib.dev_ptr(rank_t, torch.int32, "rank_t")
-            q.items_t, q.n_items_t = _lib.dev_ptr(items, torch.int32, "items_t"), items.shape[0]
+            q.items_t, q.n_items_t, q.run_rowprep = _lib.dev_ptr(items, torch.int32, "items_t"), items.shape[0], 1
             q.ranks, q.ld_rank = _lib.dev_ptr(ranks, torch.int16, "ranks"), ranks.stride(0)
             rc = _lib.lib().pna_segreduce_bwd_pull_f32(ctypes.byref(q), _lib.stream_ptr(dev))
             _lib.check(rc, "pna_segreduce_bwd_pull_f32")

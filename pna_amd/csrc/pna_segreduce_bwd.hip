@@ -239,7 +239,8 @@ struct PArgs {
   const float* g[6]; const float* mean; const float* stdv; const float* var; const float* dst_term;
   const int32_t* argmax; const int32_t* argmin;
   float* table; float* grad_dst; float* grad_x;
-  long ld_g, ld_stat, ld_dst, ld_table, ld_gd, ld_arg, ld_gx, ts_in, ts_g, ts_stat;
+  unsigned short* ranks;             // nullable: (V, ld_rank) [rank of argmax | rank of argmin] in the row's in-edge list (0xFFFF: none)
+  long ld_g, ld_stat, ld_dst, ld_table, ld_gd, ld_arg, ld_gx, ts_in, ts_g, ts_stat, ld_rank;
   int V, F, T, has_var;
 };
 
@@ -279,6 +280,13 @@ __global__ __launch_bounds__(kBlock) void k_bwd_rowprep(const PArgs a) {
       if (a.g[PNA_AGG_MIN]) gd = gd + a.g[PNA_AGG_MIN][og];
     }
     a.grad_dst[(size_t)v * a.ld_gd + c] = gd;
+  }
+  if (a.ranks) {                     // for pna_segreduce_bwd_pull_f32: where in the row's in-edge list argmax / argmin sit
+    const size_t oa = (size_t)v * a.ld_arg + (size_t)t * a.ts_in + f;
+    const int beg = a.rowptr[v];
+    const int ex = a.argmax ? a.argmax[oa] : -1, en = a.argmin ? a.argmin[oa] : -1;
+    a.ranks[(size_t)v * a.ld_rank + c] = ex < 0 ? (unsigned short)0xFFFF : (unsigned short)(ex - beg);
+    a.ranks[(size_t)v * a.ld_rank + TF + c] = en < 0 ? (unsigned short)0xFFFF : (unsigned short)(en - beg);
   }
 }
 
@@ -501,8 +509,13 @@ extern "C" int pna_segreduce_bwd_pull_f32(const pna_segreduce_bwd_pull_args* q, 
                                         "(ld >= 2 T F), the transposed graph (col_t, rank_t, items_t), a ranks workspace (ld >= 2 T F) and 4 <= F <= 256");
   hipStream_t st = (hipStream_t)stream;
   const long n = (long)p->V * TF;
-  hipLaunchKernelGGL(k_bwd_ranks, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, p->rowptr, p->argmax, p->argmin, (long)p->ld_arg,
-                     (long)k.ts_in, p->V, F, T, q->ranks, (long)q->ld_rank);
+  if (q->run_rowprep) {              // rowprep (table, grad_dst) and the ranks in ONE pass over the rows
+    k.table = const_cast<float*>(q->table); k.ld_table = q->ld_table; k.ranks = q->ranks; k.ld_rank = q->ld_rank;
+    hipLaunchKernelGGL(k_bwd_rowprep, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, k);
+  } else {
+    hipLaunchKernelGGL(k_bwd_ranks, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, p->rowptr, p->argmax, p->argmin, (long)p->ld_arg,
+                       (long)k.ts_in, p->V, F, T, q->ranks, (long)q->ld_rank);
+  }
   LArgs a;
   memset(&a, 0, sizeof(a));
   a.items = q->items_t; a.col_t = q->col_t; a.rank_t = q->rank_t; a.table = q->table; a.gmax = k.g[PNA_AGG_MAX]; a.gmin = k.g[PNA_AGG_MIN];
