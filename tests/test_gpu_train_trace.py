@@ -119,7 +119,7 @@ def test_two_epoch_loss_trace_matches_the_reference(cuda_device, name):
     gradients into lr-sized parameter differences; the plain-torch restatement of the layer run on the GPU in this same harness
     drifts from the CPU trace just as far (tools/train_trace_diag.py: 2e-5 .. 3e-4 per step over the eight steps for both).  And
     the GPU backward of the dense variant sums its scatter with hardware atomics, whose order varies from run to run: over
-    repeated runs of this test the worst step was <= 1e-3 in five of six and 2.8e-3 in the sixth -- the bar leaves room for that
+    repeated runs of this test the worst step was 3.2e-4 .. 6e-4 in 29 of 31 and 2.8e-3 in two -- the bar leaves room for that
     spread (it is not a property of the layer under test: parts (1) and (2) are deterministic and tight)."""
     from pna_amd.pytorch.pna.layer import PNALayer
     meta, a, sd = load_golden(name)
@@ -167,4 +167,7 @@ def test_two_epoch_loss_trace_matches_the_reference(cuda_device, name):
             opt.step()
             got.append(float(loss.item()))
     rel = [abs(g - w) / abs(w) for g, w in zip(got, want)]
+    import os
+    if os.environ.get("PNA_TRACE_PRINT"):
+        print("TRACE_MAX_REL", max(rel))
     assert len(got) == len(want) == 8 and max(rel) <= 5e-3, (got, want, rel)
