@@ -225,8 +225,8 @@ def pk_src1_hi_selects(lines):
     out = []
     for ln, _, mn, ops in parse(lines):
         if mn and _PK_F32.match(mn):
-            m = re.search(r"op_sel:\[([01]),([01])", ops)
-            if m and m.group(2) == "1":
+            m = re.search(r"op_sel:\[([01]),([01])(?:,([01]))?", ops)          # (src2 of an fma: not measured, treated alike)
+            if m and (m.group(2) == "1" or m.group(3) == "1"):
                 out.append((ln, mn, ops))
     return out
 
