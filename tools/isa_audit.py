@@ -87,18 +87,22 @@ def audit(lines, verbose=False):
     ins = parse(lines)
     labels = {name: k for k, (_, a, mn, name) in enumerate(ins) if mn == "label"}
     problems, seen_prob, visited = [], set(), set()
-    stack = [(0, (), ())]            # (pc, VMEM fifo, LGKM fifo); entries: sorted tuple of dst regs (empty for ops without a tracked dst)
+    # (pc, VMEM fifo, LGKM fifo, known loop flags, vcc); fifo entries: sorted tuple of dst regs (empty for ops without a tracked dst).
+    # Loop flags: hipcc lowers `break` out of a loop as `s_mov_b64 s[a:b], -1 / 0` on the two ways into a common block that then
+    # tests `s_and_b64 vcc, exec, s[a:b]; s_cbranch_vccnz exit` -- without following that constant the audit walks "break, then the
+    # loop header anyway", a path that does not exist (and on which loads requested for the next iteration are never waited for).
+    stack = [(0, (), (), (), None)]
     steps = 0
     while stack:
-        k, fifo, lgkm = stack.pop()
-        fifo, lgkm = list(fifo), list(lgkm)
+        k, fifo, lgkm, flags, vcc = stack.pop()
+        fifo, lgkm, flags = list(fifo), list(lgkm), dict(flags)
         while k < len(ins):
             ln, in_asm, mn, ops = ins[k]
             steps += 1
             if steps > 20_000_000:
                 raise SystemExit("isa_audit: state explosion (more than 2e7 steps)")
             if mn == "label":
-                key = (k, tuple(fifo), tuple(lgkm))
+                key = (k, tuple(fifo), tuple(lgkm), tuple(sorted(flags.items())), vcc)
                 if key in visited:
                     break
                 visited.add(key)
@@ -110,9 +114,29 @@ def audit(lines, verbose=False):
                 k = labels[ops.strip()]
                 continue
             if mn.startswith("s_cbranch"):
-                stack.append((labels[ops.strip()], tuple(fifo), tuple(lgkm)))
+                taken = {"s_cbranch_vccnz": vcc, "s_cbranch_vccz": None if vcc is None else not vcc}.get(mn)
+                if taken is True:
+                    k = labels[ops.strip()]
+                    continue
+                if taken is None:
+                    stack.append((labels[ops.strip()], tuple(fifo), tuple(lgkm), tuple(sorted(flags.items())), vcc))
                 k += 1
                 continue
+            if not in_asm and (mn.startswith("s_") or mn.startswith("v_cmp") or mn.startswith("v_readlane") or mn.startswith("v_readfirstlane")
+                               or "_co_" in mn):
+                parts = [x.strip() for x in ops.split(",")]
+                m = re.match(r"s_mov_b64$", mn) and re.match(r"s\[(\d+):(\d+)\]$", parts[0]) and parts[1] in ("0", "-1")
+                if mn in ("s_and_b64", "s_andn2_b64") and parts[0] == "vcc" and parts[1] == "exec" and parts[2] in flags:
+                    vcc = (flags[parts[2]] != 0) == (mn == "s_and_b64")          # (exec is never empty where a wavefront runs)
+                else:
+                    dst = parts[0] if not (("_co_" in mn) and len(parts) > 1) else parts[1]
+                    if dst == "vcc" or dst.startswith("vcc"):
+                        vcc = None
+                    written = _regs(_SREG, dst, 0)
+                    for key_ in [f for f in flags if _regs(_SREG, f, 0) & written]:
+                        del flags[key_]
+                    if m:
+                        flags[parts[0]] = int(parts[1])
             if mn == "s_waitcnt":
                 m = re.search(r"vmcnt\((\d+)\)", ops)
                 if m:
