@@ -52,3 +52,19 @@ def test_packed_fp32_low_lane_reading_the_high_half_of_src1_is_flagged():
             "v_pk_mov_b32 v[0:1], v[2:3], v[2:3] op_sel:[1,0]", "v_pk_add_f32 v[0:1], v[0:1], v[4:5]"]
     assert len(isa_audit.pk_src1_hi_selects(_k(bad + fine))) == 3
     assert not isa_audit.pk_src1_hi_selects(_k(fine))
+
+
+def test_loop_exit_flags_keep_the_audit_on_paths_that_exist():
+    """hipcc lowers `break` as a flag (s_mov_b64 s[a:b], -1 / 0) tested in a common block: a load requested for the NEXT iteration is
+    in flight on the break path too, but that path leaves the loop -- it must not be followed into the loop header."""
+    load = [";;#ASMSTART", "global_load_dwordx4 v[4:7], v0, s[2:3]", ";;#ASMEND"]
+    body = (load + ["s_cbranch_scc1 .LBB0_BREAK",
+                    ";;#ASMSTART", "s_waitcnt vmcnt(0)", ";;#ASMEND", "s_mov_b64 s[16:17], 0", "s_branch .LBB0_JOIN",
+                    ".LBB0_BREAK:", "s_mov_b64 s[16:17], -1",
+                    ".LBB0_JOIN:", "s_and_b64 vcc, exec, s[16:17]", "s_cbranch_vccnz .LBB0_EXIT",
+                    "v_add_f32_e32 v1, v5, v1",              # (the loop header: reads the register)
+                    ".LBB0_EXIT:", "s_waitcnt vmcnt(0)"])
+    assert not isa_audit.audit(_k(body))
+    # without the constant (the flag comes from a comparison) both ways out of the join are possible: flagged
+    unknown = [l if l != "s_mov_b64 s[16:17], -1" else "s_cselect_b64 s[16:17], -1, 0" for l in body]
+    assert isa_audit.audit(_k(unknown))
