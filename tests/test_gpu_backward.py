@@ -329,3 +329,26 @@ def test_pyg_layers_train_with_isolated_nodes_and_var(cuda_device, conv):
         num = (f(x.detach() + eps * d) - f(x.detach() - eps * d)) / (2 * eps)
     ana = (g1.double() * d.double()).sum().item()
     assert abs(num - ana) <= 3e-2 * abs(ana), (num, ana)
+
+
+def test_ranked_pull_entry_point_rejects_incomplete_arguments(cuda_device):
+    """pna_segreduce_bwd_pull_f32 needs max, min and std / var among the aggregators, both position arrays, the transposed graph and
+    its workspaces: anything else is PNA_E_INVALID with a message, never a launch."""
+    import ctypes
+    from pna_amd import _lib
+    L = _lib.lib()
+    b = _lib.PnaSegreduceBwdArgs()
+    q = _lib.PnaSegreduceBwdPullArgs()
+    assert L.pna_segreduce_bwd_pull_f32(ctypes.byref(q), None) < 0 and b"null" in L.pna_last_error()
+    V, F = 64, 8
+    rowptr = torch.zeros(V + 1, dtype=torch.int32, device=cuda_device)
+    gagg = torch.zeros(V, 4 * F, device=cuda_device)
+    b.rowptr, b.V, b.F = _lib.dev_ptr(rowptr, torch.int32, "rowptr"), V, F
+    b.n_tower, b.n_aggr = 1, 2
+    b.aggr[0], b.aggr[1] = _lib.AGG_CODES["mean"], _lib.AGG_CODES["max"]          # no min, no std
+    b.gagg, b.ld_g = _lib.dev_ptr(gagg, torch.float32, "gagg"), gagg.stride(0)
+    q.base = ctypes.cast(ctypes.pointer(b), ctypes.c_void_p)
+    q.n_items_t = 1
+    assert L.pna_segreduce_bwd_pull_f32(ctypes.byref(q), _lib.stream_ptr(cuda_device)) < 0
+    assert b"pna_segreduce_bwd_pull_f32" in L.pna_last_error()
+    torch.cuda.synchronize()
