@@ -172,21 +172,15 @@ class Graph:
         """dgl.batch of edge lists with LOCAL node ids, on the device: one concatenation, then the member-graph
         offsets are applied inside the CSR build (pna_collate_csr_i32) -- data/molecules.py:153-164 without the
         per-graph host work.  Returns the batched Graph (global ids in .src/.dst, CSR already built)."""
-        sizes = [int(n) for n in num_nodes_list]
-        src = torch.cat([torch.as_tensor(s) for s in srcs]).to(device) if device is not None else torch.cat([torch.as_tensor(s) for s in srcs])
-        dst = torch.cat([torch.as_tensor(d) for d in dsts]).to(src.device)
-        dev = src.device
-        counts = torch.tensor([int(torch.as_tensor(s).numel()) for s in srcs], device=dev)
-        node_offset = torch.zeros(len(sizes), dtype=torch.long, device=dev)
-        if len(sizes) > 1:
-            node_offset[1:] = torch.cumsum(torch.tensor(sizes[:-1], device=dev), 0)
-        edge_graph = torch.repeat_interleave(torch.arange(len(sizes), device=dev), counts)
-        V = sum(sizes)
-        csr = build_csr(src, dst, V, edge_graph, node_offset)
-        off = node_offset[edge_graph]
-        g = Graph(src.long() + off, dst.long() + off, V, sizes)
-        g._csr = csr
-        return g
+        # one conversion and ONE concatenation per side (on the host when the members live there: a single copy to the device),
+        # then the flat path.  What remains is the caller's data layout: concatenating 2 x 2048 small host tensors costs ~3.5 ms of
+        # the 4.1 ms this takes for a 2048-molecule batch; a data set stored as one edge array + counts uses collate_flat (0.5 ms)
+        ss = [torch.as_tensor(s) for s in srcs]
+        dd = [torch.as_tensor(d) for d in dsts]
+        counts = torch.tensor([t.numel() for t in ss], dtype=torch.long)
+        src = torch.cat(ss) if ss else torch.zeros(0, dtype=torch.long)
+        dst = torch.cat(dd) if dd else torch.zeros(0, dtype=torch.long)
+        return Graph.collate_flat(src, dst, counts, [int(n) for n in num_nodes_list], device=device if device is not None else src.device)
 
     @staticmethod
     def collate_flat(src_local, dst_local, edge_counts, num_nodes, device=None):
