@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""Randomised parity sweep of the one-kernel layer (pna_fused_degree_f32, all shape classes incl. the wide ones and the tower mode)
+against the two-kernel degree-grouped path on random graphs / shapes / epilogue options: statistics bit-identical, outputs within
+2e-6 of max|y| (the same combined weight up to the order of its fp32 combination).  Prints one line per case and a summary.
+    python tools/fuzz_fused.py [seconds] [seed]"""
+import os, sys, time, random, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pna_amd import Graph, degree_groups as DG, functional as PF
+from pna_amd.dgl.pna_layer import PNALayer, PNASimpleLayer
+from pna_amd.synth import powerlaw_graph
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+dev = torch.device("cuda:0")
+DG.MIN_ROWS, DG.MIN_OUT, DG.TWO_SCALER_MIN_OUT, PF.SMALL_SIMPLE_ROWS, PF.SMALL_TOWER_ROWS = 1, 1, 1, 0, 0
+t0, n_ok, n_skip, worst = time.time(), 0, 0, 0.0
+while time.time() - t0 < budget:
+    tower = rnd.random() < 0.25
+    wide = (not tower) and rnd.random() < 0.3
+    if tower:
+        F = rnd.randint(49, 80); N = rnd.choice([F, rnd.randint(4, 80)])
+    elif wide:
+        F, N = rnd.choice([(rnd.randint(113, 128), rnd.randint(81, 128)), (rnd.randint(113, 128), rnd.randint(4, 80)), (rnd.randint(49, 64), rnd.randint(81, 128))])
+    else:
+        F = rnd.randint(17, 80); N = rnd.randint(4, 80)
+    V = rnd.choice([3000, 20000, 70000, 150000])
+    E = int(V * rnd.choice([2, 4, 8, 14]))
+    E += (E - 2 * V) % 2
+    src, dst = powerlaw_graph(V, E, seed=rnd.randint(0, 10 ** 6), device=dev)
+    if rnd.random() < 0.5:                                  # some rows without in-edges
+        keep = dst >= rnd.randint(1, 200)
+        src, dst = src[keep], dst[keep]
+    g = Graph(src, dst, V)
+    scalers = rnd.choice(["identity amplification attenuation", "identity amplification attenuation", "identity amplification", "amplification attenuation"])
+    torch.manual_seed(rnd.randint(0, 10 ** 6))
+    pitch = 128 if F > 96 else (F + 7) // 8 * 8
+    h = torch.randn(V, pitch, device=dev)[:, :F]
+    if tower:
+        scalers = "identity amplification attenuation"
+        layer = PNALayer(F, N, "mean max min std", scalers, {"log": torch.tensor(2.1)}, 0.0, rnd.random() < 0.5, rnd.random() < 0.5, towers=1, divide_input=False,
+                         residual=(F == N and rnd.random() < 0.5)).to(dev).eval()
+        args = (g, h, None, g.snorm_n())
+    else:
+        layer = PNASimpleLayer(F, N, "mean max min std", scalers, {"log": torch.tensor(2.1)}, 0.0, True, F == N and rnd.random() < 0.5).to(dev).eval()
+        args = (g, h)
+    with torch.no_grad():
+        if tower:
+            ok_path = PF.tower_layer_degree_grouped_applies(layer, g, h) and PF.tower_layer_degree_fused_applies(layer, g, h)
+        else:
+            ok_path = layer._degree_grouped_path(g, h) and DG.fused_applies(g, h, F, N)
+        for m in layer.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(); m.running_var.uniform_(0.5, 2.0)
+        if not ok_path:
+            n_skip += 1
+            continue
+        DG.FUSED = True
+        y_f = layer(*args)
+        if not tower:
+            plan = DG.plan_of(g)
+            dump = torch.zeros(plan.NV, 4 * F, device=dev)
+            PF.simple_layer_degree_fused(layer, g, h, agg_out=dump)
+            ref_agg = PF.degree_grouped_aggregate(layer, g, h, plan)[:plan.NV]
+            real = plan.perm >= 0
+            assert torch.equal(dump[real], ref_agg[real]), ("statistics differ", V, E, F, N)
+        DG.FUSED = False
+        y_g = layer(*args)
+        DG.FUSED = True
+    s = y_g.abs().max().item()
+    err = (y_f - y_g).abs().max().item() / max(s, 1e-30)
+    bar = 1e-5 if tower else 2e-6
+    assert torch.isfinite(y_f).all() and err <= bar, ("output differs", V, E, F, N, tower, err)
+    worst = max(worst, err)
+    n_ok += 1
+    print(f"ok  {'tower' if tower else 'wide ' if wide else 'plain'} V={V} E={src.numel()} F={F} N={N} scalers={len(scalers.split())} err={err:.1e}", flush=True)
+print(f"SUMMARY {n_ok} cases passed, {n_skip} skipped (path did not apply), worst relative difference {worst:.2e}, {time.time() - t0:.0f} s")
