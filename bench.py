@@ -486,13 +486,18 @@ def main():
             from pna_amd import degree_groups as DG
             if DG.fused_applies(g, x_ext, F, F):
                 call = PF.FusedDegreeCall(layer, g, h, x=x_ext)
+                # (the kernel as the step launches it: on a large graph it leaves DG.FUSED_SPARE_WGS workgroups out and the rest
+                # rows' launches run beside it on a second stream -- functional.run_fused_call; timed alone here, each on its own)
+                beside = plan.rest_overlap_applies()
+                call.args.spare_workgroups = DG.FUSED_SPARE_WGS if beside else 0
                 t_fused = event_time_ms(call.group_rows, args.kernel_iters)
                 t_rest = event_time_ms(call.rest_rows, args.kernel_iters)
                 rows_g = grouped["rows_in_groups"]
                 deg_l = (csr.rowptr[1:] - csr.rowptr[:-1]).long()
                 e_g = int(deg_l[plan.perm[plan.perm >= 0].long()].sum().item())
                 fused = {"ms_group_rows_kernel": t_fused, "ms_rest_rows_two_kernel_path": t_rest, "rows": rows_g, "edges": e_g,
-                         "padded_rows": plan.NV, "id_records": plan.fused_tables()[2]}
+                         "padded_rows": plan.NV, "id_records": plan.fused_tables()[2],
+                         "rest_rows_beside_kernel": bool(beside), "spare_workgroups": int(call.args.spare_workgroups)}
         t_halo = event_time_ms(lambda: g.source_features(h), args.kernel_iters) if world > 1 else 0.0
         # socket power and shader clock while each kernel runs alone (rocm-smi; best effort, N = 1 only): the bf16x3 contraction
         # runs at the package power cap and the firmware lowers the clock to hold it -- the dense MFMA peak at THAT clock is the
@@ -547,7 +552,10 @@ def main():
                     "edges_per_s_kernel_only": e_g / tf, "rows": rows_g, "edges": e_g,
                     "rest_rows_two_kernel_path_ms": fused["ms_rest_rows_two_kernel_path"],
                     "mfma_frac_executed_flops": 2.0 * plan.NV * (4 * F) * F / tf / (MFMA_BF16_PEAK / 6),
-                    "note": "units of this launch: the rows of the degree groups (their edges); hub rows and rare degrees take the two-kernel rest path"}
+                    "rest_rows_beside_kernel": fused["rest_rows_beside_kernel"], "spare_workgroups": fused["spare_workgroups"],
+                    "note": "units of this launch: the rows of the degree groups (their edges); hub rows and rare degrees take the two-kernel rest path"
+                            + (" -- in the step on a second stream BESIDE this kernel, which leaves spare_workgroups of its 2-per-CU workgroups out for them"
+                               " (both timed alone here)" if fused["rest_rows_beside_kernel"] else "")}
         ftp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(ftp) and args.workload == "c3" and world == 1 and args.nodes_per_gpu == V_PER_GPU and args.edges_per_gpu == E_PER_GPU:
             try:

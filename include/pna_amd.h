@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define PNA_ABI_VERSION 16 /* 16: + pna_segreduce_bwd_pull_f32 (the backward's max / min terms inside the pull: no scatter atomics).
+#define PNA_ABI_VERSION 17 /* 17: + pna_fused_degree_args.spare_workgroups (the rest-row launches beside the persistent kernel).
+                              16: + pna_segreduce_bwd_pull_f32 (the backward's max / min terms inside the pull: no scatter atomics).
                               15: pna_fused_degree_*: wide shapes (F in 113..128 and / or N in 81..128).
                               14: pna_segreduce_args.edge_type / n_edge_types (edge terms from a table of edge types); the hand-scheduled gather takes
                                   edge terms (per edge or per type).
@@ -529,6 +530,10 @@ typedef struct pna_fused_degree_args {
   const float* h_self;    /* (n_nodes, ld_h) */
   int64_t ld_h;
   const float* row_post;  /* [M], virtual row order */
+  int32_t spare_workgroups; /* ABI 17: workgroups to leave OUT of the launch (0: two per CU, the whole device).  The kernel is
+                             * persistent and books every register of a CU, so launches on another stream wait until it retires;
+                             * with a few workgroups left out they run beside it (the caller's rest-row launches: DESIGN.md 4.8.9). */
+  int32_t _pad4;
 } pna_fused_degree_args;
 
 int64_t pna_fused_degree_image_bytes(int32_t F, int32_t N);   /* 0 = unsupported shape */

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to the HI
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpna_amd.so")
 
-PNA_ABI_VERSION = 16
+PNA_ABI_VERSION = 17
 PNA_MAX_AGGR = 8
 PNA_MAX_SCALER = 8
 
@@ -119,6 +119,7 @@ class PnaFusedDegreeArgs(ctypes.Structure):
         ("y", ctypes.c_void_p), ("ldy", ctypes.c_int64), ("relu", ctypes.c_int32), ("act_slope", ctypes.c_float),
         ("agg_out", ctypes.c_void_p), ("ld_agg", ctypes.c_int64),
         ("x_dst", ctypes.c_void_p), ("ld_xdst", ctypes.c_int64), ("h_self", ctypes.c_void_p), ("ld_h", ctypes.c_int64), ("row_post", ctypes.c_void_p),
+        ("spare_workgroups", ctypes.c_int32), ("_pad4", ctypes.c_int32),
     ]
 
 

@@ -801,6 +801,7 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
       (p->residual && (p->ld_res < p->N || p->n_nodes * p->ld_res * 4 >= (1ll << 32))) || p->image_stride <= 0)
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: bad n_nodes / ldy / ld_res / image_stride (y and residual must be < 4 GiB)");
   if (p->relu < 0 || p->relu > 2) return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: relu must be 0, 1 or 2");
+  if (p->spare_workgroups < 0) return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: spare_workgroups must be >= 0");
   if ((p->col_scale == nullptr) != (p->col_shift == nullptr))
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: col_scale and col_shift come together");
   if (p->agg_out && p->ld_agg < 4 * (int64_t)p->F) return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: ld_agg < 4 F");
@@ -836,7 +837,9 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
   if (const char* e = getenv("PNA_FD_WGS")) per_cu = atoi(e) > 0 ? atoi(e) : 2;
 #endif
   if (p->agg_out) per_cu = 1;                             // (the verification instantiation is built for one workgroup per CU)
-  const int wgs = ntiles < per_cu * cus ? ntiles : per_cu * cus;
+  int wgs = per_cu * cus;
+  if (p->spare_workgroups > 0) wgs = wgs - p->spare_workgroups > cus ? wgs - p->spare_workgroups : cus;   // (never below one per CU)
+  if (ntiles < wgs) wgs = ntiles;
   hipStream_t st = (hipStream_t)stream;
   const int rc = p->agg_out ? launch_shape<true>(g, wgs, st) : launch_shape<false>(g, wgs, st);
   if (rc != 0) return pna_set_error(PNA_E_LAUNCH, rc == -2 ? "pna_fused_degree_f32: no instantiation for this F" : "pna_fused_degree_f32: hipFuncSetAttribute failed");

@@ -88,6 +88,7 @@ class DegreePlan:
         self.rows = self.NV + self.NRp
         self._rest_scales = {}
         self._fused, self._rest_items, self._vmap32, self._perm_all, self._rest_items_node, self._ones_rows = None, None, None, None, None, None
+        self._edge_split = None
         self._deg, self._csr = deg, csr
 
     def fused_tables(self):
@@ -155,6 +156,21 @@ class DegreePlan:
             hout = (self._vmap[hs.heavy_rows.long()] - self.NV).to(torch.int32).contiguous() if hs.n_heavy > 0 else None
             self._rest_items = (items, hout, hs)
         return self._rest_items
+
+    def edge_split(self):
+        """(edges of the group rows, edges of the rest rows), counted once per plan."""
+        if self._edge_split is None:
+            live = self.perm[self.perm >= 0].long()
+            e_g = int(self._deg[live].sum().item())
+            self._edge_split = (e_g, int(self._deg.sum().item()) - e_g)
+        return self._edge_split
+
+    def rest_overlap_applies(self):
+        """Whether the rest-row launches should run beside the one-kernel layer instead of behind it (see FUSED_SPARE_WGS)."""
+        if FUSED_SPARE_WGS <= 0 or not self.NR or self.NV < FUSED_OVERLAP_MIN_ROWS:
+            return False
+        e_g, e_r = self.edge_split()
+        return e_r <= FUSED_OVERLAP_MAX_REST_EDGES * e_g
 
     def ones_rows(self):
         """float32 [NV] of ones: the per-row factor of a layer without graph norm."""
@@ -310,6 +326,12 @@ TOWERS = True              # the tower layers (PNALayer) through the degree-grou
 FUSED = True               # gather + contraction in ONE kernel (pna_fused_degree_f32) where it applies; False: the two-kernel grouped path
 MAX_REST_FRACTION = 0.5    # more rest rows than this: the grouping is overhead, the ordinary path takes the graph
 FUSED_HALO_MAX_INTERIOR = 0.5   # shards: below this fraction of rows without remote sources, exchange first and run ONE kernel
+# The rest-row launches BESIDE the one-kernel layer (functional.run_fused_call): the persistent kernel leaves this
+# many of its 2-per-CU workgroups out and the rest rows' gather / finalize / contraction run on a second stream in the slots left
+# free (measured on the benchmark graph: 24 is too few -- the chain of small launches then outlasts the kernel -- 32..40 hide it).
+FUSED_SPARE_WGS = 32
+FUSED_OVERLAP_MIN_ROWS = 1 << 18   # smaller graphs: the kernel is too short to hide a chain of launches confined to a few CUs
+FUSED_OVERLAP_MAX_REST_EDGES = 1.0 / 12   # ... and so it is when the rest rows hold more than this fraction of the group rows' edges
 
 
 def fused_applies(graph, x, F, N):

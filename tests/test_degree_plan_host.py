@@ -102,3 +102,19 @@ def test_plan_without_any_group():
     assert torch.equal(torch.sort(plan.perm_rest[:500].long()).values, torch.arange(500)) and bool((plan.perm_rest[500:] < 0).all())
     assert torch.equal(torch.sort(plan.items[:, 0].long()).values, torch.arange(500))
     assert DG.DegreePlan(g).serial != plan.serial                                          # cache keys tell two plans apart
+
+
+def test_rest_rows_run_beside_the_kernel_only_on_large_graphs(graph_and_plan, monkeypatch):
+    """DegreePlan.rest_overlap_applies (functional.run_fused_call): the rest-row launches go beside the one-kernel layer only when
+    the kernel is long enough to hide them -- enough group rows, few rest edges."""
+    g, plan = graph_and_plan
+    e_g, e_r = plan.edge_split()
+    deg = g.in_degrees().long()
+    assert e_g + e_r == g.number_of_edges() and e_g == int(deg[plan.perm[plan.perm >= 0].long()].sum())
+    assert not plan.rest_overlap_applies()                                                 # 30 k rows: far too short a kernel
+    monkeypatch.setattr(DG, "FUSED_OVERLAP_MIN_ROWS", 1024)
+    assert plan.rest_overlap_applies() == (e_r <= DG.FUSED_OVERLAP_MAX_REST_EDGES * e_g)
+    monkeypatch.setattr(DG, "FUSED_OVERLAP_MAX_REST_EDGES", 1.0)
+    assert plan.rest_overlap_applies()
+    monkeypatch.setattr(DG, "FUSED_SPARE_WGS", 0)
+    assert not plan.rest_overlap_applies()

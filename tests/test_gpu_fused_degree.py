@@ -219,6 +219,40 @@ def test_fused_layer_200_runs_identical_bits_at_full_size(cuda_device, c3):
         assert torch.equal(dump[real], ref[real])
 
 
+def test_rest_rows_beside_the_kernel_same_bits_as_behind_it_at_full_size(cuda_device, c3):
+    """functional.run_fused_call: on a large graph the rest-row launches run on a second stream BESIDE the persistent kernel, which
+    leaves DG.FUSED_SPARE_WGS workgroups out for them (pna_fused_degree_args.spare_workgroups, ABI 17).  Same kernels over the same
+    rows: the bits of the serial order, every time -- eager, and replayed from a hipGraph (the fork / join events are captured)."""
+    from pna_amd import degree_groups as DG, functional as PF
+    from pna_amd.capture import GraphedForward
+    g, layer, h = c3
+    plan = DG.plan_of(g)
+    assert plan.rest_overlap_applies() and sum(plan.edge_split()) == g.number_of_edges()
+    spare = DG.FUSED_SPARE_WGS
+    with torch.no_grad():
+        try:
+            DG.FUSED_SPARE_WGS = 0
+            assert not plan.rest_overlap_applies()
+            y_serial = PF.simple_layer_degree_fused(layer, g, h).clone()
+        finally:
+            DG.FUSED_SPARE_WGS = spare
+        bad = 0
+        for _ in range(50):
+            bad += int(not torch.equal(PF.simple_layer_degree_fused(layer, g, h), y_serial))
+        assert bad == 0, f"{bad} of 50 runs differ from the serial order"
+        # ... with work queued on the caller's stream before and after (the call must order itself against both)
+        for _ in range(10):
+            h2 = torch.empty(h.shape[0], h.stride(0), dtype=h.dtype, device=h.device)[:, :h.shape[1]].copy_(h)   # (the 16-byte row pitch)
+            assert DG.fused_applies(g, h2, 75, 75)
+            y2 = PF.simple_layer_degree_fused(layer, g, h2)
+            z = y2 + 1.0
+            del h2
+            assert torch.equal(z, y_serial + 1.0)
+    graphed = GraphedForward(lambda t: PF.simple_layer_degree_fused(layer, g, t), h, alias_inputs=True)
+    for _ in range(5):
+        assert torch.equal(graphed(h), y_serial)
+
+
 def test_fused_path_falls_back_without_an_aligned_table(cuda_device):
     """Rows of pitch 75 floats are not 16-byte aligned: the layer takes the two-kernel grouped path, same result."""
     from pna_amd import Graph, degree_groups as DG
