@@ -488,7 +488,7 @@ def main():
                 call = PF.FusedDegreeCall(layer, g, h, x=x_ext)
                 # (the kernel as the step launches it: on a large graph it leaves DG.FUSED_SPARE_WGS workgroups out and the rest
                 # rows' launches run beside it on a second stream -- functional.run_fused_call; timed alone here, each on its own)
-                beside = plan.rest_overlap_applies()
+                beside = plan.rest_overlap_applies(F)
                 call.args.spare_workgroups = DG.FUSED_SPARE_WGS if beside else 0
                 t_fused = event_time_ms(call.group_rows, args.kernel_iters)
                 t_rest = event_time_ms(call.rest_rows, args.kernel_iters)

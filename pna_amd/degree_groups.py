@@ -165,9 +165,10 @@ class DegreePlan:
             self._edge_split = (e_g, int(self._deg.sum().item()) - e_g)
         return self._edge_split
 
-    def rest_overlap_applies(self):
-        """Whether the rest-row launches should run beside the one-kernel layer instead of behind it (see FUSED_SPARE_WGS)."""
-        if FUSED_SPARE_WGS <= 0 or not self.NR or self.NV < FUSED_OVERLAP_MIN_ROWS:
+    def rest_overlap_applies(self, F):
+        """Whether the rest-row launches of a layer of F input features should run beside the one-kernel layer instead of behind it
+        (see FUSED_SPARE_WGS)."""
+        if FUSED_SPARE_WGS <= 0 or not self.NR or self.NV < FUSED_OVERLAP_MIN_ROWS or F < FUSED_OVERLAP_MIN_F:
             return False
         e_g, e_r = self.edge_split()
         return e_r <= FUSED_OVERLAP_MAX_REST_EDGES * e_g
@@ -330,7 +331,8 @@ FUSED_HALO_MAX_INTERIOR = 0.5   # shards: below this fraction of rows without re
 # many of its 2-per-CU workgroups out and the rest rows' gather / finalize / contraction run on a second stream in the slots left
 # free (measured on the benchmark graph: 24 is too few -- the chain of small launches then outlasts the kernel -- 32..40 hide it).
 FUSED_SPARE_WGS = 32
-FUSED_OVERLAP_MIN_ROWS = 1 << 18   # smaller graphs: the kernel is too short to hide a chain of launches confined to a few CUs
+FUSED_OVERLAP_MIN_ROWS = 1 << 19   # smaller graphs: the kernel is too short to hide a chain of launches confined to a few CUs
+FUSED_OVERLAP_MIN_F = 64           # ... and so it is with few features (the chain is latency, the kernel's time follows F); measured: 75, 128
 FUSED_OVERLAP_MAX_REST_EDGES = 1.0 / 12   # ... and so it is when the rest rows hold more than this fraction of the group rows' edges
 
 

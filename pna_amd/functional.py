@@ -531,7 +531,7 @@ def run_fused_call(call):
     halves write disjoint rows of y).  The caller's stream sees one call: everything it issued before is visible to both halves,
     everything it issues afterwards waits for both."""
     plan = call.plan
-    if not plan.rest_overlap_applies():
+    if not plan.rest_overlap_applies(call.args.F):
         call.args.spare_workgroups = 0
         call.group_rows()
         return call.rest_rows()

@@ -111,10 +111,10 @@ def test_rest_rows_run_beside_the_kernel_only_on_large_graphs(graph_and_plan, mo
     e_g, e_r = plan.edge_split()
     deg = g.in_degrees().long()
     assert e_g + e_r == g.number_of_edges() and e_g == int(deg[plan.perm[plan.perm >= 0].long()].sum())
-    assert not plan.rest_overlap_applies()                                                 # 30 k rows: far too short a kernel
+    assert not plan.rest_overlap_applies(75)                                               # 30 k rows: far too short a kernel
     monkeypatch.setattr(DG, "FUSED_OVERLAP_MIN_ROWS", 1024)
-    assert plan.rest_overlap_applies() == (e_r <= DG.FUSED_OVERLAP_MAX_REST_EDGES * e_g)
+    assert plan.rest_overlap_applies(75) == (e_r <= DG.FUSED_OVERLAP_MAX_REST_EDGES * e_g)
     monkeypatch.setattr(DG, "FUSED_OVERLAP_MAX_REST_EDGES", 1.0)
-    assert plan.rest_overlap_applies()
+    assert plan.rest_overlap_applies(75) and plan.rest_overlap_applies(128) and not plan.rest_overlap_applies(40)
     monkeypatch.setattr(DG, "FUSED_SPARE_WGS", 0)
-    assert not plan.rest_overlap_applies()
+    assert not plan.rest_overlap_applies(75)

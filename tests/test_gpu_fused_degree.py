@@ -227,12 +227,12 @@ def test_rest_rows_beside_the_kernel_same_bits_as_behind_it_at_full_size(cuda_de
     from pna_amd.capture import GraphedForward
     g, layer, h = c3
     plan = DG.plan_of(g)
-    assert plan.rest_overlap_applies() and sum(plan.edge_split()) == g.number_of_edges()
+    assert plan.rest_overlap_applies(75) and not plan.rest_overlap_applies(32) and sum(plan.edge_split()) == g.number_of_edges()
     spare = DG.FUSED_SPARE_WGS
     with torch.no_grad():
         try:
             DG.FUSED_SPARE_WGS = 0
-            assert not plan.rest_overlap_applies()
+            assert not plan.rest_overlap_applies(75)
             y_serial = PF.simple_layer_degree_fused(layer, g, h).clone()
         finally:
             DG.FUSED_SPARE_WGS = spare
