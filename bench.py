@@ -492,12 +492,18 @@ def main():
                 call.args.spare_workgroups = DG.FUSED_SPARE_WGS if beside else 0
                 t_fused = event_time_ms(call.group_rows, args.kernel_iters)
                 t_rest = event_time_ms(call.rest_rows, args.kernel_iters)
+                t_fused_full = t_fused
+                if beside:                                # ... and on the whole device (what the step launched before ABI 17)
+                    call.args.spare_workgroups = 0
+                    t_fused_full = event_time_ms(call.group_rows, args.kernel_iters)
+                    call.args.spare_workgroups = DG.FUSED_SPARE_WGS
                 rows_g = grouped["rows_in_groups"]
                 deg_l = (csr.rowptr[1:] - csr.rowptr[:-1]).long()
                 e_g = int(deg_l[plan.perm[plan.perm >= 0].long()].sum().item())
                 fused = {"ms_group_rows_kernel": t_fused, "ms_rest_rows_two_kernel_path": t_rest, "rows": rows_g, "edges": e_g,
                          "padded_rows": plan.NV, "id_records": plan.fused_tables()[2],
-                         "rest_rows_beside_kernel": bool(beside), "spare_workgroups": int(call.args.spare_workgroups)}
+                         "rest_rows_beside_kernel": bool(beside), "spare_workgroups": int(call.args.spare_workgroups),
+                         "ms_group_rows_kernel_full_grid": t_fused_full}
         t_halo = event_time_ms(lambda: g.source_features(h), args.kernel_iters) if world > 1 else 0.0
         # socket power and shader clock while each kernel runs alone (rocm-smi; best effort, N = 1 only): the bf16x3 contraction
         # runs at the package power cap and the firmware lowers the clock to hold it -- the dense MFMA peak at THAT clock is the
@@ -553,6 +559,10 @@ def main():
                     "rest_rows_two_kernel_path_ms": fused["ms_rest_rows_two_kernel_path"],
                     "mfma_frac_executed_flops": 2.0 * plan.NV * (4 * F) * F / tf / (MFMA_BF16_PEAK / 6),
                     "rest_rows_beside_kernel": fused["rest_rows_beside_kernel"], "spare_workgroups": fused["spare_workgroups"],
+                    "full_grid": {"ms_per_launch": fused["ms_group_rows_kernel_full_grid"],
+                                  "frac": fused_bytes / (fused["ms_group_rows_kernel_full_grid"] * 1e-3) / HBM_PEAK,
+                                  "note": "the same kernel on every workgroup slot of the device (spare_workgroups = 0): its own ceiling; the step "
+                                          "trades this for the rest rows running beside it"},
                     "note": "units of this launch: the rows of the degree groups (their edges); hub rows and rare degrees take the two-kernel rest path"
                             + (" -- in the step on a second stream BESIDE this kernel, which leaves spare_workgroups of its 2-per-CU workgroups out for them"
                                " (both timed alone here)" if fused["rest_rows_beside_kernel"] else "")}
