@@ -515,11 +515,11 @@ _SIDE_STREAMS = {}
 
 
 def _side_stream(device):
-    """(second stream, fork event, join event) of a device: where the rest-row launches of the one-kernel layers run."""
+    """The second stream of a device: where the rest-row launches of the one-kernel layers run."""
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     hit = _SIDE_STREAMS.get(key)
     if hit is None:
-        hit = _SIDE_STREAMS[key] = (torch.cuda.Stream(device=key), torch.cuda.Event(), torch.cuda.Event())
+        hit = _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
     return hit
 
 
@@ -538,7 +538,7 @@ def run_fused_call(call):
     from . import degree_groups as DG
     dev = call.y.device
     main = torch.cuda.current_stream(dev)
-    side, fork, join = _side_stream(dev)
+    side, fork, join = _side_stream(dev), torch.cuda.Event(), torch.cuda.Event()   # (events per call: callers on several streams / threads)
     call.args.spare_workgroups = DG.FUSED_SPARE_WGS
     fork.record(main)
     call.group_rows()
