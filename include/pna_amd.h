@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define PNA_ABI_VERSION 17 /* 17: + pna_fused_degree_args.spare_workgroups (the rest-row launches beside the persistent kernel).
+#define PNA_ABI_VERSION 18 /* 18: + pna_bn_tail_{workspace_bytes,fwd_f32,bwd_f32}: batch-statistics BatchNorm + ReLU + residual of the training path.
+                              17: + pna_fused_degree_args.spare_workgroups (the rest-row launches beside the persistent kernel).
                               16: + pna_segreduce_bwd_pull_f32 (the backward's max / min terms inside the pull: no scatter atomics).
                               15: pna_fused_degree_*: wide shapes (F in 113..128 and / or N in 81..128).
                               14: pna_segreduce_args.edge_type / n_edge_types (edge terms from a table of edge types); the hand-scheduled gather takes
@@ -655,6 +656,55 @@ int pna_collate_csr_i32(const int32_t* src, const int32_t* dst, int64_t n_edges,
  */
 int pna_pack_rows_f32(const float* x, int64_t ldx, const int32_t* idx, int64_t n, int32_t F, float* out, int64_t ldo,
                       pna_stream_t stream);
+
+/* ---- the tail of PNASimpleLayer's TRAINING forward, and its backward (ABI 18) ----------------------------------------
+ * replaces: models/dgl/pna_layer.py:207-213 in training mode -- `h = self.batchnorm_h(h)` (nn.BatchNorm1d, batch statistics),
+ * `h = F.relu(h)`, `h = h_in + h` -- and their autograd nodes:
+ *
+ *   mean_c, var_c = batch statistics of y[:, c] (biased variance);  save_mean = mean, save_invstd = 1 / sqrt(var + eps)
+ *   out = residual + act((y - mean) * (gamma * save_invstd) + beta)                   act = ReLU when relu != 0
+ *   running_mean = (1 - momentum) running_mean + momentum mean;  running_var likewise with var * M / (M - 1)
+ *                                                                 (both skipped when running_mean is NULL or momentum < 0)
+ *   backward (g' = grad_out where the activation passed, xhat = (y - mean) save_invstd):
+ *   grad_beta = sum_r g',  grad_gamma = sum_r g' xhat,  grad_y = gamma save_invstd (g' - mean_r g' - xhat mean_r(g' xhat))
+ *   (the residual's gradient is grad_out itself: the caller's)
+ *
+ * Two streaming passes each way (column sums, then the element-wise pass) instead of the ~10 library passes; column sums are
+ * taken of y - y[0, c] in fp32 per 512 rows and in float64 across them.  M >= 2 rows (nn.BatchNorm1d raises below that: the
+ * caller's), 1 <= N <= 128, rows 4-byte aligned, ld >= N.  workspace: pna_bn_tail_workspace_bytes(M, N) bytes, no
+ * initialisation needed, not kept between the two calls.
+ */
+typedef struct pna_bn_tail_args {
+  const float* y;          /* (M, ldy): the posttrans output */
+  int64_t ldy;
+  int64_t M;
+  int32_t N;
+  int32_t relu;
+  const float* gamma;      /* nullable [N] (affine=False: 1) */
+  const float* beta;       /* nullable [N] */
+  float eps;
+  float momentum;          /* < 0: leave the running statistics alone */
+  float* running_mean;     /* nullable [N]; with running_var */
+  float* running_var;
+  const float* residual;   /* fwd, nullable (M, ld_res) */
+  int64_t ld_res;
+  float* out;              /* fwd (M, ld_out) */
+  int64_t ld_out;
+  float* save_mean;        /* [N]: written by fwd, read by bwd */
+  float* save_invstd;      /* [N] */
+  void* workspace;
+  int64_t workspace_bytes;
+  const float* grad_out;   /* bwd (M, ld_go) */
+  int64_t ld_go;
+  float* grad_y;           /* bwd (M, ld_gy) */
+  int64_t ld_gy;
+  float* grad_gamma;       /* bwd, nullable [N] */
+  float* grad_beta;        /* bwd, nullable [N] */
+} pna_bn_tail_args;
+
+int64_t pna_bn_tail_workspace_bytes(int64_t M, int32_t N);
+int pna_bn_tail_fwd_f32(const pna_bn_tail_args* args, pna_stream_t stream);
+int pna_bn_tail_bwd_f32(const pna_bn_tail_args* args, pna_stream_t stream);
 
 const char* pna_last_error(void);
 int pna_abi_version(void);

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to the HI
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpna_amd.so")
 
-PNA_ABI_VERSION = 17
+PNA_ABI_VERSION = 18
 PNA_MAX_AGGR = 8
 PNA_MAX_SCALER = 8
 
@@ -123,6 +123,18 @@ class PnaFusedDegreeArgs(ctypes.Structure):
     ]
 
 
+class PnaBnTailArgs(ctypes.Structure):
+    _fields_ = [
+        ("y", ctypes.c_void_p), ("ldy", ctypes.c_int64), ("M", ctypes.c_int64), ("N", ctypes.c_int32), ("relu", ctypes.c_int32),
+        ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("eps", ctypes.c_float), ("momentum", ctypes.c_float),
+        ("running_mean", ctypes.c_void_p), ("running_var", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("ld_res", ctypes.c_int64),
+        ("out", ctypes.c_void_p), ("ld_out", ctypes.c_int64), ("save_mean", ctypes.c_void_p), ("save_invstd", ctypes.c_void_p),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
+        ("grad_out", ctypes.c_void_p), ("ld_go", ctypes.c_int64), ("grad_y", ctypes.c_void_p), ("ld_gy", ctypes.c_int64),
+        ("grad_gamma", ctypes.c_void_p), ("grad_beta", ctypes.c_void_p),
+    ]
+
+
 class PnaSmallLinearArgs(ctypes.Structure):
     _fields_ = [
         ("x", ctypes.c_void_p), ("ldx", ctypes.c_int64), ("M", ctypes.c_int32), ("K", ctypes.c_int32), ("N", ctypes.c_int32),
@@ -203,6 +215,11 @@ def lib():
         L.pna_fused_degree_pack_f32.restype = ctypes.c_int
         L.pna_segreduce_bwd_pull_f32.argtypes = [ctypes.POINTER(PnaSegreduceBwdPullArgs), ctypes.c_void_p]
         L.pna_segreduce_bwd_pull_f32.restype = ctypes.c_int
+        L.pna_bn_tail_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32]
+        L.pna_bn_tail_workspace_bytes.restype = ctypes.c_int64
+        for fn in (L.pna_bn_tail_fwd_f32, L.pna_bn_tail_bwd_f32):
+            fn.argtypes = [ctypes.POINTER(PnaBnTailArgs), ctypes.c_void_p]
+            fn.restype = ctypes.c_int
         L.pna_fused_tower_image_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32]
         L.pna_fused_tower_image_bytes.restype = ctypes.c_int64
         L.pna_fused_tower_pack_f32.argtypes = L.pna_fused_degree_pack_f32.argtypes

@@ -5,6 +5,9 @@
 `PosttransFn`  : forward = pna_posttrans_f32; its backward is three plain GEMMs (grad_agg, grad_weight,
                  grad_h) -- library matmuls through torch (rocBLAS/hipBLASLt), like the other non-hot
                  linears of the path.
+`BnTailFn`     : forward = pna_bn_tail_fwd_f32 (batch-statistics BatchNorm1d + ReLU + residual of PNASimpleLayer's
+                 training forward, models/dgl/pna_layer.py:207-213), backward = pna_bn_tail_bwd_f32: two streaming
+                 passes each instead of the library's ~10.
 No CPU or eager fallback for the forward; gradients of the degree scalers themselves are not needed
 (they depend on the graph only).
 """
@@ -387,3 +390,73 @@ class PosttransFn(torch.autograd.Function):
         if Kh and ctx.needs_input_grad[5]:
             g_h = gy @ weight[:, :Kh]
         return g_agg, None, g_w, g_b, None, g_h
+
+
+def bn_tail_applies(bn, y, residual):
+    """Whether BnTailFn serves nn.BatchNorm1d `bn` in training mode on `y` (+ residual): fp32 rows on a GPU, batch statistics
+    with an exponential running average (momentum=None, the cumulative average, and M < 2 -- where torch raises -- stay torch's)."""
+    return (BN_TAIL and bn.training and y.is_cuda and y.dtype == torch.float32 and y.dim() == 2 and y.stride(1) == 1
+            and 2 <= y.shape[0] and 1 <= y.shape[1] <= 128 and bn.track_running_stats and bn.momentum is not None
+            and bn.running_mean is not None
+            and (residual is None or (residual.shape == y.shape and residual.dtype == torch.float32 and residual.is_cuda)))
+
+
+BN_TAIL = os.environ.get("PNA_AMD_BN_TAIL", "1") != "0"
+
+
+def bn_relu_residual(bn, y, residual=None, relu=True):
+    """residual + relu(bn(y)) for nn.BatchNorm1d `bn` in TRAINING mode: updates the running statistics and
+    num_batches_tracked like the module's own forward."""
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return BnTailFn.apply(y, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, float(bn.momentum), float(bn.eps), bool(relu))
+
+
+class BnTailFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, gamma, beta, residual, running_mean, running_var, momentum, eps, relu):
+        M, N = y.shape
+        dev = y.device
+        res = None if residual is None else (residual if residual.stride(1) == 1 else residual.contiguous())
+        out = torch.empty(M, N, dtype=torch.float32, device=dev)
+        stats = torch.empty(2, N, dtype=torch.float32, device=dev)
+        ws = torch.empty(_lib.lib().pna_bn_tail_workspace_bytes(M, N) // 4, dtype=torch.float32, device=dev)
+        a = _lib.PnaBnTailArgs()
+        a.y, a.ldy, a.M, a.N, a.relu = _lib.dev_ptr(y, torch.float32, "y"), y.stride(0), M, N, int(relu)
+        if gamma is not None:
+            a.gamma, a.beta = _lib.dev_ptr(gamma, torch.float32, "gamma"), _lib.dev_ptr(beta, torch.float32, "beta")
+        a.eps, a.momentum = eps, momentum
+        a.running_mean, a.running_var = _lib.dev_ptr(running_mean, torch.float32, "running_mean"), _lib.dev_ptr(running_var, torch.float32, "running_var")
+        if res is not None:
+            a.residual, a.ld_res = _lib.dev_ptr(res, torch.float32, "residual"), res.stride(0)
+        a.out, a.ld_out = _lib.dev_ptr(out, torch.float32, "out"), out.stride(0)
+        a.save_mean, a.save_invstd = _lib.dev_ptr(stats[0], torch.float32, "save_mean"), _lib.dev_ptr(stats[1], torch.float32, "save_invstd")
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        _lib.check(_lib.lib().pna_bn_tail_fwd_f32(ctypes.byref(a), _lib.stream_ptr(dev)), "pna_bn_tail_fwd_f32")
+        ctx.save_for_backward(y, gamma, beta, stats)
+        ctx.relu, ctx.has_res, ctx.eps = relu, residual is not None, eps
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        y, gamma, beta, stats = ctx.saved_tensors
+        M, N = y.shape
+        dev = y.device
+        go = go if go.stride(1) == 1 else go.contiguous()
+        gy = torch.empty(M, N, dtype=torch.float32, device=dev)
+        gwb = torch.empty(2, N, dtype=torch.float32, device=dev)
+        ws = torch.empty(_lib.lib().pna_bn_tail_workspace_bytes(M, N) // 4, dtype=torch.float32, device=dev)
+        a = _lib.PnaBnTailArgs()
+        a.y, a.ldy, a.M, a.N, a.relu = _lib.dev_ptr(y, torch.float32, "y"), y.stride(0), M, N, int(ctx.relu)
+        if gamma is not None:
+            a.gamma, a.beta = _lib.dev_ptr(gamma, torch.float32, "gamma"), _lib.dev_ptr(beta, torch.float32, "beta")
+        a.eps, a.momentum = ctx.eps, -1.0
+        a.save_mean, a.save_invstd = _lib.dev_ptr(stats[0], torch.float32, "save_mean"), _lib.dev_ptr(stats[1], torch.float32, "save_invstd")
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        a.grad_out, a.ld_go = _lib.dev_ptr(go, torch.float32, "grad_out"), go.stride(0)
+        a.grad_y, a.ld_gy = _lib.dev_ptr(gy, torch.float32, "grad_y"), gy.stride(0)
+        a.grad_gamma, a.grad_beta = _lib.dev_ptr(gwb[0], torch.float32, "grad_gamma"), _lib.dev_ptr(gwb[1], torch.float32, "grad_beta")
+        _lib.check(_lib.lib().pna_bn_tail_bwd_f32(ctypes.byref(a), _lib.stream_ptr(dev)), "pna_bn_tail_bwd_f32")
+        has_affine = gamma is not None
+        return (gy, gwb[0] if has_affine and ctx.needs_input_grad[1] else None, gwb[1] if has_affine and ctx.needs_input_grad[2] else None,
+                go if ctx.has_res else None, None, None, None, None, None)

@@ -436,6 +436,12 @@ class PNASimpleLayer(nn.Module):
         y = PF.posttrans(agg, K, lin.weight, lin.bias, scales)
         y = self.posttrans.tail(y)
         if self.batch_norm:
+            from ..autograd import bn_relu_residual, bn_tail_applies
+            res = h_in if self.residual else None
+            if bn_tail_applies(self.batchnorm_h, y, res):
+                # training: batch-statistics BatchNorm + ReLU + residual in two streaming passes, two more in the backward
+                # (pna_bn_tail_*_f32) instead of the library's ~10 over the (V, out_dim) tensors
+                return F.dropout(bn_relu_residual(self.batchnorm_h, y, res), self.dropout, training=self.training)
             y = self.batchnorm_h(y)
         y = F.relu(y)
         if self.residual:

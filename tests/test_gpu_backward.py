@@ -352,3 +352,92 @@ def test_ranked_pull_entry_point_rejects_incomplete_arguments(cuda_device):
     assert L.pna_segreduce_bwd_pull_f32(ctypes.byref(q), _lib.stream_ptr(cuda_device)) < 0
     assert b"pna_segreduce_bwd_pull_f32" in L.pna_last_error()
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,pitch,residual,affine,relu", [
+    (4000, 75, 75, True, True, True), (4000, 75, 80, True, True, True), (1537, 128, 128, False, True, True),
+    (513, 3, 3, True, False, True), (2, 5, 8, True, True, False), (100_000, 70, 72, True, True, True)])
+def test_bn_tail_forward_backward_vs_torch_float64(cuda_device, M, N, pitch, residual, affine, relu):
+    """pna_bn_tail_{fwd,bwd}_f32 (autograd.BnTailFn) against nn.BatchNorm1d (training) + F.relu + residual in float64
+    (models/dgl/pna_layer.py:207-213): output, running statistics, and every gradient; columns of large mean included."""
+    from pna_amd.autograd import bn_relu_residual, bn_tail_applies
+    gen = torch.Generator().manual_seed(M + N)
+    y64 = torch.randn(M, N, generator=gen, dtype=torch.float64) * (0.5 + torch.rand(N, generator=gen, dtype=torch.float64) * 3)
+    y64 = y64 + torch.randn(N, generator=gen, dtype=torch.float64) * 20                    # means far from 0: the shifted sums
+    r64 = torch.randn(M, N, generator=gen, dtype=torch.float64)
+    R64 = torch.randn(M, N, generator=gen, dtype=torch.float64)
+    bn64 = torch.nn.BatchNorm1d(N, affine=affine, momentum=0.1).double()
+    bn32 = torch.nn.BatchNorm1d(N, affine=affine, momentum=0.1)
+    if affine:
+        with torch.no_grad():
+            bn64.weight.copy_(torch.rand(N, generator=gen, dtype=torch.float64) + 0.5)
+            bn64.bias.copy_(torch.randn(N, generator=gen, dtype=torch.float64))
+            bn32.weight.copy_(bn64.weight.float()); bn32.bias.copy_(bn64.bias.float())
+    bn32 = bn32.to(cuda_device).train()
+    ya = y64.clone().requires_grad_(True)
+    ra = r64.clone().requires_grad_(True)
+    z = bn64(ya)
+    want = (torch.relu(z) if relu else z) + (ra if residual else 0)
+    (want * R64).sum().backward()
+    yg = torch.empty(M, pitch, device=cuda_device)[:, :N].copy_(y64.float()).requires_grad_(True)
+    rg = r64.float().to(cuda_device).requires_grad_(True)
+    assert bn_tail_applies(bn32, yg, rg if residual else None)
+    got = bn_relu_residual(bn32, yg, rg if residual else None, relu=relu)
+    (got * R64.float().to(cuda_device)).sum().backward()
+
+    def close(a, b, what, tol=1e-5):
+        err = (a.double().cpu() - b).abs().max().item() / max(1.0, b.abs().max().item())
+        assert err <= tol, (what, err)
+    close(got, want.detach(), "out")
+    close(bn32.running_mean, bn64.running_mean, "running_mean", 1e-6)
+    close(bn32.running_var, bn64.running_var, "running_var", 1e-6)
+    assert int(bn32.num_batches_tracked) == 1
+    # rows whose pre-activation sits within fp32 rounding of 0 may take the other branch of the ReLU: leave them out of grad_y
+    edge = (z.detach().abs() < 1e-5).any(dim=1) if relu else torch.zeros(M, dtype=torch.bool)
+    gy = yg.grad.double().cpu()
+    scale = max(1.0, ya.grad.abs().max().item())
+    # (two rows: xhat = +-1 and grad_y is a difference of nearly equal terms times a large 1 / std -- fp32 torch is no closer)
+    assert ((gy - ya.grad).abs()[~edge].max().item() if (~edge).any() else 0.0) <= (2e-5 if M >= 100 else 2e-4) * scale
+    if residual:
+        close(rg.grad, ra.grad, "grad_residual", 1e-6)
+    if affine:
+        close(bn32.weight.grad, bn64.weight.grad, "grad_gamma", 2e-5)
+        close(bn32.bias.grad, bn64.bias.grad, "grad_beta", 2e-5)
+
+
+@pytest.mark.gpu
+def test_simple_layer_training_step_uses_the_bn_tail_and_matches_the_library_route(cuda_device, monkeypatch):
+    """PNASimpleLayer in training mode: the streaming BatchNorm tail against the nn.BatchNorm1d / F.relu route (PNA_AMD_BN_TAIL=0),
+    same weights: output, input gradient, parameter gradients and running statistics; nn.BatchNorm1d's error for one row stays."""
+    from pna_amd import autograd as AG
+    from pna_amd.synth import powerlaw_graph
+    V, E, F = 20_000, 160_000, 75
+    src, dst = powerlaw_graph(V, E, seed=3)
+    g = Graph(src, dst, V).to(cuda_device)
+    avg = {"log": float(torch.log(g.in_degrees().float() + 1).mean())}
+    outs = []
+    for tail in (True, False):
+        monkeypatch.setattr(AG, "BN_TAIL", tail)
+        torch.manual_seed(0)
+        layer = PNASimpleLayer(F, F, "mean max min std", "identity amplification attenuation", avg, 0.0, True, True).to(cuda_device).train()
+        h = torch.randn(V, F, generator=torch.Generator().manual_seed(1)).to(cuda_device).requires_grad_(True)
+        calls = []
+        real = AG.bn_relu_residual
+        monkeypatch.setattr(AG, "bn_relu_residual", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        out = layer(g, h)
+        (out * out).sum().backward()
+        monkeypatch.setattr(AG, "bn_relu_residual", real)
+        assert bool(calls) == tail
+        # (the posttrans bias sits in front of a batch-statistics BatchNorm: its true gradient is 0, both routes return rounding noise)
+        outs.append((out.detach(), h.grad, [p.grad for n, p in layer.named_parameters() if not n.endswith("linear.bias")],
+                     layer.batchnorm_h.running_mean, layer.batchnorm_h.running_var))
+    (o1, gh1, gp1, rm1, rv1), (o0, gh0, gp0, rm0, rv0) = outs
+    rel = lambda a, b: (a - b).abs().max().item() / max(1.0, b.abs().max().item())
+    assert rel(o1, o0) <= 1e-5 and rel(rm1, rm0) <= 1e-6 and rel(rv1, rv0) <= 1e-6
+    # gradients: a pre-activation within fp32 rounding of 0 takes the other branch of the ReLU on one of the two routes (a
+    # handful of the 1.5 M elements) and its gradient, a whole unit, travels on: all but a few entries agree to 1e-4
+    off = ((gh1 - gh0).abs() > 1e-4 * max(1.0, gh0.abs().max().item())).float().mean().item()
+    assert off <= 1e-3 and rel(gh1, gh0) <= 2e-2, (off, rel(gh1, gh0))
+    for a, b in zip(gp1, gp0):
+        assert rel(a, b) <= 1e-3
