@@ -1,4 +1,4 @@
-"""world_size-2 (and 3) CPU tests of the multi-GPU path over the gloo backend: destination-range
+"""world_size-2 (3 and 8) CPU tests of the multi-GPU path over the gloo backend: destination-range
 sharding, halo de-duplication, the all-to-all exchange and its backward.  The aggregation kernel itself
 needs a GPU, so here the exchange is validated against the global feature table directly: after
 `source_features`, gathering with the shard's remapped source ids must equal gathering the global table
@@ -183,7 +183,7 @@ def test_bfs_order_is_a_permutation_and_restores_locality():
     assert cut(new_id[src], new_id[dst]) == 2 * 7 and cut(src, dst) > 1000
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_halo_exchange_gloo(world):
     mp.spawn(_worker, args=(world, _free_port(), 500, 6000, 5), nprocs=world, join=True)
 
@@ -268,7 +268,7 @@ def _worker_block_pipeline(rank, world, port, n_blocks):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_blocks", [(2, 1), (2, 4), (3, 5)])
+@pytest.mark.parametrize("world,n_blocks", [(2, 1), (2, 4), (3, 5), (8, 3)])
 def test_block_pipelined_exchange_gloo(world, n_blocks):
     """BlockPipeline (inter-layer halo exchange cut into row blocks, posted while the layer's remaining blocks are computed):
     three layers of an exact integer-valued message-passing step on 2 / 3 ranks equal the unsharded result bit for bit."""
