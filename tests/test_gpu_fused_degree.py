@@ -253,6 +253,28 @@ def test_rest_rows_beside_the_kernel_same_bits_as_behind_it_at_full_size(cuda_de
         assert torch.equal(graphed(h), y_serial)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,E,F,N", [(600_000, 5_000_000, 128, 128), (560_000, 6_000_000, 64, 100)])
+def test_rest_rows_beside_the_kernel_wide_shapes(cuda_device, V, E, F, N):
+    """The same for the wide instantiations (two gather passes and / or two column panels): beside = behind, bit for bit."""
+    from pna_amd import Graph, degree_groups as DG, functional as PF
+    from pna_amd.synth import powerlaw_graph
+    src, dst = powerlaw_graph(V, E, seed=V % 97, device=cuda_device)
+    g = Graph(src, dst, V)
+    layer, h = _layer(F, N, cuda_device, residual=F == N, seed=2), _features(V, F, cuda_device, seed=4)
+    plan = DG.plan_of(g)
+    with torch.no_grad():
+        assert DG.fused_applies(g, h, F, N) and plan.rest_overlap_applies(F)
+        spare = DG.FUSED_SPARE_WGS
+        try:
+            DG.FUSED_SPARE_WGS = 0
+            y_serial = PF.simple_layer_degree_fused(layer, g, h).clone()
+        finally:
+            DG.FUSED_SPARE_WGS = spare
+        bad = sum(int(not torch.equal(PF.simple_layer_degree_fused(layer, g, h), y_serial)) for _ in range(20))
+    assert bad == 0, f"{bad} of 20 runs differ from the serial order"
+
+
 def test_fused_path_falls_back_without_an_aligned_table(cuda_device):
     """Rows of pitch 75 floats are not 16-byte aligned: the layer takes the two-kernel grouped path, same result."""
     from pna_amd import Graph, degree_groups as DG
