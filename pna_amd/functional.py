@@ -530,7 +530,9 @@ def run_fused_call(call):
     the chain goes to a second stream, forked and joined with events around the call (benchmark graph: 0.852 -> 0.807 ms; the two
     halves write disjoint rows of y).  The caller's stream sees one call: everything it issued before is visible to both halves,
     everything it issues afterwards waits for both."""
+    from . import _lib
     plan = call.plan
+    call.stream = _lib.stream_ptr(call.y.device)             # (the kernel goes to the stream that is current NOW, like every other launch)
     if not plan.rest_overlap_applies(call.args.F):
         call.args.spare_workgroups = 0
         call.group_rows()
