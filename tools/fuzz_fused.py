@@ -2,7 +2,8 @@
 """Randomised parity sweep of the one-kernel layer (pna_fused_degree_f32, all shape classes incl. the wide ones and the tower mode)
 against the two-kernel degree-grouped path on random graphs / shapes / epilogue options: statistics bit-identical, outputs within
 2e-6 of max|y| (the same combined weight up to the order of its fp32 combination).  Prints one line per case and a summary.
-    python tools/fuzz_fused.py [seconds] [seed]"""
+    python tools/fuzz_fused.py [seconds] [seed] [big]      big: graphs of 0.6 .. 1.2 M nodes and F >= 64 -- the rest rows then run
+                                                           BESIDE the kernel (functional.run_fused_call)"""
 import os, sys, time, random, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,6 +13,8 @@ from pna_amd.synth import powerlaw_graph
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
+n_beside = 0
 dev = torch.device("cuda:0")
 DG.MIN_ROWS, DG.MIN_OUT, DG.TWO_SCALER_MIN_OUT, PF.SMALL_SIMPLE_ROWS, PF.SMALL_TOWER_ROWS = 1, 1, 1, 0, 0
 t0, n_ok, n_skip, worst = time.time(), 0, 0, 0.0
@@ -24,7 +27,9 @@ while time.time() - t0 < budget:
         F, N = rnd.choice([(rnd.randint(113, 128), rnd.randint(81, 128)), (rnd.randint(113, 128), rnd.randint(4, 80)), (rnd.randint(49, 64), rnd.randint(81, 128))])
     else:
         F = rnd.randint(17, 80); N = rnd.randint(4, 80)
-    V = rnd.choice([3000, 20000, 70000, 150000])
+    if BIG and not wide:
+        F = max(F, rnd.randint(64, 80))
+    V = rnd.choice([600000, 900000, 1200000]) if BIG else rnd.choice([3000, 20000, 70000, 150000])
     E = int(V * rnd.choice([2, 4, 8, 14]))
     E += (E - 2 * V) % 2
     src, dst = powerlaw_graph(V, E, seed=rnd.randint(0, 10 ** 6), device=dev)
@@ -57,6 +62,7 @@ while time.time() - t0 < budget:
             continue
         DG.FUSED = True
         y_f = layer(*args)
+        n_beside += int(DG.plan_of(g).rest_overlap_applies(F))
         if not tower:
             plan = DG.plan_of(g)
             dump = torch.zeros(plan.NV, 4 * F, device=dev)
@@ -74,4 +80,4 @@ while time.time() - t0 < budget:
     worst = max(worst, err)
     n_ok += 1
     print(f"ok  {'tower' if tower else 'wide ' if wide else 'plain'} V={V} E={src.numel()} F={F} N={N} scalers={len(scalers.split())} err={err:.1e}", flush=True)
-print(f"SUMMARY {n_ok} cases passed, {n_skip} skipped (path did not apply), worst relative difference {worst:.2e}, {time.time() - t0:.0f} s")
+print(f"SUMMARY {n_ok} cases passed ({n_beside} with the rest rows beside the kernel), {n_skip} skipped (path did not apply), worst relative difference {worst:.2e}, {time.time() - t0:.0f} s")
