@@ -441,3 +441,40 @@ def test_simple_layer_training_step_uses_the_bn_tail_and_matches_the_library_rou
     assert off <= 1e-3 and rel(gh1, gh0) <= 2e-2, (off, rel(gh1, gh0))
     for a, b in zip(gp1, gp0):
         assert rel(a, b) <= 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", __import__("conftest").golden_names("dgl_simple_train"))
+def test_simple_layer_training_step_golden(cuda_device, name):
+    """One training step of PNASimpleLayer against the REFERENCE's own (models/dgl/pna_layer.py:197-216 in train mode, run by
+    oracle/make_golden_simple_train.py): output, the gradients of (out * R).sum() w.r.t. the input and every parameter, and the
+    BatchNorm running statistics -- through the arg-tracking gather, the bf16x3 contraction, the streaming BatchNorm tail
+    (pna_bn_tail_*) and the pull backward."""
+    from conftest import load_golden
+    from pna_amd import autograd as AG
+    meta, a, sd = load_golden(name)
+    layer = PNASimpleLayer(meta["F"], meta["out_dim"], meta["aggregators"], meta["scalers"], {"log": a["avg_log"]}, 0.0, True, meta["residual"])
+    layer.load_state_dict(sd)
+    layer = layer.to(cuda_device).train()
+    g = Graph(a["src"], a["dst"], meta["N"]).to(cuda_device)
+    h = a["h"].to(cuda_device).requires_grad_(True)
+    used = []
+    real = AG.bn_relu_residual
+    AG.bn_relu_residual = lambda *x, **k: (used.append(1), real(*x, **k))[1]
+    try:
+        out = layer(g, h)
+    finally:
+        AG.bn_relu_residual = real
+    assert used, "the streaming BatchNorm tail did not take the call"
+    (out * a["R"].to(cuda_device)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), a["out"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(layer.batchnorm_h.running_mean.cpu(), a["running_mean_after"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(layer.batchnorm_h.running_var.cpu(), a["running_var_after"], rtol=1e-5, atol=1e-6)
+    assert int(layer.batchnorm_h.num_batches_tracked) == int(sd["batchnorm_h.num_batches_tracked"]) + 1
+    scale = lambda t: max(1.0, t.abs().max().item())
+    assert (h.grad.cpu() - a["grad_h"]).abs().max().item() <= 1e-4 * scale(a["grad_h"])
+    wscale = scale(a["grad/posttrans.fully_connected.0.linear.weight"])
+    for k, p in layer.named_parameters():
+        ref = a["grad/" + k]
+        # (the posttrans bias sits in front of the batch-statistics BatchNorm: its true gradient is 0, the reference stores rounding noise)
+        assert (p.grad.cpu() - ref).abs().max().item() <= 1e-4 * max(scale(ref), wscale if k.endswith("linear.bias") else 0.0), k
