@@ -478,3 +478,54 @@ def test_simple_layer_training_step_golden(cuda_device, name):
         ref = a["grad/" + k]
         # (the posttrans bias sits in front of the batch-statistics BatchNorm: its true gradient is 0, the reference stores rounding noise)
         assert (p.grad.cpu() - ref).abs().max().item() <= 1e-4 * max(scale(ref), wscale if k.endswith("linear.bias") else 0.0), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", __import__("conftest").golden_names("dgl_tower_train"))
+def test_tower_layer_training_step_golden(cuda_device, name):
+    """One training step of PNALayer with towers against the REFERENCE's own (models/dgl/pna_layer.py:130-148 over :55-76 in
+    train mode, oracle/make_golden_simple_train.py): output, gradients w.r.t. node features, edge features and every parameter,
+    the towers' running statistics.  Bar per element: 3e-4 of the tensor's largest entry (1e-5 for the output) + 4 x the reference's OWN fp32 error
+    on the row (its value against the oracle's float64 evaluation of the same step): the reference takes the std of `a_u + b_v` as
+    E[m^2] - E[m]^2 in fp32, which loses the variance's low digits when the destination's term dwarfs the spread of its
+    neighbours (fixture t4_div: six rows, gradient entries off by 1e-3 of the largest) -- the product takes the std of `a_u`
+    alone and lands on the float64 value."""
+    from conftest import load_golden
+    from oracle import torch_oracle as O
+    meta, a, sd = load_golden(name)
+    ef = meta["edge_dim"] > 0
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    out64, gh64, ge64, gp64, _ = O.dgl_layer_train_step(sd64, a["src"], a["dst"], meta["N"], a["h"].double(), a["e"].double(), a["snorm_n"].double(),
+                                                        meta["aggregators"].split(), meta["scalers"].split(), a["avg_log"].double(), meta["towers"],
+                                                        meta["divide_input"], ef, a["R"].double())
+    layer = PNALayer(meta["in_dim"], meta["out_dim"], meta["aggregators"], meta["scalers"], {"log": a["avg_log"]}, 0.0, True, True,
+                     towers=meta["towers"], pretrans_layers=1, posttrans_layers=1, divide_input=meta["divide_input"], residual=True,
+                     edge_features=ef, edge_dim=meta["edge_dim"])
+    layer.load_state_dict(sd)
+    layer = layer.to(cuda_device).train()
+    g = Graph(a["src"], a["dst"], meta["N"], meta["sizes"]).to(cuda_device)
+    h = a["h"].to(cuda_device).requires_grad_(True)
+    e = a["e"].to(cuda_device).requires_grad_(True) if ef else None
+    out = layer(g, h, e, a["snorm_n"].to(cuda_device))
+    (out * a["R"].to(cuda_device)).sum().backward()
+
+    def close(got, ref, exact, what, base, by_row=True, scale=None):
+        ref_err = (ref.double() - exact).abs()
+        # (the ill-conditioned entries share a ROW of the node tensors -- one destination -- and spread over a whole weight matrix)
+        ref_err = ref_err.max(dim=1, keepdim=True).values if by_row and ref_err.dim() == 2 else ref_err.max()
+        diff, scale = (got.double().cpu() - ref.double()).abs(), scale or max(1.0, ref.abs().max().item())
+        bad = diff > base * scale + 4.0 * ref_err
+        # ... and the product has such entries of its own (it takes the std of a_u alone: other destinations, the same size of
+        # error): a few entries may sit outside the bar, none further than 5e-3 of the largest entry
+        assert int(bad.sum()) <= max(2, 5e-3 * bad.numel()) and diff.max().item() <= 5e-3 * scale, (what, int(bad.sum()), diff.max().item(), ref_err.max().item())
+    close(out.detach(), a["out"], out64, "out", 1e-5)
+    # (3e-4: the same ill-conditioning in the product's own fp32 arithmetic -- other rows than the reference's, the same size)
+    close(h.grad, a["grad_h"], gh64, "grad_h", 3e-4)
+    if ef:
+        close(e.grad, a["grad_e"], ge64, "grad_e", 3e-4)
+    wscale = max(v.abs().max().item() for k, v in a.items() if k.startswith("grad/"))       # (one scale for all parameters: the
+    for k, p in layer.named_parameters():                                                     # noise of those entries reaches each)
+        close(p.grad, a["grad/" + k], gp64[k], k, 3e-4, by_row=False, scale=wscale)
+    for k, b in layer.named_buffers():
+        if "running" in k:
+            torch.testing.assert_close(b.cpu(), a["after/" + k], rtol=1e-5, atol=1e-6)
