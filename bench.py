@@ -60,6 +60,8 @@ def parse():
     p.add_argument("--no-power-probe", action="store_true", help="skip the rocm-smi power / clock samples (2 x ~1.5 s)")
     p.add_argument("--no-cold", action="store_true", help="skip the cold-cache leg (3 rotating copies of the inputs)")
     p.add_argument("--check-rows", type=int, default=96, help="rows re-computed on the host after the timed loop")
+    p.add_argument("--no-c5-leg", action="store_true", help="N = 1, default workload: skip the extra leg that runs BASELINE configs[4]'s per-GPU "
+                                                            "shape (--workload c5) in a child process and adds its line as `configs4_per_gpu_shape`")
     p.add_argument("--no-prewarm", action="store_true", help="skip the ~150 ms of untimed steps in front of the W warm-up steps")
     p.add_argument("--layers", type=int, default=1, help="> 1: a step = this many stacked layers (N > 1: inter-layer halo exchange cut into row "
                    "blocks, pna_amd.shard.BlockPipeline); a reduced JSON line, the default line describes ONE layer")
@@ -174,6 +176,28 @@ def cpu_baseline(src, dst, V, h, layer_sd, avg_log, sample_rows):
             "sample": f"destination rows [0,{n}) of the same graph = {e_n} edges, 1 layer forward, best of 2 at "
                       f"{threads} threads (fastest of {ncpu}, {ncpu // 2}, {ncpu // 4}; {t:.2f} s); C/OpenMP port of "
                       f"reduce_func + torch CPU Linear/BN/ReLU"}
+
+
+def other_workload_leg(extra, timeout_s=240):
+    """One more bench.py call in a CHILD process (its own device context; a failure or a timeout costs this field, not the line):
+    -> the child's JSON line cut down to what a reader compares, or {"error": ...}."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(extra)
+    try:
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout_s, text=True, env=env, cwd=ROOT)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if out.returncode != 0 or not lines:
+            return {"error": f"child exited {out.returncode} without a line", "command": " ".join(cmd[1:])}
+        d = json.loads(lines[-1])
+        r = d.get("roofline") or {}
+        return {"command": "python " + " ".join(os.path.relpath(c, ROOT) if os.path.isabs(c) else c for c in cmd[1:]),
+                "workload": (d.get("config") or {}).get("workload"), "ms_per_step": d.get("ms_per_step"), "value": d.get("value"), "unit": d.get("unit"),
+                "steps": d.get("steps"), "warmup": d.get("warmup"), "prewarm_steps_untimed": d.get("prewarm_steps_untimed"),
+                "roofline": {k: r.get(k) for k in ("kernel", "frac", "ms_per_launch", "achieved", "unit", "rest_rows_beside_kernel", "full_grid")},
+                "roofline_layer_frac": (d.get("roofline_layer") or {}).get("frac"), "parity_check": d.get("parity_check")}
+    except Exception as ex:                                         # (timeout, JSON, OS): never the parent's problem
+        return {"error": repr(ex), "command": " ".join(cmd[1:])}
 
 
 def sampled_check(g, h_ext, y, layer_sd, avg_log, n_rows, lo=0):
@@ -661,6 +685,12 @@ def main():
             rec["cpu_baseline_reference_source"] = json.load(open(rpath))
         except Exception:
             pass
+    if (rank == 0 and world == 1 and args.workload == "c3" and not args.no_c5_leg and args.layers == 1
+            and args.nodes_per_gpu == V_PER_GPU and args.edges_per_gpu == E_PER_GPU):
+        # BASELINE configs[4] (V = 16 M, E = 160 M, F = 128 over 8 GPUs) is the driver's to launch; its PER-GPU shape on this one GPU
+        # rides along with every default call, so that the number is driver-run too
+        rec["configs4_per_gpu_shape"] = other_workload_leg(["--workload", "c5", "--no-cpu-baseline", "--no-cold", "--no-power-probe",
+                                                            "--steps", "10", "--warmup", "3"])
     if rank == 0:
         print(json.dumps(rec), flush=True)
     if world > 1:
