@@ -178,7 +178,7 @@ def cpu_baseline(src, dst, V, h, layer_sd, avg_log, sample_rows):
                       f"reduce_func + torch CPU Linear/BN/ReLU"}
 
 
-def other_workload_leg(extra, timeout_s=240):
+def other_workload_leg(extra, timeout_s=150):
     """One more bench.py call in a CHILD process (its own device context; a failure or a timeout costs this field, not the line):
     -> the child's JSON line cut down to what a reader compares, or {"error": ...}."""
     import subprocess
