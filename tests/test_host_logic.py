@@ -281,3 +281,27 @@ def test_avg_d_producers_match_the_reference_formulas():
     b = avg_d_from_adjacency([adj1, adj2])
     assert b["lin"].item() == pytest.approx((1.0 + 4 / 3) / 2)
     assert b["log"].item() == pytest.approx((math.log(2) + (math.log(3) + 2 * math.log(2)) / 3) / 2, rel=1e-6)
+
+
+def test_bench_child_leg_never_sinks_the_line(monkeypatch):
+    """bench.py's default call runs BASELINE configs[4]'s per-GPU shape in a child process (`configs4_per_gpu_shape`): a child that
+    fails, prints nothing or times out costs that field only; a child's line is cut down to the fields a reader compares."""
+    import importlib.util
+    import json
+    import subprocess
+    import types
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    line = open(os.path.join(ROOT, "profiles", "r03_bench_c5_shard_shape_n1.json")).read().strip()
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: types.SimpleNamespace(returncode=0, stdout="a warning\n" + line + "\n"))
+    r = bench.other_workload_leg(["--workload", "c5"])
+    assert "error" not in r and r["ms_per_step"] > 0 and r["parity_check"]["ok"] and r["roofline"]["frac"] > 0 and "F=128" in r["workload"]
+    json.dumps(r)
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: types.SimpleNamespace(returncode=1, stdout=""))
+    assert "error" in bench.other_workload_leg(["--workload", "c5"])
+
+    def boom(*a, **k):
+        raise subprocess.TimeoutExpired(cmd="bench.py", timeout=1)
+    monkeypatch.setattr(subprocess, "run", boom)
+    assert "TimeoutExpired" in bench.other_workload_leg(["--workload", "c5"])["error"]
