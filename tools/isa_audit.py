@@ -81,6 +81,53 @@ def is_vmem(mn):
                           "global_atomic"))
 
 
+def _sgpr_result_is_dead(ins, labels, k, limit=4000):
+    """True when the SGPR written by instruction k (a compiler-generated v_readfirstlane_b32 / v_readlane_b32) is overwritten before
+    it is read on EVERY path from k (bounded walk of the control-flow graph).  hipcc materialises an undefined value of a
+    structurizer flow block as `v_readfirstlane_b32 sN, v0` -- a lane read of WHATEVER sits in v0, possibly a register whose load is
+    in flight -- and overwrites sN before anything looks at it: reading stale bits into a dead register is harmless."""
+    dst = _regs(_SREG, ins[k][3].split(",")[0], 0)
+    if len(dst) != 1:
+        return False
+    (d,) = dst
+    stack, seen, steps = [k + 1], set(), 0
+    while stack:
+        j = stack.pop()
+        while j < len(ins):
+            if j in seen:
+                break
+            seen.add(j)
+            steps += 1
+            if steps > limit:
+                return False
+            _, _, mn, ops = ins[j]
+            if mn == "label":
+                j += 1
+                continue
+            if mn == "s_endpgm":
+                break
+            if mn == "s_branch":
+                j = labels[ops.strip()]
+                continue
+            if mn.startswith("s_cbranch"):
+                stack.append(labels[ops.strip()])
+                j += 1
+                continue
+            parts = [x.strip() for x in ops.split(",")]
+            writes = _regs(_SREG, parts[0], 0) if parts and (mn.startswith(("s_", "v_readlane", "v_readfirstlane", "v_cmp")) and not mn.startswith(("s_cmp", "s_waitcnt", "s_nop", "s_bitcmp", "s_setprio", "s_sleep", "s_barrier"))) else set()
+            if "_co_" in mn and len(parts) > 1:
+                writes = _regs(_SREG, parts[1], 0)
+            reads = _regs(_SREG, ",".join(parts[1:]) if writes else ops, 0)
+            if mn in ("s_cmp_eq_u32",) or mn.startswith(("s_cmp", "s_bitcmp")):
+                reads = _regs(_SREG, ops, 0)
+            if d in reads:
+                return False
+            if d in writes:
+                break                                        # overwritten on this path: dead
+            j += 1
+    return True
+
+
 def audit(lines, verbose=False):
     """Explores the kernel's control-flow graph (both sides of every conditional branch; a (block, FIFO) state is visited once, so
     loops converge as soon as their in-flight picture repeats).  Returns [(line, mnemonic, operands, registers)]."""
@@ -165,6 +212,8 @@ def audit(lines, verbose=False):
                 k += 1
                 continue
             bad = allregs(ops) & inflight
+            if bad and not in_asm and mn in ("v_readfirstlane_b32", "v_readlane_b32") and _sgpr_result_is_dead(ins, labels, k):
+                bad = set()                                  # (an undefined value's lane read into a register nobody reads)
             if bad and (ln, tuple(sorted(bad))) not in seen_prob:
                 seen_prob.add((ln, tuple(sorted(bad))))
                 problems.append((ln, mn, ops, sorted(bad)))
