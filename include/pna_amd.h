@@ -552,8 +552,8 @@ int pna_fused_tower_pack_f32(const float* w_ref, int64_t ldw_ref, int32_t N, int
  * pna_fused_roles_f32 computes what pna_fused_degree_f32 computes for the rows of the degree groups (PNASimpleLayer.forward,
  * models/dgl/pna_layer.py:197-216 over reduce_func :189-194; same statistics bit for bit) with a different division of labour on
  * the CU: per SIMD one wavefront that only gathers (a register ring of edge packets kept full across tile boundaries) and one
- * that only multiplies -- EXACT fp32 products on v_mfma_f32_16x16x4_f32 against the degree group's whole weight image, resident in
- * LDS (pna_fused_roles_pack_f32; no bf16x3 split, no weight streaming); the statistics pass through LDS.  Tables for it (pna_amd/degree_groups.py::DegreePlan.roles_tables):
+ * that only multiplies (the bf16x3 contraction of pna_fused_degree_f32 over the same weight images: pna_fused_degree_pack_f32); the
+ * statistics pass through LDS.  Tables for it (pna_amd/degree_groups.py::DegreePlan.roles_tables):
  *   tile_desc   int32 [n_tiles][4]  = {first id record, in-degree D, weight image, 0} per 64-row TILE of the virtual row order
  *                                     (rows 64 t .. 64 t + 64 of row_perm; all of one in-degree; an all-padding tile has D = 0)
  *   tile_ids    int32, FOUR arrays ids_stride bytes apart, one per 16-row block b of a tile: record (first + e)[i] = source row
@@ -600,11 +600,7 @@ typedef struct pna_fused_roles_args {
 } pna_fused_roles_args;
 
 int32_t pna_fused_roles_supported(int32_t F, int32_t N);      /* 1 when pna_fused_roles_f32 has an instantiation for the shape */
-int64_t pna_fused_roles_image_bytes(int32_t F, int32_t N);    /* bytes of one degree group's fp32 weight image; 0 = unsupported shape */
-/* w_ref (N, n_scaler * 4F) = the posttrans Linear's weight, scale (n_img, n_scaler) = every group's scaler values: n_img images
- * W_D = sum_s scale[i][s] W_s (fp32, scaler order), pna_fused_roles_image_bytes apart */
-int pna_fused_roles_pack_f32(const float* w_ref, int64_t ldw_ref, int32_t N, int32_t F, int32_t n_scaler, const float* scale,
-                             int32_t n_img, void* img, pna_stream_t stream);
+int64_t pna_fused_roles_image_bytes(int32_t F, int32_t N);    /* = pna_fused_degree_image_bytes for the shapes it serves; 0 = unsupported */
 int32_t pna_fused_roles_grid(int32_t spare_units);            /* workgroups that fill the current device, minus spare_units CUs */
 int pna_fused_roles_f32(const pna_fused_roles_args* args, pna_stream_t stream);
 

@@ -247,9 +247,6 @@ def lib():
         L.pna_fused_roles_grid.restype = ctypes.c_int32
         L.pna_fused_roles_image_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32]
         L.pna_fused_roles_image_bytes.restype = ctypes.c_int64
-        L.pna_fused_roles_pack_f32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
-                                               ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
-        L.pna_fused_roles_pack_f32.restype = ctypes.c_int
         L.pna_posttrans_packed_floats.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                   ctypes.POINTER(ctypes.c_int64)]
         L.pna_posttrans_packed_floats.restype = ctypes.c_int64

@@ -57,13 +57,15 @@ struct FRArgs {
   unsigned ldyb, ldrb;         // row pitch of y / residual in bytes
   int F, N, relu;
   float slope;
-  int prio_g, prio_m;          // experiments build only: s_setprio of the two roles (default 2 / 0)
+  int prio_g, prio_m;          // experiments build only: s_setprio of the two roles (default 0 / 2)
   int abl;                     // experiments build only: parts skipped for timing (bit 0 MFMAs, 1 fragment maths, 2 the fold, 3 the y
 };                             // stores, 4 the weight reads, 5 the whole M side but the hand-over): results are then meaningless
 
 constexpr int kNW = 80, kG = 4, kM = 4, kThreads = 64 * (kG + kM);
 constexpr int kNT = kNW / 16;                             // column tiles
-constexpr int kChunkB = kNT * 2 * 1024;                   // bytes of one chunk of the fp32 image: [column tile][half][lane][4 k] floats
+__host__ __device__ constexpr int ahead_of(int nc) { return nc < 5 ? nc : 5; }   // a chunk image is requested at the start of the step this many steps before it is read
+constexpr int kChunkV = 3 * 4 * kNW;                      // 16-byte pieces of one chunk image: [term][lane group][80 cols][8 k] bf16
+constexpr int kNI = (kChunkV + 64 * kM - 1) / (64 * kM);  // global_load_lds instructions per M wavefront per chunk
 constexpr int kSpin = 1 << 20;                            // polls before a wavefront gives up
 
 __host__ __device__ constexpr int shape_full(int F) { return (F % 32 == 0 || F % 32 > 16) ? (F + 31) / 32 : F / 32; }
@@ -136,12 +138,13 @@ __device__ __forceinline__ unsigned long long now() { return __builtin_readcycle
 __device__ __forceinline__ unsigned long long now() { return 0; }
 #endif
 
-// LDS map (bytes): [the degree group's whole fp32 weight image][4 hand-over buffers][3 x 80 column constants][flags]
+// LDS map (bytes): [kNBuf weight buffers][4 hand-over buffers][3 x 80 column constants][flags]
 template <int NC, int NP>
 struct Lds {
-  static constexpr int img = NC * kChunkB;                 // F = 75: 102 400 bytes
+  static constexpr int NBUF = ahead_of(NC) + 2;            // weight buffers (F = 75: seven)
+  static constexpr int CHB = kChunkV * 16;                 // one chunk image (15 360 bytes)
   static constexpr int SB = 2 * NP * 1024;                 // one hand-over PHASE of one tile: two quantities x NP pieces x [lane][4 floats]
-  static constexpr int stats = img;
+  static constexpr int stats = NBUF * CHB;
   static constexpr int colc = stats + kG * SB;
   static constexpr int flags = colc + 3 * kNW * 4;         // full[4] | empty[4] | (unused)[4] | arrive[4]
   static constexpr int total = flags + 64;
@@ -158,6 +161,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_fused_roles(const FRArgs g) {
   static_assert(NC >= 4, "every shape has at least 4 steps");
   static_assert((RING - 1) * LB < 64, "vmcnt is a 6-bit count");
   using L = Lds<NC, NP>;
+  constexpr int kAhead = ahead_of(NC), kNBuf = L::NBUF;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
   const int tid = threadIdx.x;
@@ -242,8 +246,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_fused_roles(const FRArgs g) {
         }
     };
     // The tile's RAW statistics to the M wavefront in TWO phases through one buffer ([quantity][16-byte piece][lane][4 floats]; a
-    // full block is two pieces, the half block one): sum | sum of squares, then max | min -- the whole image of the weights
-    // lives in LDS, which leaves 10 KB per SIMD pair.  full / empty count phases.  At the end of the stream (or when a spin gave up) T = T1 and no
+    // full block is two pieces, the half block one): sum | sum of squares, then max | min -- seven weight buffers (the copies'
+    // latency under the gather's load needs that many in flight) leave 10 KB per SIMD pair.  full / empty count phases.  At the end of the stream (or when a spin gave up) T = T1 and no
     // further boundary comes.
     auto boundary = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -280,16 +284,18 @@ __global__ __launch_bounds__(kThreads, 2) void k_fused_roles(const FRArgs g) {
 #pragma unroll
     for (int j = 0; j < RING; ++j) ld4(idr[j], idsw, nid + (unsigned)j * 64u);
     nid += (unsigned)RING * 64u;
-    static_assert(RING >= 3 && RING <= 7, "ring slots");
-    if constexpr (RING == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(idr[0]), "+v"(idr[1]), "+v"(idr[2]) : : "memory");
-    if constexpr (RING == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(idr[0]), "+v"(idr[1]), "+v"(idr[2]), "+v"(idr[RING > 3 ? 3 : 0]) : : "memory");
-    if constexpr (RING == 5) asm volatile("s_waitcnt vmcnt(0)" : "+v"(idr[0]), "+v"(idr[1]), "+v"(idr[2]), "+v"(idr[RING > 3 ? 3 : 0]), "+v"(idr[RING > 4 ? 4 : 0]) : : "memory");
-    if constexpr (RING == 6) asm volatile("s_waitcnt vmcnt(0)" : "+v"(idr[0]), "+v"(idr[1]), "+v"(idr[2]), "+v"(idr[RING > 3 ? 3 : 0]), "+v"(idr[RING > 4 ? 4 : 0]), "+v"(idr[RING > 5 ? 5 : 0]) : : "memory");
-    if constexpr (RING == 7) asm volatile("s_waitcnt vmcnt(0)" : "+v"(idr[0]), "+v"(idr[1]), "+v"(idr[2]), "+v"(idr[RING > 3 ? 3 : 0]), "+v"(idr[RING > 4 ? 4 : 0]), "+v"(idr[RING > 5 ? 5 : 0]), "+v"(idr[RING > 6 ? 6 : 0]) : : "memory");
-    using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>; using J2 = std::integral_constant<int, 2>;
+    static_assert(RING >= 2 && RING <= 7, "ring slots");
+    if constexpr (RING == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(idr[0]), "+v"(idr[1]) : : "memory");
+    if constexpr (RING == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(idr[0]), "+v"(idr[1]), "+v"(idr[RING > 2 ? 2 : 0]) : : "memory");
+    if constexpr (RING == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(idr[0]), "+v"(idr[1]), "+v"(idr[RING > 2 ? 2 : 0]), "+v"(idr[RING > 3 ? 3 : 0]) : : "memory");
+    if constexpr (RING == 5) asm volatile("s_waitcnt vmcnt(0)" : "+v"(idr[0]), "+v"(idr[1]), "+v"(idr[RING > 2 ? 2 : 0]), "+v"(idr[RING > 3 ? 3 : 0]), "+v"(idr[RING > 4 ? 4 : 0]) : : "memory");
+    if constexpr (RING == 6) asm volatile("s_waitcnt vmcnt(0)" : "+v"(idr[0]), "+v"(idr[1]), "+v"(idr[RING > 2 ? 2 : 0]), "+v"(idr[RING > 3 ? 3 : 0]), "+v"(idr[RING > 4 ? 4 : 0]), "+v"(idr[RING > 5 ? 5 : 0]) : : "memory");
+    if constexpr (RING == 7) asm volatile("s_waitcnt vmcnt(0)" : "+v"(idr[0]), "+v"(idr[1]), "+v"(idr[RING > 2 ? 2 : 0]), "+v"(idr[RING > 3 ? 3 : 0]), "+v"(idr[RING > 4 ? 4 : 0]), "+v"(idr[RING > 5 ? 5 : 0]), "+v"(idr[RING > 6 ? 6 : 0]) : : "memory");
+    using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>; using J2 = std::integral_constant<int, (RING > 2 ? 2 : 0)>;
     using J3 = std::integral_constant<int, (RING > 3 ? 3 : 0)>; using J4 = std::integral_constant<int, (RING > 4 ? 4 : 0)>;
     using J5 = std::integral_constant<int, (RING > 5 ? 5 : 0)>; using J6 = std::integral_constant<int, (RING > 6 ? 6 : 0)>;
-    issue(J0{}); issue(J1{}); issue(J2{});
+    issue(J0{}); issue(J1{});
+    if constexpr (RING > 2) issue(J2{});
     if constexpr (RING > 3) issue(J3{});
     if constexpr (RING > 4) issue(J4{});
     if constexpr (RING > 5) issue(J5{});
@@ -299,12 +305,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_fused_roles(const FRArgs g) {
 #ifdef PNA_AMD_EXPERIMENTS
     if (g.prio_g == 0) __builtin_amdgcn_s_setprio(0); else if (g.prio_g == 1) __builtin_amdgcn_s_setprio(1); else if (g.prio_g == 3) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
 #else
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(0);
 #endif
     // (no exit in the middle of a trip: hipcc fills the merge points of such a loop with lane reads of undefined registers)
 #define FR_SLOT(J) { wait_slot<(RING - 1) * LB, NL>(sl[J::value], idr[J::value]); fold(J{}); issue(J{}); if (--rem == 0) boundary(); }
     while (T != T1) {
-      FR_SLOT(J0) FR_SLOT(J1) FR_SLOT(J2)
+      FR_SLOT(J0) FR_SLOT(J1)
+      if constexpr (RING > 2) FR_SLOT(J2)
       if constexpr (RING > 3) FR_SLOT(J3)
       if constexpr (RING > 4) FR_SLOT(J4)
       if constexpr (RING > 5) FR_SLOT(J5)
@@ -313,13 +320,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_fused_roles(const FRArgs g) {
 #undef FR_SLOT
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the packets requested past the stream's end
   } else {
-    // =========================================== M: finish, multiply, epilogue ===========================================
+    // =========================================== M: finish, split, multiply, epilogue ====================================
     const int m = wave - kG;
     const unsigned a_full = lds0 + L::flags + m * 4, a_empty = lds0 + L::flags + 16 + m * 4;
     const unsigned a_arr = lds0 + L::flags + 48, a_my = a_arr + m * 4;
     const unsigned a_stats = lds0 + L::stats + m * L::SB + lane * 16;
     const unsigned a_colc = lds0 + L::colc + lg * 16;
-    const unsigned a_img = lds0 + lane * 16;               // the lane's piece of the image's [chunk][column tile][half]
     f4 acc[NT], res[NT];
     f4 raw[4][NP];                                         // the tile's raw statistics: sum | sum of squares | max | min
     int deg = 0;                                           // the tile's in-degree
@@ -329,7 +335,21 @@ __global__ __launch_bounds__(kThreads, 2) void k_fused_roles(const FRArgs g) {
     int na = 0;                                            // arrivals of this wavefront so far
     bool dead = false;
     unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tq = now();   // experiments build: cycles per phase of the tile loop
+    unsigned long long tst[5] = {0, 0, 0, 0, 0}, tsq = 0;           // ... and inside a step: wait for the others | image request | first half | own pieces | rest
+    auto slap = [&](int i) __attribute__((always_inline)) { const unsigned long long t = now(); tst[i] += t - tsq; tsq = t; };
     auto lap = [&](int i) __attribute__((always_inline)) { const unsigned long long t = now(); tph[i] += t - tq; tq = t; };
+    // weight chunks: global -> LDS, asynchronously (every M wavefront issues exactly kNI copies per chunk)
+    auto stage = [&](int c, int buf, long ib) __attribute__((always_inline)) {
+      const unsigned char* src = g.w_img + ib + (size_t)c * kChunkV * 16;
+      unsigned char* dst = lds + (size_t)buf * kChunkV * 16;
+#pragma unroll
+      for (int i = 0; i < kNI; ++i) {
+        int w0 = (i * kM + m) * 64;
+        if (w0 >= kChunkV) w0 = w0 % kChunkV;             // a slot past the image re-copies an earlier piece (same bytes, same address)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(w0 + lane) * 16),
+                                         (__attribute__((address_space(3))) void*)(dst + (size_t)w0 * 16), 16, 0, 0);
+      }
+    };
     auto arrive = [&]() __attribute__((always_inline)) { ++na; if (lane == 0) lds_poke(a_my, na); };
     auto waitall = [&]() __attribute__((always_inline)) {
       const unsigned long long tp = now();
@@ -340,9 +360,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_fused_roles(const FRArgs g) {
       }
       tw1 += now() - tp; spins += n;
     };
-    // chunk c: the lane's eight B values (one per MFMA), finished from the raw statistics (pna_rowstats.h arithmetic: the bits
-    // of pna_segreduce_fwd_f32).  Full block fb, chunk 4 fb + a: aggregator a (0 mean, 1 max, 2 min, 3 std) of the lane's 8
-    // features; half block, chunk 4 NFBF + h: aggregators 2h | 2h + 1 of its 4 features.
+    // chunk c: the lane's eight A values, finished from the raw statistics (pna_rowstats.h arithmetic: the bits of
+    // pna_segreduce_fwd_f32) and split into three bf16 terms.  Full block fb, chunk 4 fb + a: aggregator a (0 mean, 1 max, 2 min,
+    // 3 std) of the lane's 8 features; half block, chunk 4 NFBF + h: aggregators 2h | 2h + 1 of its 4 features.
     auto rawv = [&](int q, int fb, int j) __attribute__((always_inline)) -> float { return raw[q][2 * fb + (j >> 2)][j & 3]; };
     auto stat = [&](int fb, int j, int a, int f) __attribute__((always_inline)) -> float {
       const float Df = (float)deg, invD = 1.0f / Df;
@@ -364,19 +384,66 @@ __global__ __launch_bounds__(kThreads, 2) void k_fused_roles(const FRArgs g) {
       return r;                                             // padding columns may hold anything)
     };
     int Tm = 0;                                            // (the tile, for the verification output)
-    float v[8];
-    auto frag = [&](auto c_c) __attribute__((always_inline)) {
-      constexpr int c = decltype(c_c)::value;
-      if (FR_ABL(1)) { asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])); return; }
+    // FAST tiles (every raw statistic finite, in-degree > 0: all but pathological inputs; decided per tile from the sums of squares):
+    // the same arithmetic without the special-value selects -- div_rn's NaN / Inf fall-back, the NaN test of max / min, sqrtf's
+    // denormal scaling and class test (var + 1e-5 is a normal number), the Inf test of the split -- and with the mean kept from
+    // the block's first chunk: ~900 VALU instructions per tile instead of ~1500.  The bits are the slow path's.
+    float meanc[8];
+    auto sqrt_rn = [&](float x) __attribute__((always_inline)) -> float {     // correctly rounded for normal x (hipcc's own sequence
+      const float r = __builtin_amdgcn_sqrtf(x);                               // behind v_sqrt_f32, less the denormal scaling)
+      const float rm = bfloat(fbits(r) - 1u), rp = bfloat(fbits(r) + 1u);
+      const float e1 = __builtin_fmaf(-rm, r, x), e2 = __builtin_fmaf(-rp, r, x);
+      float o = e1 <= 0.f ? rm : r;
+      o = e2 > 0.f ? rp : o;
+      return o;
+    };
+    auto stat_fast = [&](int fb, int j, int a) __attribute__((always_inline)) -> float {
+      const float Df = (float)deg, invD = 1.0f / Df;
+      if (a == 1) return rawv(2, fb, j);
+      if (a == 2) return rawv(3, fb, j);
+      if (a == 0) {
+        const float sv = rawv(0, fb, j);
+        const float q0 = sv * invD, q1 = __builtin_fmaf(__builtin_fmaf(-Df, q0, sv), invD, q0);
+        meanc[j] = q1;
+        return q1;
+      }
+      const float q = rawv(1, fb, j);
+      const float m0 = q * invD, msq = __builtin_fmaf(__builtin_fmaf(-Df, m0, q), invD, m0);
+      const float mean = meanc[j];
+      float var = msq - mean * mean;
+      var = pna_dev::vmax(var, 0.f);
+      return sqrt_rn(var + 1e-5f);
+    };
+    u4 pc[3], pn[3];                                       // the A fragments (three bf16 terms) of the step being multiplied / of the next
+    // half `part` (values 4 part .. + 4) of chunk c -> pn
+    auto fragpart = [&](auto c_c, auto part_c, auto fast_c) __attribute__((always_inline)) {
+      constexpr int c = decltype(c_c)::value, part = decltype(part_c)::value;
+      constexpr bool FAST = decltype(fast_c)::value;
+      if (FR_ABL(1)) { asm volatile("" : "+v"(pn[0]), "+v"(pn[1]), "+v"(pn[2])); return; }
+      float v[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int jj = 0; jj < 4; ++jj) {
+        const int j = 4 * part + jj;
         int fb, sj, a, f;
         if constexpr (c < 4 * NFBF) { fb = c / 4; sj = j; a = c % 4; f = fb * 32 + lg * 8 + j; }
         else { fb = NFBF; sj = j & 3; a = 2 * (c - 4 * NFBF) + (j >> 2); f = fb * 32 + lg * 4 + (j & 3); }
-        v[j] = stat(fb, sj, a, f);
+        v[jj] = FAST ? stat_fast(fb, sj, a) : stat(fb, sj, a, f);
         if constexpr (DUMP) {
-          if (f < g.F) g.agg_out[(size_t)(Tm * 64 + m * 16 + li) * g.ld_agg + a * g.F + f] = v[j];
+          if (f < g.F) g.agg_out[(size_t)(Tm * 64 + m * 16 + li) * g.ld_agg + a * g.F + f] = v[jj];
         }
+      }
+      const bool inf = !FAST && __builtin_amdgcn_ballot_w64(pna_dev::vmax(pna_dev::vmax(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])),
+                                                                           pna_dev::vmax(__builtin_fabsf(v[2]), __builtin_fabsf(v[3]))) == INFINITY) != 0;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {                      // (pna_x3_split.h: split8 / split8_inf, one pair of values at a time)
+        const float xe = v[2 * h2], xo = v[2 * h2 + 1];
+        const bool ie = inf && __builtin_fabsf(xe) == INFINITY, io = inf && __builtin_fabsf(xo) == INFINITY;
+        const float fe = ie ? 0.f : xe, fo = io ? 0.f : xo;
+        const float re = fe - top16(fe), ro = fo - top16(fo);
+        const float se = re - top16(re), so = ro - top16(ro);
+        pn[0][2 * part + h2] = pack_hi(fe, fo);
+        pn[1][2 * part + h2] = pack_hi(re, ro);
+        pn[2][2 * part + h2] = pack_hi(ie ? xe : se, io ? xo : so);
       }
     };
 
@@ -384,34 +451,30 @@ __global__ __launch_bounds__(kThreads, 2) void k_fused_roles(const FRArgs g) {
     auto desc_off = [&](int tt) -> unsigned { return (unsigned)min(tt, T1 - 1) * 16u; };
     sld16(td_cur, g.wdesc, desc_off(T0));
     sld16(td_nxt, g.wdesc, desc_off(T0 + 1));
-    int T = T0, k = 0, cur_img = -1;
+    long ib_cur = (long)td_cur.z * g.img_stride, ib_next = (long)td_nxt.z * g.img_stride;
+    if (FR_ABL(6)) { ib_cur = 0; ib_next = 0; }            // (experiment: every tile multiplies the FIRST group's image: one image live in L2)
+    int T = T0, k = 0, buf = 0;
 #ifdef PNA_AMD_EXPERIMENTS
-    if (g.prio_m == 1) __builtin_amdgcn_s_setprio(1); else if (g.prio_m == 2) __builtin_amdgcn_s_setprio(2); else if (g.prio_m == 3) __builtin_amdgcn_s_setprio(3);
+    if (g.prio_m == 0) __builtin_amdgcn_s_setprio(0); else if (g.prio_m == 1) __builtin_amdgcn_s_setprio(1); else if (g.prio_m == 3) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
+#else
+    __builtin_amdgcn_s_setprio(2);                         // (its rare memory instructions go ahead of the gather's: measured)
 #endif
     ld4(pr_next, g.perm, (unsigned)(T * 64 + m * 16 + li) * 4u);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(pr_next) : : "memory");
+    // The (tile, chunk) pipeline (F = 75: kNBuf = 7 buffers, kAhead = 5).  Step k reads LDS buffer k % 7.  At the START of step k every M wavefront has arrived (their
+    // pieces of step k's image have landed; each is past the middle of step k - 1, i.e. done with step k - 2): buffer (k - 2) % 7 is
+    // free and step k + 5's image is requested into it.  In the MIDDLE of step k a wavefront waits for ITS pieces of step k + 1
+    // (requested at the start of step k - 4: four younger images stay in flight) and arrives.  The copies queue behind the gather
+    // wavefronts' requests in the CU's memory pipeline (4 us under load, measured: with 2.5 steps of cover the M side ran at
+    // 1.6 us per step): hence seven buffers, and a gather ring no deeper than the bandwidth needs.
+#pragma unroll
+    for (int c = 0; c < kAhead; ++c) {
+      if (c < NC) stage(c, c, ib_cur); else stage(c - NC, c, ib_next);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"((kAhead - 1) * kNI) : "memory");       // this wavefront's pieces of step 0
+    arrive();
 
     while (true) {
-      // ---- the tile's weight image: the WHOLE fp32 image of its degree group lives in LDS (a workgroup's tiles are a contiguous
-      //      range of the degree order: one to three images in its life).  A change: every M wavefront is done with the old image
-      //      (arrive / wait), each copies a quarter of the new one, all quarters have landed (arrive / wait). -------------------
-      if (td_cur.z != cur_img) {
-        arrive(); waitall();
-        if (dead) break;
-        const unsigned char* src = g.w_img + (long)td_cur.z * g.img_stride;
-        constexpr int PW = L::img / 16 / kM / 64;           // 1 KB copies per wavefront
-        static_assert(PW * 64 * kM * 16 == L::img, "the image splits into whole wavefront copies");
-#pragma unroll 5
-        for (int i = 0; i < PW; ++i) {
-          const int w0 = (i * kM + m) * 64;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(w0 + lane) * 16),
-                                           (__attribute__((address_space(3))) void*)(lds + (size_t)w0 * 16), 16, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        arrive(); waitall();
-        if (dead) break;
-        cur_img = td_cur.z;
-      }
       lap(6);
       // ---- the tile's raw statistics from the G wavefront, two phases ----------------------------------------------------------
       deg = td_cur.y; Tm = T;
@@ -444,7 +507,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_fused_roles(const FRArgs g) {
       if (dead) break;
       ++k;
       lap(0);
-      // ---- the tile's rows: residual now (lands under the multiply), the next tile's nodes ------------------------------------
+      // ---- the tile's rows: residual now (lands under the first steps), the next tile's nodes ------------------------------
       pr = pr_next;
       {
         const unsigned rrow = (unsigned)max(pr, 0) * g.ldrb;
@@ -454,63 +517,117 @@ __global__ __launch_bounds__(kThreads, 2) void k_fused_roles(const FRArgs g) {
       }
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[n] = (f4){0.f, 0.f, 0.f, 0.f};
-
-      // ---- multiply: out^T = W_D . stats^T on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate: an fmaf chain).  The
-      //      lane's weight of MFMA j of chunk c for column tile n is one float of the image: 8 floats = two ds_read_b128 per
-      //      (chunk, column tile); column tiles in pairs with alternating accumulators, the next pair's weights in flight
-      //      behind the pair being multiplied. -------------------------------------------------------------------------------------
-      lap(1);
-      f4 W[2][4];                                          // [buffer][column tile of the pair x half]
-      constexpr int NPAIR = (NT + 1) / 2;                  // (0,1) (2,3) (4)
-      // weights of pair pp of chunk c -> buffer bsel (the image offset of a chunk does not fit the 16-bit offset field: one add)
-      auto read_w = [&](int c, int pp, int bsel) __attribute__((always_inline)) {
-        if (FR_ABL(4)) return;
-        const unsigned ac = a_img + (unsigned)c * kChunkB;
-#define FR_RW(I, N_, H_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(W[bsel][I]) : "v"(ac), "n"(((N_) * 2 + (H_)) * 1024) : "memory")
-        if (pp == 0) { FR_RW(0, 0, 0); FR_RW(1, 0, 1); FR_RW(2, 1, 0); FR_RW(3, 1, 1); }
-        else if (pp == 1) { FR_RW(0, 2, 0); FR_RW(1, 2, 1); FR_RW(2, 3, 0); FR_RW(3, 3, 1); }
-        else { FR_RW(0, 4, 0); FR_RW(1, 4, 1); }
-#undef FR_RW
-      };
-      auto wait_w = [&](int bsel) __attribute__((always_inline)) {
-        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(W[bsel][0]), "+v"(W[bsel][1]), "+v"(W[bsel][2]), "+v"(W[bsel][3]) : "n"(0) : "memory");
-      };
-      static_assert(NT == 5, "the pairing above");
-      if (!FR_ABL(5)) {
-        frag(std::integral_constant<int, 0>{});
-        read_w(0, 0, 0);
-        auto chunk = [&](auto c_c) __attribute__((always_inline)) {
-          constexpr int c = decltype(c_c)::value;
+      // a tile is FAST when every sum of squares of the lane's features is finite (then every message was) and it has in-edges
+      float qs = 0.f;
 #pragma unroll
-          for (int pp = 0; pp < NPAIR; ++pp) {
-            const int bsel = (c * NPAIR + pp) & 1;
-            // (the waits are lgkmcnt(0): the pair in flight is the only LDS traffic of this wavefront; the next pair is requested
-            // right behind the wait, into the other buffer, whose MFMAs were issued one pair ago)
-            wait_w(bsel);
-            if (pp + 1 < NPAIR) read_w(c, pp + 1, bsel ^ 1);
-            else if (c + 1 < NC) read_w(c + 1, 0, bsel ^ 1);
-            if (!FR_ABL(0)) {
-              const int n0 = 2 * pp;
+      for (int pc_ = 0; pc_ < NP; ++pc_)
 #pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                acc[n0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[bsel][j >> 2][j & 3], v[j], acc[n0], 0, 0, 0);
-                if (n0 + 1 < NT) acc[n0 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[bsel][2 + (j >> 2)][j & 3], v[j], acc[n0 + 1], 0, 0, 0);
-              }
-            }
-          }
-          if constexpr (c + 1 < NC) frag(std::integral_constant<int, (c + 1 < NC ? c + 1 : 0)>{});
-        };
-        chunk(std::integral_constant<int, 0>{}); chunk(std::integral_constant<int, 1>{});
-        chunk(std::integral_constant<int, 2>{}); chunk(std::integral_constant<int, 3>{});
-        if constexpr (NC > 4) { chunk(std::integral_constant<int, (NC > 4 ? 4 : 0)>{}); chunk(std::integral_constant<int, (NC > 4 ? 5 : 0)>{}); }
-        if constexpr (NC > 6) { chunk(std::integral_constant<int, (NC > 6 ? 6 : 0)>{}); chunk(std::integral_constant<int, (NC > 6 ? 7 : 0)>{}); }
-        if constexpr (NC > 8) { chunk(std::integral_constant<int, (NC > 8 ? 8 : 0)>{}); chunk(std::integral_constant<int, (NC > 8 ? 9 : 0)>{}); }
+        for (int e = 0; e < 4; ++e) qs = qs + raw[1][pc_][e];
+      const bool fast_tile = deg > 0 && __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(qs) < INFINITY)) == 0;
+      if (fast_tile) {                                     // padding features of the last block (beyond F): raw zeros (weights 0)
+        constexpr int PL = NP - 1;                          // the last 16-byte piece: the half block's, or the last full block's upper half
+        const int fbase = HALF ? NFBF * 32 + lg * 4 : (NFBF - 1) * 32 + lg * 8 + 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (fbase + e >= g.F) { raw[0][PL][e] = 0.f; raw[1][PL][e] = 0.f; raw[2][PL][e] = 0.f; raw[3][PL][e] = 0.f; }
+        if constexpr (!HALF) {
+          const int fb2 = (NFBF - 1) * 32 + lg * 8;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (fb2 + e >= g.F) { raw[0][PL - 1][e] = 0.f; raw[1][PL - 1][e] = 0.f; raw[2][PL - 1][e] = 0.f; raw[3][PL - 1][e] = 0.f; }
+        }
       }
-      lap(2);
-      // the residual rows and the next tile's nodes: nothing else of this wavefront is in flight
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]), "+v"(pr_next) : : "memory");
+      lap(1);
 
+      // One step = one chunk of 32 k values: 30 MFMAs (column tiles in pairs (0,1) (2,3) (4), alternating accumulators; the
+      // TRANSPOSED product: the weight fragment is the MFMA's A operand, the statistics' the B operand) with the NEXT chunk's
+      // statistics finished and split in two halves behind the first two MFMA groups (VALU beside the matrix pipe), the next
+      // pair's weight fragments requested behind each group, and at its end: every M wavefront has arrived for the next step,
+      // the image kAhead steps ahead is requested, the next step's first fragments are requested.
+      bf8 B[2][3];
+      constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
+#define FR_READ_B(slot, n)                                                                                                                  \
+      _Pragma("unroll") for (int tm_ = 0; tm_ < 3; ++tm_)                                                                                   \
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(B[slot][tm_]) : "v"(ba0), "n"(tm_ * 4 * kNW * 16 + (n) * 256) : "memory")
+#define FR_WAIT_B() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(B[0][0]), "+v"(B[0][1]), "+v"(B[0][2]), "+v"(B[1][0]), "+v"(B[1][1]), "+v"(B[1][2]) : : "memory")
+#define FR_MM(n, slot) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[slot][TB[pp]], __builtin_bit_cast(bf8, pc[TA[pp]]), acc[n], 0, 0, 0)
+      unsigned ba0 = 0;
+      // the step's opening: all arrived, the image kAhead steps ahead requested, the step's first fragments requested
+      auto open_step = [&](auto s_c) __attribute__((always_inline)) {
+        constexpr int s = decltype(s_c)::value;             // the step being opened (s == NC: the next tile's step 0 is opened by that tile)
+        tsq = now();
+        waitall();
+        slap(0);
+        {
+          const int bufn = buf + kAhead >= kNBuf ? buf + kAhead - kNBuf : buf + kAhead;
+          if (s + kAhead < NC) stage(s + kAhead, bufn, ib_cur);
+          else stage(s + kAhead - NC, bufn, ib_next);
+        }
+        static_assert(kAhead <= NC, "a step's image lies in this tile or the next");
+        slap(1);
+        ba0 = lds0 + (unsigned)(buf * kChunkV + lg * kNW + li) * 16u;
+        if (!FR_ABL(4)) { FR_READ_B(0, 0); FR_READ_B(1, 1); }
+      };
+      auto step = [&](auto s_c, auto fast_c) __attribute__((always_inline)) {
+        constexpr int s = decltype(s_c)::value;
+        using CN = std::integral_constant<int, (s + 1 < NC ? s + 1 : 0)>;
+        tsq = now();
+        FR_WAIT_B();
+        if (!FR_ABL(0))
+#pragma unroll
+        for (int pp = 0; pp < 6; ++pp) { FR_MM(0, 0); FR_MM(1, 1); }
+        if (!FR_ABL(4)) { FR_READ_B(0, 2); FR_READ_B(1, 3); }
+        if constexpr (s + 1 < NC) fragpart(CN{}, std::integral_constant<int, 0>{}, fast_c);
+        FR_WAIT_B();
+        // this wavefront's pieces of step s + 1; younger: the images of the next kAhead - 1 steps and, in a tile's first kAhead - 1
+        // steps, its residual rows and the next tile's nodes (requested at the tile's start, before step 0's image request)
+        constexpr int young = s < kAhead - 1 ? NT + 1 : 0;
+        slap(2);
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"((kAhead - 1) * kNI + young) : "memory");
+        slap(3);
+        arrive();
+        if (!FR_ABL(0))
+#pragma unroll
+        for (int pp = 0; pp < 6; ++pp) { FR_MM(2, 0); FR_MM(3, 1); }
+        if (!FR_ABL(4)) { FR_READ_B(0, 4); }
+        if constexpr (s + 1 < NC) fragpart(CN{}, std::integral_constant<int, 1>{}, fast_c);
+        FR_WAIT_B();
+        if (!FR_ABL(0))
+#pragma unroll
+        for (int pp = 0; pp < 6; ++pp) FR_MM(4, 0);
+        slap(4);
+        buf = buf == kNBuf - 1 ? 0 : buf + 1;
+        if constexpr (s + 1 < NC) {
+          open_step(CN{});
+          pc[0] = pn[0]; pc[1] = pn[1]; pc[2] = pn[2];
+        }
+      };
+      auto steps = [&](auto fast_c) __attribute__((always_inline)) {
+        fragpart(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, fast_c);
+        fragpart(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, fast_c);
+        pc[0] = pn[0]; pc[1] = pn[1]; pc[2] = pn[2];
+        open_step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 0>{}, fast_c); step(std::integral_constant<int, 1>{}, fast_c);
+        step(std::integral_constant<int, 2>{}, fast_c); step(std::integral_constant<int, 3>{}, fast_c);
+        if constexpr (NC > 4) { step(std::integral_constant<int, (NC > 4 ? 4 : 0)>{}, fast_c); step(std::integral_constant<int, (NC > 4 ? 5 : 0)>{}, fast_c); }
+        if constexpr (NC > 6) { step(std::integral_constant<int, (NC > 6 ? 6 : 0)>{}, fast_c); step(std::integral_constant<int, (NC > 6 ? 7 : 0)>{}, fast_c); }
+        if constexpr (NC > 8) { step(std::integral_constant<int, (NC > 8 ? 8 : 0)>{}, fast_c); step(std::integral_constant<int, (NC > 8 ? 9 : 0)>{}, fast_c); }
+      };
+      static_assert(NT == 5, "the column-tile pairing of a step");
+      if (!FR_ABL(5)) {
+        if (fast_tile) steps(std::true_type{});
+        else steps(std::false_type{});
+      }
+#undef FR_READ_B
+#undef FR_WAIT_B
+#undef FR_MM
+      if (dead) break;
+      lap(2);
+      // the residual rows and the next tile's nodes are older than the last kAhead - 1 image requests (every shape has >= 4 steps)
+      if (!FR_ABL(5)) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]), "+v"(pr_next) : "n"((kAhead - 1) * kNI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]), "+v"(pr_next) : : "memory");
       lap(3);
+
       // ---- epilogue: lane (li, lg) holds columns 16 n + 4 lg .. + 4 of row li: bias, BatchNorm scale / shift, ReLU, residual ----
       {
         const float lo = g.relu ? 0.f : -INFINITY;
@@ -554,13 +671,17 @@ __global__ __launch_bounds__(kThreads, 2) void k_fused_roles(const FRArgs g) {
       if (++T == T1) break;
       td_cur = td_nxt;
       sld16(td_nxt, g.wdesc, desc_off(T + 1));
+      ib_cur = ib_next;
+      ib_next = FR_ABL(6) ? 0 : (long)td_nxt.z * g.img_stride;
       lap(5);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the copies issued for steps that do not exist
 #ifdef PNA_AMD_EXPERIMENTS
     if (g.dbg && lane == 0) {
       unsigned long long* d = g.dbg + ((size_t)gridDim.x * (kG + kM) * 4) + ((size_t)blockIdx.x * kM + m) * 8;
       for (int i = 0; i < 7; ++i) d[i] = tph[i];
+      unsigned long long* d2 = g.dbg + ((size_t)gridDim.x * (kG + kM) * 4) + (size_t)gridDim.x * kM * 8 + ((size_t)blockIdx.x * kM + m) * 8;
+      for (int i = 0; i < 5; ++i) d2[i] = tst[i];
     }
 #endif
   }
@@ -574,37 +695,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_fused_roles(const FRArgs g) {
 #endif
 }
 
-// ---- weight images: W_D = sum_s scale[i][s] W_s in fp32 (scaler order: the sums of pna_fused_degree_pack_f32), laid out as the
-//      kernel reads them: [chunk][column tile][half][lane = 16 lane group + column][4 k] floats -- MFMA j = 4 half + e of chunk c
-//      multiplies the weights of k value j of every lane group (its feature: chunk 4 fb + a -> aggregator a, feature 32 fb + 8 lg
-//      + j; half block, chunk 4 nfull + h -> aggregator 2h + (j >> 2), feature 32 nfull + 4 lg + (j & 3)) against column 16 n + li.
-__global__ void k_pack_fused_roles(const float* w_ref, long ldw, int N, int F, int S, const float* scale, int n_img, float* img) {
-  const int nfull = shape_full(F), NC = shape_chunks(F), K = 4 * F;
-  const long per = (long)NC * kChunkB / 4;
-  const long total = per * n_img;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    long r = i;
-    const int e = r % 4; r /= 4;
-    const int li = r % 16; r /= 16;
-    const int lgp = r % 4; r /= 4;
-    const int hh = r % 2; r /= 2;
-    const int nt = r % kNT; r /= kNT;
-    const int c = r % NC; r /= NC;
-    const int im = (int)r;
-    const int n = nt * 16 + li, j = hh * 4 + e;
-    int a, f;
-    if (c < 4 * nfull) { a = c % 4; f = (c / 4) * 32 + lgp * 8 + j; }
-    else { a = 2 * (c - 4 * nfull) + (j >> 2); f = nfull * 32 + lgp * 4 + (j & 3); }
-    float w = 0.f;
-    if (n < N && f < F) {
-      const float* row = w_ref + (long)n * ldw + a * F + f;
-      w = scale ? scale[(long)im * S] * row[0] : row[0];
-      for (int sidx = 1; sidx < S; ++sidx) w = w + (scale ? scale[(long)im * S + sidx] * row[(long)sidx * K] : row[(long)sidx * K]);
-    }
-    img[i] = w;
-  }
-}
-
 template <int NFBF, bool HALF, bool DUMP, int RING>
 int launch(const FRArgs& g, int wgs, hipStream_t st) {
   constexpr int NC = 4 * NFBF + (HALF ? 2 : 0), NP = 2 * NFBF + (HALF ? 1 : 0);
@@ -614,23 +704,25 @@ int launch(const FRArgs& g, int wgs, hipStream_t st) {
   hipLaunchKernelGGL(fn, dim3((unsigned)wgs), dim3(kThreads), lds, st, g);
   return 0;
 }
-// ring depth: what fits beside 80 running statistics without spilling (5 packets of 5 strips = 100 registers; the smaller shapes 6)
+// ring depth: the gather's throughput does not depend on it between 3 and 6 packets (measured at C3); everything of the gather
+// wavefronts that is in flight stands in front of the M wavefronts' weight copies in the CU's memory pipeline, so: as few as
+// the bandwidth needs
 template <bool DUMP>
 int launch_shape(const FRArgs& g, int wgs, int ring, hipStream_t st) {
   const int nf = shape_full(g.F);
   const bool half = shape_half(g.F);
 #ifdef PNA_AMD_EXPERIMENTS
   if constexpr (!DUMP) {
+    if (nf == 2 && half && ring == 2) return launch<2, true, false, 2>(g, wgs, st);
     if (nf == 2 && half && ring == 4) return launch<2, true, false, 4>(g, wgs, st);
-    if (nf == 2 && half && ring == 3) return launch<2, true, false, 3>(g, wgs, st);
-    if (nf == 2 && half && ring == 6) return launch<2, true, false, 6>(g, wgs, st);
+    if (nf == 2 && half && ring == 5) return launch<2, true, false, 5>(g, wgs, st);
   }
 #endif
   (void)ring;
-  if (nf == 1 && !half) return launch<1, false, DUMP, 6>(g, wgs, st);
-  if (nf == 1 && half) return launch<1, true, DUMP, 6>(g, wgs, st);
-  if (nf == 2 && !half) return launch<2, false, DUMP, 6>(g, wgs, st);
-  if (nf == 2 && half) return launch<2, true, DUMP, 5>(g, wgs, st);
+  if (nf == 1 && !half) return launch<1, false, DUMP, 3>(g, wgs, st);
+  if (nf == 1 && half) return launch<1, true, DUMP, 3>(g, wgs, st);
+  if (nf == 2 && !half) return launch<2, false, DUMP, 3>(g, wgs, st);
+  if (nf == 2 && half) return launch<2, true, DUMP, 3>(g, wgs, st);
   return -2;
 }
 
@@ -640,21 +732,8 @@ extern "C" int32_t pna_fused_roles_supported(int32_t F, int32_t N) {
   return F >= 17 && F <= 80 && N >= 4 && N <= kNW ? 1 : 0;
 }
 
-extern "C" int64_t pna_fused_roles_image_bytes(int32_t F, int32_t N) {
-  return pna_fused_roles_supported(F, N) ? (int64_t)shape_chunks(F) * kChunkB : 0;
-}
-
-extern "C" int pna_fused_roles_pack_f32(const float* w_ref, int64_t ldw, int32_t N, int32_t F, int32_t n_scaler, const float* scale,
-                                        int32_t n_img, void* img, pna_stream_t stream) {
-  if (!w_ref || !img || n_img < 1 || n_scaler < 1 || n_scaler > PNA_MAX_SCALER || !pna_fused_roles_supported(F, N) ||
-      ldw < (int64_t)n_scaler * 4 * F || (n_scaler > 1 && !scale))
-    return pna_set_error(PNA_E_INVALID, "pna_fused_roles_pack_f32: bad arguments (F in 17..80, N in 4..80, ldw >= n_scaler * 4 F; scale required for n_scaler > 1)");
-  const int64_t elems = pna_fused_roles_image_bytes(F, N) / 4 * n_img;
-  const int blocks = (int)((elems + 255) / 256 > 8192 ? 8192 : (elems + 255) / 256);
-  hipLaunchKernelGGL(k_pack_fused_roles, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ref, (long)ldw, N, F, n_scaler, scale, n_img, (float*)img);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
-  return PNA_OK;
+extern "C" int64_t pna_fused_roles_image_bytes(int32_t F, int32_t N) {   // (the images are pna_fused_degree_pack_f32's)
+  return pna_fused_roles_supported(F, N) ? pna_fused_degree_image_bytes(F, N) : 0;
 }
 
 extern "C" int32_t pna_fused_roles_grid(int32_t spare_units) {
@@ -693,12 +772,12 @@ extern "C" int pna_fused_roles_f32(const pna_fused_roles_args* p, pna_stream_t s
   g.ldyb = (unsigned)(p->ldy * 4); g.ldrb = p->residual ? (unsigned)(p->ld_res * 4) : 0u;
   g.N = p->N; g.relu = p->relu; g.slope = p->relu == 2 ? p->act_slope : 0.f;
   g.agg_out = p->agg_out; g.ld_agg = p->ld_agg; g.err = p->err;
-  int ring = 6;
+  int ring = 3;
 #ifdef PNA_AMD_EXPERIMENTS
   if (const char* e = getenv("PNA_FR_DBG_PTR")) g.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // device buffer: 4 counters per wavefront
   if (const char* e = getenv("PNA_FR_ABL")) g.abl = atoi(e);
   if (const char* e = getenv("PNA_FR_RING")) ring = atoi(e);
-  g.prio_g = 2; g.prio_m = 0;
+  g.prio_g = 0; g.prio_m = 2;
   if (const char* e = getenv("PNA_FR_PRIO_G")) g.prio_g = atoi(e);
   if (const char* e = getenv("PNA_FR_PRIO_M")) g.prio_m = atoi(e);
 #endif

@@ -357,25 +357,19 @@ def fused_tower_images(weight, F, row_scales, plan):
     return fused_images(weight, F, row_scales, plan, tower=True)
 
 
-def roles_images(weight, F, row_scales, plan):
-    """fp32 images of W_D = sum_s s_s(D) W_s for pna_fused_roles_f32 (one per degree group, in the kernel's LDS layout), cached on the
-    weight like fused_images."""
-    return fused_images(weight, F, row_scales, plan, roles=True)
-
-
-def fused_images(weight, F, row_scales, plan, tower=False, roles=False):
+def fused_images(weight, F, row_scales, plan, tower=False):
     """Packed images of W_D = sum_s s_s(D) W_s for pna_fused_degree_f32 (K in the kernel's chunk order), one per degree group,
     cached on the weight like combined_images.  The combination and the bf16x3 split happen in the pack kernel
     (pna_fused_degree_pack_f32) from the (G, S) matrix of the groups' scaler values."""
     N, G, S = weight.shape[0], plan.G, len(row_scales)
-    key = ("roles" if roles else "fused", tower, weight._version, weight.data_ptr(), str(weight.device), tuple(weight.shape), F, plan.serial, G,
+    key = ("fused", tower, weight._version, weight.data_ptr(), str(weight.device), tuple(weight.shape), F, plan.serial, G,
            tuple(None if rs is None else (rs.data_ptr(), rs._version) for rs in row_scales))
-    attr = "_pna_amd_roles_img" if roles else "_pna_amd_fused_img"
+    attr = "_pna_amd_fused_img"
     hit = getattr(weight, attr, None)
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
     L = _lib.lib()
-    stride = L.pna_fused_roles_image_bytes(F, N) if roles else L.pna_fused_tower_image_bytes(F, N) if tower else L.pna_fused_degree_image_bytes(F, N)
+    stride = L.pna_fused_tower_image_bytes(F, N) if tower else L.pna_fused_degree_image_bytes(F, N)
     if stride <= 0:
         raise RuntimeError(f"pna_fused_degree: unsupported shape F={F}, N={N}")
     with torch.no_grad():
@@ -386,7 +380,7 @@ def fused_images(weight, F, row_scales, plan, tower=False, roles=False):
         scale = scale.contiguous()
     img = torch.empty(G * stride // 4, dtype=torch.float32, device=weight.device)
     w = weight.detach()
-    pack = L.pna_fused_roles_pack_f32 if roles else L.pna_fused_tower_pack_f32 if tower else L.pna_fused_degree_pack_f32
+    pack = L.pna_fused_tower_pack_f32 if tower else L.pna_fused_degree_pack_f32
     rc = pack(_lib.dev_ptr(w, torch.float32, "weight"), w.stride(0), N, F, S, _lib.dev_ptr(scale, torch.float32, "scale"),
               G, _lib.dev_ptr(img, torch.float32, "w_img"), _lib.stream_ptr(weight.device))
     _lib.check(rc, "pna_fused_tower_pack_f32" if tower else "pna_fused_degree_pack_f32")
@@ -397,7 +391,8 @@ def fused_images(weight, F, row_scales, plan, tower=False, roles=False):
     return img, stride
 
 
-ROLES = os.environ.get("PNA_AMD_ROLES", "1") != "0"   # the one-kernel layer with gather / multiply wavefront roles (pna_fused_roles_f32) where it has an instantiation
+ROLES = os.environ.get("PNA_AMD_ROLES", "0") != "0"   # the one-kernel layer with gather / multiply wavefront roles (pna_fused_roles_f32): parity-green but
+                                                      # 2.4x slower than pna_fused_degree_f32 at C3: an experiment, off by default
 ROLES_TILE_COST = float(os.environ.get("PNA_AMD_ROLES_TILE_COST", "3"))   # a tile's constant cost in the workgroup partition, in edge packets
 ROLES_XCD_INTERLEAVE = False
 ROLES_SPARE_UNITS = int(os.environ.get("PNA_AMD_ROLES_SPARE", "16"))      # CUs left to the rest-row launches beside the kernel (cf. FUSED_SPARE_WGS)

@@ -717,7 +717,7 @@ class FusedRolesCall(FusedDegreeCall):
         V = h.shape[0]
         self.y = y = torch.empty(V, (N + 3) // 4 * 4, dtype=torch.float32, device=h.device)[:, :N] if out is None else out
         self.cs, self.ct, self.res = cs, ct, res = _layer_tail_operands(layer, h)
-        self.img, self.stride = DG.roles_images(lin.weight, F, scales, plan)
+        self.img, self.stride = DG.fused_images(lin.weight, F, scales, plan)
         self.err = plan.roles_err()
         self.lin, self.agg_out, self.h = lin, agg_out, h
         self.lib, self.check, self.stream = _lib.lib(), _lib.check, _lib.stream_ptr(h.device)

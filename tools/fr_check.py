@@ -144,12 +144,13 @@ if "c3" in STAGES or "abl" in STAGES:
         DG.ROLES_XCD_INTERLEAVE = False
         if EXP and "abl" in STAGES:
             n_wg = _lib.lib().pna_fused_roles_grid(0)
-            dbg = torch.zeros(n_wg * 8 * 4 + n_wg * 4 * 8, dtype=torch.int64, device=dev)
+            dbg = torch.zeros(n_wg * 8 * 4 + 2 * n_wg * 4 * 8, dtype=torch.int64, device=dev)
             os.environ["PNA_FR_DBG_PTR"] = hex(dbg.data_ptr())
             c_new.group_rows()
             torch.cuda.synchronize()
             del os.environ["PNA_FR_DBG_PTR"]
-            mph = dbg[n_wg * 32:].view(n_wg, 4, 8).double()
+            mph = dbg[n_wg * 32:n_wg * 64].view(n_wg, 4, 8).double()
+            mst = dbg[n_wg * 64:].view(n_wg, 4, 8).double()
             d = dbg[:n_wg * 32].view(n_wg, 8, 4)
             tot = d[:, :, 3].double()
             hw = (d[:, :, 2] & 0xFFFFFFFF)
@@ -181,14 +182,15 @@ if "c3" in STAGES or "abl" in STAGES:
                 per.append([lo, hi, int(cum[hi] - cum[lo]), float(tot[b].max()), float(d[b, :4, 0].double().mean()), float(d[b, 4:, 0].double().mean())])
             out["c3_per_wg"] = per
             def m_phases():
-                dbg2 = torch.zeros(n_wg * 8 * 4 + n_wg * 4 * 8, dtype=torch.int64, device=dev)
+                dbg2 = torch.zeros(n_wg * 8 * 4 + 2 * n_wg * 4 * 8, dtype=torch.int64, device=dev)
                 os.environ["PNA_FR_DBG_PTR"] = hex(dbg2.data_ptr())
                 c_new.group_rows()
                 torch.cuda.synchronize()
                 del os.environ["PNA_FR_DBG_PTR"]
-                mp = dbg2[n_wg * 32:].view(n_wg, 4, 8).double()
-                return [round((mp[:, :, i].mean(dim=1) / ntile).mean().item()) for i in range(7)]
-            for abl, what in [(0, "nothing skipped"), (1, "no MFMAs"), (2, "no statistics maths"), (4, "no fold"), (8, "no y stores"), (16, "no weight reads"),
+                mp = dbg2[n_wg * 32:n_wg * 64].view(n_wg, 4, 8).double()
+                ms = dbg2[n_wg * 64:].view(n_wg, 4, 8).double()
+                return [round((mp[:, :, i].mean(dim=1) / ntile).mean().item()) for i in range(7)] + ["step:"] + [round((ms[:, :, i].mean(dim=1) / ntile).mean().item()) for i in range(5)]
+            for abl, what in [(0, "nothing skipped"), (64, "ONE weight image for every tile (wrong results: L2 residency test)"), (1, "no MFMAs"), (2, "no statistics maths"), (4, "no fold"), (8, "no y stores"), (16, "no weight reads"),
                               (3, "no MFMAs, no statistics maths"), (18, "no statistics maths, no weight reads"), (32, "M side: hand-over and epilogue only"),
                               (36, "no fold, M side hand-over and epilogue only"), (0, "nothing skipped (again)")]:
                 os.environ["PNA_FR_ABL"] = str(abl)
@@ -197,7 +199,7 @@ if "c3" in STAGES or "abl" in STAGES:
                 out[k.replace("_ms", "_M_phase_cycles_per_tile")] = ph = m_phases()
                 print(f"ablation {abl:2d} ({what}): {out[k]:.4f} ms; M cycles per tile [hand-over, residual issue, multiply, vmcnt, epilogue, descriptor, image] = {ph}", flush=True)
             del os.environ["PNA_FR_ABL"]
-            for ring, pg, pm in [(5, 2, 0), (3, 2, 0), (3, 0, 2), (5, 0, 2), (5, 1, 3), (5, 0, 0), (3, 0, 0), (5, 3, 0)]:
+            for ring, pg, pm in [(3, 0, 2), (4, 0, 2)]:
                 os.environ["PNA_FR_RING"], os.environ["PNA_FR_PRIO_G"], os.environ["PNA_FR_PRIO_M"] = str(ring), str(pg), str(pm)
                 key = f"ring{ring}_prioG{pg}_prioM{pm}"
                 out[key + "_ms"] = ev(c_new.group_rows)
