@@ -89,6 +89,11 @@ __device__ __forceinline__ void ld16(f4& dst, const void* base, unsigned voff) {
 __device__ __forceinline__ void ld16_hi(f4& dst, const void* base, unsigned voff) {
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
 }
+// 64-bit lane address + immediate (the gather of the source table: no 4 GiB / 2^24-row limit, rows of any 4-byte aligned pitch)
+template <int OFF>
+__device__ __forceinline__ void ldx16(f4& dst, const char* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(OFF) : "memory");
+}
 __device__ __forceinline__ void ld16i(i4& dst, const void* base, unsigned voff) {
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
 }
@@ -239,14 +244,15 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
   td_n2 = td_nxt;
   const unsigned lib = (unsigned)li * 4u;
   int idr[kRing];
-  i4 pr;                                                  // rows of y / residual of the lane's four C rows 4 lg + r (-1: padding)
-  int pn = 0;                                             // tower mode: the node of tile row li (-1: padding)
-  f4 rp;                                                  // tower mode: the per-row factor of the lane's four C rows
-  f4 res[NTA];                                            // residual, TRANSPOSED layout: row 4 lg + (li & 3), columns 16 n + 4 (li >> 2) .. + 4
+  int pr = -1;                                            // the node (row of y / residual) of tile row li (-1: padding)
+  int pn = 0;                                             // tower mode: the same, requested before the gather (the panels need it early)
+  float rp = 1.f;                                         // tower mode: the per-row factor of tile row li
+  f4 res[NTA];                                            // residual: row li, columns 16 n + 4 lg .. + 4
 
   // ---- the gather: running statistics of the wavefront's 16 rows ----------------------------------------------------------
   float S_[NB][8], Q_[NB][8], MX[NB][8], MN[NB][8];       // (a half block uses [0..3])
   int deg = 0;                                            // in-degree of the tile's rows (wave-uniform)
+  bool fast_tile = false;                                 // the tile's statistics are all finite and it has in-edges (set by gather())
   unsigned f0b[NB];                                       // byte offset of the lane's strip of feature block fb inside a row
 #pragma unroll
   for (int fb = 0; fb < NB; ++fb) {
@@ -256,16 +262,21 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     f0b[fb] = (unsigned)f0 * 4u;                                           // dropped in frag())
   }
   const unsigned ldb = g.ldb;
+  // lane addresses of the source strips (round 4: 64-bit, so that tables >= 4 GiB / >= 2^24 rows and contiguous (V, F) rows take this
+  // kernel).  A: the lane's strip of block 0 of a row (block fb lies 128 fb bytes further: an immediate); L: the strip of the LAST
+  // block of the last gather pass -- the only one that can lie past F: such a lane re-reads the row's last strip (f0b above).
+  const char* const xA = reinterpret_cast<const char*>(g.x) + (size_t)lg * 32;
+  const char* const xL = reinterpret_cast<const char*>(g.x) + f0b[NB - 1] + (size_t)((GP - 1) * NFBF * 128);
   const void* const resb = g.residual ? (const void*)g.residual : (const void*)g.y;
   const bool has_res = g.residual != nullptr;
 
-  // The epilogue works on a 4 x 4 TRANSPOSE of the accumulator tiles inside every quad of lanes: lane (li = 4 q + s, lg) then holds
-  // row 4 lg + s, columns 16 n + 4 q .. + 4 of column tile n -- 16 contiguous bytes: the residual is 5 loads and y 5 stores of 16
-  // bytes per lane instead of 20 + 20 of 4 bytes (round 3, first version: per-element; skipping its stores took 0.10 of 0.84 ms).
-  const int sq = li & 3, qq = li >> 2;
-  auto prow = [&]() __attribute__((always_inline)) -> int { return sq == 0 ? pr[0] : sq == 1 ? pr[1] : sq == 2 ? pr[2] : pr[3]; };
+  // The multiply computes the TRANSPOSED product (round 4): the weight fragment is the MFMA's A operand, the statistics' the B
+  // operand, so lane (li, lg) holds columns 16 n + 4 lg .. + 4 of ROW li of column tile n -- 16 contiguous bytes of y: the residual
+  // is 5 loads and y 5 stores of 16 bytes per lane with no transpose (round 3 transposed 4 x 4 blocks inside every quad of lanes:
+  // two DPP butterflies, 32 VALU instructions per column tile).
+  auto prow = [&]() __attribute__((always_inline)) -> int { return TOWER ? pn : pr; };
   // byte offset of the 16-byte window of column tile n inside a row; a window past N slides back to [N - 4, N) (realigned by fix4)
-  auto res_col = [&](int n) __attribute__((always_inline)) -> unsigned { return (unsigned)max(0, min(n * 16 + 4 * qq, g.N - 4)) * 4u; };
+  auto res_col = [&](int n) __attribute__((always_inline)) -> unsigned { return (unsigned)max(0, min(n * 16 + 4 * lg, g.N - 4)) * 4u; };
 
   // P: the gather pass (features P * 32 NFBF ..); after a pass that is not the last, the ring's ids are refilled with the SAME
   // tile's first edges
@@ -274,11 +285,10 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     const int D = td_cur.y;
     const unsigned rb = (unsigned)td_cur.x * 64u;                                        // byte offset of this tile's records ...
     const unsigned rbn = P + 1 < GP ? rb : (unsigned)td_nxt.x * 64u;                     // ... and of the records the next gather starts with
-    const unsigned poff = (unsigned)(P * NFBF * 128);                                    // byte offset of the pass's features inside a row
     deg = D;
     // (tower mode: the rows of y and their factors are needed from step RSTEP on only: requested with the panels)
     if constexpr (TOWER) ld4(pn, g.perm, (unsigned)((t * kWaves + wave) * 16 + li) * 4u);
-    else if constexpr (P == 0) ld16i(pr, g.perm, (unsigned)((t * kWaves + wave) * 16 + 4 * lg) * 4u);
+    else if constexpr (P == 0) ld4(pr, g.perm, (unsigned)((t * kWaves + wave) * 16 + li) * 4u);
 #pragma unroll
     for (int fb = 0; fb < NB; ++fb)
 #pragma unroll
@@ -290,11 +300,20 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     // rows of the edge whose id sits in idr[j] -> ring slot j, then the id slot j gathers next (record at byte `nrec`) -> idr[j]
     auto issue = [&](auto jc, unsigned nrec) __attribute__((always_inline)) {
       constexpr int j = decltype(jc)::value;
-#pragma unroll
-      for (int fb = 0; fb < NB; ++fb) {
-        const unsigned vo = __umul24((unsigned)idr[j], ldb) + f0b[fb] + poff;
-        ld16(sl[j][2 * fb], g.x, vo);
-        if (!(HALF && fb == NFBF)) ld16_hi(sl[j][2 * fb + 1], g.x, vo);
+      constexpr bool LASTP = P == GP - 1;                 // the pass that holds the row's last block
+      constexpr int NFA = LASTP ? NB - 1 : NB;             // blocks addressed through A (never past F)
+      constexpr int PO = P * NFBF * 128;                    // byte offset of the pass's features inside a row
+      const size_t ro = (size_t)(unsigned)idr[j] * ldb;
+      if constexpr (NFA > 0) {
+        const char* const pa = xA + ro;
+        ldx16<PO>(sl[j][0], pa); ldx16<PO + 16>(sl[j][1], pa);
+        if constexpr (NFA > 1) { ldx16<PO + 128>(sl[j][NFA > 1 ? 2 : 0], pa); ldx16<PO + 144>(sl[j][NFA > 1 ? 3 : 0], pa); }
+        static_assert(NFA <= 2, "blocks addressed through A");
+      }
+      if constexpr (LASTP) {
+        const char* const pl = xL + ro;
+        ldx16<0>(sl[j][2 * (NB - 1)], pl);
+        if constexpr (!HALF) ldx16<16>(sl[j][HALF ? 0 : 2 * (NB - 1) + 1], pl);
       }
       ld4(idr[j], g.ids, nrec + (unsigned)j * 64u + lib);
     };
@@ -341,6 +360,26 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     wait_slot<2 * LB + NR, NL>(sl[1], idr[1]); fold(J1{}, e0 + 1 < D);
     wait_slot<1 * LB + NR, NL>(sl[2], idr[2]); fold(J2{}, e0 + 2 < D);
     wait_slot<NR, NL>(sl[3], idr[3]);          fold(J3{}, e0 + 3 < D);
+    // FAST tiles (round 4): every sum of squares of the lane's features finite (then every message was: the terms are >= 0) and
+    // in-edges present -- all but pathological inputs.  Their statistics are finished without the special-value selects (frag()).
+    // The padding features of the last block (>= F; whatever the strip past the row held) become raw zeros: their weights are 0.
+    {
+      float qs = 0.f;
+#pragma unroll
+      for (int fb = 0; fb < NB; ++fb)
+#pragma unroll
+        for (int j = 0; j < ((HALF && fb == NFBF) ? 4 : 8); ++j) qs = qs + Q_[fb][j];
+      // (not in the tower instantiation with a half block: 256 registers are taken there)
+      fast_tile = !(TOWER && HALF) && D > 0 && __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(qs) < INFINITY)) == 0;
+      if (fast_tile) {
+        constexpr int fbl = NB - 1;
+#pragma unroll
+        for (int j = 0; j < ((HALF && fbl == NFBF) ? 4 : 8); ++j) {
+          const int f = (P * NFBF + fbl) * 32 + ((HALF && fbl == NFBF) ? lg * 4 : lg * 8) + j;
+          if (f >= g.F) { S_[fbl][j] = 0.f; Q_[fbl][j] = 0.f; MX[fbl][j] = 0.f; MN[fbl][j] = 0.f; }
+        }
+      }
+    }
   };
 
   // ---- chunk c: the lane's eight A values, split into three bf16 terms.  Full block fb, chunk 4 fb + a: aggregator a (0 mean,
@@ -365,12 +404,38 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     if (f >= g.F) r = 0.f;                                // padding features of the last block (their weights are 0; the table's
     return r;                                             // padding columns may hold anything)
   };
+  // The same arithmetic for a FAST tile, without div_rn's NaN / Inf fall-back, the NaN test of max / min, sqrtf's denormal scaling
+  // and class test (var + 1e-5 is a normal number) and the padding / empty-row selects: the bits of stat().  (The mean is computed
+  // again for the std: eight registers to keep it are not there at F = 75.)
+  auto sqrt_rn = [&](float x) __attribute__((always_inline)) -> float {     // correctly rounded for normal x (hipcc's own sequence behind
+    const float r = __builtin_amdgcn_sqrtf(x);                               // v_sqrt_f32, less the denormal scaling and the class test)
+    const float rm = bfloat(fbits(r) - 1u), rp2 = bfloat(fbits(r) + 1u);
+    const float e1 = __builtin_fmaf(-rm, r, x), e2 = __builtin_fmaf(-rp2, r, x);
+    float o = e1 <= 0.f ? rm : r;
+    o = e2 > 0.f ? rp2 : o;
+    return o;
+  };
+  auto stat_fast = [&](int fb, int j, int a) __attribute__((always_inline)) -> float {
+    const float D = (float)deg, invD = 1.0f / D;
+    if (a == 1) return MX[fb][j];
+    if (a == 2) return MN[fb][j];
+    if (a == 0) {
+      const float sv = S_[fb][j];
+      const float q0 = sv * invD;
+      return __builtin_fmaf(__builtin_fmaf(-D, q0, sv), invD, q0);
+    }
+    const float sv = S_[fb][j], q = Q_[fb][j];
+    const float q0 = sv * invD, mean = __builtin_fmaf(__builtin_fmaf(-D, q0, sv), invD, q0);
+    const float m0 = q * invD, msq = __builtin_fmaf(__builtin_fmaf(-D, m0, q), invD, m0);
+    float var = msq - mean * mean;
+    var = pna_dev::vmax(var, 0.f);
+    return sqrt_rn(var + 1e-5f);
+  };
   f4 pk[2][NL];                                           // tower mode: strips of x_dst (0) and h (1) of the row's own node
-  constexpr int NPL = 2 * NL + 2;                         // loads of the panel request: the strips, the rows of y, their factors
+  constexpr int NPL = 2 * NL + 1;                         // loads of the panel request: the strips, the rows' factors
   auto issue_panels = [&]() __attribute__((always_inline)) {
     const unsigned r0 = (unsigned)max(pn, 0);
-    ld16i_ws(pr, g.perm, (unsigned)((t * kWaves + wave) * 16 + 4 * lg) * 4u);
-    ld16_ws(rp, g.row_post, (unsigned)((t * kWaves + wave) * 16 + 4 * lg) * 4u);
+    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(rp) : "v"((unsigned)((t * kWaves + wave) * 16 + li) * 4u), "s"(g.row_post) : "memory");
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const void* const base = p == 0 ? (const void*)g.xd : (const void*)g.xh;
@@ -402,6 +467,20 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
       return;
     }
     float v[8];
+    if (!(TOWER && HALF) && fast_tile) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int fb, sj, a, f;
+        if constexpr (c < 4 * NFBF) { fb = c / 4; sj = j; a = c % 4; f = (P * NFBF + fb) * 32 + lg * 8 + j; }
+        else { fb = NFBF; sj = j & 3; a = 2 * (c - 4 * NFBF) + (j >> 2); f = fb * 32 + lg * 4 + (j & 3); }
+        v[j] = stat_fast(fb, sj, a);
+        if constexpr (DUMP) {
+          if (f < g.F) g.agg_out[(size_t)((t * kWaves + wave) * 16 + li) * g.ld_agg + a * g.F + f] = v[j];
+        }
+      }
+      split8((f4){v[0], v[1], v[2], v[3]}, (f4){v[4], v[5], v[6], v[7]}, A[0], A[1], A[2]);
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       int fb, sj, a, f;
@@ -418,29 +497,10 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
   };
 
   // ---- epilogue: BatchNorm / ReLU / residual, rows scattered to node order through perm -----------------------------------
-  const unsigned colc_b = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(kNBuf * CHV * 16) + lib;
+  const unsigned colc_b = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(kNBuf * CHV * 16) + (unsigned)lg * 16u;
   auto epilogue = [&]() __attribute__((always_inline)) {
     const float lo = g.relu ? 0.f : -INFINITY;
     const bool leaky = g.relu == 2;
-    // the column constants, read through inline asm: an LDS read hipcc can see while a weight copy is in flight makes it
-    // drain the copies (vmcnt(0)) first (DESIGN.md 4.2c point 1)
-    float cb[NTA], cs[NTA], ct[NTA];
-#pragma unroll
-    for (int n = 0; n < NTA; ++n) {
-      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(cb[n]) : "v"(colc_b), "n"(n * 64) : "memory");
-      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(cs[n]) : "v"(colc_b), "n"(NWA * 4 + n * 64) : "memory");
-      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(ct[n]) : "v"(colc_b), "n"(2 * NWA * 4 + n * 64) : "memory");
-    }
-    static_assert(NTA == 5 || NTA == 8, "operand lists of the wait below");
-    if constexpr (NTA == 5)
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(cb[0]), "+v"(cb[1]), "+v"(cb[2]), "+v"(cb[3]), "+v"(cb[4]), "+v"(cs[0]), "+v"(cs[1]), "+v"(cs[2]), "+v"(cs[3]), "+v"(cs[4]),
-                     "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]), "+v"(ct[4]) : : "memory");
-    else
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(cb[0]), "+v"(cb[1]), "+v"(cb[2]), "+v"(cb[3]), "+v"(cb[4]), "+v"(cb[5]), "+v"(cb[6]), "+v"(cb[NTA - 1]),
-                     "+v"(cs[0]), "+v"(cs[1]), "+v"(cs[2]), "+v"(cs[3]), "+v"(cs[4]), "+v"(cs[5]), "+v"(cs[6]), "+v"(cs[NTA - 1]),
-                     "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]), "+v"(ct[4]), "+v"(ct[5]), "+v"(ct[6]), "+v"(ct[NTA - 1]) : : "memory");
     const int row = prow();
     if constexpr (TOWER) {
       // the residual rows were requested at the end of step RSTEP; younger than them: the weight copies of the three steps since
@@ -451,31 +511,25 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
       for (int n = 0; n < NTA; ++n) res[n] = reinterpret_cast<const f4u*>(rbase + res_col(n))->v;
     }
     char* const yrow = reinterpret_cast<char*>(g.y) + (size_t)(unsigned)max(row, 0) * g.ldyb;
-    const bool odd = (sq & 1) != 0, upper = (sq & 2) != 0;
 #pragma unroll
     for (int n = 0; n < NTA; ++n) {
-      float x[4];
+      // the column constants of the lane's four columns, read through inline asm: an LDS read hipcc can see while a weight copy
+      // is in flight makes it drain the copies (vmcnt(0)) first (DESIGN.md 4.2c point 1)
+      f4 cb, cs, ct;
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(cb) : "v"(colc_b), "n"(n * 64) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(cs) : "v"(colc_b), "n"(NWA * 4 + n * 64) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ct) : "v"(colc_b), "n"(2 * NWA * 4 + n * 64) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cb), "+v"(cs), "+v"(ct) : : "memory");
+      float z[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = acc[n][r] + cb[n];
-        if constexpr (TOWER) v = v * rp[r];
-        v = __builtin_fmaf(v, cs[n], ct[n]);
-        x[r] = v < lo ? (leaky ? v * g.slope : 0.f) : v;  // ReLU / LeakyReLU / none (lo = -inf); NaN < lo is false: NaN is kept
+        float v = acc[n][r] + cb[r];
+        if constexpr (TOWER) v = v * rp;
+        v = __builtin_fmaf(v, cs[r], ct[r]);
+        z[r] = v < lo ? (leaky ? v * g.slope : 0.f) : v;  // ReLU / LeakyReLU / none (lo = -inf); NaN < lo is false: NaN is kept
       }
-      // 4 x 4 transpose inside the quad: two butterfly stages (lane ^ 1, lane ^ 2), one DPP move + one select per element each
-      float y1[4], z[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float tq = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x[r ^ 1]), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-        y1[r] = (odd != ((r & 1) != 0)) ? tq : x[r];
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float tq = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, y1[r ^ 2]), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
-        z[r] = (upper != ((r & 2) != 0)) ? tq : y1[r];
-      }
-      // z[j] = column 16 n + 4 q + j of row 4 lg + s
-      const int c0 = n * 16 + 4 * qq;
+      // z[j] = column 16 n + 4 lg + j of row li
+      const int c0 = n * 16 + 4 * lg;
       if (has_res) {
         const f4 rr = fix4(c0, g.N, res[n]);
 #pragma unroll
@@ -553,8 +607,8 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     if (!FD_ABL(0))
 #pragma unroll
     for (int pp = 0; pp < 6; ++pp) {
-      acc[a0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[0][TB[pp]], acc[a0], 0, 0, 0);
-      acc[a0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[1][TB[pp]], acc[a0 + 1], 0, 0, 0);
+      acc[a0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[0][TB[pp]], A[TA[pp]], acc[a0], 0, 0, 0);
+      acc[a0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[1][TB[pp]], A[TA[pp]], acc[a0 + 1], 0, 0, 0);
     }
     FD_FENCE();
     if (!FD_ABL(4)) { FD_READ_B(0, 2); FD_READ_B(1, 3); }
@@ -569,7 +623,7 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     else asm volatile("s_barrier" ::: "memory");
     if constexpr (TOWER && c == PWAIT) {                  // (the wait above left only the two youngest images in flight)
       static_assert(NL == 4 || NL == 5, "tower shapes");
-      asm volatile("" : "+v"(pr), "+v"(rp));
+      asm volatile("" : "+v"(rp));
       if constexpr (NL == 4)
         asm volatile("" : "+v"(pk[0][0]), "+v"(pk[0][1]), "+v"(pk[0][2]), "+v"(pk[0][3]), "+v"(pk[1][0]), "+v"(pk[1][1]), "+v"(pk[1][2]), "+v"(pk[1][3]));
       else
@@ -581,8 +635,8 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     if (!FD_ABL(0))
 #pragma unroll
     for (int pp = 0; pp < 6; ++pp) {
-      acc[a0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[0][TB[pp]], acc[a0 + 2], 0, 0, 0);
-      acc[a0 + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[1][TB[pp]], acc[a0 + 3], 0, 0, 0);
+      acc[a0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[0][TB[pp]], A[TA[pp]], acc[a0 + 2], 0, 0, 0);
+      acc[a0 + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[1][TB[pp]], A[TA[pp]], acc[a0 + 3], 0, 0, 0);
     }
     FD_FENCE();
     if constexpr (NT == 5) {
@@ -590,7 +644,7 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
       FD_WAIT_B();
       if (!FD_ABL(0))
 #pragma unroll
-      for (int pp = 0; pp < 6; ++pp) acc[a0 + 4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[pp]], B[0][TB[pp]], acc[a0 + 4], 0, 0, 0);
+      for (int pp = 0; pp < 6; ++pp) acc[a0 + 4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[0][TB[pp]], A[TA[pp]], acc[a0 + 4], 0, 0, 0);
       FD_FENCE();
     }
 #undef FD_READ_B
@@ -791,10 +845,13 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
   if (pna_fused_degree_image_bytes(p->F, p->N) == 0)
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: F in 17..80 or 113..128, N in 4..128 (N > 80 needs F in 49..64 or 113..128)");
   const int need = shape_wide_f(p->F) ? 128 : shape_half(p->F) ? (p->F + 3) / 4 * 4 : (p->F + 7) / 8 * 8;
-  if (p->ldx < need || p->ldx % 4 != 0 || ((uintptr_t)p->x & 15) != 0)
-    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: x must be 16-byte aligned with a row pitch that is a multiple of 4 floats and covers the last strip (round_up(F, 8); round_up(F, 4) when F % 32 is in 1..16)");
-  if (p->x_rows < 1 || p->x_rows >= (1 << 24) || (int64_t)p->x_rows * p->ldx * 4 >= (1ll << 32))
-    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: the source table must have < 2^24 rows and < 4 GiB");
+  // (round 4: the source rows are read through 64-bit lane addresses -- any 4-byte aligned pitch >= F, no 4 GiB / 2^24-row limit; the
+  // strips of a row's last block are 16-byte reads that may reach up to `need` floats from the row's start: the caller's storage
+  // must be readable there, which a (V, F) tensor's is for every row but the last)
+  if (p->ldx < p->F || ((uintptr_t)p->x & 3) != 0 || (int64_t)p->ldx * 4 >= (1ll << 31))
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: x must be 4-byte aligned with a row pitch >= F (< 2^29 floats)");
+  if (p->x_rows < 1 || p->x_rows >= (1ll << 32))
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: the source table must have 1 <= x_rows < 2^32");
   if (p->M < 0 || p->M % (kWaves * 16) != 0 || p->M >= (1ll << 31))
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: M must be a multiple of 64");
   if (p->n_records < 4 || p->n_records * 64 >= (1ll << 32))
@@ -812,7 +869,7 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
     if (!p->x_dst || !p->h_self || !p->row_post || p->agg_out || tower_image_bytes(p->F, p->N) == 0)
       return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: tower mode takes x_dst, h_self and row_post together, 49 <= F <= 80, no agg_out");
     if (p->ld_xdst < need || p->ld_xdst % 4 != 0 || ((uintptr_t)p->x_dst & 15) != 0 || p->ld_h < need || p->ld_h % 4 != 0 || ((uintptr_t)p->h_self & 15) != 0 ||
-        p->n_nodes >= (1 << 24) || p->n_nodes * p->ld_xdst * 4 >= (1ll << 32) || p->n_nodes * p->ld_h * 4 >= (1ll << 32))
+        p->ldx < need || p->n_nodes >= (1 << 24) || p->n_nodes * p->ld_xdst * 4 >= (1ll << 32) || p->n_nodes * p->ld_h * 4 >= (1ll << 32))
       return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: x_dst / h_self must be 16-byte aligned (n_nodes, F) tables below 4 GiB with a row pitch like x's");
     if (p->residual && (((uintptr_t)p->residual & 15) != 0 || p->ld_res % 4 != 0))
       return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: tower mode reads the residual in 16-byte pieces: 16-byte aligned, ld_res a multiple of 4");

@@ -65,7 +65,16 @@ with torch.no_grad():
     out["max_diff_vs_two_kernel_of_max"] = (y_f - y_g).abs().max().item() / s
     out["rows_differing_over_2e-6"] = int(((y_f - y_g).abs().max(dim=1).values > 2e-6 * s).sum())
     print(f"parity: one-kernel vs two-kernel grouped {out['max_diff_vs_two_kernel_of_max']:.2e} of max|y| ({out['rows_differing_over_2e-6']} rows over 2e-6)", flush=True)
+    hc = h.contiguous()                                       # (V, F) rows of 300 bytes: what a drop-in caller passes
+    if hc.untyped_storage().nbytes() // 4 < (V - 1) * F + (F + 7) // 8 * 8:
+        hc = torch.cat([hc.reshape(-1), torch.zeros(8, device=dev)])[:V * F].view(V, F)
+    assert DG.fused_applies(g, hc, F, F), "the one-kernel path does not take a contiguous table"
+    call_c = PF.FusedDegreeCall(layer, g, hc)
+    y_c = PF.simple_layer_degree_fused(layer, g, hc).clone()
+    out["contiguous_x_max_diff_vs_pitch80_of_max"] = (y_c - y_f).abs().max().item() / s
     for rep in range(2):
+        out[f"rep{rep}_fused_group_rows_contiguous_x_ms"] = ev(call_c.group_rows)
+        print(f"rep {rep}: fused group-rows kernel over a CONTIGUOUS (V, {F}) table {out[f'rep{rep}_fused_group_rows_contiguous_x_ms']:.3f} ms (max diff vs pitch 80: {out['contiguous_x_max_diff_vs_pitch80_of_max']:.1e})", flush=True)
         t_f, t_r = ev(call.group_rows), ev(call.rest_rows)
         t_layer_f = ev(lambda: layer(g, h))
         DG.FUSED = False
