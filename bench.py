@@ -306,8 +306,10 @@ def main():
     # x ~ N(0,1), seed 1234.  N=1: generated on the host so the CPU baseline sees the same values; N>1:
     # every rank draws only its own rows (per-rank seed) -- an 8M x 75 host tensor per rank would only slow start-up
     h_all = torch.randn(V, F, generator=torch.Generator().manual_seed(1234)) if world == 1 else None
-    # node features live in a 16-byte aligned row pitch (80 floats for F=75), the layout a multi-layer net keeps
-    # its activations in; the kernels accept any pitch (--x-pitch 75 = dense rows, ~3 % slower gather)
+    # node features live in a 16-byte aligned row pitch (80 floats for F=75), the layout a multi-layer net keeps its activations
+    # in (this library's layers write their outputs at such a pitch).  Since round 4 the one-kernel layer takes ANY pitch: a
+    # contiguous (V, 75) tensor -- what a drop-in caller of PNASimpleLayer.forward passes -- lands on the same kernel; the step
+    # over such a table is timed too (`ms_per_step_contiguous_input`, 3-7 % slower: 300-byte rows straddle more 64-byte sectors)
     if world > 1:
         # multi-GPU: the features live in the shard's resident [local | halo] table, so the halo exchange of the
         # timed step receives the peers' rows in place (no concatenation pass)
@@ -462,6 +464,28 @@ def main():
             sync()
         ms_per_step_cold = (time.perf_counter() - t1) / args.steps * 1e3
         del copies
+
+    # ---- the same step over a CONTIGUOUS (V, F) feature tensor (the headline must be reachable through the
+    # reference API: PNASimpleLayer.forward(g, h) with h = torch.randn(V, 75)) -------------------------------------------------
+    ms_per_step_contig, contig_one_kernel, contig_same_bits = None, None, None
+    if world == 1:
+        from pna_amd import degree_groups as _DG
+        h_c = torch.empty(n_local * F + 8, device=dev)[:n_local * F].view(n_local, F)     # (storage covers the last row's rounded-up strip)
+        h_c.copy_(h)
+        with torch.no_grad():
+            contig_one_kernel = bool(_DG.FUSED and hasattr(layer, "_degree_grouped_path") and layer._degree_grouped_path(g, h_c)
+                                     and _DG.fused_applies(g, h_c, F, F))
+            for _ in range(max(args.warmup, 3)):
+                layer(g, h_c)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                layer(g, h_c)
+            sync()
+            ms_per_step_contig = (time.perf_counter() - t1) / args.steps * 1e3
+            y_c = layer(g, h_c)
+            contig_same_bits = bool(torch.equal(y_c, layer(g, h)))
+        del h_c
 
     # the same step with the contraction forced onto the exact f32-input MFMA (reported beside the headline number)
     from pna_amd import ops as _ops
@@ -672,6 +696,11 @@ def main():
                       "segreduce": t_seg, "posttrans": t_post, "posttrans_exact_f32_mfma": t_post_f32, "halo_all_to_all": t_halo,
                       "csr_build_once_per_graph": csr_build_ms},
         "ms_per_step_exact_f32_mfma": ms_per_step_f32, "value_exact_f32_mfma": E / (ms_per_step_f32 * 1e-3),
+        "ms_per_step_contiguous_input": ms_per_step_contig,
+        "contiguous_input": ({"what": "the same K steps with h a CONTIGUOUS (V, F) tensor (row pitch F floats = 300 bytes at F = 75): the reference API's input",
+                              "takes_the_one_kernel_layer": contig_one_kernel, "output_bits_equal_the_aligned_step": contig_same_bits,
+                              "value": E / (ms_per_step_contig * 1e-3), "ratio_to_headline": ms_per_step_contig / ms_per_step}
+                             if ms_per_step_contig else None),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

@@ -31,6 +31,7 @@ ENABLED = True
 # 2 scalers F = 75: 1.297 / 1.288, 128: 1.880 / 2.277.
 MIN_OUT = 40               # narrower outputs keep the ordinary path (no gain measured at 20 and 32)
 TWO_SCALER_MIN_OUT = 81    # two scaler blocks -> one saves half, not two thirds: a gain only on the 128-column block
+TILE_ORDER = os.environ.get("PNA_AMD_TILE_ORDER", "ascending")   # order of the 128-row tiles of the virtual row order: ascending | interleave
 AGG_ALIGN = 32             # the aggregate's row pitch is rounded up to this many floats (32 = 128-byte lines; 1 = packed rows), see agg_pitch
 
 
@@ -65,9 +66,21 @@ class DegreePlan:
             vpos = (vstart[big_index[gid].clamp(min=0)] + rank)[in_big]
         else:                                                            # no degree value fills a tile: every row is a rest row
             vpos = torch.zeros(0, dtype=torch.long, device=dev)
+        tile_image = torch.repeat_interleave(torch.arange(self.G, device=dev, dtype=torch.int32), padded // TILE)
+        if TILE_ORDER in ("interleave", "descending") and self.NV:
+            # The tiles in ascending degree make the whole device multiply-bound first (few edges per tile) and gather-bound last.
+            # Interleaved -- lowest, highest, second lowest, ... -- every workgroup alternates between the two kinds, the memory
+            # system sees an even load from start to end, and two weight images are live at a time instead of one.
+            nt = self.NV // TILE
+            k = torch.arange(nt, device=dev)
+            src_tile = torch.where(k % 2 == 0, k // 2, nt - 1 - k // 2) if TILE_ORDER == "interleave" else nt - 1 - k   # new tile k <- ascending tile src_tile[k]
+            new_of = torch.empty(nt, dtype=torch.long, device=dev)
+            new_of[src_tile] = k
+            vpos = new_of[vpos // TILE] * TILE + vpos % TILE
+            tile_image = tile_image[src_tile]
         perm[vpos] = order[in_big].to(torch.int32)
         self.perm = perm[:self.NV].contiguous()
-        self.tile_image = torch.repeat_interleave(torch.arange(self.G, device=dev, dtype=torch.int32), padded // TILE).contiguous()
+        self.tile_image = tile_image.contiguous()
         self.group_first_row = order[start[big]] if self.G else order[:0]           # a row of each group (its scalers = the group's)
         self.group_degree = ud[big]
         rest = order[~in_big]
