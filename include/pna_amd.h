@@ -55,6 +55,12 @@ extern "C" {
 
 typedef void* pna_stream_t; /* a hipStream_t (0 = the null stream) */
 
+/* Every *_args struct starts with `struct_size` = sizeof of the struct in the header the CALLER was compiled against (ABI 19, round 4:
+ * fields had been appended through 18 ABI versions with only pna_abi_version() between a stale binding and a wild pointer).  An entry
+ * point refuses a struct shorter than its own (PNA_E_INVALID, pna_last_error names the two sizes); fields appended in later ABI
+ * versions therefore never read past a caller's struct.  PNA_ARGS_INIT zero-fills and stamps a struct in C. */
+#define PNA_ARGS_INIT(type) ((type){ .struct_size = (uint32_t)sizeof(type) })
+
 /* Aggregator codes -- models/dgl/aggregators.py:54-56 (AGGREGATORS dict) and
  * models/pytorch/pna/aggregators.py:149-152.  The order of codes in `aggr[]` is the order of the
  * F-wide blocks in the output, exactly like the order of names on the reference's command line. */
@@ -123,6 +129,8 @@ typedef struct pna_tuning {
  * not depend on the launch geometry.  heavy_threshold <= 0 disables the split.
  */
 typedef struct pna_segreduce_args {
+  uint32_t struct_size;    /* sizeof(pna_segreduce_args) of the CALLER's header (ABI 19): a shorter struct is refused with PNA_E_INVALID */
+  uint32_t _abi_reserved;  /* 0 */
   const int32_t* rowptr; /* [V+1] */
   const int32_t* col;    /* [E] or NULL */
   int32_t V;
@@ -223,6 +231,8 @@ int64_t pna_segreduce_partials_bytes(int32_t n_seg, int32_t F, int32_t n_tower);
  * x / dst_term / edge_term are only read when std or var is among aggr[].
  */
 typedef struct pna_segreduce_bwd_args {
+  uint32_t struct_size;    /* sizeof(pna_segreduce_bwd_args) of the CALLER's header (ABI 19): a shorter struct is refused with PNA_E_INVALID */
+  uint32_t _abi_reserved;  /* 0 */
   const int32_t* rowptr;
   const int32_t* col; /* nullable: x edge-resident */
   int32_t V;
@@ -289,6 +299,8 @@ int pna_segreduce_bwd_argscatter_f32(const pna_segreduce_bwd_args* args, pna_str
  * items_t: its work list {source row, beg, end, slot} (slot < 0: whole row; slot >= 0: a segment, added atomically).  ranks:
  * workspace (V, ld_rank >= 2 T F) of uint16 -- in-degrees up to 65534.  4 <= F <= 256. */
 typedef struct pna_segreduce_bwd_pull_args {
+  uint32_t struct_size;    /* sizeof(pna_segreduce_bwd_pull_args) of the CALLER's header (ABI 19): a shorter struct is refused with PNA_E_INVALID */
+  uint32_t _abi_reserved;  /* 0 */
   const pna_segreduce_bwd_args* base;
   const float* table;
   int64_t ld_table;
@@ -338,6 +350,8 @@ int pna_posttrans_pack_f32(const float* w_ref, int64_t ldw_ref, int32_t N, int32
                            float* w_img, float* wh_img /* nullable when Kh == 0 */, pna_stream_t stream);
 
 typedef struct pna_posttrans_args {
+  uint32_t struct_size;    /* sizeof(pna_posttrans_args) of the CALLER's header (ABI 19): a shorter struct is refused with PNA_E_INVALID */
+  uint32_t _abi_reserved;  /* 0 */
   const float* a;   /* (M, lda), K columns used */
   int64_t lda;
   int32_t M;
@@ -434,6 +448,8 @@ int pna_posttrans_x3_f32(const pna_posttrans_args* args, pna_stream_t stream);
  * summation order over hub rows' edges and over k (tolerance-level, not bit-level, agreement).
  */
 typedef struct pna_fused_simple_args {
+  uint32_t struct_size;    /* sizeof(pna_fused_simple_args) of the CALLER's header (ABI 19): a shorter struct is refused with PNA_E_INVALID */
+  uint32_t _abi_reserved;  /* 0 */
   const int32_t* rowptr; /* [V+1] CSR by destination */
   const int32_t* col;    /* [E] source row of x per edge */
   const float* x;        /* (x_rows, ldx) source features */
@@ -504,6 +520,8 @@ int pna_fused_simple_f32(const pna_fused_simple_args* args, pna_stream_t stream)
  * weight (pna_amd/functional.py::_tower_collapsed_weights).  No agg_out in this mode.
  */
 typedef struct pna_fused_degree_args {
+  uint32_t struct_size;    /* sizeof(pna_fused_degree_args) of the CALLER's header (ABI 19): a shorter struct is refused with PNA_E_INVALID */
+  uint32_t _abi_reserved;  /* 0 */
   const int32_t* tile_desc;
   const int32_t* tile_ids;
   int64_t n_records;
@@ -635,6 +653,8 @@ int64_t pna_small_packed_floats(int32_t N, int32_t K);
 int pna_small_pack_f32(const float* w_ref, int64_t ldw_ref, int32_t N, int32_t K, float* img, pna_stream_t stream);
 
 typedef struct pna_small_linear_args {
+  uint32_t struct_size;    /* sizeof(pna_small_linear_args) of the CALLER's header (ABI 19): a shorter struct is refused with PNA_E_INVALID */
+  uint32_t _abi_reserved;  /* 0 */
   const float* x;        /* (M, ldx), K columns used */
   int64_t ldx;
   int32_t M;
@@ -658,6 +678,8 @@ int pna_tower_post_pack_f32(const float* w_ref, int64_t ldw_ref, int32_t Fi, int
                             pna_stream_t stream);
 
 typedef struct pna_tower_layer_args {
+  uint32_t struct_size;    /* sizeof(pna_tower_layer_args) of the CALLER's header (ABI 19): a shorter struct is refused with PNA_E_INVALID */
+  uint32_t _abi_reserved;  /* 0 */
   const int32_t* rowptr;  /* [V+1] CSR by destination */
   const int32_t* col;     /* [E] source node per CSR edge */
   int32_t V;
@@ -734,6 +756,8 @@ int pna_pack_rows_f32(const float* x, int64_t ldx, const int32_t* idx, int64_t n
  * initialisation needed, not kept between the two calls.
  */
 typedef struct pna_bn_tail_args {
+  uint32_t struct_size;    /* sizeof(pna_bn_tail_args) of the CALLER's header (ABI 19): a shorter struct is refused with PNA_E_INVALID */
+  uint32_t _abi_reserved;  /* 0 */
   const float* y;          /* (M, ldy): the posttrans output */
   int64_t ldy;
   int64_t M;

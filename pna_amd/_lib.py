@@ -19,14 +19,23 @@ PNA_MAX_SCALER = 8
 AGG_CODES = {"mean": 0, "sum": 1, "max": 2, "min": 3, "std": 4, "var": 5, "var_raw": 6}
 
 
+class _Args(ctypes.Structure):
+    """Base of the *_args mirrors: `struct_size` (the first field of every args struct since ABI 19) is stamped on construction."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.struct_size = ctypes.sizeof(self)
+
+
 class PnaTuning(ctypes.Structure):
     _fields_ = [("lanes_per_row", ctypes.c_int32), ("unroll", ctypes.c_int32), ("rows_per_group", ctypes.c_int32),
                 ("vec", ctypes.c_int32), ("nt_store", ctypes.c_int32), ("prefetch", ctypes.c_int32),
                 ("debug", ctypes.c_int32), ("generic", ctypes.c_int32)]
 
 
-class PnaSegreduceArgs(ctypes.Structure):
+class PnaSegreduceArgs(_Args):
     _fields_ = [
+        ("struct_size", ctypes.c_uint32), ("_abi_reserved", ctypes.c_uint32),
         ("rowptr", ctypes.c_void_p), ("col", ctypes.c_void_p), ("V", ctypes.c_int32), ("F", ctypes.c_int32),
         ("x", ctypes.c_void_p), ("ldx", ctypes.c_int64), ("x_rows", ctypes.c_int64),
         ("dst_term", ctypes.c_void_p), ("ld_dst", ctypes.c_int64),
@@ -51,8 +60,9 @@ class PnaSegreduceArgs(ctypes.Structure):
     ]
 
 
-class PnaSegreduceBwdArgs(ctypes.Structure):
+class PnaSegreduceBwdArgs(_Args):
     _fields_ = [
+        ("struct_size", ctypes.c_uint32), ("_abi_reserved", ctypes.c_uint32),
         ("rowptr", ctypes.c_void_p), ("col", ctypes.c_void_p), ("V", ctypes.c_int32), ("F", ctypes.c_int32),
         ("x", ctypes.c_void_p), ("ldx", ctypes.c_int64),
         ("dst_term", ctypes.c_void_p), ("ld_dst", ctypes.c_int64),
@@ -72,8 +82,9 @@ class PnaSegreduceBwdArgs(ctypes.Structure):
     ]
 
 
-class PnaPosttransArgs(ctypes.Structure):
+class PnaPosttransArgs(_Args):
     _fields_ = [
+        ("struct_size", ctypes.c_uint32), ("_abi_reserved", ctypes.c_uint32),
         ("a", ctypes.c_void_p), ("lda", ctypes.c_int64), ("M", ctypes.c_int32), ("K", ctypes.c_int32),
         ("N", ctypes.c_int32), ("n_scaler", ctypes.c_int32),
         ("row_scale", ctypes.c_void_p * PNA_MAX_SCALER),
@@ -91,8 +102,9 @@ class PnaPosttransArgs(ctypes.Structure):
     ]
 
 
-class PnaFusedSimpleArgs(ctypes.Structure):
+class PnaFusedSimpleArgs(_Args):
     _fields_ = [
+        ("struct_size", ctypes.c_uint32), ("_abi_reserved", ctypes.c_uint32),
         ("rowptr", ctypes.c_void_p), ("col", ctypes.c_void_p), ("x", ctypes.c_void_p), ("ldx", ctypes.c_int64),
         ("V", ctypes.c_int32), ("F", ctypes.c_int32), ("N", ctypes.c_int32), ("n_scaler", ctypes.c_int32),
         ("row_scale", ctypes.c_void_p * PNA_MAX_SCALER),
@@ -102,15 +114,17 @@ class PnaFusedSimpleArgs(ctypes.Structure):
     ]
 
 
-class PnaSegreduceBwdPullArgs(ctypes.Structure):
+class PnaSegreduceBwdPullArgs(_Args):
     _fields_ = [
+        ("struct_size", ctypes.c_uint32), ("_abi_reserved", ctypes.c_uint32),
         ("base", ctypes.c_void_p), ("table", ctypes.c_void_p), ("ld_table", ctypes.c_int64), ("col_t", ctypes.c_void_p), ("rank_t", ctypes.c_void_p),
         ("items_t", ctypes.c_void_p), ("n_items_t", ctypes.c_int32), ("run_rowprep", ctypes.c_int32), ("ranks", ctypes.c_void_p), ("ld_rank", ctypes.c_int64),
     ]
 
 
-class PnaFusedDegreeArgs(ctypes.Structure):
+class PnaFusedDegreeArgs(_Args):
     _fields_ = [
+        ("struct_size", ctypes.c_uint32), ("_abi_reserved", ctypes.c_uint32),
         ("tile_desc", ctypes.c_void_p), ("tile_ids", ctypes.c_void_p), ("n_records", ctypes.c_int64),
         ("x", ctypes.c_void_p), ("ldx", ctypes.c_int64), ("x_rows", ctypes.c_int64), ("F", ctypes.c_int32), ("N", ctypes.c_int32),
         ("row_perm", ctypes.c_void_p), ("M", ctypes.c_int64), ("n_nodes", ctypes.c_int64),
@@ -123,7 +137,7 @@ class PnaFusedDegreeArgs(ctypes.Structure):
     ]
 
 
-class PnaFusedRolesArgs(ctypes.Structure):
+class PnaFusedRolesArgs(_Args):
     _fields_ = [
         ("struct_size", ctypes.c_uint32), ("F", ctypes.c_int32), ("N", ctypes.c_int32), ("relu", ctypes.c_int32),
         ("tile_desc", ctypes.c_void_p), ("tile_ids", ctypes.c_void_p), ("ids_stride", ctypes.c_int64), ("n_records", ctypes.c_int64),
@@ -136,8 +150,9 @@ class PnaFusedRolesArgs(ctypes.Structure):
     ]
 
 
-class PnaBnTailArgs(ctypes.Structure):
+class PnaBnTailArgs(_Args):
     _fields_ = [
+        ("struct_size", ctypes.c_uint32), ("_abi_reserved", ctypes.c_uint32),
         ("y", ctypes.c_void_p), ("ldy", ctypes.c_int64), ("M", ctypes.c_int64), ("N", ctypes.c_int32), ("relu", ctypes.c_int32),
         ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("eps", ctypes.c_float), ("momentum", ctypes.c_float),
         ("running_mean", ctypes.c_void_p), ("running_var", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("ld_res", ctypes.c_int64),
@@ -148,8 +163,9 @@ class PnaBnTailArgs(ctypes.Structure):
     ]
 
 
-class PnaSmallLinearArgs(ctypes.Structure):
+class PnaSmallLinearArgs(_Args):
     _fields_ = [
+        ("struct_size", ctypes.c_uint32), ("_abi_reserved", ctypes.c_uint32),
         ("x", ctypes.c_void_p), ("ldx", ctypes.c_int64), ("M", ctypes.c_int32), ("K", ctypes.c_int32), ("N", ctypes.c_int32),
         ("act", ctypes.c_int32), ("img", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("act_slope", ctypes.c_float),
         ("_pad", ctypes.c_int32), ("residual", ctypes.c_void_p), ("ld_res", ctypes.c_int64), ("y", ctypes.c_void_p),
@@ -157,8 +173,9 @@ class PnaSmallLinearArgs(ctypes.Structure):
     ]
 
 
-class PnaTowerLayerArgs(ctypes.Structure):
+class PnaTowerLayerArgs(_Args):
     _fields_ = [
+        ("struct_size", ctypes.c_uint32), ("_abi_reserved", ctypes.c_uint32),
         ("rowptr", ctypes.c_void_p), ("col", ctypes.c_void_p), ("V", ctypes.c_int32), ("n_tower", ctypes.c_int32),
         ("Fi", ctypes.c_int32), ("Fo", ctypes.c_int32), ("divide_input", ctypes.c_int32), ("n_scaler", ctypes.c_int32),
         ("h", ctypes.c_void_p), ("ldh", ctypes.c_int64), ("x_cat", ctypes.c_void_p), ("ldx", ctypes.c_int64),

@@ -207,6 +207,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const TArgs a) {
 int fill(const pna_bn_tail_args* p, TArgs& a, bool bwd, const char* who) {
   memset(&a, 0, sizeof(a));
   if (!p) return pna_set_error(PNA_E_INVALID, who);
+  if (int rc_ss = pna_check_struct_size(bwd ? "pna_bn_tail_bwd_f32" : "pna_bn_tail_fwd_f32", p->struct_size, sizeof(*p))) return rc_ss;
   if (p->M < 2 || p->N <= 0 || p->N > kColLanes * kMaxJ || !p->y || p->ldy < p->N || !p->save_mean || !p->save_invstd || !p->workspace)
     return pna_set_error(PNA_E_INVALID, who);
   if (p->workspace_bytes < pna_bn_tail_workspace_bytes(p->M, p->N)) return pna_set_error(PNA_E_INVALID, who);

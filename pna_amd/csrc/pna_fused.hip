@@ -302,6 +302,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_fused_simple(const UArgs a) {
 
 extern "C" int pna_fused_simple_f32(const pna_fused_simple_args* p, pna_stream_t stream) {
   if (!p) return pna_set_error(PNA_E_INVALID, "pna_fused_simple_f32: null args");
+  if (int rc_ss = pna_check_struct_size("pna_fused_simple_f32", p->struct_size, sizeof(*p))) return rc_ss;
   if (p->V < 0 || p->F < 4 || p->F > 80 || p->N < 1 || p->N > kNW || p->n_scaler < 1 || p->n_scaler > 3)
     return pna_set_error(PNA_E_INVALID, "pna_fused_simple_f32: supported range is 4 <= F <= 80, N <= 80, 1..3 scalers");
   if (p->V == 0) return PNA_OK;

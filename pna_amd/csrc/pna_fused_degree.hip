@@ -839,6 +839,7 @@ extern "C" int pna_fused_degree_pack_f32(const float* w_ref, int64_t ldw, int32_
 
 extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t stream) {
   if (!p) return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: null args");
+  if (int rc_ss = pna_check_struct_size("pna_fused_degree_f32", p->struct_size, sizeof(*p))) return rc_ss;
   if (p->M == 0) return PNA_OK;
   if (!p->tile_desc || !p->tile_ids || !p->x || !p->row_perm || !p->w_img || !p->y)
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: tile_desc / tile_ids / x / row_perm / w_img / y must be non-null");

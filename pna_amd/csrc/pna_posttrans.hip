@@ -329,6 +329,7 @@ extern "C" int pna_posttrans_pack_f32(const float* w_ref, int64_t ldw, int32_t N
 
 extern "C" int pna_posttrans_f32(const pna_posttrans_args* p, pna_stream_t stream) {
   if (!p) return pna_set_error(PNA_E_INVALID, "pna_posttrans_f32: null args");
+  if (int rc_ss = pna_check_struct_size("pna_posttrans_f32", p->struct_size, sizeof(*p))) return rc_ss;
   if (p->M < 0 || p->K <= 0 || p->N <= 0) return pna_set_error(PNA_E_INVALID, "pna_posttrans_f32: bad M/K/N");
   if (p->M == 0) return PNA_OK;
   if (!p->a || !p->w_img || !p->y) return pna_set_error(PNA_E_INVALID, "pna_posttrans_f32: a/w_img/y must be non-null");

@@ -863,6 +863,7 @@ extern "C" int64_t pna_segreduce_partials_bytes(int32_t n_seg, int32_t F, int32_
 
 extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t stream) {
   if (!p) return pna_set_error(PNA_E_INVALID, "pna_segreduce_fwd_f32: null args");
+  if (int rc_ss = pna_check_struct_size("pna_segreduce_fwd_f32", p->struct_size, sizeof(*p))) return rc_ss;
   if (p->V < 0 || p->F <= 0) return pna_set_error(PNA_E_INVALID, "pna_segreduce_fwd_f32: bad V/F");
   if (p->V == 0) return PNA_OK;
   if (!p->rowptr || !p->x || !p->out) return pna_set_error(PNA_E_INVALID, "pna_segreduce_fwd_f32: rowptr/x/out must be non-null");

@@ -409,6 +409,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_pull(const LArgs a) {
 int fill_pull_args(const pna_segreduce_bwd_args* p, PArgs& k, const char* who) {
   memset(&k, 0, sizeof(k));
   if (!p) return pna_set_error(PNA_E_INVALID, "null args");
+  if (int rc_ss = pna_check_struct_size(who, p->struct_size, sizeof(*p))) return rc_ss;
   if (p->V < 0 || p->F <= 0 || !p->rowptr || !p->gagg || p->n_aggr <= 0 || p->n_aggr > PNA_MAX_AGGR) return pna_set_error(PNA_E_INVALID, who);
   const int T = p->n_tower > 1 ? p->n_tower : 1;
   for (int i = 0; i < p->n_aggr; ++i) {
@@ -430,6 +431,7 @@ int fill_pull_args(const pna_segreduce_bwd_args* p, PArgs& k, const char* who) {
 
 extern "C" int pna_segreduce_bwd_f32(const pna_segreduce_bwd_args* p, pna_stream_t stream) {
   if (!p) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: null args");
+  if (int rc_ss = pna_check_struct_size("pna_segreduce_bwd_f32", p->struct_size, sizeof(*p))) return rc_ss;
   if (p->V < 0 || p->F <= 0) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: bad V/F");
   if (p->V == 0) return PNA_OK;
   if (!p->rowptr || !p->gagg) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: rowptr/gagg must be non-null");
@@ -497,6 +499,7 @@ extern "C" int pna_segreduce_bwd_rowprep_f32(const pna_segreduce_bwd_args* p, fl
 
 extern "C" int pna_segreduce_bwd_pull_f32(const pna_segreduce_bwd_pull_args* q, pna_stream_t stream) {
   if (!q || !q->base) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_pull_f32: null args");
+  if (int rc_ss = pna_check_struct_size("pna_segreduce_bwd_pull_f32", q->struct_size, sizeof(*q))) return rc_ss;
   const pna_segreduce_bwd_args* p = q->base;
   PArgs k;
   int rc = fill_pull_args(p, k, "pna_segreduce_bwd_pull_f32: bad arguments");

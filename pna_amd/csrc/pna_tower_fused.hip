@@ -521,6 +521,8 @@ extern "C" int pna_small_pack_f32(const float* w_ref, int64_t ldw_ref, int32_t N
 }
 
 extern "C" int pna_small_linear_f32(const pna_small_linear_args* p, pna_stream_t stream) {
+  if (!p) return pna_set_error(PNA_E_INVALID, "pna_small_linear_f32: null args");
+  if (int rc_ss = pna_check_struct_size("pna_small_linear_f32", p->struct_size, sizeof(*p))) return rc_ss;
   if (!p || !p->x || !p->img || !p->y || p->M < 0 || p->K <= 0 || p->N <= 0 || p->act < 0 || p->act > 2)
     return pna_set_error(PNA_E_INVALID, "pna_small_linear_f32: bad argument");
   if (p->M == 0) return PNA_OK;
@@ -561,6 +563,8 @@ extern "C" int pna_tower_post_pack_f32(const float* w_ref, int64_t ldw_ref, int3
 }
 
 extern "C" int pna_tower_layer_f32(const pna_tower_layer_args* p, pna_stream_t stream) {
+  if (!p) return pna_set_error(PNA_E_INVALID, "pna_tower_layer_f32: null args");
+  if (int rc_ss = pna_check_struct_size("pna_tower_layer_f32", p->struct_size, sizeof(*p))) return rc_ss;
   if (!p || !p->rowptr || !p->h || !p->x_cat || !p->proj_img || !p->post_img || !p->y)      // (col may be NULL: a graph without edges)
     return pna_set_error(PNA_E_INVALID, "pna_tower_layer_f32: null argument");
   const int T = p->n_tower, Fi = p->Fi, Fo = p->Fo, S = p->n_scaler;

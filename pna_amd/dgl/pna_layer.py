@@ -167,7 +167,11 @@ def _towers_forward(towers, graph, h, e, snorm_n, divide_input):
         if e is None:
             raise ValueError("edge_features=True but no edge features were given")
         no_grad = not torch.is_grad_enabled() or not (h.requires_grad or e.requires_grad or any(p.requires_grad for t in towers for p in t.parameters()))
-        if no_grad and e.is_cuda and type(graph) is Graph and all(t.pretrans.is_affine for t in towers):
+        # (not while a hipGraph is being captured -- capture.GraphedForward with `e` as an input: the table is built from the VALUES of
+        # e with host syncs, a replay with other values would gather through the captured example's types; the per-edge product
+        # below is captured as kernels and replays correctly -- ADVICE r3)
+        if (no_grad and e.is_cuda and type(graph) is Graph and all(t.pretrans.is_affine for t in towers)
+                and not torch.cuda.is_current_stream_capturing()):
             etab = graph.edge_type_table(e)                   # edge features that are an embedding of <= 4 edge types: a table
         e_csr = e[csr.eid] if etab is None else None          # per-edge features in CSR (dst-sorted) order
     hs = [h[:, t * Fi:(t + 1) * Fi] if divide_input else h for t in range(T)]

@@ -741,7 +741,6 @@ class FusedRolesCall(FusedDegreeCall):
                 raise RuntimeError("pna_fused_roles: the graph's id records exceed 4 GiB")
             desc, ids, ids_stride, n_rec, wg_range = tabs
             a = _lib.PnaFusedRolesArgs()
-            a.struct_size = ctypes.sizeof(_lib.PnaFusedRolesArgs)
             a.F, a.N, a.relu, a.act_slope = F, N, 1, 0.0
             a.tile_desc, a.tile_ids = _lib.dev_ptr(desc, torch.int32, "tile_desc"), _lib.dev_ptr(ids, torch.int32, "tile_ids")
             a.ids_stride, a.n_records, a.n_tiles = ids_stride, n_rec, desc.shape[0]

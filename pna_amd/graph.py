@@ -313,24 +313,29 @@ class Graph:
         MAX_EDGE_TYPES distinct values -- the molecule nets' edge features are an EMBEDDING of the bond type
         (realworld_benchmark/nets/molecules_graph_regression/pna_net.py: `e = self.embedding_e(e)`), so the W_e . ef part of a
         factorised pretrans is a table with one row per type -- else None.  Found by hashing the rows (one sort of E scalars) and
-        VERIFIED against e (a hash collision makes it None, never a wrong table); cached per (tensor, version)."""
+        VERIFIED against e (a hash collision makes it None, never a wrong table); cached per (tensor object, version).  It reads the
+        VALUES of e on the host side of the stream (syncs): callers skip it while a stream is capturing (dgl/pna_layer.py)."""
+        import weakref
         key = (e.data_ptr(), e._version, tuple(e.shape), str(e.device))
         hit = self.__dict__.get("_edge_types")
-        if hit is not None and hit[0] == key:
+        if hit is not None and hit[0] == key and hit[2]() is e:     # (the SAME tensor object: a freed tensor's address can come back)
             return hit[1]
         res = None
         with torch.no_grad():
             if e.dim() == 2 and e.shape[0] == self.csr.col.numel() and e.shape[0] > 0:
                 gen = torch.Generator(device="cpu").manual_seed(0x5eed)
                 w = torch.randn(e.shape[1], dtype=torch.float64, generator=gen).to(e.device)
-                uniq, inv = torch.unique(e.double() @ w, return_inverse=True)
-                if uniq.numel() <= self.MAX_EDGE_TYPES:
-                    rep = torch.zeros(uniq.numel(), dtype=torch.long, device=e.device)
-                    rep.scatter_(0, inv, torch.arange(e.shape[0], device=e.device))      # any edge of each type
-                    rows = e[rep].contiguous()
-                    if torch.equal(rows[inv], e):
-                        res = (inv[self.csr.eid].to(torch.int32).contiguous(), rows)
-        self.__dict__["_edge_types"] = (key, res, e)          # (`e` kept alive: the key holds its address)
+                # continuous edge features fail on a few thousand rows already: no sort of E doubles for them (ADVICE r3)
+                probe = e[:4096].double() @ w
+                if torch.unique(probe).numel() <= self.MAX_EDGE_TYPES:
+                    uniq, inv = torch.unique(e.double() @ w, return_inverse=True)
+                    if uniq.numel() <= self.MAX_EDGE_TYPES:
+                        rep = torch.zeros(uniq.numel(), dtype=torch.long, device=e.device)
+                        rep.scatter_(0, inv, torch.arange(e.shape[0], device=e.device))      # any edge of each type
+                        rows = e[rep].contiguous()
+                        if torch.equal(rows[inv], e):
+                            res = (inv[self.csr.eid].to(torch.int32).contiguous(), rows)
+        self.__dict__["_edge_types"] = (key, res, weakref.ref(e))     # (a weak reference: the cache does not pin the feature tensor)
         return res
 
     def snorm_n(self):

@@ -354,3 +354,32 @@ def test_hipgraph_capture_replays_the_layer(cuda_device):
         gf = GraphedForward(lambda x: layer(g, x, None, snorm), h1)
         assert torch.equal(gf(h1).clone(), layer(g, h1, None, snorm))
         assert torch.equal(gf(h2).clone(), layer(g, h2, None, snorm))
+
+
+@pytest.mark.gpu
+def test_hipgraph_capture_with_varying_edge_features(cuda_device):
+    """edge features that are an embedding of a few bond types take a table path built from the VALUES of `e` (host
+    syncs); captured with `e` as a varying input it would replay the example's types.  The layer skips the table while a stream
+    is capturing: a replay with OTHER bond types must equal eager."""
+    from pna_amd.capture import GraphedForward
+    from pna_amd.synth import molecule_batch
+    src, dst, sizes = molecule_batch(16, seed=5)
+    V = sum(sizes)
+    g = Graph(src, dst, V, sizes).to(cuda_device)
+    E = src.numel()
+    avg = {"log": torch.tensor(1.1)}
+    layer = PNALayer(30, 30, "mean max min std", "identity amplification attenuation", avg, 0.0, True, True, towers=5,
+                     divide_input=False, residual=True, edge_features=True, edge_dim=8).to(cuda_device).eval()
+    snorm = g.snorm_n()
+    emb = torch.randn(3, 8, device=cuda_device)
+    t1 = torch.randint(0, 3, (E,), device=cuda_device)
+    t2 = (t1 + 1) % 3                                          # every edge changes its type
+    e1, e2 = emb[t1].contiguous(), emb[t2].contiguous()
+    h = torch.randn(V, 30, device=cuda_device)
+    with torch.no_grad():
+        assert g.edge_type_table(e1) is not None               # (eager calls DO take the table)
+        gf = GraphedForward(lambda x, ef: layer(g, x, ef, snorm), h, e1)
+        y1, y2 = layer(g, h, e1, snorm), layer(g, h, e2, snorm)
+        assert not torch.equal(y1, y2)
+        torch.testing.assert_close(gf(h, e1).clone(), y1, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(gf(h, e2).clone(), y2, rtol=1e-5, atol=1e-5)
