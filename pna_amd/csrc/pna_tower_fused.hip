@@ -585,6 +585,7 @@ extern "C" int pna_tower_layer_f32(const pna_tower_layer_args* p, pna_stream_t s
   // launch 1: x_cat = h [W_a ; W_b]^T + [0 ; b] for every tower
   pna_small_linear_args l;
   memset(&l, 0, sizeof(l));
+  l.struct_size = (uint32_t)sizeof(l);
   l.x = p->h; l.ldx = p->ldh; l.M = p->V; l.K = Fin; l.N = 2 * T * Fi; l.img = p->proj_img; l.bias = p->proj_bias;
   l.y = p->x_cat; l.ldy = p->ldx;
   const int rc = pna_small_linear_f32(&l, stream);
