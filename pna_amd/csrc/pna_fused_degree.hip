@@ -114,6 +114,9 @@ __device__ __forceinline__ void ld16_ws(f4& dst, const void* base, unsigned voff
 __device__ __forceinline__ void ld16_hi_ws(f4& dst, const void* base, unsigned voff) {
   asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:16" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
 }
+__device__ __forceinline__ void ld4_ws(int& dst, const void* base, unsigned voff) {
+  asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
+}
 __device__ __forceinline__ void ld16i_ws(i4& dst, const void* base, unsigned voff) {
   asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
 }
@@ -253,20 +256,28 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
   float S_[NB][8], Q_[NB][8], MX[NB][8], MN[NB][8];       // (a half block uses [0..3])
   int deg = 0;                                            // in-degree of the tile's rows (wave-uniform)
   bool fast_tile = false;                                 // the tile's statistics are all finite and it has in-edges (set by gather())
-  unsigned f0b[NB];                                       // byte offset of the lane's strip of feature block fb inside a row
+  // The lane's strip of feature block fb starts at feature 32 fb + 8 lg (a half block: + 4 lg) -- except in the row's LAST block,
+  // where a window that would reach past F slides back to end at F (round 4): no read ever leaves the row (rows of any pitch >= F,
+  // the table's last row included), no statistic is ever made of padding.  A feature the slide covers twice counts once: the
+  // pack kernel zeroes the weights of a lane group's slots below its nominal start (k_pack_fused_degree, same rule).
+  constexpr int WL = HALF ? 4 : 8;                         // features per lane in the last block
+  const int fl_nom = ((GP - 1) * NFBF + NB - 1) * 32 + lg * WL;             // (absolute feature: wide shapes gather in two passes)
+  const int fl_abs = min(fl_nom, g.F - WL);
+  unsigned f0b[NB];                                       // byte offset of the lane's strip of feature block fb inside a row (one pass)
 #pragma unroll
-  for (int fb = 0; fb < NB; ++fb) {
-    const bool half = HALF && fb == NFBF;
-    int f0 = fb * 32 + (half ? lg * 4 : lg * 8);
-    if (f0 >= g.F) f0 = half ? (g.F - 1) / 4 * 4 : (g.F - 1) / 8 * 8;     // a strip past the row: re-read the row's last strip (values
-    f0b[fb] = (unsigned)f0 * 4u;                                           // dropped in frag())
-  }
+  for (int fb = 0; fb < NB; ++fb) f0b[fb] = (unsigned)(fb * 32 + (HALF && fb == NFBF ? lg * 4 : lg * 8)) * 4u;
+  if constexpr (GP == 1) f0b[NB - 1] = (unsigned)fl_abs * 4u;
+  // first feature of the lane's slots of block fb in gather pass P, and whether slot j repeats a lower lane group's feature
+  auto feat0 = [&](int P_, int fb) __attribute__((always_inline)) -> int {
+    return (P_ == GP - 1 && fb == NB - 1) ? fl_abs : (P_ * NFBF + fb) * 32 + (HALF && fb == NFBF ? lg * 4 : lg * 8);
+  };
+  auto is_dup = [&](int P_, int fb, int f) __attribute__((always_inline)) -> bool { return P_ == GP - 1 && fb == NB - 1 && f < fl_nom; };
   const unsigned ldb = g.ldb;
   // lane addresses of the source strips (round 4: 64-bit, so that tables >= 4 GiB / >= 2^24 rows and contiguous (V, F) rows take this
   // kernel).  A: the lane's strip of block 0 of a row (block fb lies 128 fb bytes further: an immediate); L: the strip of the LAST
-  // block of the last gather pass -- the only one that can lie past F: such a lane re-reads the row's last strip (f0b above).
+  // block of the last gather pass (slid back to end at F: fl_abs above).
   const char* const xA = reinterpret_cast<const char*>(g.x) + (size_t)lg * 32;
-  const char* const xL = reinterpret_cast<const char*>(g.x) + f0b[NB - 1] + (size_t)((GP - 1) * NFBF * 128);
+  const char* const xL = reinterpret_cast<const char*>(g.x) + (size_t)fl_abs * 4;
   const void* const resb = g.residual ? (const void*)g.residual : (const void*)g.y;
   const bool has_res = g.residual != nullptr;
 
@@ -287,8 +298,8 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     const unsigned rbn = P + 1 < GP ? rb : (unsigned)td_nxt.x * 64u;                     // ... and of the records the next gather starts with
     deg = D;
     // (tower mode: the rows of y and their factors are needed from step RSTEP on only: requested with the panels)
-    if constexpr (TOWER) ld4(pn, g.perm, (unsigned)((t * kWaves + wave) * 16 + li) * 4u);
-    else if constexpr (P == 0) ld4(pr, g.perm, (unsigned)((t * kWaves + wave) * 16 + li) * 4u);
+    if constexpr (TOWER) ld4_ws(pn, g.perm, (unsigned)((t * kWaves + wave) * 16 + li) * 4u);
+    else if constexpr (P == 0) ld4_ws(pr, g.perm, (unsigned)((t * kWaves + wave) * 16 + li) * 4u);
 #pragma unroll
     for (int fb = 0; fb < NB; ++fb)
 #pragma unroll
@@ -315,7 +326,7 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
         ldx16<0>(sl[j][2 * (NB - 1)], pl);
         if constexpr (!HALF) ldx16<16>(sl[j][HALF ? 0 : 2 * (NB - 1) + 1], pl);
       }
-      ld4(idr[j], g.ids, nrec + (unsigned)j * 64u + lib);
+      ld4_ws(idr[j], g.ids, nrec + (unsigned)j * 64u + lib);      // (_ws: under SGPR pressure the base of the ids is reloaded right in front)
     };
     auto fold = [&](auto jc, bool on) __attribute__((always_inline)) {
       constexpr int j = decltype(jc)::value;
@@ -362,7 +373,6 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
     wait_slot<NR, NL>(sl[3], idr[3]);          fold(J3{}, e0 + 3 < D);
     // FAST tiles (round 4): every sum of squares of the lane's features finite (then every message was: the terms are >= 0) and
     // in-edges present -- all but pathological inputs.  Their statistics are finished without the special-value selects (frag()).
-    // The padding features of the last block (>= F; whatever the strip past the row held) become raw zeros: their weights are 0.
     {
       float qs = 0.f;
 #pragma unroll
@@ -371,14 +381,6 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
         for (int j = 0; j < ((HALF && fb == NFBF) ? 4 : 8); ++j) qs = qs + Q_[fb][j];
       // (not in the tower instantiation with a half block: 256 registers are taken there)
       fast_tile = !(TOWER && HALF) && D > 0 && __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(qs) < INFINITY)) == 0;
-      if (fast_tile) {
-        constexpr int fbl = NB - 1;
-#pragma unroll
-        for (int j = 0; j < ((HALF && fbl == NFBF) ? 4 : 8); ++j) {
-          const int f = (P * NFBF + fbl) * 32 + ((HALF && fbl == NFBF) ? lg * 4 : lg * 8) + j;
-          if (f >= g.F) { S_[fbl][j] = 0.f; Q_[fbl][j] = 0.f; MX[fbl][j] = 0.f; MN[fbl][j] = 0.f; }
-        }
-      }
     }
   };
 
@@ -401,8 +403,7 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
       r = q != q ? q : e;                                 // v_max / v_min drop NaN; q is NaN iff a message is (pna_rowstats.h)
     }
     if (deg <= 0) r = 0.f;                                // rows without in-edges: DGL leaves them at zero
-    if (f >= g.F) r = 0.f;                                // padding features of the last block (their weights are 0; the table's
-    return r;                                             // padding columns may hold anything)
+    return r;                                             // (f: every slot holds a feature < F since round 4: no padding)
   };
   // The same arithmetic for a FAST tile, without div_rn's NaN / Inf fall-back, the NaN test of max / min, sqrtf's denormal scaling
   // and class test (var + 1e-5 is a normal number) and the padding / empty-row selects: the bits of stat().  (The mean is computed
@@ -456,11 +457,10 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
       constexpr bool halfc = pc >= 2 * NFBF;
       constexpr int p = halfc ? 0 : pc / NFBF, fb = halfc ? NFBF : pc % NFBF;
       f4 lo4 = pk[p][2 * fb], hi4 = halfc ? pk[1][2 * fb] : pk[p][2 * fb + 1];
-      const int fl = halfc ? fb * 32 + lg * 4 : fb * 32 + lg * 8, fh = halfc ? fl : fl + 4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (fl + j >= g.F || ((halfc || p == 0) && deg <= 0)) lo4[j] = 0.f;     // (the x_dst panel: not for rows without in-edges)
-        if (fh + j >= g.F || (!halfc && p == 0 && deg <= 0)) hi4[j] = 0.f;
+        if ((halfc || p == 0) && deg <= 0) lo4[j] = 0.f;     // (the x_dst panel: not for rows without in-edges)
+        if (!halfc && p == 0 && deg <= 0) hi4[j] = 0.f;
       }
       if (__builtin_amdgcn_ballot_w64(absmax8(lo4, hi4) == INFINITY) != 0) split8_inf(lo4, hi4, A[0], A[1], A[2]);
       else split8(lo4, hi4, A[0], A[1], A[2]);
@@ -471,11 +471,11 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         int fb, sj, a, f;
-        if constexpr (c < 4 * NFBF) { fb = c / 4; sj = j; a = c % 4; f = (P * NFBF + fb) * 32 + lg * 8 + j; }
-        else { fb = NFBF; sj = j & 3; a = 2 * (c - 4 * NFBF) + (j >> 2); f = fb * 32 + lg * 4 + (j & 3); }
+        if constexpr (c < 4 * NFBF) { fb = c / 4; sj = j; a = c % 4; f = feat0(P, fb) + j; }
+        else { fb = NFBF; sj = j & 3; a = 2 * (c - 4 * NFBF) + (j >> 2); f = feat0(P, fb) + (j & 3); }
         v[j] = stat_fast(fb, sj, a);
         if constexpr (DUMP) {
-          if (f < g.F) g.agg_out[(size_t)((t * kWaves + wave) * 16 + li) * g.ld_agg + a * g.F + f] = v[j];
+          if (!is_dup(P, fb, f)) g.agg_out[(size_t)((t * kWaves + wave) * 16 + li) * g.ld_agg + a * g.F + f] = v[j];
         }
       }
       split8((f4){v[0], v[1], v[2], v[3]}, (f4){v[4], v[5], v[6], v[7]}, A[0], A[1], A[2]);
@@ -484,11 +484,11 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       int fb, sj, a, f;
-      if constexpr (c < 4 * NFBF) { fb = c / 4; sj = j; a = c % 4; f = (P * NFBF + fb) * 32 + lg * 8 + j; }
-      else { fb = NFBF; sj = j & 3; a = 2 * (c - 4 * NFBF) + (j >> 2); f = fb * 32 + lg * 4 + (j & 3); }
+      if constexpr (c < 4 * NFBF) { fb = c / 4; sj = j; a = c % 4; f = feat0(P, fb) + j; }
+      else { fb = NFBF; sj = j & 3; a = 2 * (c - 4 * NFBF) + (j >> 2); f = feat0(P, fb) + (j & 3); }
       v[j] = stat(fb, sj, a, f);
       if constexpr (DUMP) {
-        if (f < g.F) g.agg_out[(size_t)((t * kWaves + wave) * 16 + li) * g.ld_agg + a * g.F + f] = v[j];
+        if (!is_dup(P, fb, f)) g.agg_out[(size_t)((t * kWaves + wave) * 16 + li) * g.ld_agg + a * g.F + f] = v[j];
       }
     }
     const f4 lo4 = (f4){v[0], v[1], v[2], v[3]}, hi4 = (f4){v[4], v[5], v[6], v[7]};
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
   for (int c = 0; c < kAhead; ++c) stage(c, c, ib_cur);   // (every shape has at least 4 steps)
   // the ids of the first tile's edges 0..3 (later tiles: fetched by the previous tile's last packets)
 #pragma unroll
-  for (int j = 0; j < kRing; ++j) ld4(idr[j], g.ids, (unsigned)td_cur.x * 64u + (unsigned)j * 64u + lib);
+  for (int j = 0; j < kRing; ++j) ld4_ws(idr[j], g.ids, (unsigned)td_cur.x * 64u + (unsigned)j * 64u + lib);
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(idr[0]), "+v"(idr[1]), "+v"(idr[2]), "+v"(idr[3]) : : "memory");
   gather(t, std::integral_constant<int, 0>{});
   frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -741,11 +741,17 @@ __global__ void k_pack_fused_degree(const float* w_ref, long ldw, int N, int F, 
     const int c = r % NC; r /= NC;
     const int im = (int)r;
     const int n = pan * nwp + nn;                         // output column
-    int a, f;                                             // a: aggregator 0..3; 4: the self panel; 5: the x_dst panel
-    if (c < 4 * nfull) { a = c % 4; f = (c / 4) * 32 + lgp * 8 + e; }
-    else if (c < NCS) { a = 2 * (c - 4 * nfull) + (e >> 2); f = nfull * 32 + lgp * 4 + (e & 3); }
-    else if (c - NCS < 2 * nfull) { a = (c - NCS) / nfull == 0 ? 5 : 4; f = ((c - NCS) % nfull) * 32 + lgp * 8 + e; }
-    else { a = (e >> 2) == 0 ? 5 : 4; f = nfull * 32 + lgp * 4 + (e & 3); }
+    int a, f, fb, sj;                                     // a: aggregator 0..3; 4: the self panel; 5: the x_dst panel; fb: feature block
+    if (c < 4 * nfull) { a = c % 4; fb = c / 4; sj = e; }
+    else if (c < NCS) { a = 2 * (c - 4 * nfull) + (e >> 2); fb = nfull; sj = e & 3; }
+    else if (c - NCS < 2 * nfull) { a = (c - NCS) / nfull == 0 ? 5 : 4; fb = (c - NCS) % nfull; sj = e; }
+    else { a = (e >> 2) == 0 ? 5 : 4; fb = nfull; sj = e & 3; }
+    // the lane group's window of block fb: its nominal start, slid back in the row's LAST block to end at F; a slot below the
+    // nominal start repeats a feature a lower lane group multiplies: weight 0 (the kernel's feat0 / is_dup)
+    const bool halfb = fb == nfull, lastb = fb == nfull + (shape_half(F) ? 1 : 0) - 1;
+    const int wl = halfb ? 4 : 8, nom = fb * 32 + lgp * wl, st = lastb ? (nom < F - wl ? nom : F - wl) : nom;
+    f = st + sj;
+    const bool dup = f < nom;
     auto combined = [&](int col) -> float {               // W_D[n][col] = sum_s scale_s(D) W_s[n][col], scaler order
       const float* row = w_ref + (long)n * ldw + col;
       float w = scale ? scale[(long)im * S] * row[0] : row[0];
@@ -753,7 +759,7 @@ __global__ void k_pack_fused_degree(const float* w_ref, long ldw, int N, int F, 
       return w;
     };
     float w = 0.f;
-    if (n < N && f < F) w = a < 5 ? combined(a * F + f) : (combined(f) + combined(F + f)) + combined(2 * F + f);
+    if (n < N && f < F && !dup) w = a < 5 ? combined(a * F + f) : (combined(f) + combined(F + f)) + combined(2 * F + f);
     img[i] = weight_term(w, term);
   }
 }
@@ -869,11 +875,9 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
   if (tower) {
     if (!p->x_dst || !p->h_self || !p->row_post || p->agg_out || tower_image_bytes(p->F, p->N) == 0)
       return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: tower mode takes x_dst, h_self and row_post together, 49 <= F <= 80, no agg_out");
-    if (p->ld_xdst < need || p->ld_xdst % 4 != 0 || ((uintptr_t)p->x_dst & 15) != 0 || p->ld_h < need || p->ld_h % 4 != 0 || ((uintptr_t)p->h_self & 15) != 0 ||
-        p->ldx < need || p->n_nodes >= (1 << 24) || p->n_nodes * p->ld_xdst * 4 >= (1ll << 32) || p->n_nodes * p->ld_h * 4 >= (1ll << 32))
-      return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: x_dst / h_self must be 16-byte aligned (n_nodes, F) tables below 4 GiB with a row pitch like x's");
-    if (p->residual && (((uintptr_t)p->residual & 15) != 0 || p->ld_res % 4 != 0))
-      return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: tower mode reads the residual in 16-byte pieces: 16-byte aligned, ld_res a multiple of 4");
+    if (p->ld_xdst < p->F || ((uintptr_t)p->x_dst & 3) != 0 || p->ld_h < p->F || ((uintptr_t)p->h_self & 3) != 0 ||
+        p->n_nodes >= (1 << 24) || p->n_nodes * p->ld_xdst * 4 >= (1ll << 32) || p->n_nodes * p->ld_h * 4 >= (1ll << 32))
+      return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: x_dst / h_self must be 4-byte aligned (n_nodes, >= F) tables below 4 GiB and 2^24 rows");
   }
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)

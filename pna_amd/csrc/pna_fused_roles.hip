@@ -202,8 +202,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_fused_roles(const FRArgs g) {
     // immediate); L: the LAST block's strip -- the half block, or the last full block of a shape whose F ends inside it -- which
     // is the only one that can lie past F: such a lane re-reads the row's last strip (its values are masked in stat()).
     constexpr int NFA = HALF ? NFBF : NFBF - 1;            // full blocks addressed through A
-    int fl = HALF ? NFBF * 32 + lg * 4 : (NFBF - 1) * 32 + lg * 8;
-    if (fl >= g.F) fl = HALF ? (g.F - 1) / 4 * 4 : (g.F - 1) / 8 * 8;
+    // (a window that would reach past F slides back to end at F: no read leaves the row; the pack kernel zeroes the weights of the
+    // slots that then repeat a lower lane group's feature -- pna_fused_degree.hip, feat0 / is_dup)
+    const int fl = min(HALF ? NFBF * 32 + lg * 4 : (NFBF - 1) * 32 + lg * 8, g.F - (HALF ? 4 : 8));
     const char* const xA = g.x + (size_t)lg * 32;
     const char* const xL = g.x + (size_t)fl * 4;
     const unsigned ldb = g.ldb;
@@ -380,10 +381,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_fused_roles(const FRArgs g) {
         r = q != q ? q : e;                                 // v_max / v_min drop NaN; q is NaN iff a message is (pna_rowstats.h)
       }
       if (deg <= 0) r = 0.f;                                // rows without in-edges: DGL leaves them at zero
-      if (f >= g.F) r = 0.f;                                // padding features of the last block (their weights are 0; the table's
-      return r;                                             // padding columns may hold anything)
+      return r;                                             // (every slot holds a feature < F: no padding)
     };
     int Tm = 0;                                            // (the tile, for the verification output)
+    constexpr int WL = HALF ? 4 : 8;                       // the last block's window (pna_fused_degree.hip: feat0 / is_dup)
+    const int fl_nom = (NB - 1) * 32 + lg * WL, fl_abs = min(fl_nom, g.F - WL);
+    auto feat0 = [&](int fb) __attribute__((always_inline)) -> int { return fb == NB - 1 ? fl_abs : fb * 32 + lg * 8; };
     // FAST tiles (every raw statistic finite, in-degree > 0: all but pathological inputs; decided per tile from the sums of squares):
     // the same arithmetic without the special-value selects -- div_rn's NaN / Inf fall-back, the NaN test of max / min, sqrtf's
     // denormal scaling and class test (var + 1e-5 is a normal number), the Inf test of the split -- and with the mean kept from
@@ -425,11 +428,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_fused_roles(const FRArgs g) {
       for (int jj = 0; jj < 4; ++jj) {
         const int j = 4 * part + jj;
         int fb, sj, a, f;
-        if constexpr (c < 4 * NFBF) { fb = c / 4; sj = j; a = c % 4; f = fb * 32 + lg * 8 + j; }
-        else { fb = NFBF; sj = j & 3; a = 2 * (c - 4 * NFBF) + (j >> 2); f = fb * 32 + lg * 4 + (j & 3); }
+        if constexpr (c < 4 * NFBF) { fb = c / 4; sj = j; a = c % 4; f = feat0(fb) + j; }
+        else { fb = NFBF; sj = j & 3; a = 2 * (c - 4 * NFBF) + (j >> 2); f = feat0(fb) + (j & 3); }
         v[jj] = FAST ? stat_fast(fb, sj, a) : stat(fb, sj, a, f);
         if constexpr (DUMP) {
-          if (f < g.F) g.agg_out[(size_t)(Tm * 64 + m * 16 + li) * g.ld_agg + a * g.F + f] = v[jj];
+          if (!(fb == NB - 1 && f < fl_nom)) g.agg_out[(size_t)(Tm * 64 + m * 16 + li) * g.ld_agg + a * g.F + f] = v[jj];
         }
       }
       const bool inf = !FAST && __builtin_amdgcn_ballot_w64(pna_dev::vmax(pna_dev::vmax(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])),
@@ -524,19 +527,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_fused_roles(const FRArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) qs = qs + raw[1][pc_][e];
       const bool fast_tile = deg > 0 && __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(qs) < INFINITY)) == 0;
-      if (fast_tile) {                                     // padding features of the last block (beyond F): raw zeros (weights 0)
-        constexpr int PL = NP - 1;                          // the last 16-byte piece: the half block's, or the last full block's upper half
-        const int fbase = HALF ? NFBF * 32 + lg * 4 : (NFBF - 1) * 32 + lg * 8 + 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (fbase + e >= g.F) { raw[0][PL][e] = 0.f; raw[1][PL][e] = 0.f; raw[2][PL][e] = 0.f; raw[3][PL][e] = 0.f; }
-        if constexpr (!HALF) {
-          const int fb2 = (NFBF - 1) * 32 + lg * 8;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (fb2 + e >= g.F) { raw[0][PL - 1][e] = 0.f; raw[1][PL - 1][e] = 0.f; raw[2][PL - 1][e] = 0.f; raw[3][PL - 1][e] = 0.f; }
-        }
-      }
       lap(1);
 
       // One step = one chunk of 32 k values: 30 MFMAs (column tiles in pairs (0,1) (2,3) (4), alternating accumulators; the

@@ -426,17 +426,13 @@ FUSED_OVERLAP_MAX_REST_EDGES = 1.0 / 12   # ... and so it is when the rest rows 
 
 def fused_applies(graph, x, F, N):
     """Whether pna_fused_degree_f32 serves this call (whole-graph inference path already chosen by `applies`): a shape it is
-    instantiated for and a unit-stride, 4-byte aligned source table whose storage covers every row's rounded-up last strip.  Since
-    round 4 the rows are read through 64-bit lane addresses: any pitch >= F -- a CONTIGUOUS (V, F) tensor included -- and tables
-    beyond 4 GiB / 2^24 rows (a shard's [local | halo] table at BASELINE configs[4] x 8)."""
+    instantiated for and a unit-stride, 4-byte aligned source table.  Since round 4 the rows are read through 64-bit lane addresses and
+    no read leaves a row (the last feature block's window slides back to end at F): any pitch >= F -- a CONTIGUOUS (V, F) tensor
+    included -- and tables beyond 4 GiB / 2^24 rows (a shard's [local | halo] table at BASELINE configs[4] x 8)."""
     # F: one gather pass (17..80) or two (113..128; BASELINE configs[4]: 128 -> 128); N: one panel of 80 columns or two of 64
     if not FUSED or _lib.lib().pna_fused_degree_image_bytes(F, N) <= 0:
         return False
-    need = 128 if F > 96 else (F + 3) // 4 * 4 if 1 <= F % 32 <= 16 else (F + 7) // 8 * 8
     if x.dim() != 2 or x.stride(1) != 1 or x.stride(0) < F or x.data_ptr() % 4 != 0 or x.shape[0] < 1:
-        return False
-    # (the last row's last strip may reach past F: the storage must cover it)
-    if x.untyped_storage().nbytes() // 4 - x.storage_offset() < (x.shape[0] - 1) * x.stride(0) + need:
         return False
     plan = plan_of(graph)
     return plan.G > 0 and plan.fused_tables() is not False

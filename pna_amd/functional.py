@@ -773,17 +773,12 @@ class FusedRolesCall(FusedDegreeCall):
 
 def roles_applies(graph, x, F, N):
     """Whether pna_fused_roles_f32 serves this call (whole-graph inference path already chosen by `applies`): a shape it is
-    instantiated for and a unit-stride source table whose storage covers every row's last 16-byte strip.  No pitch, alignment or
-    size conditions (64-bit lane addresses): a contiguous (V, F) tensor qualifies."""
+    instantiated for and a unit-stride source table.  No pitch, alignment or size conditions (64-bit lane addresses, no read leaves a
+    row): a contiguous (V, F) tensor qualifies."""
     from . import _lib, degree_groups as DG
     if not (DG.FUSED and DG.ROLES) or not _lib.lib().pna_fused_roles_supported(F, N):
         return False
-    need = (F + 3) // 4 * 4 if 1 <= F % 32 <= 16 else (F + 7) // 8 * 8
     if x.dim() != 2 or x.stride(1) != 1 or x.stride(0) < F or x.data_ptr() % 4 != 0 or x.shape[0] < 1:
-        return False
-    # the last row's last strip may reach past F: the storage must cover it
-    last = (x.shape[0] - 1) * x.stride(0) + need
-    if x.untyped_storage().nbytes() // 4 - x.storage_offset() < last:
         return False
     plan = DG.plan_of(graph)
     return plan.G > 0

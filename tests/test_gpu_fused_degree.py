@@ -275,20 +275,26 @@ def test_rest_rows_beside_the_kernel_wide_shapes(cuda_device, V, E, F, N):
     assert bad == 0, f"{bad} of 20 runs differ from the serial order"
 
 
-def test_fused_path_falls_back_without_an_aligned_table(cuda_device):
-    """Rows of pitch 75 floats are not 16-byte aligned: the layer takes the two-kernel grouped path, same result."""
+@pytest.mark.parametrize("F,N", [(75, 75), (64, 64), (40, 72), (50, 50), (20, 64), (33, 40), (65, 70), (128, 128), (117, 100)])
+def test_contiguous_table_takes_the_one_kernel_path_with_the_same_bits(cuda_device, F, N):
+    """PNASimpleLayer.forward(g, h) with a CONTIGUOUS (V, F) tensor -- what a caller of the reference API passes -- must
+    land on the one-kernel path.  Rows of 4 F bytes are read through 64-bit lane addresses; the last feature block's window slides
+    back to end at F, so no 16-byte strip reaches past a row (not even the table's last row, whose storage ends with it: the
+    tensor here is allocated exactly).  Same bits as the 16-byte aligned table."""
     from pna_amd import Graph, degree_groups as DG
     from pna_amd.synth import powerlaw_graph
-    V, E, F = 140_000, 1_000_000, 75
+    V, E = 140_000, 1_000_000
     src, dst = powerlaw_graph(V, E, seed=8, device=cuda_device)
     g = Graph(src, dst, V)
-    layer = _layer(F, F, cuda_device, seed=4)
+    layer = _layer(F, N, cuda_device, seed=4, residual=F == N)
     ha = _features(V, F, cuda_device, seed=2)
-    hp = ha.contiguous()
+    hp = torch.empty(V * F, device=cuda_device).view(V, F)                 # storage of exactly V * F floats
+    hp.copy_(ha)
     with torch.no_grad(), _Knobs(fused=True, small_graphs=True):
-        assert DG.fused_applies(g, ha, F, F) and not DG.fused_applies(g, hp, F, F)
+        assert DG.fused_applies(g, ha, F, N) and DG.fused_applies(g, hp, F, N)
+        assert hp.is_contiguous() and hp.untyped_storage().nbytes() == V * F * 4
         ya, yp = layer(g, ha), layer(g, hp)
-    assert (ya - yp).abs().max().item() <= 2e-6 * yp.abs().max().item()
+    assert torch.equal(ya, yp)
 
 
 def test_fused_entry_point_rejects_bad_arguments(cuda_device):

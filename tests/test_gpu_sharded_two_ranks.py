@@ -128,6 +128,8 @@ def _worker_grouped(rank, world, port, V, E, F):
                 want = layer(g, h)[lo:hi]
                 agg_want = PF.aggregate(g, h, F, layer.aggregators)[lo:hi]
                 DG.ENABLED, DG.MIN_ROWS = True, 1
+                DG.FUSED = False                      # (the TWO-kernel overlap path is the subject here; since round 4 the one-kernel layer
+                                                      # would take any pitch: _worker_fused_shard covers it)
                 assert layer._degree_grouped_path(gs, hr)
                 got = layer(gs, hr)
                 plan = DG.plan_of(gs)
