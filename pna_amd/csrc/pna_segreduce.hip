@@ -401,6 +401,10 @@ __device__ __forceinline__ void aload64(i2& dst, const void* base, unsigned voff
 __device__ __forceinline__ void aload128(f4& dst, const void* base, unsigned voff) {
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
 }
+// 64-bit lane address (round 4: source tables >= 4 GiB / >= 2^24 rows -- a shard's [local | halo] table at BASELINE configs[4] x 8)
+__device__ __forceinline__ void aload128x(f4& dst, const char* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
 // The same behind five wait states ("VALU writes SGPR -> VMEM reads that SGPR": hipcc reloads a spilled base pointer with
 // v_readlane_b32 directly in front of an inline-asm load and does not insert the s_nop itself -- pna_fused_degree.hip has the
 // story; tools/isa_audit.py::sgpr_hazards checks every kernel).  For the once-per-item loads of the instantiations whose
@@ -552,7 +556,7 @@ __device__ __forceinline__ void fast_finalize_store(const FArgs& a, const AccF& 
 }
 
 // U gathers of one row issued back to back from the ids held by the group's lanes, then folded in order.
-template <int U, bool PARTIAL, bool DST, bool ARG, int ET>
+template <int U, bool PARTIAL, bool DST, bool ARG, int ET, bool X64>
 __device__ __forceinline__ void fast_batch(const float* x, AccF& acc, ArgF& ag, int idx, int src_lane0, unsigned ldb,
                                            unsigned offb, int nvalid, const f4 dt, int e0, const float* et, unsigned lde_b,
                                            int ety, const EtF& tb) {
@@ -565,7 +569,8 @@ __device__ __forceinline__ void fast_batch(const float* x, AccF& acc, ArgF& ag, 
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    aload128(v[u], x, __umul24((unsigned)id[u], ldb) + offb);
+    if constexpr (X64) aload128x(v[u], reinterpret_cast<const char*>(x) + offb + (size_t)(unsigned)id[u] * ldb);
+    else aload128(v[u], x, __umul24((unsigned)id[u], ldb) + offb);
     if constexpr (ET == 1) aload128(w[u], et, (unsigned)(e0 + (PARTIAL ? min(u, nvalid - 1) : u)) * lde_b + offb);
   }
   Drain<0, U, DST, ARG, ET>::run(acc, ag, v, w, ty, tb, nvalid, PARTIAL, dt, e0);
@@ -579,7 +584,7 @@ __device__ __forceinline__ void fast_batch(const float* x, AccF& acc, ArgF& ag, 
 // dst_term needs it) -- the tower layers' aggregate written in degree order (ABI 12).  Fetched one item ahead like the ids.
 // ARG: also writes argmax / argmin (see ArgF); heavy segments then write k_segreduce's seven-quantity partials and are finished by
 // k_heavy_finalize<4, true>.
-template <int U, bool DST, bool OROW = false, bool ARG = false, int ET = 0>
+template <int U, bool DST, bool OROW = false, bool ARG = false, int ET = 0, bool X64 = false>
 __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -683,9 +688,9 @@ __global__ __launch_bounds__(kBlock) void k_segreduce_fast(const FArgs a) {
       }
       int j = 0;
       for (; j + U <= nidx; j += U)
-        fast_batch<U, false, DST, ARG, ET>(a.x, acc, ag, idx, grp_lane0 + j, ldb, offb, U, dt_c, cb + j, a.et, a.lde_b, ety, tb);
+        fast_batch<U, false, DST, ARG, ET, X64>(a.x, acc, ag, idx, grp_lane0 + j, ldb, offb, U, dt_c, cb + j, a.et, a.lde_b, ety, tb);
       if (j < nidx)
-        fast_batch<U, true, DST, ARG, ET>(a.x, acc, ag, idx, grp_lane0 + j, ldb, offb, nidx - j, dt_c, cb + j, a.et, a.lde_b, ety, tb);
+        fast_batch<U, true, DST, ARG, ET, X64>(a.x, acc, ag, idx, grp_lane0 + j, ldb, offb, nidx - j, dt_c, cb + j, a.et, a.lde_b, ety, tb);
     }
     if (lane_ok && PNA_STORES_ON(a, acc.s.x)) {
       if (slot < 0) {
@@ -949,8 +954,13 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
   // hand-scheduled kernel for the configuration the layers issue (see k_segreduce_fast / FArgs)
   const bool std4 = p->n_aggr == 4 && p->aggr[0] == PNA_AGG_MEAN && p->aggr[1] == PNA_AGG_MAX && p->aggr[2] == PNA_AGG_MIN &&
                     p->aggr[3] == PNA_AGG_STD && p->n_scaler == 1 && p->row_scale[0] == nullptr;
-  const bool fast_ok = vec == 4 && !extra_fast && std4 && p->col != nullptr && idx32 && p->x_rows < (1 << 24) &&
-                       p->ldx * 4 < (1 << 24) && (int64_t)T * ts_in * 4 < (1 << 30) && p->work_items != nullptr &&
+  // the source rows through 32-bit offsets (24-bit multiply) where the table allows, else through 64-bit lane addresses (round 4:
+  // the instantiations the layers' large-graph paths issue: default unroll, no edge terms / argument tracking)
+  const bool small_x = idx32 && p->x_rows < (1 << 24) && p->ldx * 4 < (1 << 24);
+  const bool x64 = !small_x;
+  const bool x64_ok = p->x_rows > 0 && p->x_rows < (1ll << 32) && p->ldx * 4 < (1ll << 31) && et_mode == 0 && !want_arg && U == 4;
+  const bool fast_ok = vec == 4 && !extra_fast && std4 && p->col != nullptr && (small_x || x64_ok) &&
+                       (int64_t)T * ts_in * 4 < (1 << 30) && p->work_items != nullptr &&
                        p->n_work_items > 0 && p->n_work_items < (1 << 27) && p->n_edges > 0 && p->n_edges < (1LL << 30) &&
                        (!p->dst_term || (p->V < (1 << 24) && p->ld_dst * 4 < (1 << 24) &&
                                          (double)p->V * (double)p->ld_dst * 4.0 < 4294967296.0)) &&
@@ -982,6 +992,10 @@ extern "C" int pna_segreduce_fwd_f32(const pna_segreduce_args* p, pna_stream_t s
     } else if (want_arg) {
       if (p->dst_term) hipLaunchKernelGGL((k_segreduce_fast<4, true, false, true>), fgrid, dim3(kBlock), dyn_lds, st, f);
       else hipLaunchKernelGGL((k_segreduce_fast<4, false, false, true>), fgrid, dim3(kBlock), dyn_lds, st, f);
+    } else if (x64) {
+      if (p->dst_term && p->out_row_of) hipLaunchKernelGGL((k_segreduce_fast<4, true, true, false, 0, true>), fgrid, dim3(kBlock), dyn_lds, st, f);
+      else if (p->dst_term) hipLaunchKernelGGL((k_segreduce_fast<4, true, false, false, 0, true>), fgrid, dim3(kBlock), dyn_lds, st, f);
+      else hipLaunchKernelGGL((k_segreduce_fast<4, false, false, false, 0, true>), fgrid, dim3(kBlock), dyn_lds, st, f);
     } else if (p->dst_term && p->out_row_of) {
       hipLaunchKernelGGL((k_segreduce_fast<4, true, true>), fgrid, dim3(kBlock), dyn_lds, st, f);
     } else if (p->dst_term) {

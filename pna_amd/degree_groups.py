@@ -445,8 +445,9 @@ def applies(graph, V, N, n_scaler, aggregators, F=None, n_edges=None, x_rows=Non
             and tuple(aggregators) == ("mean", "max", "min", "std") and V * (80 if N <= 80 else 128) * 4 < (1 << 32)):
         return False
     # the gather of this path REQUIRES the hand-scheduled kernel (only it writes the plan's row order): its own preconditions
-    # (pna_segreduce.hip fast_ok: dwordx4 lanes, 32-bit edge positions, 24-bit row ids) -- ADVICE r2
-    if (F is not None and F < 4) or (n_edges is not None and not 0 < n_edges < (1 << 30)) or (x_rows is not None and x_rows >= (1 << 24)):
+    # (pna_segreduce.hip fast_ok: dwordx4 lanes, 32-bit edge positions; since round 4 source tables beyond 2^24 rows / 4 GiB through
+    # its 64-bit-address instantiations) -- ADVICE r2
+    if (F is not None and F < 4) or (n_edges is not None and not 0 < n_edges < (1 << 30)) or (x_rows is not None and x_rows >= (1 << 32)):
         return False
     plan = plan_of(graph)
     return plan.G > 0 and plan.NR <= MAX_REST_FRACTION * V

@@ -16,12 +16,14 @@ CSRC = os.path.join(ROOT, "pna_amd", "csrc")
 # (the grouped one-block kernel runs two 8-wavefront workgroups per CU: above 128 registers it would silently drop to one; the
 #  three-block grouped kernel runs 12 wavefronts per CU: 168)
 @pytest.mark.parametrize("src,max_vgpr", [("pna_posttrans_x3.hip", {"k_posttrans_x3": 256, "k_posttrans_x3ILi1ELb0ELi80ELi5ELi1ELi8ELi3ELb0ELb1EEE": 128,
-                                                                    "k_posttrans_x3ILi3ELb0ELi80ELi5ELi1ELi12ELi3ELb0ELb1EEE": 168}), ("pna_segreduce.hip", {"k_segreduce_fastILi4ELb0ELb0ELb0ELi0E": 80, "k_segreduce_fastILi4ELb1ELb0ELb0ELi0E": 80, "k_segreduce_fastILi4ELb1ELb1ELb0ELi0E": 80,
+                                                                    "k_posttrans_x3ILi3ELb0ELi80ELi5ELi1ELi12ELi3ELb0ELb1EEE": 168}), ("pna_segreduce.hip", {"k_segreduce_fastILi4ELb0ELb0ELb0ELi0ELb0E": 80, "k_segreduce_fastILi4ELb1ELb0ELb0ELi0ELb0E": 80, "k_segreduce_fastILi4ELb1ELb1ELb0ELi0ELb0E": 80,
+                                                                                        # (the 64-bit-address instantiations for source tables beyond 2^24 rows / 4 GiB: five wavefronts per SIMD)
+                                                                                        "k_segreduce_fastILi4ELb0ELb0ELb0ELi0ELb1E": 80, "k_segreduce_fastILi4ELb1ELb0ELb0ELi0ELb1E": 88, "k_segreduce_fastILi4ELb1ELb1ELb0ELi0ELb1E": 88,
                                                                                         # (the arg-tracking instantiations of the training forward and the edge-term ones: four to five wavefronts per SIMD)
                                                                                         "k_segreduce_fastILi4ELb0ELb0ELb1ELi0E": 104, "k_segreduce_fastILi4ELb1ELb0ELb1ELi0E": 104,
                                                                                         "k_segreduce_fastILi4ELb1ELb0ELb0ELi1E": 104, "k_segreduce_fastILi4ELb1ELb0ELb0ELi2E": 104}),
                                           ("pna_posttrans.hip", {}), ("pna_pack.hip", {}), ("pna_tower_fused.hip", {}), ("pna_fused.hip", {}),
-                                          ("pna_segreduce_bwd.hip", {}),
+                                          ("pna_segreduce_bwd.hip", {}), ("pna_fused_roles.hip", {"k_fused_roles": 256}),
                                           # the one-kernel layer: two 4-wavefront workgroups per CU (the production instantiations: DUMP = false)
                                           # (incl. the tower instantiations ...ELb0ELb1ELb0EEE of the two-full-block shapes)
                                           ("pna_fused_degree.hip", {"k_fused_degreeILi1ELb0ELb0E": 256, "k_fused_degreeILi1ELb1ELb0E": 256,
