@@ -387,17 +387,28 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
   // ---- chunk c: the lane's eight A values, split into three bf16 terms.  Full block fb, chunk 4 fb + a: aggregator a (0 mean,
   //      1 max, 2 min, 3 std) of the lane's 8 features; half block, chunk 4 NFBF + h: aggregators 2h | 2h + 1 of its 4 features ----
   bf8 A[3];
+  // (single VALU instructions through inline asm, like the fold: written as plain C++ hipcc packs two features' chains into
+  // v_pk_fma_f32 / v_pk_mul_f32 with op_sel swizzles -- the form that drops results beside MFMA wavefronts)
+  auto mul1 = [](float a, float b) __attribute__((always_inline)) -> float { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+  auto fma1 = [](float a, float b, float c) __attribute__((always_inline)) -> float { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; };
+  auto fnma1 = [](float a, float b, float c) __attribute__((always_inline)) -> float { float r; asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; };
+  auto sub1 = [](float a, float b) __attribute__((always_inline)) -> float { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+  auto add1 = [](float a, float b) __attribute__((always_inline)) -> float { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+  auto div_rn1 = [&](float a, float D_, float invD_) __attribute__((always_inline)) -> float {   // pna_rowstats.h div_rn, op by op
+    const float q0 = mul1(a, invD_), q = fma1(fnma1(D_, q0, a), invD_, q0);
+    return (q == q && __builtin_fabsf(q) != INFINITY) ? q : q0;
+  };
   auto stat = [&](int fb, int j, int a, int f) __attribute__((always_inline)) -> float {
     const float D = (float)deg, invD = 1.0f / D;
     const float s = S_[fb][j], q = Q_[fb][j];
     float r;
     if (a == 0) {
-      r = div_rn(s, D, invD);
+      r = div_rn1(s, D, invD);
     } else if (a == 3) {
-      const float mean = div_rn(s, D, invD), msq = div_rn(q, D, invD);
-      float var = msq - mean * mean;
+      const float mean = div_rn1(s, D, invD), msq = div_rn1(q, D, invD);
+      float var = sub1(msq, mul1(mean, mean));
       var = var < 0.f ? 0.f : var;
-      r = sqrtf(var + 1e-5f);
+      r = sqrtf(add1(var, 1e-5f));
     } else {
       const float e = a == 1 ? MX[fb][j] : MN[fb][j];
       r = q != q ? q : e;                                 // v_max / v_min drop NaN; q is NaN iff a message is (pna_rowstats.h)
@@ -411,26 +422,24 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
   auto sqrt_rn = [&](float x) __attribute__((always_inline)) -> float {     // correctly rounded for normal x (hipcc's own sequence behind
     const float r = __builtin_amdgcn_sqrtf(x);                               // v_sqrt_f32, less the denormal scaling and the class test)
     const float rm = bfloat(fbits(r) - 1u), rp2 = bfloat(fbits(r) + 1u);
-    const float e1 = __builtin_fmaf(-rm, r, x), e2 = __builtin_fmaf(-rp2, r, x);
+    const float e1 = fnma1(rm, r, x), e2 = fnma1(rp2, r, x);
     float o = e1 <= 0.f ? rm : r;
     o = e2 > 0.f ? rp2 : o;
     return o;
+  };
+  auto div_fast = [&](float a, float D_, float invD_) __attribute__((always_inline)) -> float {   // div_rn without its NaN / Inf fall-back
+    const float q0 = mul1(a, invD_);
+    return fma1(fnma1(D_, q0, a), invD_, q0);
   };
   auto stat_fast = [&](int fb, int j, int a) __attribute__((always_inline)) -> float {
     const float D = (float)deg, invD = 1.0f / D;
     if (a == 1) return MX[fb][j];
     if (a == 2) return MN[fb][j];
-    if (a == 0) {
-      const float sv = S_[fb][j];
-      const float q0 = sv * invD;
-      return __builtin_fmaf(__builtin_fmaf(-D, q0, sv), invD, q0);
-    }
-    const float sv = S_[fb][j], q = Q_[fb][j];
-    const float q0 = sv * invD, mean = __builtin_fmaf(__builtin_fmaf(-D, q0, sv), invD, q0);
-    const float m0 = q * invD, msq = __builtin_fmaf(__builtin_fmaf(-D, m0, q), invD, m0);
-    float var = msq - mean * mean;
+    if (a == 0) return div_fast(S_[fb][j], D, invD);
+    const float mean = div_fast(S_[fb][j], D, invD), msq = div_fast(Q_[fb][j], D, invD);
+    float var = sub1(msq, mul1(mean, mean));
     var = pna_dev::vmax(var, 0.f);
-    return sqrt_rn(var + 1e-5f);
+    return sqrt_rn(add1(var, 1e-5f));
   };
   f4 pk[2][NL];                                           // tower mode: strips of x_dst (0) and h (1) of the row's own node
   constexpr int NPL = 2 * NL + 1;                         // loads of the panel request: the strips, the rows' factors

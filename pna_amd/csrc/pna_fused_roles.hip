@@ -365,17 +365,28 @@ __global__ __launch_bounds__(kThreads, 2) void k_fused_roles(const FRArgs g) {
     // pna_segreduce_fwd_f32) and split into three bf16 terms.  Full block fb, chunk 4 fb + a: aggregator a (0 mean, 1 max, 2 min,
     // 3 std) of the lane's 8 features; half block, chunk 4 NFBF + h: aggregators 2h | 2h + 1 of its 4 features.
     auto rawv = [&](int q, int fb, int j) __attribute__((always_inline)) -> float { return raw[q][2 * fb + (j >> 2)][j & 3]; };
+    // (single VALU instructions through inline asm, like the fold: written as plain C++ hipcc packs two features' chains into
+    // v_pk_fma_f32 / v_pk_mul_f32 with op_sel swizzles -- the form that drops results beside MFMA wavefronts)
+    auto mul1 = [](float a, float b) __attribute__((always_inline)) -> float { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+    auto fma1 = [](float a, float b, float c) __attribute__((always_inline)) -> float { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; };
+    auto fnma1 = [](float a, float b, float c) __attribute__((always_inline)) -> float { float r; asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; };
+    auto sub1 = [](float a, float b) __attribute__((always_inline)) -> float { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+    auto add1 = [](float a, float b) __attribute__((always_inline)) -> float { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+    auto div_rn1 = [&](float a, float D_, float invD_) __attribute__((always_inline)) -> float {   // pna_rowstats.h div_rn, op by op
+      const float q0 = mul1(a, invD_), q = fma1(fnma1(D_, q0, a), invD_, q0);
+      return (q == q && __builtin_fabsf(q) != INFINITY) ? q : q0;
+    };
     auto stat = [&](int fb, int j, int a, int f) __attribute__((always_inline)) -> float {
       const float Df = (float)deg, invD = 1.0f / Df;
       const float sv = rawv(0, fb, j), q = rawv(1, fb, j);
       float r;
       if (a == 0) {
-        r = div_rn(sv, Df, invD);
+        r = div_rn1(sv, Df, invD);
       } else if (a == 3) {
-        const float mean = div_rn(sv, Df, invD), msq = div_rn(q, Df, invD);
-        float var = msq - mean * mean;
+        const float mean = div_rn1(sv, Df, invD), msq = div_rn1(q, Df, invD);
+        float var = sub1(msq, mul1(mean, mean));
         var = var < 0.f ? 0.f : var;
-        r = sqrtf(var + 1e-5f);
+        r = sqrtf(add1(var, 1e-5f));
       } else {
         const float e = a == 1 ? rawv(2, fb, j) : rawv(3, fb, j);
         r = q != q ? q : e;                                 // v_max / v_min drop NaN; q is NaN iff a message is (pna_rowstats.h)
@@ -391,31 +402,27 @@ __global__ __launch_bounds__(kThreads, 2) void k_fused_roles(const FRArgs g) {
     // the same arithmetic without the special-value selects -- div_rn's NaN / Inf fall-back, the NaN test of max / min, sqrtf's
     // denormal scaling and class test (var + 1e-5 is a normal number), the Inf test of the split -- and with the mean kept from
     // the block's first chunk: ~900 VALU instructions per tile instead of ~1500.  The bits are the slow path's.
-    float meanc[8];
-    auto sqrt_rn = [&](float x) __attribute__((always_inline)) -> float {     // correctly rounded for normal x (hipcc's own sequence
-      const float r = __builtin_amdgcn_sqrtf(x);                               // behind v_sqrt_f32, less the denormal scaling)
-      const float rm = bfloat(fbits(r) - 1u), rp = bfloat(fbits(r) + 1u);
-      const float e1 = __builtin_fmaf(-rm, r, x), e2 = __builtin_fmaf(-rp, r, x);
+      auto sqrt_rn = [&](float x) __attribute__((always_inline)) -> float {     // correctly rounded for normal x (hipcc's own sequence behind
+      const float r = __builtin_amdgcn_sqrtf(x);                               // v_sqrt_f32, less the denormal scaling and the class test)
+      const float rm = bfloat(fbits(r) - 1u), rp2 = bfloat(fbits(r) + 1u);
+      const float e1 = fnma1(rm, r, x), e2 = fnma1(rp2, r, x);
       float o = e1 <= 0.f ? rm : r;
-      o = e2 > 0.f ? rp : o;
+      o = e2 > 0.f ? rp2 : o;
       return o;
+    };
+    auto div_fast = [&](float a, float D_, float invD_) __attribute__((always_inline)) -> float {   // div_rn without its NaN / Inf fall-back
+      const float q0 = mul1(a, invD_);
+      return fma1(fnma1(D_, q0, a), invD_, q0);
     };
     auto stat_fast = [&](int fb, int j, int a) __attribute__((always_inline)) -> float {
       const float Df = (float)deg, invD = 1.0f / Df;
       if (a == 1) return rawv(2, fb, j);
       if (a == 2) return rawv(3, fb, j);
-      if (a == 0) {
-        const float sv = rawv(0, fb, j);
-        const float q0 = sv * invD, q1 = __builtin_fmaf(__builtin_fmaf(-Df, q0, sv), invD, q0);
-        meanc[j] = q1;
-        return q1;
-      }
-      const float q = rawv(1, fb, j);
-      const float m0 = q * invD, msq = __builtin_fmaf(__builtin_fmaf(-Df, m0, q), invD, m0);
-      const float mean = meanc[j];
-      float var = msq - mean * mean;
+      if (a == 0) return div_fast(rawv(0, fb, j), Df, invD);
+      const float mean = div_fast(rawv(0, fb, j), Df, invD), msq = div_fast(rawv(1, fb, j), Df, invD);
+      float var = sub1(msq, mul1(mean, mean));
       var = pna_dev::vmax(var, 0.f);
-      return sqrt_rn(var + 1e-5f);
+      return sqrt_rn(add1(var, 1e-5f));
     };
     u4 pc[3], pn[3];                                       // the A fragments (three bf16 terms) of the step being multiplied / of the next
     // half `part` (values 4 part .. + 4) of chunk c -> pn
