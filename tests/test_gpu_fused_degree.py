@@ -186,16 +186,30 @@ def test_fused_layer_rows_vs_float64_at_full_size(cuda_device, c3):
     amp, att = g.degree_scalers(2.3)
     lin, bn = layer.posttrans.fully_connected[0].linear, layer.batchnorm_h
     W, b = lin.weight.double(), lin.bias.double()
+    # the north star's bar PER ELEMENT (not normalised by the row's largest value): 1e-5 relative + the fp32
+    # rounding floor of a K = 12F sum evaluated in another order, 2e-6 x sum_k |w_k a_k| carried through BatchNorm's scale
+    # (bench.py::sampled_check's bar).  The statistics here are float64 of the fp32 inputs: the std of the fp32 pipeline
+    # (E[x^2] - E[x]^2 in fp32, models/dgl/aggregators.py:18-19) carries its own cancellation error, 2e-7 (E[x^2] + E[x]^2) / (2 std)
+    # per feature -- added to the floor through |w|.
     worst = 0.0
+    bn_scale = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
     for v in rows.tolist():
         lo, hi = int(csr.rowptr[v]), int(csr.rowptr[v + 1])
         m = h[csr.col[lo:hi].long()].double()
-        a = torch.cat([m.mean(0), m.max(0).values, m.min(0).values, torch.sqrt(torch.relu((m * m).mean(0) - m.mean(0) ** 2) + 1e-5)])
-        z = b + W @ torch.cat([a, a * amp[v].double(), a * att[v].double()])
-        z = (z - bn.running_mean.double()) / torch.sqrt(bn.running_var.double() + bn.eps) * bn.weight.double() + bn.bias.double()
+        mean, msq = m.mean(0), (m * m).mean(0)
+        std = torch.sqrt(torch.relu(msq - mean ** 2) + 1e-5)
+        a = torch.cat([mean, m.max(0).values, m.min(0).values, std])
+        a3 = torch.cat([a, a * amp[v].double(), a * att[v].double()])
+        z = b + W @ a3
+        z = (z - bn.running_mean.double()) * bn_scale + bn.bias.double()
         ref = h[v].double() + torch.relu(z)
-        worst = max(worst, (y[v].double() - ref).abs().max().item() / max(1.0, ref.abs().max().item()))
-    assert worst <= 1e-5, worst
+        std_err = 2e-7 * (msq + mean ** 2) / (2 * std)
+        e = torch.cat([torch.zeros_like(mean), torch.zeros_like(mean), torch.zeros_like(mean), std_err])
+        e3 = torch.cat([e, e * amp[v].double().abs(), e * att[v].double().abs()])
+        mass = (W.abs() @ a3.abs() + b.abs()) * bn_scale.abs()
+        tol = 1e-5 * ref.abs() + 2e-6 * mass + (W.abs() @ e3) * bn_scale.abs()
+        worst = max(worst, ((y[v].double() - ref).abs() / tol).max().item())
+    assert worst <= 1.0, worst
 
 
 def test_fused_layer_200_runs_identical_bits_at_full_size(cuda_device, c3):
@@ -350,13 +364,29 @@ def test_tower_mode_rows_vs_float64_and_100_identical_runs_at_full_size(cuda_dev
             a = torch.cat([m.mean(0), m.max(0).values, m.min(0).values, torch.sqrt(torch.relu((m * m).mean(0) - m.mean(0) ** 2) + 1e-5)])
         else:
             a = torch.zeros(4 * F, dtype=torch.float64, device=cuda_device)
-        z = bo + Wo @ torch.cat([hv, a, a * amp[v].double(), a * att[v].double()])
+        cat = torch.cat([hv, a, a * amp[v].double(), a * att[v].double()])
+        z = bo + Wo @ cat
         z = z * snorm[v].double()
-        z = (z - bn.running_mean.double()) / torch.sqrt(bn.running_var.double() + bn.eps) * bn.weight.double() + bn.bias.double()
+        bn_scale = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+        z = (z - bn.running_mean.double()) * bn_scale + bn.bias.double()
         z = Wm @ z + bm
         ref = hv + torch.where(z >= 0, z, z * slope)
-        worst = max(worst, (y[v].double() - ref).abs().max().item() / max(1.0, ref.abs().max().item()))
-    assert worst <= 1e-5, worst
+        # per element: 1e-5 relative + the fp32 rounding floor of the chain's sums carried to the output --
+        # 2e-6 x the absolute mass of pretrans (in the aggregates), posttrans and mixing products; the fp32 std's own
+        # cancellation error, 2e-7 (E[x^2] + E[x]^2) / (2 std), enters through |W| like in the simple layer's test
+        if hi > lo:
+            pm = (torch.cat([hu, hv.expand(hi - lo, F)], dim=1).abs() @ Wp.abs().t() + bp.abs()).max(0).values
+            mean, msq = m.mean(0), (m * m).mean(0)
+            std = torch.sqrt(torch.relu(msq - mean ** 2) + 1e-5)
+            ea = torch.cat([2e-6 * pm, 2e-6 * pm, 2e-6 * pm, (2e-7 * (msq + mean ** 2) + 4e-6 * pm * m.abs().max(0).values) / (2 * std)])
+        else:
+            ea = torch.zeros(4 * F, dtype=torch.float64, device=cuda_device)
+        ecat = torch.cat([torch.zeros_like(hv), ea, ea * amp[v].double().abs(), ea * att[v].double().abs()])
+        mass_z = (Wo.abs() @ (2e-6 * cat.abs() + ecat) + 2e-6 * bo.abs()) * snorm[v].double().abs() * bn_scale.abs()
+        zb = ((bo + Wo @ cat) * snorm[v].double() - bn.running_mean.double()) * bn_scale + bn.bias.double()
+        tol = 1e-5 * ref.abs() + Wm.abs() @ (mass_z + 2e-6 * zb.abs()) + 2e-6 * bm.abs()
+        worst = max(worst, ((y[v].double() - ref).abs() / tol).max().item())
+    assert worst <= 1.0, worst
 
 
 def test_source_table_beyond_4_gib_and_2_pow_24_rows(cuda_device):
