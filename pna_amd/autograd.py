@@ -236,6 +236,31 @@ def _tall_tn(p, q, chunks=256):
     return out
 
 
+def _argscatter_sorted(gx, col, amx, amn, gagg, aggs, T, F):
+    """grad_x[col[argmax[v, c]], c] += G_max[v, c] (and the min term) without atomics: deterministic, for small graphs."""
+    V, TF, A = amx.shape[0], T * F, len(aggs)
+    g4 = gagg[:, :T * A * F].reshape(V, T, A, F)
+    cols = torch.arange(TF, device=gx.device)
+    keys, vals = [], []
+    for name, arg in (("max", amx), ("min", amn)):
+        if name in aggs and arg is not None:
+            G = g4[:, :, aggs.index(name), :].reshape(V, TF)
+            e = arg[:, :TF].long()
+            ok = e >= 0
+            key = col[e.clamp(min=0)].long() * TF + cols
+            keys.append(key[ok])
+            vals.append(G[ok])
+    if not keys:
+        return
+    key, val = torch.cat(keys), torch.cat(vals)
+    order = torch.sort(key, stable=True).indices
+    key, val = key[order], val[order].contiguous()
+    uniq, counts = torch.unique_consecutive(key, return_counts=True)
+    sums = torch.segment_reduce(val, "sum", lengths=counts)
+    flat = gx.view(-1)                                       # (contiguous (rows, TF) by construction)
+    flat[uniq] = flat[uniq] + sums
+
+
 def _backward_pull(graph, x, dst_term, ident, amx, amn, gagg, aggs, all_aggs, T, F, need_x, need_d):
     """Gradient of the aggregation w.r.t. the source table / destination term WITHOUT one atomic per edge and feature
     (the scatter kernel: 750 M atomics = 11.4 ms on the roofline workload).  With messages m_k = x[u_k] + dst_term[v]:
@@ -323,9 +348,16 @@ def _backward_pull(graph, x, dst_term, ident, amx, amn, gagg, aggs, all_aggs, T,
         gx = (S[:, :TF] + x[:, :TF] * S[:, TF:]) if has_var else S
         gx = gx.contiguous()
         if amx is not None:
-            b.grad_x, b.ld_gx = _lib.dev_ptr(gx, torch.float32, "grad_x"), gx.stride(0)
-            rc = _lib.lib().pna_segreduce_bwd_argscatter_f32(ctypes.byref(b), _lib.stream_ptr(dev))
-            _lib.check(rc, "pna_segreduce_bwd_argscatter_f32")
+            if F < 4 or os.environ.get("PNA_AMD_BWD_DETERMINISTIC", "0") == "1":
+                # Narrow towers (the dense variant's multitask nets: F = 2 or 4 per tower, a few thousand nodes) do not qualify for
+                # the ranked pull (4 features per lane); the atomic scatter's order varies from run to run, which Adam amplifies over
+                # a training trace (tests/test_gpu_train_trace.py: 2.8e-3 in 2 of 31 runs).  Here the max / min terms are summed in a
+                # FIXED order: stable sort of (source, feature) keys, one sequential sum per key.
+                _argscatter_sorted(gx, csr.col, amx, amn, gagg, aggs, T, F)
+            else:
+                b.grad_x, b.ld_gx = _lib.dev_ptr(gx, torch.float32, "grad_x"), gx.stride(0)
+                rc = _lib.lib().pna_segreduce_bwd_argscatter_f32(ctypes.byref(b), _lib.stream_ptr(dev))
+                _lib.check(rc, "pna_segreduce_bwd_argscatter_f32")
         if x.shape[1] != TF:
             full = torch.zeros_like(x)
             full[:, :TF] = gx

@@ -2,7 +2,7 @@
 against the loss trace the reference itself produced on CPU (oracle/make_golden_c1_train.py: reference GNN + reference PNALayer +
 reference data, labels and loss, seed 42).  Here the same network is assembled around pna_amd.pytorch.pna.layer.PNALayer -- HIP
 kernels forward and backward -- starts from the reference's initial state_dict (strict load) and must reproduce the first loss
-to 1e-6, the oracle-autograd gradients of its parameters to 5e-4 and every step's loss to 5e-3 relative (see the test for why not 1e-4).
+to 1e-6, the oracle-autograd gradients of its parameters to 5e-4 and every step's loss to 1e-3 relative (see the test for why not 1e-4).
 
 Only the PNA layers run on the GPU; the recurrent / readout modules around them stay on the CPU, where they execute the very ops
 the reference run executed.  With those on the GPU as well the trace drifts by 1e-3 .. 1e-2 within eight Adam steps -- for the
@@ -115,12 +115,12 @@ def _oracle_layer_type(meta, avg_d):
 def test_two_epoch_loss_trace_matches_the_reference(cuda_device, name):
     """(1) step 1 (forward only): the reference's loss to 1e-6; (2) step-1 gradients of every PNA-layer parameter against
     autograd through the oracle's plain-torch restatement of the layer: 5e-4 of the parameter's largest gradient; (3) the eight-step
-    Adam trace: 5e-3 per step.  Why not 1e-4 for (3): Adam's update g / (|g| + eps) turns fp32-level differences in small
+    Adam trace: 1e-3 per step.  Why not 1e-4 for (3): Adam's update g / (|g| + eps) turns fp32-level differences in small
     gradients into lr-sized parameter differences; the plain-torch restatement of the layer run on the GPU in this same harness
-    drifts from the CPU trace just as far (tools/train_trace_diag.py: 2e-5 .. 3e-4 per step over the eight steps for both).  And
-    the GPU backward of the dense variant sums its scatter with hardware atomics, whose order varies from run to run: over
-    repeated runs of this test the worst step was 3.2e-4 .. 6e-4 in 29 of 31 and 2.8e-3 in two -- the bar leaves room for that
-    spread (it is not a property of the layer under test: parts (1) and (2) are deterministic and tight)."""
+    drifts from the CPU trace just as far (tools/train_trace_diag.py: 2e-5 .. 3e-4 per step over the eight steps for both).
+    Round 3 held 5e-3: the dense variant's narrow towers (F = 2 / 4) summed the max / min gradient terms with hardware atomics whose
+    order varied from run to run (2.8e-3 in 2 of 31 runs).  Round 4 sums them in a fixed order (autograd._argscatter_sorted): ten
+    repeats of this test gave 3.2e-4 .. 4.7e-4 (the rest of the spread: library GEMM / reduction orders outside the layer)."""
     from pna_amd.pytorch.pna.layer import PNALayer
     meta, a, sd = load_golden(name)
     dev = cuda_device
@@ -170,4 +170,4 @@ def test_two_epoch_loss_trace_matches_the_reference(cuda_device, name):
     import os
     if os.environ.get("PNA_TRACE_PRINT"):
         print("TRACE_MAX_REL", max(rel))
-    assert len(got) == len(want) == 8 and max(rel) <= 5e-3, (got, want, rel)
+    assert len(got) == len(want) == 8 and max(rel) <= 1e-3, (got, want, rel)
