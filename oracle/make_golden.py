@@ -254,6 +254,10 @@ def main():
     golden_tower("tower_deep_mlps", 45, in_dim=16, out_dim=16, towers=2, divide_input=False, pretrans_layers=2,
                  posttrans_layers=2, graph_norm=False)
     golden_tower("tower_f75", 46, in_dim=75, out_dim=70, towers=5, divide_input=False, n_graphs=3)
+    # BASELINE.json configs[3] words the MolHIV net as "8 towers" at hidden 80: the reference's HIV net has no towers
+    # (nets/HIV_graph_classification/pna_net.py:30-38), so this is an EXTENSION: DGL PNALayer(towers=8, divide_input=True) at 80 -> 80
+    # (10 features per tower), SURVEY 8d C4
+    golden_tower("tower_hiv_t8_div", 49, in_dim=80, out_dim=80, towers=8, divide_input=True, n_graphs=12)
     # --- whole molecules net incl. embeddings, graph readout, MLPReadout ---
     golden_net("net_zinc_sum_edgefeat", 41, hidden=20, out_dim=20, L=3, towers=5, edge_dim=6, readout="sum")
     golden_net("net_zinc_mean_gru", 42, hidden=16, out_dim=16, L=2, towers=4, edge_dim=0, readout="mean", gru=True)

@@ -171,6 +171,24 @@ with torch.no_grad():
 out["molhiv_simple_layer"] = dict(batch_build_ms=t_build, batch_build_flat_ms=t_build_flat, batch_build_plus_first_layer_ms=t_build_first, graphs=2048, V=V, E=E, hidden=80, eager_ms=eager, hipgraph_ms=graphed,
                                   edges_per_s_hipgraph=E / graphed * 1e3, cpu_oracle_ms=cpu, max_abs_err_vs_oracle=err, max_rel_err_vs_oracle=err / ref.abs().max().item())
 
+# ---- configs[3] as BASELINE.json WORDS it ("8 towers"): an EXTENSION -- the reference's HIV net has no towers
+# (nets/HIV_graph_classification/pna_net.py:30-38); this is DGL PNALayer(towers=8, divide_input=True) at hidden 80 (10 features per
+# tower) on the same 2048-graph batch; golden: tests/golden/tower_hiv_t8_div.npz ----
+layer8 = PNALayer(80, 80, AGG, SCA, avg, 0.0, True, True, towers=8, divide_input=True, residual=True).eval()
+randomise(layer8)
+sd8 = {k: v.clone() for k, v in layer8.state_dict().items()}
+lay8 = layer8.to(dev)
+snorm8 = g.snorm_n()
+with torch.no_grad():
+    eager8 = gpu_ms(lambda: lay8(g, hd, None, snorm8))
+    gf8 = GraphedForward(lambda x: lay8(g, x, None, snorm8), hd)
+    graphed8 = gpu_ms(lambda: gf8(hd))
+    ref8 = O.dgl_layer_forward(sd8, src, dst, V, h, None, snorm8.cpu(), AGG.split(), SCA.split(), avg["log"], 8, True, True, True, True, False)
+    err8 = (gf8(hd).cpu() - ref8).abs().max().item()
+out["molhiv_8_towers_extension"] = dict(note="not a reference configuration: BASELINE.json's wording of configs[3]; PNALayer(towers=8, divide_input=True), 80 -> 80",
+                                        graphs=2048, V=V, E=E, hidden=80, towers=8, eager_ms=eager8, hipgraph_ms=graphed8,
+                                        edges_per_s_hipgraph=E / graphed8 * 1e3, max_abs_err_vs_oracle=err8, max_rel_err_vs_oracle=err8 / ref8.abs().max().item())
+
 # ---- the whole MolHIV net of the reference's README (PNASimpleLayer x 4, hidden 80, mean readout), same batch ----
 from pna_amd.nets import PNANetHIV  # noqa: E402
 net = PNANetHIV(dict(hidden_dim=80, out_dim=80, in_feat_dropout=0.0, dropout=0.3, L=4, readout="mean", batch_norm=True,
