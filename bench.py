@@ -553,6 +553,19 @@ def main():
                          "rest_rows_beside_kernel": bool(beside), "spare_workgroups": int(call.args.spare_workgroups),
                          "ms_group_rows_kernel_full_grid": t_fused_full}
         t_halo = event_time_ms(lambda: g.source_features(h), args.kernel_iters) if world > 1 else 0.0
+        # N > 1: the exchange priced against the links it crosses.  Rank 0's received + sent halo bytes (whole rows of the resident
+        # table, pitch ldx floats) over the standalone exchange time, beside ONE xGMI link's ~153 GB/s per direction: the all-to-all
+        # spreads over world - 1 peers (one link each on an 8-GPU node), so the per-link rate is the total / (world - 1).
+        halo_rate = None
+        if world > 1 and t_halo > 0:
+            pitch_b = int(x_ext.stride(0)) * 4
+            rb, sb = int(sum(g.recv_splits)) * pitch_b, int(sum(g.send_splits)) * pitch_b
+            halo_rate = {"ms_rank0": t_halo, "recv_bytes_rank0": rb, "send_bytes_rank0": sb, "row_bytes": pitch_b,
+                         "recv_GB_per_s_rank0": rb / (t_halo * 1e-3) / 1e9, "send_GB_per_s_rank0": sb / (t_halo * 1e-3) / 1e9,
+                         "recv_GB_per_s_per_peer_link": rb / (t_halo * 1e-3) / 1e9 / (world - 1),
+                         "xgmi_link_peak_GB_per_s_per_direction": 153.0,
+                         "share_of_step": t_halo / ms_per_step if ms_per_step else None,
+                         "note": "standalone, synchronous exchange (pack + all_to_all_single); inside the step it runs beside the interior rows"}
         # socket power and shader clock while each kernel runs alone (rocm-smi; best effort, N = 1 only): the bf16x3 contraction
         # runs at the package power cap and the firmware lowers the clock to hold it -- the dense MFMA peak at THAT clock is the
         # ceiling the kernel can be priced against (DESIGN.md 4.2c point 6, profiles/r02_power_probe.txt)
@@ -621,6 +634,11 @@ def main():
                 if tj:
                     roofline["traffic"] = tj.get("hbm_bytes_per_launch")
                     roofline["traffic_source"] = "profiles/hbm_traffic.json (pna_fused_degree_c3): " + tj.get("collected", "") + "; NOT measured in this run"
+                    # the counters' bytes over THIS run's launch time: what the memory system delivered.  traffic > algorithmic here is line
+                    # granularity, not re-reads (a 300-byte row lies on three 128-byte lines: hbm_traffic.json line_granular_floor)
+                    roofline["traffic_over_algorithmic"] = roofline["traffic"] / fused_bytes
+                    roofline["traffic_GB_per_s"] = roofline["traffic"] / tf / 1e9
+                    roofline["traffic_frac_of_peak"] = roofline["traffic"] / tf / HBM_PEAK
             except Exception:
                 pass
     flops = 2.0 * n_local * (12 * F) * F
@@ -695,6 +713,7 @@ def main():
                       "fused_degree_rest_rows": fused["ms_rest_rows_two_kernel_path"] if fused else None,
                       "segreduce": t_seg, "posttrans": t_post, "posttrans_exact_f32_mfma": t_post_f32, "halo_all_to_all": t_halo,
                       "csr_build_once_per_graph": csr_build_ms},
+        "halo_exchange": halo_rate,
         "ms_per_step_exact_f32_mfma": ms_per_step_f32, "value_exact_f32_mfma": E / (ms_per_step_f32 * 1e-3),
         "ms_per_step_contiguous_input": ms_per_step_contig,
         "contiguous_input": ({"what": "the same K steps with h a CONTIGUOUS (V, F) tensor (row pitch F floats = 300 bytes at F = 75): the reference API's input",
