@@ -710,6 +710,14 @@ typedef struct pna_tower_layer_args {
   int64_t ld_res;
   float* y;               /* (V, ldy) */
   int64_t ldy;
+  /* edge features that are an embedding of <= 4 edge types (the molecule nets: pna_net.py `e = self.embedding_e(e)`; the W_e . ef
+   * part of the factorised pretrans, models/dgl/pna_layer.py:35-40): message = (W_a h_u + (W_b h_v + b)) + edge_table[edge_type[k]].
+   * All NULL / 0: a layer without edge features. */
+  const int32_t* edge_type;  /* nullable [E]: type of every CSR edge, 0 <= type < n_edge_types (not checked on the device) */
+  const float* edge_table;   /* (n_edge_types, ld_edge_table): row t = W_e . ef_t of every tower, concatenated (n_tower * Fi columns) */
+  int64_t ld_edge_table;
+  int32_t n_edge_types;      /* 1..4 with edge_type */
+  int32_t _pad2;
 } pna_tower_layer_args;
 
 int pna_tower_layer_f32(const pna_tower_layer_args* args, pna_stream_t stream);

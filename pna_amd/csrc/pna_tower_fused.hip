@@ -197,6 +197,7 @@ struct TArgs {
   int No, mix_act; float mix_slope;
   const float* residual; long ld_res;
   float* y; long ldy;
+  const int32_t* etype; const float* etab; long ldet; int n_types;   // edge features that are <= 4 types: type per CSR edge, (n_types, T*Fi) table of W_e . ef
 #ifdef PNA_AMD_EXPERIMENTS
   unsigned long long* dbg;
 #endif
@@ -301,10 +302,16 @@ __global__ __launch_bounds__(kThreads) void k_tower_rows(const TArgs g) {
       const float* const xs = g.xcat + c0;
       for (int cb = 0; cb < CF; cb += 64 * kMaxCh) {
         float s[2][kMaxCh], q[2][kMaxCh], mx[2][kMaxCh], mn[2][kMaxCh], dt[2][kMaxCh];
+        float et[4][kMaxCh];                              // the lane's columns of every edge type's term (edge-feature layers only)
         int cc[kMaxCh];
 #pragma unroll
         for (int j = 0; j < kMaxCh; ++j) {
           cc[j] = min(cb + 64 * j + lane, CF - 1);        // (lanes past the last column redo it; their result is not stored)
+          if (g.etype) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              et[t][j] = (t < g.n_types && cb + 64 * j < CF) ? g.etab[(size_t)t * g.ldet + c0 + cc[j]] : 0.f;
+          }
 #pragma unroll
           for (int r = 0; r < 2; ++r) {
             s[r][j] = 0.f; q[r][j] = 0.f; mx[r][j] = -INFINITY; mn[r][j] = INFINITY;
@@ -312,21 +319,25 @@ __global__ __launch_bounds__(kThreads) void k_tower_rows(const TArgs g) {
           }
         }
         for (int base = 0; base < maxdeg; base += 64) {
-          int myid[2], n[2];
+          int myid[2], myty[2], n[2];
 #pragma unroll
           for (int r = 0; r < 2; ++r) {
             n[r] = min(64, deg[r] - base);
             myid[r] = lane < n[r] ? g.col[eb[r] + base + lane] : 0;
+            myty[r] = (g.etype && lane < n[r]) ? g.etype[eb[r] + base + lane] : 0;      // (the same round trip as the ids)
           }
           for (int k = 0; k < max(n[0], n[1]); k += kEU) {
             float v[2][kEU][kMaxCh];
             bool on[2][kEU];
+            int ty[2][kEU];
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
               for (int kk = 0; kk < kEU; ++kk) {
                 on[r][kk] = k + kk < n[r];                // wavefront-uniform
+                ty[r][kk] = 0;
                 if (on[r][kk]) {
+                  if (g.etype) ty[r][kk] = __builtin_amdgcn_readlane(myty[r], k + kk);
                   const size_t o = (size_t)__builtin_amdgcn_readlane(myid[r], k + kk) * g.ldx;
 #pragma unroll
                   for (int j = 0; j < kMaxCh; ++j)
@@ -341,7 +352,11 @@ __global__ __launch_bounds__(kThreads) void k_tower_rows(const TArgs g) {
 #pragma unroll
                   for (int j = 0; j < kMaxCh; ++j)
                     if (cb + 64 * j < CF) {
-                      const float m = v[r][kk][j] + dt[r][j];
+                      float m = v[r][kk][j] + dt[r][j];
+                      if (g.etype) {                      // (x_src + x_dst) + W_e . ef: the order of the large-graph gather (pna_segreduce.hip Drain)
+                        const int t = ty[r][kk];          // wavefront-uniform
+                        m = m + (t == 0 ? et[0][j] : t == 1 ? et[1][j] : t == 2 ? et[2][j] : et[3][j]);
+                      }
                       s[r][j] = s[r][j] + m; q[r][j] = q[r][j] + m * m;
                       mx[r][j] = pna_dev::vmax(mx[r][j], m); mn[r][j] = pna_dev::vmin(mn[r][j], m);
                     }
@@ -575,6 +590,8 @@ extern "C" int pna_tower_layer_f32(const pna_tower_layer_args* p, pna_stream_t s
     return pna_set_error(PNA_E_INVALID, "pna_tower_layer_f32: leading dimension too small");
   if (p->mix_img && p->No <= 0) return pna_set_error(PNA_E_INVALID, "pna_tower_layer_f32: mixing network without an output width");
   if (p->col_scale && !p->col_shift) return pna_set_error(PNA_E_INVALID, "pna_tower_layer_f32: col_scale without col_shift");
+  if (p->edge_type && (!p->edge_table || p->n_edge_types < 1 || p->n_edge_types > 4 || p->ld_edge_table < (int64_t)T * Fi))
+    return pna_set_error(PNA_E_INVALID, "pna_tower_layer_f32: edge_type needs edge_table (n_edge_types in 1..4 rows of >= n_tower * Fi floats)");
   if (p->V == 0) return PNA_OK;
   const int No = p->mix_img ? p->No : T * Fo;
   int TG = T;
@@ -598,6 +615,7 @@ extern "C" int pna_tower_layer_f32(const pna_tower_layer_args* p, pna_stream_t s
   g.post_img = p->post_img; g.post_bias = p->post_bias; g.row_post = p->row_post; g.col_scale = p->col_scale; g.col_shift = p->col_shift;
   g.mix_img = p->mix_img; g.mix_bias = p->mix_bias; g.No = p->mix_img ? p->No : T * Fo; g.mix_act = p->mix_act; g.mix_slope = p->mix_slope;
   g.residual = p->residual; g.ld_res = (long)p->ld_res; g.y = p->y; g.ldy = (long)p->ldy;
+  g.etype = p->edge_type; g.etab = p->edge_table; g.ldet = (long)p->ld_edge_table; g.n_types = p->n_edge_types;
 #ifdef PNA_AMD_EXPERIMENTS
   g.dbg = nullptr;
   if (const char* e = getenv("PNA_TF_DBG_ROWS")) g.dbg = (unsigned long long*)strtoull(e, nullptr, 0);

@@ -286,10 +286,11 @@ class PNALayer(nn.Module):
 
     def _small_structure_ok(self):
         """The structural conditions of the one-call path (they do not change after construction): 1-layer pretrans and
-        posttrans, no edge features, the four standard aggregators, <= 3 scalers, a mixing network without batch-norm."""
+        posttrans, the four standard aggregators, <= 3 scalers, a mixing network without batch-norm.  Edge features: served when the
+        call's feature rows are an embedding of <= 4 types (forward checks that per call: Graph.edge_type_table)."""
         towers = list(self.towers)
         t0, mix = towers[0], self.mixing_network
-        return (not self.edge_features and tuple(t0.aggregators) == ("mean", "max", "min", "std") and len(t0.scalers) <= 3
+        return (all(t.edge_features == t0.edge_features and t.edge_dim == t0.edge_dim for t in towers) and tuple(t0.aggregators) == ("mean", "max", "min", "std") and len(t0.scalers) <= 3
                 and all(len(t.pretrans.fully_connected) == 1 and len(t.posttrans.fully_connected) == 1
                         and t.pretrans.fully_connected[0].activation is None and t.posttrans.fully_connected[0].activation is None
                         and t.pretrans.fully_connected[0].b_norm is None and t.posttrans.fully_connected[0].b_norm is None
@@ -315,8 +316,18 @@ class PNALayer(nn.Module):
         graph = as_graph(g)
         if self._small_batch_path(graph, h):
             t0 = self.towers[0]
-            return PF.tower_layer_small(self, list(self.towers), self.mixing_network, graph, h, snorm_n,
-                                        _row_scales(graph, t0.scalers, t0.avg_d, h.device), self.divide_input, self.residual)
+            etab = None
+            if self.edge_features:
+                # ZINC with --edge_feat True (realworld_benchmark/README.md:62): e = embedding_e(bond type), <= 4 distinct rows -> the
+                # W_e . ef term is a 4-row table the one-call kernel indexes by edge type (not while a hipGraph is being captured: the
+                # table is read from the VALUES of e with host syncs; the general route below is captured instead)
+                if e is None:
+                    raise ValueError("edge_features=True but no edge features were given")
+                if e.is_cuda and not e.requires_grad and not torch.cuda.is_current_stream_capturing():
+                    etab = graph.edge_type_table(e)
+            if etab is not None or not self.edge_features:
+                return PF.tower_layer_small(self, list(self.towers), self.mixing_network, graph, h, snorm_n,
+                                            _row_scales(graph, t0.scalers, t0.avg_d, h.device), self.divide_input, self.residual, etab)
         if PF.tower_layer_degree_grouped_applies(self, graph, h):
             # large whole graphs, inference: node-level projections, gather in degree order, ONE grouped contraction for posttrans,
             # graph norm, BatchNorm and the mixing network (functional.tower_layer_degree_grouped)

@@ -180,10 +180,15 @@ class _SmallTowerPlan:
     host side of this path is on the critical path (the two launches take ~50 us for a 128-molecule batch), so a call only
     compares the parameters' version counters and fills in the per-call pointers."""
 
+    edge_dim = 0                                               # (plans without edge features: _SmallSimplePlan)
+    _etab = None
+
     def __init__(self, towers, mix, divide_input):
         import ctypes
         from . import _lib
         t0 = towers[0]
+        self.edge_dim = t0.edge_dim if t0.edge_features else 0
+        self._etab = None                                      # (type-row tensor of the graph's cache, its projection W_e . ef_t)
         pre = [t.pretrans.fully_connected[0].linear for t in towers]
         post = [t.posttrans.fully_connected[0].linear for t in towers]
         ts = [p for l in pre + post for p in (l.weight, l.bias) if p is not None]
@@ -207,6 +212,8 @@ class _SmallTowerPlan:
             else:
                 Wcat = torch.cat(Wa + Wb, dim=0)
             b = torch.cat([l.bias if l.bias is not None else torch.zeros(Fi, device=Wcat.device) for l in pre])
+            # W_e of every tower stacked (T*Fi, edge_dim): the <= 4 edge-type rows are projected through it once per (graph batch, e)
+            self.We = torch.cat([l.weight[:, 2 * Fi:2 * Fi + self.edge_dim] for l in pre], dim=0).contiguous() if self.edge_dim else None
             keep = dict(proj_img=ops.pack_small(Wcat.contiguous()), proj_bias=torch.cat([torch.zeros_like(b), b]).contiguous(),
                         post_img=ops.pack_tower_post([l.weight for l in post], Fi, Fo, S),
                         post_bias=torch.cat([l.bias for l in post]).contiguous() if post[0].bias is not None else None)
@@ -245,7 +252,16 @@ class _SmallTowerPlan:
     def stale(self):
         return self._state() != self.versions
 
-    def run(self, graph, h, snorm_n, row_scales, residual):
+    def edge_table(self, etab):
+        """(n_types, T*Fi) = type rows @ W_e^T, kept while the graph's type table (graph.edge_type_table: cached per feature tensor)
+        is the same object -- the weights' own staleness replaces the whole plan."""
+        hit = self._etab
+        if hit is None or hit[0] is not etab[1]:
+            with torch.no_grad():
+                hit = self._etab = (etab[1], (etab[1].to(torch.float32) @ self.We.t()).contiguous())
+        return hit[1]
+
+    def run(self, graph, h, snorm_n, row_scales, residual, etab=None):
         if h.stride(-1) != 1:
             h = h.contiguous()
         dev = h.device
@@ -277,6 +293,11 @@ class _SmallTowerPlan:
         else:
             a.residual = None
         a.y, a.ldy = out.data_ptr(), self.width
+        if self.edge_dim:
+            if etab is None:
+                raise RuntimeError("tower_layer_small: an edge-feature layer needs the graph's edge-type table")
+            tab = self.edge_table(etab)
+            a.edge_type, a.edge_table, a.ld_edge_table, a.n_edge_types = etab[0].data_ptr(), tab.data_ptr(), tab.stride(0), tab.shape[0]
         rc = self.fn(ctypes.byref(a), self.stream_ptr(dev))
         if rc != 0:
             self.check(rc, "pna_tower_layer_f32")
@@ -879,14 +900,14 @@ def simple_layer_small(layer, graph, h, row_scales):
     return plan.run(graph, h, None, row_scales, layer.residual)
 
 
-def tower_layer_small(owner, towers, mix, graph, h, snorm_n, row_scales, divide_input, residual):
+def tower_layer_small(owner, towers, mix, graph, h, snorm_n, row_scales, divide_input, residual, etab=None):
     """models/dgl/pna_layer.py:133-148 in eval mode through pna_tower_layer_f32.  `mix`: the mixing FCLayer (Linear + LeakyReLU /
     ReLU / none, no batch-norm) or None.  The plan is cached on `owner` (dropped by PNALayer._apply on device / dtype moves)."""
     plan = owner.__dict__.get("_pna_amd_small")
     if plan is None or plan.divide_input != divide_input or plan.stale():
         plan = _SmallTowerPlan(towers, mix, divide_input)
         owner.__dict__["_pna_amd_small"] = plan
-    return plan.run(graph, h, snorm_n, row_scales, residual)
+    return plan.run(graph, h, snorm_n, row_scales, residual, etab)
 
 
 class SimpleLayerRows:

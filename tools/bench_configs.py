@@ -117,7 +117,8 @@ out["zinc_tower_layer"] = dict(batch_build_ms=t_build, batch_build_flat_ms=t_bui
 
 # ---- the same ZINC-shaped batch with --edge_feat True: edge features = an embedding (edge_dim 50) of 4 bond types
 #      (nets/molecules_graph_regression/pna_net.py); the W_e . ef part of the factorised pretrans is a 4-row table the gather
-#      indexes by type (ABI 14).  Edge-feature layers are not on the one-call small-batch kernel: four launches. ----
+#      indexes by type (ABI 14).  Round 4: eager calls ride the one-call small-batch kernel (pna_tower_layer_f32 edge_type /
+#      edge_table); a captured hipGraph keeps the four-launch route (the type table is read from e's VALUES, capture skips it). ----
 small_rows = PF.SMALL_TOWER_ROWS
 gen_e = torch.Generator().manual_seed(5)
 emb = torch.randn(4, 50, generator=gen_e)
@@ -134,13 +135,14 @@ with torch.no_grad():
     graphed_e = gpu_ms(lambda: gf_e(hd))
     ref_e = O.dgl_layer_forward(sd_e, src, dst, V, h, e_feat, snorm.cpu(), AGG.split(), SCA.split(), avg["log"], 5, False, True, True, True, True)
     err_e = (gf_e(hd).cpu() - ref_e).abs().max().item()
+    err_e_eager = (lay_e(g, hd, ed, snorm).cpu() - ref_e).abs().max().item()
     PF.SMALL_TOWER_ROWS = 0                                   # the same four-launch path for the layer WITHOUT edge features
     try:
         eager_noe = gpu_ms(lambda: lay(g, hd, None, snorm))
     finally:
         PF.SMALL_TOWER_ROWS = small_rows
 out["zinc_tower_layer_edge_feat"] = dict(graphs=128, V=V, E=E, hidden=75, towers=5, edge_dim=50, edge_types=4, eager_ms=eager_e, hipgraph_ms=graphed_e,
-                                         same_path_without_edge_features_eager_ms=eager_noe, max_abs_err_vs_oracle=err_e,
+                                         same_path_without_edge_features_eager_ms=eager_noe, max_abs_err_vs_oracle=err_e, max_abs_err_vs_oracle_eager_one_call_kernel=err_e_eager,
                                          max_rel_err_vs_oracle=err_e / ref_e.abs().max().item())
 
 # ---- configs[3]: MolHIV-shaped batch, PNASimpleLayer hidden 80, 2048 graphs ----
