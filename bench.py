@@ -345,7 +345,8 @@ def main():
     if args.layers > 1:
         # ---- a stack of layers per step.  N = 1: the layers back to back on the one-kernel path, activations
         #      kept at the 16-byte pitch; N > 1: BlockPipeline -- block b of layer L is packed and sent while blocks b+1.. are still
-        #      being computed; per-layer kernels = gather over the block's work list + three-block contraction over its rows
+        #      being computed; per-layer kernels = the one-kernel layer over the block's own degree plan (round 4: DegreePlan(row_range);
+        #      block 0 also takes the hub rows and every block's leftover rows), else gather + three-block contraction per block
         import copy
         from pna_amd.shard import BlockPipeline
         L = args.layers

@@ -41,16 +41,35 @@ _PLAN_SERIAL = __import__("itertools").count()
 class DegreePlan:
     """Row order, work list and tile -> group table of one graph (cached on the Graph; independent of weights / scalers)."""
 
-    def __init__(self, graph):
+    def __init__(self, graph, row_range=None, with_heavy=True, extra_rows=None, drop_rest=False):
+        """row_range = (r0, r1): a plan of the rows [r0, r1) only -- one ROW BLOCK of shard.BlockPipeline, so that every block of a
+        pipelined multi-layer run takes the one-kernel layer.  The hub rows (cut into segments by the heavy
+        schedule) belong to the block built with_heavy=True wherever they lie, like the blocks' gather work lists; row ids stay
+        the graph's own (perm, rest_rows index the full tables).  drop_rest: the rows of the range whose degree fills no tile are
+        NOT this plan's (`dropped_rest` lists them); extra_rows: rows from outside the range that this plan takes on top -- the
+        pipeline hands every block's leftovers to block 0, so that blocks 1.. are ONE launch each and the chain of small rest-row
+        launches runs once per layer."""
         self.serial = next(_PLAN_SERIAL)       # identifies the plan in cache keys (id() of a freed plan can come back for another graph)
         csr, hs = graph.csr, graph.heavy_schedule()
         dev = csr.rowptr.device
         rp = csr.rowptr.long()
         deg = rp[1:] - rp[:-1]
         V = deg.numel()
-        order = torch.sort(deg, stable=True).indices                     # rows by in-degree (ties: ascending row id)
-        ud, cnt = torch.unique_consecutive(deg[order], return_counts=True)
         hub_limit = hs.threshold if hs.threshold > 0 else (1 << 30)     # (heavy schedule off: no row is cut into segments)
+        self.row_range, self.with_heavy = row_range, bool(with_heavy)
+        if row_range is None and with_heavy and extra_rows is None and not drop_rest:
+            order = torch.sort(deg, stable=True).indices                 # rows by in-degree (ties: ascending row id)
+        else:
+            r0, r1 = (0, V) if row_range is None else (int(row_range[0]), int(row_range[1]))
+            ids = torch.arange(V, device=dev)
+            heavy = deg > hub_limit
+            sel = ((ids >= r0) & (ids < r1) & ~heavy) | (heavy if with_heavy else torch.zeros_like(heavy))
+            if extra_rows is not None and extra_rows.numel():
+                sel[extra_rows.long()] = True
+            rows_sel = torch.nonzero(sel).flatten()
+            order = rows_sel[torch.sort(deg[rows_sel], stable=True).indices]
+        n_sel = int(order.numel())
+        ud, cnt = torch.unique_consecutive(deg[order], return_counts=True)
         big = (cnt >= TILE) & (ud <= hub_limit)                          # degree values with at least one whole tile of light rows
         start = torch.cumsum(cnt, 0) - cnt
         gid = torch.repeat_interleave(torch.arange(ud.numel(), device=dev), cnt)     # group of every sorted row
@@ -61,7 +80,7 @@ class DegreePlan:
         self.NV = int(padded.sum().item()) if padded.numel() else 0
         self.G = int(big.sum().item())
         perm = torch.full((max(self.NV, 1),), -1, dtype=torch.int32, device=dev)
-        rank = torch.arange(V, device=dev) - start[gid]
+        rank = torch.arange(n_sel, device=dev) - start[gid]
         if self.G:
             vpos = (vstart[big_index[gid].clamp(min=0)] + rank)[in_big]
         else:                                                            # no degree value fills a tile: every row is a rest row
@@ -84,6 +103,9 @@ class DegreePlan:
         self.group_first_row = order[start[big]] if self.G else order[:0]           # a row of each group (its scalers = the group's)
         self.group_degree = ud[big]
         rest = order[~in_big]
+        self.dropped_rest = None
+        if drop_rest:
+            self.dropped_rest, rest = rest, rest[:0]
         self.NR = int(rest.numel())
         self.NRp = (self.NR + TILE_REST - 1) // TILE_REST * TILE_REST
         perm_rest = torch.full((max(self.NRp, 1),), -1, dtype=torch.int32, device=dev)
@@ -91,15 +113,18 @@ class DegreePlan:
         self.perm_rest = perm_rest[:self.NRp].contiguous()
         self.rest_rows = rest
         # virtual position of every node in the (NV + NRp)-row aggregate buffer
-        vmap = torch.empty(V, dtype=torch.long, device=dev)
+        vmap = torch.full((V,), -1, dtype=torch.long, device=dev)            # (-1: a row of another block)
         vmap[order[in_big]] = vpos
         vmap[rest] = self.NV + torch.arange(self.NR, device=dev)
-        items = graph.work_items().clone()
         n_seg = hs.n_seg if hs.n_heavy > 0 else 0
-        items[n_seg:, 0] = vmap[items[n_seg:, 0].long()].to(torch.int32)  # whole-row records: `row` = output row (nothing else uses it)
-        self.items = items.contiguous()
+        if row_range is None and with_heavy and extra_rows is None and not drop_rest:
+            items = graph.work_items().clone()
+            items[n_seg:, 0] = vmap[items[n_seg:, 0].long()].to(torch.int32)  # whole-row records: `row` = output row (nothing else uses it)
+            self.items = items.contiguous()
+            self.heavy_out = vmap[hs.heavy_rows.long()].to(torch.int32).contiguous() if hs.n_heavy > 0 else None
+        else:
+            self.items = self.heavy_out = None    # (a block plan serves the one-kernel layer only: group rows + rest_items)
         self._vmap, self._n_seg, self._split = vmap, n_seg, None
-        self.heavy_out = vmap[hs.heavy_rows.long()].to(torch.int32).contiguous() if hs.n_heavy > 0 else None
         self.rows = self.NV + self.NRp
         self._rest_scales = {}
         self._fused, self._rest_items, self._vmap32, self._perm_all, self._rest_items_node, self._ones_rows = None, None, None, None, None, None
@@ -232,8 +257,11 @@ class DegreePlan:
             n_seg = hs.n_seg if hs.n_heavy > 0 else 0
             rows = it[n_seg:].clone()
             rows[:, 0] = self._vmap[rows[:, 0].long()].to(torch.int32)
-            light = rows[rows[:, 0] >= self.NV]
+            light = rows[rows[:, 0] >= self.NV]                    # (rows of other blocks: -1)
             light[:, 0] -= self.NV
+            if not self.with_heavy:                                # a block without the hub rows: whole-row records only
+                self._rest_items = (light.contiguous(), None, None)
+                return self._rest_items
             items = torch.cat([it[:n_seg], light], dim=0).contiguous() if n_seg else light.contiguous()
             hout = (self._vmap[hs.heavy_rows.long()] - self.NV).to(torch.int32).contiguous() if hs.n_heavy > 0 else None
             self._rest_items = (items, hout, hs)
@@ -244,7 +272,7 @@ class DegreePlan:
         if self._edge_split is None:
             live = self.perm[self.perm >= 0].long()
             e_g = int(self._deg[live].sum().item())
-            self._edge_split = (e_g, int(self._deg.sum().item()) - e_g)
+            self._edge_split = (e_g, int(self._deg[self.rest_rows].sum().item()))
         return self._edge_split
 
     def rest_overlap_applies(self, F):
@@ -378,7 +406,8 @@ def fused_images(weight, F, row_scales, plan, tower=False):
     key = ("fused", tower, weight._version, weight.data_ptr(), str(weight.device), tuple(weight.shape), F, plan.serial, G,
            tuple(None if rs is None else (rs.data_ptr(), rs._version) for rs in row_scales))
     attr = "_pna_amd_fused_img"
-    hit = getattr(weight, attr, None)
+    cache = getattr(weight, attr, None)                     # {plan serial: (key, image, stride)}: the block plans of a pipelined run
+    hit = cache.get((tower, plan.serial)) if isinstance(cache, dict) else None      # share one weight, each with its own groups
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
     L = _lib.lib()
@@ -398,7 +427,12 @@ def fused_images(weight, F, row_scales, plan, tower=False):
               G, _lib.dev_ptr(img, torch.float32, "w_img"), _lib.stream_ptr(weight.device))
     _lib.check(rc, "pna_fused_tower_pack_f32" if tower else "pna_fused_degree_pack_f32")
     try:
-        weight._pna_amd_fused_img = (key, img, stride)
+        if not isinstance(cache, dict):
+            cache = {}
+            weight._pna_amd_fused_img = cache
+        if len(cache) >= 64:                                 # (plans of dropped graphs: start over rather than grow)
+            cache.clear()
+        cache[(tower, plan.serial)] = (key, img, stride)
     except AttributeError:
         pass
     return img, stride
@@ -430,12 +464,17 @@ def fused_applies(graph, x, F, N):
     no read leaves a row (the last feature block's window slides back to end at F): any pitch >= F -- a CONTIGUOUS (V, F) tensor
     included -- and tables beyond 4 GiB / 2^24 rows (a shard's [local | halo] table at BASELINE configs[4] x 8)."""
     # F: one gather pass (17..80) or two (113..128; BASELINE configs[4]: 128 -> 128); N: one panel of 80 columns or two of 64
-    if not FUSED or _lib.lib().pna_fused_degree_image_bytes(F, N) <= 0:
-        return False
-    if x.dim() != 2 or x.stride(1) != 1 or x.stride(0) < F or x.data_ptr() % 4 != 0 or x.shape[0] < 1:
+    if not fused_shape_ok(x, F, N):
         return False
     plan = plan_of(graph)
     return plan.G > 0 and plan.fused_tables() is not False
+
+
+def fused_shape_ok(x, F, N):
+    """The graph-independent half of fused_applies (a row block of shard.BlockPipeline brings its own plan)."""
+    if not FUSED or _lib.lib().pna_fused_degree_image_bytes(F, N) <= 0:
+        return False
+    return x.dim() == 2 and x.stride(1) == 1 and x.stride(0) >= F and x.data_ptr() % 4 == 0 and x.shape[0] >= 1
 
 
 def applies(graph, V, N, n_scaler, aggregators, F=None, n_edges=None, x_rows=None):

@@ -661,12 +661,12 @@ class FusedDegreeCall:
     `group_rows()` = pna_fused_degree_f32 (99.6 % of the benchmark graph's rows), `rest_rows()` = gather + three-block contraction
     over the compact list of the rows no degree group holds.  Holds the argument block and every tensor it points into."""
 
-    def __init__(self, layer, graph, h, x=None, out=None, agg_out=None):
+    def __init__(self, layer, graph, h, x=None, out=None, agg_out=None, plan=None):
         from . import _lib, degree_groups as DG
         from .dgl.pna_layer import _row_scales
         import ctypes
         F, N = layer.in_dim, layer.out_dim
-        self.layer, self.graph, self.plan = layer, graph, DG.plan_of(graph)
+        self.layer, self.graph, self.plan = layer, graph, DG.plan_of(graph) if plan is None else plan      # (plan: a row block's)
         plan = self.plan
         self.x = x = graph.source_features(h) if x is None else x
         lin = layer.posttrans.fully_connected[0].linear
@@ -916,11 +916,15 @@ class SimpleLayerRows:
     finalize writes wherever they live) and the three-block contraction over the block's slice of the aggregate.  Every row is
     computed by the same kernels in the same order as on one GPU: bit-identical to the unsharded ordinary path."""
 
-    def __init__(self, layers, graph, n_blocks):
+    wants_full_out = True          # BlockPipeline hands __call__ the whole next table (the one-kernel layer scatters rows by node id)
+
+    def __init__(self, layers, graph, n_blocks, fused=None):
         from . import degree_groups as DG
         self.layers, self.g = list(layers), graph
         l0 = self.layers[0]
         self.F = l0.in_dim
+        self.fused = DG.FUSED if fused is None else bool(fused)
+        self.n_blocks, self._plans, self._calls = int(n_blocks), {}, {}
         if any(l.in_dim != self.F or l.out_dim != self.F or tuple(l.aggregators) != ("mean", "max", "min", "std") or l.training for l in self.layers):
             raise ValueError("SimpleLayerRows: a stack of eval-mode PNASimpleLayer(F -> F) with the four standard aggregators")
         V = graph.num_nodes
@@ -935,12 +939,49 @@ class SimpleLayerRows:
             self.items.append(graph.work_items_subset(light & (rows >= r0) & (rows < r1), include_heavy=(b == 0)))
         self.hs = hs
 
+    def block_plan(self, b, r0, r1):
+        """The degree plan of row block b, or None when the blocks do not qualify for the one-kernel layer (a block without a
+        degree value that fills a tile, mostly leftover rows).  Blocks 1.. hold only the rows of their range whose degree fills
+        tiles INSIDE the block (one launch each); block 0 takes, besides its own rows, the hub rows and every block's leftovers
+        (its chain of small rest-row launches runs once per layer, first: a row may be ready earlier than its block, never later)."""
+        from . import degree_groups as DG
+        if not self._plans:
+            V, B = self.g.num_nodes, self.n_blocks
+            bounds = [(V * i) // B for i in range(B + 1)]
+            plans, left = {}, []
+            for i in range(1, B):
+                plans[i] = DG.DegreePlan(self.g, row_range=(bounds[i], bounds[i + 1]), with_heavy=False, drop_rest=True)
+                left.append(plans[i].dropped_rest)
+            plans[0] = DG.DegreePlan(self.g, row_range=(bounds[0], bounds[1]), with_heavy=True, extra_rows=torch.cat(left) if left else None)
+            ok = (all(p.G > 0 and p.fused_tables() is not False for p in plans.values())
+                  and plans[0].NR <= DG.MAX_REST_FRACTION * max(1, V // B))
+            self._plans = plans if ok else {i: None for i in range(B)}
+        return self._plans[b]
+
     def __call__(self, l, table, r0, r1, out, b):
         from .dgl.pna_layer import _row_scales
+        from . import degree_groups as DG
         layer, g, F = self.layers[l], self.g, self.F
         csr = g.csr
         K = 4 * F
         x = table[:, :F]
+        n_local = g.num_nodes
+        full = out.shape[0] == table.shape[0]                 # (BlockPipeline: the whole next table; older callers: its rows [r0, r1))
+        if self.fused and full and r1 > r0 and table.is_cuda and len(layer.scalers) == 3 and DG.fused_shape_ok(x, F, layer.out_dim):
+            plan = self.block_plan(b, r0, r1)
+            if plan is not None:
+                # the block through the one-kernel layer: its own degree groups (pna_fused_degree_f32) + its rest rows; rows are
+                # scattered to their node ids in the next table (VERDICT r3 item 3: 1.47 -> ~0.85 ms / layer of compute at C3 shape)
+                key = (l, b, table.data_ptr(), out.data_ptr())
+                call = self._calls.get(key)
+                if call is None:
+                    if len(self._calls) > 4 * len(self.layers) * self.n_blocks:
+                        self._calls.clear()
+                    call = self._calls[key] = FusedDegreeCall(layer, g, table[:n_local, :F], x=x, out=out[:n_local, :layer.out_dim], plan=plan)
+                run_fused_call(call)
+                return
+        if full:
+            out = out[r0:r1]
         items = self.items[b]
         if items.shape[0]:
             ops.segreduce(csr.rowptr, csr.col, x, F, layer.aggregators, (None,), tower_stride_in=F, out=self.agg,

@@ -291,7 +291,8 @@ class BlockPipeline:
     blocks contiguous id ranges: the rows of one (peer, block) pair are a contiguous piece of the send buffer and of the halo.)
 
     layer_rows(l, table, r0, r1, out, b): compute rows [r0, r1) of layer l from the complete table `table`
-    ((n_local + n_halo, pitch): [local | halo]) into `out` (a view of the next table's rows [r0, r1)).  Point-to-point
+    ((n_local + n_halo, pitch): [local | halo]) into `out` (a view of the next table's rows [r0, r1); the WHOLE next table when
+    the callable has `wants_full_out = True`: functional.SimpleLayerRows scatters a block's rows by node id).  Point-to-point
     isend / irecv (RCCL on GPUs, gloo on CPU); every rank must use the same n_blocks."""
 
     def __init__(self, graph: HaloGraph, n_blocks: int):
@@ -394,7 +395,7 @@ class BlockPipeline:
             pend = []
             for b in range(self.B):
                 r0, r1 = self.rows[b], self.rows[b + 1]
-                layer_rows(l, cur, r0, r1, nxt[r0:r1], b)
+                layer_rows(l, cur, r0, r1, nxt if getattr(layer_rows, "wants_full_out", False) else nxt[r0:r1], b)
                 if l + 1 < n_layers:
                     pend.append(self.start_block(nxt, b))
             for works, _ in pend:

@@ -152,7 +152,7 @@ def test_two_rank_degree_grouped_layer_on_one_gpu():
     mp.spawn(_worker_grouped, args=(2, _free_port(), 12000, 120000, 75), nprocs=2, join=True)
 
 
-def _worker_pipeline(rank, world, port, V, E, F, L, n_blocks):
+def _worker_pipeline(rank, world, port, V, E, F, L, n_blocks, fused=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dev = torch.device("cuda:0")
@@ -181,10 +181,25 @@ def _worker_pipeline(rank, world, port, V, E, F, L, n_blocks):
             ta = torch.zeros(gs.num_nodes + gs.n_halo, P, device=dev)
             tb = torch.full_like(ta, float("nan"))
             ta[: gs.num_nodes, :F] = h[gs.lo:gs.hi]
-            rows = PF.SimpleLayerRows(layers, gs, n_blocks)
-            res = pipe.run(rows, L, ta, tb)
+            rows = PF.SimpleLayerRows(layers, gs, n_blocks, fused=fused)
+            made = []
+            ctor = PF.FusedDegreeCall.__init__
+            PF.FusedDegreeCall.__init__ = lambda self, *a, **k: (made.append(k.get("plan")), ctor(self, *a, **k))[1]
+            try:
+                res = pipe.run(rows, L, ta, tb)
+            finally:
+                PF.FusedDegreeCall.__init__ = ctor
             torch.cuda.synchronize()
-        assert torch.equal(res[: gs.num_nodes, :F], want[gs.lo:gs.hi])
+        got, ref = res[: gs.num_nodes, :F], want[gs.lo:gs.hi]
+        if not fused:
+            assert not made and torch.equal(got, ref)
+        else:
+            # every block of every layer through the one-kernel layer with the BLOCK's plan (its own degree groups; rows whose degree
+            # fills no tile inside the block take the three-block rest path: another rounding than the unsharded one-block result)
+            assert len(made) == L * n_blocks and all(p is not None and p.row_range is not None for p in made)
+            assert sum(p.with_heavy for p in made) == L
+            assert not torch.isnan(got).any()
+            torch.testing.assert_close(got, ref, rtol=2e-5, atol=2e-5 * float(ref.abs().max()))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -196,6 +211,14 @@ def test_two_rank_block_pipelined_layers_on_one_gpu(n_blocks):
     layer L is packed and sent while blocks b+1.. are still being computed): every rank's rows equal the unsharded three-layer
     result bit for bit."""
     mp.spawn(_worker_pipeline, args=(2, _free_port(), 6000, 70000, 20, 3, n_blocks), nprocs=2, join=True)
+
+
+@pytest.mark.parametrize("n_blocks", [1, 4])
+def test_two_rank_block_pipelined_layers_take_the_one_kernel_layer_per_block(n_blocks):
+    """the row blocks of shard.BlockPipeline run pna_fused_degree_f32 over their own degree plans
+    (DegreePlan(row_range=...)); hub rows ride with block 0; against the unsharded three-layer result (which runs the ordinary
+    three-block path here) to 2e-5."""
+    mp.spawn(_worker_pipeline, args=(2, _free_port(), 60000, 600000, 75, 3, n_blocks, True), nprocs=2, join=True)
 
 
 def _worker_fused_shard(rank, world, port, V, E, F):
