@@ -722,6 +722,85 @@ typedef struct pna_tower_layer_args {
 
 int pna_tower_layer_f32(const pna_tower_layer_args* args, pna_stream_t stream);
 
+/* ---- weight / bias gradient of the posttrans contraction (round 4) ------------------------------------------
+ * replaces: the autograd node of `self.posttrans(torch.cat([h, scaled aggregate], dim=1))` (models/dgl/pna_layer.py:206; the
+ * training loop's loss.backward(), realworld_benchmark/train/train_molecules_graph_regression.py:29-32) for the Linear's
+ * weight and bias -- rounds 2-3 used the vendor GEMM library here:
+ *
+ *   grad_w[n, Kh + s K + k] = sum_m row_scale[s][m] gy[m, n] a[m, k]        (row_scale[s] == NULL: 1)
+ *   grad_w[n, j]            = sum_m gy[m, n] h[m, j]                        j < Kh
+ *   grad_b[n]               = sum_m gy[m, n]                                (grad_b nullable)
+ *
+ * bf16x3 arithmetic (each fp32 operand cut exactly into three bf16 terms, six partial products, fp32 accumulation per slab of
+ * rows, float64 across the slabs in a fixed order: deterministic).  Shapes: 1 <= n_scaler <= 3, n_scaler * N <= 240,
+ * K + Kh + 1 <= 384 (pna_posttrans_dw_workspace_bytes returns -1 otherwise: the caller keeps its library route); rows 4-byte
+ * aligned; with an h panel or grad_b, row_scale[0] must be NULL (they are formed from the first copy of gy -- the identity scaler
+ * comes first in every reference configuration).  Non-finite inputs give NaN in the columns / rows they touch.  workspace: no
+ * initialisation needed.
+ */
+typedef struct pna_posttrans_dw_args {
+  uint32_t struct_size;    /* sizeof(pna_posttrans_dw_args) of the CALLER's header (ABI 19): a shorter struct is refused with PNA_E_INVALID */
+  uint32_t _abi_reserved;  /* 0 */
+  const float* gy;         /* (M, ldg): gradient of the contraction's output, N columns */
+  int64_t ldg;
+  int64_t M;
+  int32_t N;
+  int32_t n_scaler;
+  const float* a;          /* (M, lda): the aggregate the forward multiplied, K columns (identity-scaled) */
+  int64_t lda;
+  int32_t K;
+  int32_t Kh;              /* columns of h (0: no self panel) */
+  const float* h;          /* nullable (M, ldh) */
+  int64_t ldh;
+  const float* row_scale[PNA_MAX_SCALER];  /* each [M] or NULL = identity */
+  float* grad_w;           /* (N, ldw): [h panel | scaler block 0 | 1 | 2], the Linear's weight layout */
+  int64_t ldw;
+  float* grad_b;           /* nullable [N] */
+  void* workspace;
+  int64_t workspace_bytes; /* >= pna_posttrans_dw_workspace_bytes(M, N, n_scaler, K, Kh) */
+} pna_posttrans_dw_args;
+
+int64_t pna_posttrans_dw_workspace_bytes(int64_t M, int32_t N, int32_t n_scaler, int32_t K, int32_t Kh);
+int pna_posttrans_dw_f32(const pna_posttrans_dw_args* args, pna_stream_t stream);
+
+/* The same gradient for the rows of a DEGREE PLAN (pna_amd/degree_groups.py: virtual rows in 128-row tiles of one in-degree).  The
+ * degree scalers are functions of the in-degree alone (models/dgl/scalers.py:7-19), so with the rows walked in plan order
+ *   grad_w block s = sum over degree runs  group_scale[group][s] * sum_{m in run} gy[m]^T a[m]
+ * needs one unscaled copy of gy and a third of the multiply-adds; the rows are loaded through row_perm (no packing pass).
+ * Covers the plan's group rows only: the caller adds the (few) rest rows' part.  Workgroup w walks tiles [wg_range[2w],
+ * wg_range[2w+1]) and writes one partial product per degree run it meets into workspace entries wg_entry[w], wg_entry[w] + 1, ...;
+ * entry_group[e] = the degree group of entry e.  N <= 80, K + Kh + 1 <= 384, n_scaler in 1..3. */
+typedef struct pna_posttrans_dw_grouped_args {
+  uint32_t struct_size;    /* sizeof(pna_posttrans_dw_grouped_args) of the CALLER's header (ABI 19): a shorter struct is refused with PNA_E_INVALID */
+  uint32_t _abi_reserved;  /* 0 */
+  const float* gy;         /* (n_nodes, ldg) */
+  int64_t ldg;
+  int32_t N;
+  int32_t n_scaler;
+  const float* a;          /* (n_nodes, lda): aggregate in NODE order, K columns */
+  int64_t lda;
+  int32_t K;
+  int32_t Kh;
+  const float* h;          /* nullable (n_nodes, ldh) */
+  int64_t ldh;
+  const int32_t* row_perm;    /* [128 * n_tiles]: node of every virtual row, -1 = padding */
+  const int32_t* tile_group;  /* [n_tiles]: degree group of every 128-row tile, runs of equal values */
+  const int32_t* wg_range;    /* [n_workgroups][2] */
+  const int32_t* wg_entry;    /* [n_workgroups] */
+  int32_t n_workgroups;
+  int32_t n_entries;
+  const int32_t* entry_group; /* [n_entries] */
+  const float* group_scale;   /* [n_groups][n_scaler] */
+  float* grad_w;           /* (N, ldw) */
+  int64_t ldw;
+  float* grad_b;           /* nullable [N] */
+  void* workspace;
+  int64_t workspace_bytes; /* >= pna_posttrans_dw_grouped_workspace_bytes(N, K, Kh, n_entries) */
+} pna_posttrans_dw_grouped_args;
+
+int64_t pna_posttrans_dw_grouped_workspace_bytes(int32_t N, int32_t K, int32_t Kh, int32_t n_entries);
+int pna_posttrans_dw_grouped_f32(const pna_posttrans_dw_grouped_args* args, pna_stream_t stream);
+
 /* ---- batching + destination-sorted CSR on the device ----------------------------------
  *
  * Replaces dgl.batch (realworld_benchmark/data/molecules.py:153-164: offset + concatenate the member graphs' edge

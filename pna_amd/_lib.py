@@ -173,6 +173,30 @@ class PnaSmallLinearArgs(_Args):
     ]
 
 
+class PnaPosttransDwArgs(_Args):
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32), ("_abi_reserved", ctypes.c_uint32),
+        ("gy", ctypes.c_void_p), ("ldg", ctypes.c_int64), ("M", ctypes.c_int64), ("N", ctypes.c_int32), ("n_scaler", ctypes.c_int32),
+        ("a", ctypes.c_void_p), ("lda", ctypes.c_int64), ("K", ctypes.c_int32), ("Kh", ctypes.c_int32),
+        ("h", ctypes.c_void_p), ("ldh", ctypes.c_int64), ("row_scale", ctypes.c_void_p * PNA_MAX_SCALER),
+        ("grad_w", ctypes.c_void_p), ("ldw", ctypes.c_int64), ("grad_b", ctypes.c_void_p),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
+    ]
+
+
+class PnaPosttransDwGroupedArgs(_Args):
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32), ("_abi_reserved", ctypes.c_uint32),
+        ("gy", ctypes.c_void_p), ("ldg", ctypes.c_int64), ("N", ctypes.c_int32), ("n_scaler", ctypes.c_int32),
+        ("a", ctypes.c_void_p), ("lda", ctypes.c_int64), ("K", ctypes.c_int32), ("Kh", ctypes.c_int32),
+        ("h", ctypes.c_void_p), ("ldh", ctypes.c_int64),
+        ("row_perm", ctypes.c_void_p), ("tile_group", ctypes.c_void_p), ("wg_range", ctypes.c_void_p), ("wg_entry", ctypes.c_void_p),
+        ("n_workgroups", ctypes.c_int32), ("n_entries", ctypes.c_int32), ("entry_group", ctypes.c_void_p), ("group_scale", ctypes.c_void_p),
+        ("grad_w", ctypes.c_void_p), ("ldw", ctypes.c_int64), ("grad_b", ctypes.c_void_p),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
+    ]
+
+
 class PnaTowerLayerArgs(_Args):
     _fields_ = [
         ("struct_size", ctypes.c_uint32), ("_abi_reserved", ctypes.c_uint32),
@@ -247,6 +271,14 @@ def lib():
         L.pna_fused_degree_pack_f32.restype = ctypes.c_int
         L.pna_segreduce_bwd_pull_f32.argtypes = [ctypes.POINTER(PnaSegreduceBwdPullArgs), ctypes.c_void_p]
         L.pna_segreduce_bwd_pull_f32.restype = ctypes.c_int
+        L.pna_posttrans_dw_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+        L.pna_posttrans_dw_workspace_bytes.restype = ctypes.c_int64
+        L.pna_posttrans_dw_f32.argtypes = [ctypes.POINTER(PnaPosttransDwArgs), ctypes.c_void_p]
+        L.pna_posttrans_dw_f32.restype = ctypes.c_int
+        L.pna_posttrans_dw_grouped_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+        L.pna_posttrans_dw_grouped_workspace_bytes.restype = ctypes.c_int64
+        L.pna_posttrans_dw_grouped_f32.argtypes = [ctypes.POINTER(PnaPosttransDwGroupedArgs), ctypes.c_void_p]
+        L.pna_posttrans_dw_grouped_f32.restype = ctypes.c_int
         L.pna_bn_tail_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32]
         L.pna_bn_tail_workspace_bytes.restype = ctypes.c_int64
         for fn in (L.pna_bn_tail_fwd_f32, L.pna_bn_tail_bwd_f32):

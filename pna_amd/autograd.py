@@ -369,12 +369,18 @@ def M_rows(t):
     return t.shape[0]
 
 
+DW_KERNEL = os.environ.get("PNA_AMD_DW_KERNEL", "1") != "0"    # 0: the library route (slab-batched GEMM) for the weight gradient
+DW_GROUPED = os.environ.get("PNA_AMD_DW_GROUPED", "1") != "0"  # 0: per-row scalers (three scaled copies of gy inside the kernel)
+DW_MIN_ROWS = int(os.environ.get("PNA_AMD_DW_MIN_ROWS", "4096"))  # below: a molecule batch's product is one small library GEMM
+
+
 class PosttransFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, agg, K, weight, bias, row_scales, h_self):
+    def forward(ctx, agg, K, weight, bias, row_scales, h_self, degree_graph=None):
         w = weight if weight.stride(-1) == 1 else weight.contiguous()
         y = ops.posttrans(agg, K, w, row_scales, bias, h_self)
         ctx.K, ctx.row_scales = K, row_scales
+        ctx.degree_graph = degree_graph                   # the graph whose DEGREE scalers row_scales are (or None): see backward
         ctx.save_for_backward(agg, weight, h_self)
         ctx.has_bias = bias is not None
         return y
@@ -389,16 +395,21 @@ class PosttransFn(torch.autograd.Function):
         # G = [scale_0 (.) gy | scale_1 (.) gy | ...]  (M, S*N): one operand for both big products, so that each is ONE
         # library GEMM (three (N x M)(M x K) products with M = 1e6 ran at 20 TF/s; the fused (S*N x M)(M x K) one tiles better)
         N = gy.shape[1]
-        if S == 1 and scales[0] is None:
-            G = gy
-        else:                                             # written block by block into place (mul + cat cost a second pass: 0.65 ms at C3)
-            G3 = gy.new_empty(gy.shape[0], S, N)
-            for s, rs in enumerate(scales):
-                if rs is None:
-                    G3[:, s].copy_(gy)
-                else:
-                    torch.mul(gy, rs.unsqueeze(1), out=G3[:, s])
-            G = G3.view(gy.shape[0], S * N)
+        _G = []
+
+        def scaled_blocks():                              # (only the library routes below need the scaled copies of gy)
+            if not _G:
+                if S == 1 and scales[0] is None:
+                    _G.append(gy)
+                else:                                     # written block by block into place (mul + cat cost a second pass: 0.65 ms at C3)
+                    G3 = gy.new_empty(gy.shape[0], S, N)
+                    for s, rs in enumerate(scales):
+                        if rs is None:
+                            G3[:, s].copy_(gy)
+                        else:
+                            torch.mul(gy, rs.unsqueeze(1), out=G3[:, s])
+                    _G.append(G3.view(gy.shape[0], S * N))
+            return _G[0]
         g_agg = g_w = g_b = g_h = None
         if ctx.needs_input_grad[0]:
             # d agg = sum_s scale_s (.) (gy W_s) is the forward contraction with the roles of K and N swapped: input gy (M, N),
@@ -408,20 +419,37 @@ class PosttransFn(torch.autograd.Function):
                 wt = torch.cat([weight[:, Kh + s * K:Kh + (s + 1) * K].t() for s in range(S)], dim=1).contiguous()   # (K, S*N)
                 g_agg = ops.posttrans(gy.contiguous(), N, wt, scales, None, arith="bf16x3")
             else:
-                g_agg = G @ torch.cat([weight[:, Kh + s * K:Kh + (s + 1) * K] for s in range(S)], dim=0)
+                g_agg = scaled_blocks() @ torch.cat([weight[:, Kh + s * K:Kh + (s + 1) * K] for s in range(S)], dim=0)
             if agg.shape[1] != K:
                 full = torch.zeros_like(agg)
                 full[:, :K] = g_agg
                 g_agg = full
+        want_b = ctx.has_bias and ctx.needs_input_grad[3]
         if ctx.needs_input_grad[2]:
-            gw = _tall_tn(G, a)                                                    # (S*N, K): block s = (scale_s gy)^T a
-            parts = ([_tall_tn(gy, h_self)] if Kh else []) + [gw[s * N:(s + 1) * N] for s in range(S)]
-            g_w = torch.cat(parts, dim=1)
-        if ctx.has_bias and ctx.needs_input_grad[3]:
+            # round 4: weight (and bias) gradient on the hand-written bf16x3 kernel (pna_posttrans_dw_f32: no scaled copies of gy, no
+            # vendor GEMM on the training step; deterministic); shapes outside it keep the slab-batched library route
+            res = None
+            if DW_KERNEL and gy.is_cuda and M_rows(gy) >= DW_MIN_ROWS:
+                dg = ctx.degree_graph
+                if dg is not None and DW_GROUPED and dg.num_nodes == M_rows(gy):
+                    # the rows in the graph's degree-plan order: 32 consecutive rows share their scaler values (ops.posttrans_dw_grouped)
+                    from . import degree_groups as DG
+                    plan = DG.plan_of(dg)
+                    if plan.G > 0 and plan.NR <= DG.MAX_REST_FRACTION * dg.num_nodes:
+                        res = ops.posttrans_dw_grouped(gy, a, K, h_self, scales, plan, want_bias=want_b)
+                if res is None:
+                    res = ops.posttrans_dw(gy, a, K, h_self, scales, want_bias=want_b)
+            if res is not None:
+                g_w, g_b = res
+            else:
+                gw = _tall_tn(scaled_blocks(), a)                                  # (S*N, K): block s = (scale_s gy)^T a
+                parts = ([_tall_tn(gy, h_self)] if Kh else []) + [gw[s * N:(s + 1) * N] for s in range(S)]
+                g_w = torch.cat(parts, dim=1)
+        if want_b and g_b is None:
             g_b = _column_sums(gy)
         if Kh and ctx.needs_input_grad[5]:
             g_h = gy @ weight[:, :Kh]
-        return g_agg, None, g_w, g_b, None, g_h
+        return g_agg, None, g_w, g_b, None, g_h, None
 
 
 def bn_tail_applies(bn, y, residual):

@@ -228,6 +228,30 @@ class DegreePlan:
         self._roles = (key, out)
         return out
 
+    def dw_tables(self, n_wgs):
+        """Tables of pna_posttrans_dw_grouped_f32 (the weight gradient over the group rows in plan order), once per plan and grid:
+        (tile_group [nt], wg_range [n_wgs][2] -- equally long contiguous tile ranges --, wg_entry [n_wgs], entry_group [n_entries]):
+        a workgroup writes one partial product per run of equal degree groups inside its range; the entries are numbered in tile
+        order."""
+        hit = self.__dict__.get("_dw_tables")
+        if hit is not None and hit[0] == int(n_wgs):
+            return hit[1]
+        dev = self.perm.device
+        nt = self.NV // TILE
+        n_wgs = int(n_wgs)
+        tg = self.tile_image.to(torch.int32).contiguous()
+        b = (torch.arange(n_wgs + 1, device=dev, dtype=torch.long) * nt) // n_wgs
+        lo, hi = b[:-1], b[1:]
+        change = torch.zeros(nt, dtype=torch.bool, device=dev)
+        if nt > 1:
+            change[1:] = tg[1:] != tg[:-1]
+        starts = torch.unique(torch.cat([lo[hi > lo], torch.nonzero(change).flatten()]))        # sorted: first tile of every entry
+        wg_entry = torch.searchsorted(starts, lo.clamp(max=max(nt - 1, 0))).to(torch.int32)
+        out = (tg, torch.stack([lo, hi], dim=1).to(torch.int32).contiguous(), wg_entry.contiguous(),
+               tg[starts].contiguous(), int(starts.numel()))
+        self.__dict__["_dw_tables"] = (n_wgs, out)
+        return out
+
     def roles_err(self):
         """int32 [1], zero: the give-up flag of pna_fused_roles_f32 (checked by the tests and by bench.py, never on the hot path)."""
         if self._roles_err is None:

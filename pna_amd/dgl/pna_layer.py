@@ -448,7 +448,7 @@ class PNASimpleLayer(nn.Module):
                                    f"({self.out_dim}) at non-singleton dimension 1")   # same failure as the reference (:213)
             return PF.posttrans(agg, K, lin.weight, lin.bias, scales, bn=self.batchnorm_h if self.batch_norm else None,
                                 relu=True, residual=h_in if self.residual else None)
-        y = PF.posttrans(agg, K, lin.weight, lin.bias, scales)
+        y = PF.posttrans(agg, K, lin.weight, lin.bias, scales, degree_graph=graph if type(graph) is Graph else None)
         y = self.posttrans.tail(y)
         if self.batch_norm:
             from ..autograd import bn_relu_residual, bn_tail_applies

@@ -82,7 +82,7 @@ def _fold_batchnorm(bn):
 
 
 def posttrans(agg, K, weight, bias, row_scales, h_self=None, *, row_post=None, bn=None, relu=False, residual=None,
-              out=None):
+              out=None, degree_graph=None):
     """y = W [h_self | s_0*agg | s_1*agg | ...] + b with `weight` in the reference's nn.Linear layout
     (N, Kh + S*K) -- models/dgl/pna_layer.py:65-68 / :206 -- computed without materialising the
     scaled copies of `agg` (row_scales[s] is a per-row vector or None for the identity scaler).
@@ -110,7 +110,9 @@ def posttrans(agg, K, weight, bias, row_scales, h_self=None, *, row_post=None, b
         from .autograd import PosttransFn
         if row_post is not None or bn is not None or relu or residual is not None:
             raise RuntimeError("the fused posttrans tail is inference-only")
-        return PosttransFn.apply(agg, K, weight, bias, tuple(row_scales), h_self)
+        # degree_graph: the (unsharded) Graph whose degree scalers `row_scales` are -- lets the weight gradient walk the rows in the
+        # graph's degree-plan order (autograd.PosttransFn.backward)
+        return PosttransFn.apply(agg, K, weight, bias, tuple(row_scales), h_self, degree_graph)
     col_scale = col_shift = None
     if bn is not None:
         if bn.training:

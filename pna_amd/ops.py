@@ -165,6 +165,105 @@ def pack_posttrans_weight_x3(weight: torch.Tensor, K: int, n_scaler: int, Kh: in
     return w_img, wh_img
 
 
+def posttrans_dw(gy: torch.Tensor, a_mat: torch.Tensor, K: int, h: Optional[torch.Tensor], row_scales: Sequence[Optional[torch.Tensor]],
+                 want_bias: bool = True):
+    """(grad_w (N, Kh + S*K), grad_b (N) or None) of the posttrans contraction through pna_posttrans_dw_f32 (bf16x3, deterministic),
+    or None when the shape is outside the kernel's (the caller keeps its library route): see include/pna_amd.h."""
+    M, N, S = gy.shape[0], gy.shape[1], len(row_scales)
+    Kh = 0 if h is None else h.shape[1]
+    if not gy.is_cuda or gy.dtype != torch.float32 or a_mat.dtype != torch.float32 or M < 1 or not 1 <= S <= _lib.PNA_MAX_SCALER:
+        return None
+    if row_scales[0] is not None and (Kh or want_bias):     # the h panel and the bias ride on the FIRST copy of gy: it must be unscaled
+        return None
+    L = _lib.lib()
+    nb = L.pna_posttrans_dw_workspace_bytes(M, N, S, K, Kh)
+    if nb < 0:
+        return None
+    gy = gy if gy.stride(1) == 1 else gy.contiguous()
+    a_mat = a_mat if a_mat.stride(1) == 1 else a_mat.contiguous()
+    if h is not None and h.stride(1) != 1:
+        h = h.contiguous()
+    dev = gy.device
+    gw = torch.empty(N, Kh + S * K, dtype=torch.float32, device=dev)
+    gb = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
+    ws = torch.empty(nb // 4, dtype=torch.float32, device=dev)
+    a = _lib.PnaPosttransDwArgs()
+    a.gy, a.ldg, a.M, a.N, a.n_scaler = _lib.dev_ptr(gy, torch.float32, "gy"), gy.stride(0), M, N, S
+    a.a, a.lda, a.K, a.Kh = _lib.dev_ptr(a_mat, torch.float32, "a"), a_mat.stride(0), K, Kh
+    if h is not None:
+        a.h, a.ldh = _lib.dev_ptr(h, torch.float32, "h"), h.stride(0)
+    keep = []
+    for s, rs in enumerate(row_scales):
+        if rs is not None:
+            rs = rs.reshape(-1)
+            rs = rs if rs.is_contiguous() and rs.dtype == torch.float32 else rs.to(torch.float32).contiguous()
+            keep.append(rs)
+            a.row_scale[s] = _lib.dev_ptr(rs, torch.float32, "row_scale")
+    a.grad_w, a.ldw = _lib.dev_ptr(gw, torch.float32, "grad_w"), gw.stride(0)
+    if gb is not None:
+        a.grad_b = _lib.dev_ptr(gb, torch.float32, "grad_b")
+    a.workspace, a.workspace_bytes = ws.data_ptr(), nb
+    _lib.check(L.pna_posttrans_dw_f32(ctypes.byref(a), _lib.stream_ptr(dev)), "pna_posttrans_dw_f32")
+    return gw, gb
+
+
+def posttrans_dw_grouped(gy, a_mat, K, h, row_scales, plan, want_bias=True):
+    """posttrans_dw over the rows of a degree plan, in plan order (pna_posttrans_dw_grouped_f32: one unscaled copy of gy, a third of
+    the multiply-adds, the scalers applied per degree run in the reduction) + the plan's few rest rows through small library
+    products.  `row_scales` must be the plan's graph's DEGREE scalers (functions of the in-degree).  None: shape outside the kernel."""
+    N, S = gy.shape[1], len(row_scales)
+    Kh = 0 if h is None else h.shape[1]
+    L = _lib.lib()
+    if (not gy.is_cuda or gy.dtype != torch.float32 or plan.G == 0 or not 1 <= S <= 3
+            or L.pna_posttrans_dw_grouped_workspace_bytes(N, K, Kh, 1) < 0):
+        return None
+    dev = gy.device
+    n_wg = torch.cuda.get_device_properties(dev).multi_processor_count
+    tg, wg_range, wg_entry, entry_group, n_entries = plan.dw_tables(n_wg)
+    gy = gy if gy.stride(1) == 1 else gy.contiguous()
+    a_mat = a_mat if a_mat.stride(1) == 1 else a_mat.contiguous()
+    if h is not None and h.stride(1) != 1:
+        h = h.contiguous()
+    key = tuple(None if rs is None else (rs.data_ptr(), rs._version) for rs in row_scales)
+    hit = plan.__dict__.get("_dw_gscale")
+    if hit is None or hit[0] != key:
+        gscale = torch.ones(plan.G, S, dtype=torch.float32, device=dev)
+        for s, rs in enumerate(row_scales):
+            if rs is not None:
+                gscale[:, s] = rs.reshape(-1)[plan.group_first_row]
+        rest = [None if rs is None else rs.reshape(-1)[plan.rest_rows].unsqueeze(1).contiguous() for rs in row_scales] if plan.NR else None
+        hit = plan.__dict__["_dw_gscale"] = (key, gscale.contiguous(), rest)
+    gscale, rest_scales = hit[1], hit[2]
+    gw = torch.empty(N, Kh + S * K, dtype=torch.float32, device=dev)
+    gb = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
+    nb = L.pna_posttrans_dw_grouped_workspace_bytes(N, K, Kh, n_entries)
+    ws = torch.empty(nb // 4, dtype=torch.float32, device=dev)
+    a = _lib.PnaPosttransDwGroupedArgs()
+    a.gy, a.ldg, a.N, a.n_scaler = _lib.dev_ptr(gy, torch.float32, "gy"), gy.stride(0), N, S
+    a.a, a.lda, a.K, a.Kh = _lib.dev_ptr(a_mat, torch.float32, "a"), a_mat.stride(0), K, Kh
+    if h is not None:
+        a.h, a.ldh = _lib.dev_ptr(h, torch.float32, "h"), h.stride(0)
+    a.row_perm, a.tile_group = _lib.dev_ptr(plan.perm, torch.int32, "row_perm"), _lib.dev_ptr(tg, torch.int32, "tile_group")
+    a.wg_range, a.wg_entry = _lib.dev_ptr(wg_range, torch.int32, "wg_range"), _lib.dev_ptr(wg_entry, torch.int32, "wg_entry")
+    a.n_workgroups, a.n_entries = n_wg, n_entries
+    a.entry_group, a.group_scale = _lib.dev_ptr(entry_group, torch.int32, "entry_group"), _lib.dev_ptr(gscale, torch.float32, "group_scale")
+    a.grad_w, a.ldw = _lib.dev_ptr(gw, torch.float32, "grad_w"), gw.stride(0)
+    if gb is not None:
+        a.grad_b = _lib.dev_ptr(gb, torch.float32, "grad_b")
+    a.workspace, a.workspace_bytes = ws.data_ptr(), nb
+    _lib.check(L.pna_posttrans_dw_grouped_f32(ctypes.byref(a), _lib.stream_ptr(dev)), "pna_posttrans_dw_grouped_f32")
+    if plan.NR:                                            # hub rows and rare degrees: a few thousand rows, plain products
+        rr = plan.rest_rows
+        g_r, a_r = gy.index_select(0, rr), a_mat.index_select(0, rr)[:, :K]
+        parts = [g_r.t() @ h.index_select(0, rr)] if Kh else []
+        for rs in rest_scales:
+            parts.append((g_r if rs is None else g_r * rs).t() @ a_r)
+        gw += torch.cat(parts, dim=1)
+        if gb is not None:
+            gb += g_r.sum(0)
+    return gw, gb
+
+
 def posttrans(a_mat: torch.Tensor, K: int, weight: torch.Tensor, row_scales: Sequence[Optional[torch.Tensor]],
               bias: Optional[torch.Tensor] = None, h: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
               row_post: Optional[torch.Tensor] = None, col_scale: Optional[torch.Tensor] = None,

@@ -24,6 +24,8 @@ CSRC = os.path.join(ROOT, "pna_amd", "csrc")
                                                                                         "k_segreduce_fastILi4ELb1ELb0ELb0ELi1E": 104, "k_segreduce_fastILi4ELb1ELb0ELb0ELi2E": 104}),
                                           ("pna_posttrans.hip", {}), ("pna_pack.hip", {}), ("pna_tower_fused.hip", {}), ("pna_fused.hip", {}),
                                           ("pna_segreduce_bwd.hip", {}), ("pna_fused_roles.hip", {"k_fused_roles": 256}),
+                                          # the weight-gradient kernels: two 4-wavefront workgroups / one 8-wavefront workgroup per CU
+                                          ("pna_posttrans_dw.hip", {"k_posttrans_dw": 256}),
                                           # the one-kernel layer: two 4-wavefront workgroups per CU (the production instantiations: DUMP = false)
                                           # (incl. the tower instantiations ...ELb0ELb1ELb0EEE of the two-full-block shapes)
                                           ("pna_fused_degree.hip", {"k_fused_degreeILi1ELb0ELb0E": 256, "k_fused_degreeILi1ELb1ELb0E": 256,

@@ -529,3 +529,84 @@ def test_tower_layer_training_step_golden(cuda_device, name):
     for k, b in layer.named_buffers():
         if "running" in k:
             torch.testing.assert_close(b.cpu(), a["after/" + k], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("M,N,K,Kh,scal", [(100_000, 75, 300, 75, "x12"), (1000, 75, 300, 75, "x12"), (97, 80, 300, 80, "x12"), (33, 16, 64, 0, "x"),
+                                           (20_011, 40, 160, 0, "12"), (5000, 75, 300, 0, "x1"), (70_001, 20, 80, 20, "x12"), (4097, 64, 256, 64, "x")])
+def test_posttrans_weight_gradient_kernel(cuda_device, M, N, K, Kh, scal):
+    """pna_posttrans_dw_f32 (round 4: the weight / bias gradient of the posttrans Linear on a hand-written bf16x3 kernel instead of the
+    vendor GEMM) against the float64 products, per element: 1e-5 relative + the fp32 floor of a length-M sum (sum_m |terms| x 2^-22)."""
+    from pna_amd import ops
+    gen = torch.Generator(device=cuda_device).manual_seed(M + N)
+    gy = torch.randn(M, N + 3, device=cuda_device, generator=gen)[:, :N]
+    a = torch.randn(M, K + 4, device=cuda_device, generator=gen)[:, :K] * 3.0 + 0.5
+    h = torch.randn(M, Kh, device=cuda_device, generator=gen) if Kh else None
+    amp = torch.rand(M, device=cuda_device, generator=gen) + 0.5
+    att = 1.0 / amp
+    scales = [{"x": None, "1": amp, "2": att}[c] for c in scal]
+    bias = scales[0] is None                               # (the bias and the h panel need an unscaled first copy of gy)
+    res = ops.posttrans_dw(gy, a, K, h, scales, want_bias=bias)
+    assert res is not None
+    gw, gb = res
+    again = ops.posttrans_dw(gy, a, K, h, scales, want_bias=bias)
+    assert torch.equal(gw, again[0]) and (not bias or torch.equal(gb, again[1]))       # deterministic
+    g64, a64 = gy.double(), a.double()
+    blocks, floors = [], []
+    if Kh:
+        blocks.append(g64.t() @ h.double()); floors.append(g64.abs().t() @ h.double().abs())
+    for rs in scales:
+        gs = g64 if rs is None else g64 * rs.double().unsqueeze(1)
+        blocks.append(gs.t() @ a64); floors.append(gs.abs().t() @ a64.abs())
+    want, floor = torch.cat(blocks, dim=1), torch.cat(floors, dim=1)
+    err = (gw.double() - want).abs()
+    tol = 1e-5 * want.abs() + floor * 2.0 ** -22
+    assert (err <= tol).all(), float((err / tol).max())
+    if bias:
+        wb = g64.sum(0)
+        assert ((gb.double() - wb).abs() <= 1e-5 * wb.abs() + g64.abs().sum(0) * 2.0 ** -22).all()
+    else:
+        assert ops.posttrans_dw(gy, a, K, h, scales, want_bias=True) is None
+
+
+@pytest.mark.parametrize("V,E,F,N", [(60_000, 600_000, 75, 75), (30_000, 240_000, 20, 24), (50_000, 500_000, 64, 80)])
+def test_posttrans_weight_gradient_in_degree_plan_order(cuda_device, V, E, F, N):
+    """pna_posttrans_dw_grouped_f32: the same gradient with the rows walked in the degree plan's order (one unscaled copy of gy, the
+    degree scalers applied per degree run in the reduction) + the plan's rest rows -- against the float64 products over ALL rows."""
+    from pna_amd import Graph, degree_groups as DG, ops
+    from pna_amd.dgl.pna_layer import _row_scales
+    from pna_amd.synth import powerlaw_graph
+    src, dst = powerlaw_graph(V, E, seed=99, device=cuda_device)
+    g = Graph(src, dst, V)
+    plan = DG.plan_of(g)
+    assert plan.G > 3 and plan.NR > 0
+    scales = _row_scales(g, ["identity", "amplification", "attenuation"], {"log": torch.tensor(2.2)}, cuda_device)
+    gen = torch.Generator(device=cuda_device).manual_seed(V)
+    K = 4 * F
+    gy = torch.randn(V, N, device=cuda_device, generator=gen)
+    a = torch.randn(V, K + 4, device=cuda_device, generator=gen)[:, :K] * 2.0 - 0.3
+    h = torch.randn(V, F, device=cuda_device, generator=gen)
+    res = ops.posttrans_dw_grouped(gy, a, K, h, scales, plan)
+    assert res is not None
+    gw, gb = res
+    again = ops.posttrans_dw_grouped(gy, a, K, h, scales, plan)
+    assert torch.equal(gw, again[0]) and torch.equal(gb, again[1])
+    g64, a64 = gy.double(), a.double()
+    blocks, floors = [g64.t() @ h.double()], [g64.abs().t() @ h.double().abs()]
+    for rs in scales:
+        gs = g64 if rs is None else g64 * rs.double().reshape(-1, 1)
+        blocks.append(gs.t() @ a64); floors.append(gs.abs().t() @ a64.abs())
+    want, floor = torch.cat(blocks, dim=1), torch.cat(floors, dim=1)
+    err = (gw.double() - want).abs()
+    tol = 1e-5 * want.abs() + floor * 2.0 ** -22
+    assert (err <= tol).all(), float((err / tol).max())
+    wb = g64.sum(0)
+    assert ((gb.double() - wb).abs() <= 1e-5 * wb.abs() + g64.abs().sum(0) * 2.0 ** -22).all()
+    row = ops.posttrans_dw(gy, a, K, h, scales)            # the per-row-scaler kernel agrees to the same bar
+    assert ((row[0].double() - want).abs() <= tol).all()
+
+
+def test_posttrans_weight_gradient_kernel_declines_other_shapes(cuda_device):
+    from pna_amd import ops
+    gy, a = torch.randn(5000, 80, device=cuda_device), torch.randn(5000, 320, device=cuda_device)
+    assert ops.posttrans_dw(gy, a, 320, torch.randn(5000, 80, device=cuda_device), [None, None, None]) is None      # K + Kh + 1 = 401 > 384
+    assert ops.posttrans_dw(torch.randn(5000, 128, device=cuda_device), a, 320, None, [None, None]) is None         # S N = 256 > 240

@@ -50,6 +50,30 @@ from torch.profiler import profile, ProfilerActivity  # noqa: E402
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
     step()
     torch.cuda.synchronize()
-rows = sorted(prof.key_averages(), key=lambda r: -r.device_time_total)[:12]
+rows = sorted(prof.key_averages(), key=lambda r: -r.device_time_total)[:14]
 res["top_kernels_us"] = {r.key[:70]: round(r.device_time_total, 1) for r in rows}
+# a roofline block per kernel of the step: ALGORITHMIC bytes of the kernel's launches in one step / their summed
+# device time (torch profiler, one traced step), against 8 TB/s.  N = F here; the arg ranks are 16-bit, the arg indices 32-bit.
+N = F
+HBM = 8.0e12
+alg = {
+    "k_segreduce_fast": ("forward gather with arg tracking: E (4F + 4) read; V (16F aggregate + 8F arg indices) written", E * (4 * F + 4) + V * 24 * F),
+    "k_posttrans_x3": ("forward contraction (V (16F + 4F) read, 4N written) + d agg = gy W^T (V 4N read, 16F written): two launches", V * (20 * F + 4 * N) + V * (4 * N + 16 * F)),
+    "k_bwd_rowprep": ("rowprep + ranks: V (16F d agg + 8F mean / std + 8F arg indices) read; V (8F table + 4F ranks) written", V * 44 * F),
+    "k_bwd_pull": ("pull over the transposed graph: per out-edge R1 | R2 (8F), G_max | G_min (8F), two 16-bit rank rows (4F), the id and its rank (8); V (4F x + 4F grad) per row", E * (20 * F + 8) + V * 8 * F),
+    "k_posttrans_dw_grouped(": ("weight gradient in degree-plan order: V (4N gy + 16F aggregate + 4F h) read once", V * (4 * N + 20 * F)),
+    "k_posttrans_dw(": ("weight gradient with per-row scalers: gy read by three column thirds", V * (12 * N + 20 * F)),
+    "k_bn_apply": ("BatchNorm tail forward + backward element-wise passes", V * 4 * N * 3 + V * 4 * N * 3),
+    "k_bn_colsums": ("BatchNorm tail column sums, forward + backward", V * 4 * N + V * 8 * N),
+}
+roof = []
+for key, (what, nbytes) in alg.items():
+    hits = [r for r in prof.key_averages() if key in r.key]
+    if hits:
+        us = sum(r.device_time_total for r in hits)
+        roof.append({"kernel": key.rstrip("("), "what": what, "launches": int(sum(r.count for r in hits)), "us": round(us, 1),
+                     "algorithmic_bytes": int(nbytes), "achieved_GB_per_s": nbytes / us / 1e3, "frac_of_8_TB_per_s": nbytes / (us * 1e-6) / HBM})
+res["roofline_per_kernel"] = roof
+lib = [r.key[:60] for r in prof.key_averages() if r.key.startswith("Cijk_") and r.device_time_total > 50]
+res["vendor_gemm_kernels_over_50us"] = lib
 print(json.dumps(res, indent=1))
