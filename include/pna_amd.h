@@ -297,7 +297,10 @@ int pna_segreduce_bwd_argscatter_f32(const pna_segreduce_bwd_args* args, pna_str
  * table) and grad_x (n_src rows; rows of hub sources -- work-list records with slot >= 0 -- must be ZERO on entry, every other row is
  * overwritten).  col_t / rank_t: destination v and in-list rank k of every edge of the TRANSPOSED CSR (edges sorted by source);
  * items_t: its work list {source row, beg, end, slot} (slot < 0: whole row; slot >= 0: a segment, added atomically).  ranks:
- * workspace (V, ld_rank >= 2 T F) of uint16 -- in-degrees up to 65534.  4 <= F <= 256. */
+ * workspace (V, ld_rank >= 2 T F) of uint16 -- in-degrees up to 65534.  4 <= F <= 256.  * PACKED rows (round 4): with run_rowprep != 0, ld_table >= 5 T F and ranks == (uint16_t*)(table + 4 T F), the rowprep pass also
+ * copies G_max | G_min to table[v][2 T F .. 4 T F) and the pull reads ONE contiguous row [R1 | R2 | G_max | G_min | ranks] per
+ * out-edge (12 cache lines at F = 75 with a 1536-byte pitch instead of ~14.7 for three separate pieces); ld_rank then = 2 ld_table.
+ */
 typedef struct pna_segreduce_bwd_pull_args {
   uint32_t struct_size;    /* sizeof(pna_segreduce_bwd_pull_args) of the CALLER's header (ABI 19): a shorter struct is refused with PNA_E_INVALID */
   uint32_t _abi_reserved;  /* 0 */

@@ -240,6 +240,7 @@ struct PArgs {
   const int32_t* argmax; const int32_t* argmin;
   float* table; float* grad_dst; float* grad_x;
   unsigned short* ranks;             // nullable: (V, ld_rank) [rank of argmax | rank of argmin] in the row's in-edge list (0xFFFF: none)
+  float* gcopy;                      // nullable: packed table rows -- G_max | G_min copied to table[v][2 T F .. 4 T F) (pna_segreduce_bwd_pull_f32)
   long ld_g, ld_stat, ld_dst, ld_table, ld_gd, ld_arg, ld_gx, ts_in, ts_g, ts_stat, ld_rank;
   int V, F, T, has_var;
 };
@@ -280,6 +281,10 @@ __global__ __launch_bounds__(kBlock) void k_bwd_rowprep(const PArgs a) {
       if (a.g[PNA_AGG_MIN]) gd = gd + a.g[PNA_AGG_MIN][og];
     }
     a.grad_dst[(size_t)v * a.ld_gd + c] = gd;
+  }
+  if (a.gcopy) {                     // packed rows: the pull then reads ONE contiguous 20 T F-byte row per out-edge instead of three pieces
+    a.gcopy[(size_t)v * a.ld_table + c] = a.g[PNA_AGG_MAX] ? a.g[PNA_AGG_MAX][og] : 0.f;
+    a.gcopy[(size_t)v * a.ld_table + TF + c] = a.g[PNA_AGG_MIN] ? a.g[PNA_AGG_MIN][og] : 0.f;
   }
   if (a.ranks) {                     // for pna_segreduce_bwd_pull_f32: where in the row's in-edge list argmax / argmin sit
     const size_t oa = (size_t)v * a.ld_arg + (size_t)t * a.ts_in + f;
@@ -512,8 +517,13 @@ extern "C" int pna_segreduce_bwd_pull_f32(const pna_segreduce_bwd_pull_args* q, 
                                         "(ld >= 2 T F), the transposed graph (col_t, rank_t, items_t), a ranks workspace (ld >= 2 T F) and 4 <= F <= 256");
   hipStream_t st = (hipStream_t)stream;
   const long n = (long)p->V * TF;
+  // PACKED rows (round 4): ld_table >= 5 T F and ranks == table + 4 T F floats -- one row [R1 | R2 | G_max | G_min | ranks] per node,
+  // 20 T F bytes contiguous: an out-edge touches 12 cache lines at F = 75 (pitch 1536 B) instead of ~14.7 for the three separate
+  // pieces (R1 | R2 in the table, G_max | G_min inside the aggregate's gradient row, the rank row).  Needs run_rowprep (the copy).
+  const bool packed = q->run_rowprep && q->ld_table >= 5L * TF && (const void*)q->ranks == (const void*)(q->table + 4L * TF);
   if (q->run_rowprep) {              // rowprep (table, grad_dst) and the ranks in ONE pass over the rows
     k.table = const_cast<float*>(q->table); k.ld_table = q->ld_table; k.ranks = q->ranks; k.ld_rank = q->ld_rank;
+    k.gcopy = packed ? const_cast<float*>(q->table) + 2L * TF : nullptr;
     hipLaunchKernelGGL(k_bwd_rowprep, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, k);
   } else {
     hipLaunchKernelGGL(k_bwd_ranks, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, p->rowptr, p->argmax, p->argmin, (long)p->ld_arg,
@@ -524,6 +534,7 @@ extern "C" int pna_segreduce_bwd_pull_f32(const pna_segreduce_bwd_pull_args* q, 
   a.items = q->items_t; a.col_t = q->col_t; a.rank_t = q->rank_t; a.table = q->table; a.gmax = k.g[PNA_AGG_MAX]; a.gmin = k.g[PNA_AGG_MIN];
   a.ranks = q->ranks; a.x = p->x; a.gx = p->grad_x;
   a.ld_table = q->ld_table; a.ld_g = p->ld_g; a.ld_rank = q->ld_rank; a.ldx = p->ldx; a.ld_gx = p->ld_gx; a.ts_g = k.ts_g;
+  if (packed) { a.gmax = q->table + 2L * TF; a.gmin = q->table + 3L * TF; a.ld_g = q->ld_table; a.ts_g = F; }
   a.n_items = q->n_items_t; a.F = F; a.T = T; a.TF = TF;
   a.L = (F + 3) / 4 > 64 ? 64 : (F + 3) / 4; a.G = 64 / a.L;
   const long groups = (long)kWaves * a.G;
