@@ -133,16 +133,18 @@ with torch.no_grad():
     eager_e = gpu_ms(lambda: lay_e(g, hd, ed, snorm))
     gf_e = GraphedForward(lambda x: lay_e(g, x, ed, snorm), hd)
     graphed_e = gpu_ms(lambda: gf_e(hd))
+    PF.SMALL_TOWER_ROWS = 0                                   # the same four-launch path for the layer WITHOUT edge features
+    try:                                                      # (a host-bound leg: timed BEFORE the CPU oracle below, whose OpenMP workers
+        eager_noe = gpu_ms(lambda: lay(g, hd, None, snorm))   #  keep spinning for a while and slowed it 10x in the first round-4 set)
+        eager_e_general = gpu_ms(lambda: lay_e(g, hd, ed, snorm))      # the edge-feature layer on the four-launch route (type table in registers)
+    finally:
+        PF.SMALL_TOWER_ROWS = small_rows
     ref_e = O.dgl_layer_forward(sd_e, src, dst, V, h, e_feat, snorm.cpu(), AGG.split(), SCA.split(), avg["log"], 5, False, True, True, True, True)
     err_e = (gf_e(hd).cpu() - ref_e).abs().max().item()
     err_e_eager = (lay_e(g, hd, ed, snorm).cpu() - ref_e).abs().max().item()
-    PF.SMALL_TOWER_ROWS = 0                                   # the same four-launch path for the layer WITHOUT edge features
-    try:
-        eager_noe = gpu_ms(lambda: lay(g, hd, None, snorm))
-    finally:
-        PF.SMALL_TOWER_ROWS = small_rows
 out["zinc_tower_layer_edge_feat"] = dict(graphs=128, V=V, E=E, hidden=75, towers=5, edge_dim=50, edge_types=4, eager_ms=eager_e, hipgraph_ms=graphed_e,
-                                         same_path_without_edge_features_eager_ms=eager_noe, max_abs_err_vs_oracle=err_e, max_abs_err_vs_oracle_eager_one_call_kernel=err_e_eager,
+                                         same_path_without_edge_features_eager_ms=eager_noe, eager_ms_four_launch_route=eager_e_general,
+                                         hipgraph_note="a captured hipGraph takes the per-edge route (the type table is read from e's VALUES: skipped while capturing)", max_abs_err_vs_oracle=err_e, max_abs_err_vs_oracle_eager_one_call_kernel=err_e_eager,
                                          max_rel_err_vs_oracle=err_e / ref_e.abs().max().item())
 
 # ---- configs[3]: MolHIV-shaped batch, PNASimpleLayer hidden 80, 2048 graphs ----

@@ -13,6 +13,8 @@ timeout 300 python bench.py --layers 4 --steps 10 --warmup 3 > $O/bench_layers4.
 timeout 600 python tools/bench_train.py > $O/train_step.json 2> $O/train_step.err; echo "train rc=$?"
 timeout 900 python tools/bench_configs.py > $O/configs.json 2> $O/configs.err; echo "configs rc=$?"
 timeout 300 python tools/tower_time.py $O/tower_time.json > $O/tower_time.log 2>&1; echo "tower rc=$?"
+timeout 300 python tools/dw_time.py > $O/dw_time.json 2> $O/dw_time.err; echo "dw rc=$?"
+timeout 400 python tools/block_pipeline_time.py > $O/block_pipeline.log 2>&1; echo "blocks rc=$?"; cp $P/gpurun_out/r04_block_pipeline_time.json $O/ 2>/dev/null
 cd /tmp; rm -rf $O/trace
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $P/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-cold --no-power-probe > $O/trace.log 2>&1; echo "trace rc=$?"
 find $O/trace -name "bench_kernel_stats.csv" -exec cp {} $O/bench_kernel_stats.csv \;
