@@ -720,7 +720,10 @@ typedef struct pna_tower_layer_args {
   const float* edge_table;   /* (n_edge_types, ld_edge_table): row t = W_e . ef_t of every tower, concatenated (n_tower * Fi columns) */
   int64_t ld_edge_table;
   int32_t n_edge_types;      /* 1..4 with edge_type */
-  int32_t _pad2;
+  int32_t no_self_panel;     /* != 0: the PNASimpleLayer form (models/dgl/pna_layer.py:197-206: messages are the raw source features, the
+                              * posttrans never reads the node's own h): no destination term (the second half of x_cat is not read) and zeros
+                              * instead of h against the image's (zero) self block -- so a node whose own feature is Inf / NaN keeps the
+                              * finite output the reference gives it instead of 0 * Inf = NaN */
 } pna_tower_layer_args;
 
 int pna_tower_layer_f32(const pna_tower_layer_args* args, pna_stream_t stream);

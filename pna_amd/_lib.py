@@ -211,7 +211,7 @@ class PnaTowerLayerArgs(_Args):
         ("mix_slope", ctypes.c_float), ("_pad", ctypes.c_int32),
         ("residual", ctypes.c_void_p), ("ld_res", ctypes.c_int64), ("y", ctypes.c_void_p), ("ldy", ctypes.c_int64),
         ("edge_type", ctypes.c_void_p), ("edge_table", ctypes.c_void_p), ("ld_edge_table", ctypes.c_int64),
-        ("n_edge_types", ctypes.c_int32), ("_pad2", ctypes.c_int32),
+        ("n_edge_types", ctypes.c_int32), ("no_self_panel", ctypes.c_int32),
     ]
 
 

@@ -197,6 +197,7 @@ struct TArgs {
   int No, mix_act; float mix_slope;
   const float* residual; long ld_res;
   float* y; long ldy;
+  int no_self;                   // the own-features operand tile is zeros (no [h] panel in this posttrans)
   const int32_t* etype; const float* etab; long ldet; int n_types;   // edge features that are <= 4 types: type per CSR edge, (n_types, T*Fi) table of W_e . ef
 #ifdef PNA_AMD_EXPERIMENTS
   unsigned long long* dbg;
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(kThreads) void k_tower_rows(const TArgs g) {
   // past the matrix's end (last tile) stay garbage: an MFMA row only feeds its own output row, which is never stored ----
   for (int i = tid; i < TH * kRows * Fi; i += kThreads) {
     const int t = i / (kRows * Fi), j = i - t * kRows * Fi, r = j / Fi, k = j - r * Fi;
-    HL[(t * kRows + r) * PH + k] = r < nrows ? g.h[(size_t)(r0 + r) * g.ldh + t * g.h_stride + k] : 0.f;
+    HL[(t * kRows + r) * PH + k] = (r < nrows && !g.no_self) ? g.h[(size_t)(r0 + r) * g.ldh + t * g.h_stride + k] : 0.f;
   }
   {
     const int pa = QA * 16 - 4 * Fi, ph = QH * 16 - Fi, pm = QM * 16 - TFo;
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(kThreads) void k_tower_rows(const TArgs g) {
 #pragma unroll
           for (int r = 0; r < 2; ++r) {
             s[r][j] = 0.f; q[r][j] = 0.f; mx[r][j] = -INFINITY; mn[r][j] = INFINITY;
-            dt[r][j] = cb + 64 * j < CF ? g.xcat[(size_t)(r0 + rw[r]) * g.ldx + TFi + c0 + cc[j]] : 0.f;
+            dt[r][j] = (cb + 64 * j < CF && !g.no_self) ? g.xcat[(size_t)(r0 + rw[r]) * g.ldx + TFi + c0 + cc[j]] : 0.f;
           }
         }
         for (int base = 0; base < maxdeg; base += 64) {
@@ -615,6 +616,7 @@ extern "C" int pna_tower_layer_f32(const pna_tower_layer_args* p, pna_stream_t s
   g.post_img = p->post_img; g.post_bias = p->post_bias; g.row_post = p->row_post; g.col_scale = p->col_scale; g.col_shift = p->col_shift;
   g.mix_img = p->mix_img; g.mix_bias = p->mix_bias; g.No = p->mix_img ? p->No : T * Fo; g.mix_act = p->mix_act; g.mix_slope = p->mix_slope;
   g.residual = p->residual; g.ld_res = (long)p->ld_res; g.y = p->y; g.ldy = (long)p->ldy;
+  g.no_self = p->no_self_panel != 0;
   g.etype = p->edge_type; g.etab = p->edge_table; g.ldet = (long)p->ld_edge_table; g.n_types = p->n_edge_types;
 #ifdef PNA_AMD_EXPERIMENTS
   g.dbg = nullptr;

@@ -538,11 +538,17 @@ _SIDE_STREAMS = {}
 
 
 def _side_stream(device):
-    """The second stream of a device: where the rest-row launches of the one-kernel layers run."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    """The second stream beside the CALLER's current stream: where the rest-row launches of the one-kernel layers run.  One side
+    stream per (device, caller stream), so callers on different streams do not serialise on one another's chains.  What stays
+    shared per GRAPH is its reallocating `graph.workspace` and the plan's lazily filled caches: layers over ONE Graph object must be
+    run from one stream / thread at a time; different Graph objects are independent."""
+    idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
     hit = _SIDE_STREAMS.get(key)
     if hit is None:
-        hit = _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+        if len(_SIDE_STREAMS) > 64:
+            _SIDE_STREAMS.clear()
+        hit = _SIDE_STREAMS[key] = torch.cuda.Stream(device=idx)
     return hit
 
 
@@ -562,7 +568,7 @@ def run_fused_call(call):
         return call.rest_rows()
     dev = call.y.device
     main = torch.cuda.current_stream(dev)
-    side, fork, join = _side_stream(dev), torch.cuda.Event(), torch.cuda.Event()   # (events per call: callers on several streams / threads)
+    side, fork, join = _side_stream(dev), torch.cuda.Event(), torch.cuda.Event()   # (events per call; one Graph object: one caller at a time)
     call.set_spare(True)
     fork.record(main)
     call.group_rows()
@@ -848,10 +854,8 @@ class _SmallSimplePlan(_SmallTowerPlan):
     the identity as pretrans (messages are the raw source features: x_cat = [I ; 0] h), no self panel in the posttrans
     (W_h = 0), and the identity as mixing network with the layer's ReLU and residual in its epilogue.  Products with 1 and sums
     with 0 are exact: the result is the three-kernel path's up to the summation order of the contraction.  One difference for
-    NON-FINITE inputs: a node whose OWN feature is Inf / NaN gets 0 * Inf = NaN from the zero self panel here, while the
-    three-kernel path and the reference (whose posttrans never reads the node's own h, pna_layer.py:206) keep its output finite
-    when its neighbours are -- PNASimpleLayer._small_batch_path therefore requires... nothing: the check would cost a pass over h
-    per call; callers with non-finite features set PNA_AMD_SMALL_SIMPLE_ROWS=0."""
+    NON-FINITE inputs: since round 4 the kernel multiplies ZEROS (not h) with the zero self block (`no_self_panel`), so a
+    node whose own feature is Inf / NaN keeps the finite output the reference and the three-kernel path give it."""
 
     def __init__(self, layer):
         import ctypes
@@ -883,6 +887,7 @@ class _SmallSimplePlan(_SmallTowerPlan):
             if v is not None:
                 setattr(a, k, _lib.dev_ptr(v, torch.float32, k))
         a.No, a.mix_act = Fo, 1                                # ReLU (pna_layer.py:211)
+        a.no_self_panel = 1                                    # (zeros, not h, against the zero self block: Inf / NaN own features stay out)
         self.args, self.ref = a, ctypes.byref(a)
         self.fn = _lib.lib().pna_tower_layer_f32
         self.check, self.stream_ptr = _lib.check, _lib.stream_ptr

@@ -176,3 +176,34 @@ def test_tower_layer_small_tracks_weight_updates():
         fresh = _layer(30, 30, 5, True, SCA, True, True, True, avg, seed=5).to(dev)
         fresh.load_state_dict(layer.state_dict())
         assert torch.equal(fresh(g, h, None, sn), y1)
+
+
+def test_small_simple_layer_keeps_a_non_finite_own_feature_out(cuda_device, monkeypatch):
+    """PNASimpleLayer's posttrans never reads the node's own h (models/dgl/pna_layer.py:206).  The one-call small-batch kernel used to
+    multiply h with a ZERO self panel (0 * Inf = NaN); with `no_self_panel` it multiplies zeros: a node whose own
+    feature is Inf / NaN but whose neighbours are finite gets the three-kernel path's finite output."""
+    from pna_amd import Graph, functional as PF
+    from pna_amd.dgl.pna_layer import PNASimpleLayer
+    from pna_amd.synth import molecule_batch
+    src, dst, sizes = molecule_batch(32, seed=3)
+    V = int(sum(sizes))
+    g = Graph(src, dst, V, sizes).to(cuda_device)
+    torch.manual_seed(1)
+    layer = PNASimpleLayer(40, 40, "mean max min std", "identity amplification attenuation", {"log": torch.tensor(1.1)}, 0.0, True, False).to(cuda_device).eval()
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.copy_(torch.randn_like(p) / (p.shape[-1] ** 0.5 if p.dim() == 2 else 2.0))
+    # a leaf-free pick: node 5's own features are poisoned; only rows that have node 5 as a SOURCE may turn non-finite
+    h = torch.randn(V, 40, device=cuda_device)
+    h[5, 3], h[5, 7] = float("inf"), float("nan")
+    with torch.no_grad():
+        y_small = layer(g, h)
+        monkeypatch.setattr(PF, "SMALL_SIMPLE_ROWS", 0)
+        y_ref = layer(g, h)
+    has5 = torch.zeros(V, dtype=torch.bool, device=cuda_device)
+    has5[g.csr.row.long()[g.csr.col.long() == 5]] = True
+    assert not bool(has5[5]) and torch.isfinite(y_ref[5]).all()
+    assert torch.isfinite(y_small[~has5]).all()
+    assert torch.equal(torch.isfinite(y_small), torch.isfinite(y_ref))
+    ok = torch.isfinite(y_ref)
+    torch.testing.assert_close(y_small[ok], y_ref[ok], rtol=1e-5, atol=1e-5)
