@@ -444,6 +444,42 @@ def test_simple_layer_training_step_uses_the_bn_tail_and_matches_the_library_rou
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("route", ["degree plan order", "per-row scalers"])
+def test_simple_layer_training_step_weight_gradient_kernels_match_the_library_route(cuda_device, monkeypatch, route):
+    """The layer's training step with the posttrans weight / bias gradient on pna_posttrans_dw_grouped_f32 (the rows in the graph's
+    degree-plan order) or pna_posttrans_dw_f32 (per-row scalers) against the slab-batched library GEMM it replaces (round 4): every
+    parameter gradient to 2e-5 of its largest entry, the same input gradient, and the kernel routes repeat bit for bit."""
+    from pna_amd import autograd as AG, ops
+    from pna_amd.synth import powerlaw_graph
+    V, E, F = 24_000, 200_000, 75
+    src, dst = powerlaw_graph(V, E, seed=5)
+    g = Graph(src, dst, V).to(cuda_device)
+    avg = {"log": float(torch.log(g.in_degrees().float() + 1).mean())}
+    monkeypatch.setattr(AG, "DW_GROUPED", route == "degree plan order")
+    res = {}
+    for kind in ("kernel", "kernel again", "library"):
+        monkeypatch.setattr(AG, "DW_KERNEL", kind != "library")
+        torch.manual_seed(0)
+        layer = PNASimpleLayer(F, F, "mean max min std", "identity amplification attenuation", avg, 0.0, False, True).to(cuda_device).train()
+        h = torch.randn(V, F, generator=torch.Generator().manual_seed(1)).to(cuda_device).requires_grad_(True)
+        seen = []
+        for fn in ("posttrans_dw_grouped", "posttrans_dw"):
+            real = getattr(ops, fn)
+            monkeypatch.setattr(ops, fn, (lambda real, fn: lambda *a, **k: (seen.append(fn), real(*a, **k))[1])(real, fn))
+        out = layer(g, h)                                       # (no BatchNorm: the bias gradient is a real one here)
+        (out * torch.linspace(0.5, 1.5, F, device=cuda_device)).sum().backward()
+        monkeypatch.undo()
+        monkeypatch.setattr(AG, "DW_GROUPED", route == "degree plan order")
+        assert seen == ([] if kind == "library" else ["posttrans_dw_grouped"] if route == "degree plan order" else ["posttrans_dw"]), seen
+        lin = layer.posttrans.fully_connected[0].linear
+        res[kind] = (lin.weight.grad.clone(), lin.bias.grad.clone(), h.grad.clone())
+    assert torch.equal(res["kernel"][0], res["kernel again"][0]) and torch.equal(res["kernel"][1], res["kernel again"][1])
+    # (the input gradient does not depend on the weight gradient; hub SOURCE rows add their segments atomically, so not bitwise)
+    torch.testing.assert_close(res["kernel"][2], res["library"][2], rtol=1e-5, atol=1e-6)
+    for a, b in zip(res["kernel"][:2], res["library"][:2]):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+
+
 @pytest.mark.parametrize("name", __import__("conftest").golden_names("dgl_simple_train"))
 def test_simple_layer_training_step_golden(cuda_device, name):
     """One training step of PNASimpleLayer against the REFERENCE's own (models/dgl/pna_layer.py:197-216 in train mode, run by
