@@ -369,6 +369,16 @@ def main():
                     for i, lay in enumerate(layers):
                         x = lay(g, x)                    # (the one-kernel path writes rows at an aligned pitch: the next layer stays on it)
                     return x
+        # the same untimed pre-conditioning as the one-layer line below (first calls: plans, weight images; then the device's
+        # sustained clock state): without it 3 + 10 steps of 4 layers measured 0.80 / 0.98 / 1.28 ms per layer on three boxes
+        prewarm_l = 0
+        if not args.no_prewarm:
+            for _ in range(2):
+                step_l()
+            prewarm_l = 2 + (16 if world > 1 else 48)         # (N > 1: every rank the same, fixed number of collectives)
+            for _ in range(prewarm_l - 2):
+                step_l()
+            torch.cuda.synchronize()
         for _ in range(args.warmup):
             step_l()
         sync()
@@ -385,7 +395,7 @@ def main():
             print(json.dumps({"metric": "PNA-layer fwd edges/sec (F=%d, 4 aggr x 3 scalers), %d stacked layers per step" % (F, L),
                               "value": E * L / (dt / args.steps), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": dt / args.steps * 1e3, "ms_per_layer": dt / args.steps * 1e3 / L, "higher_is_better": True,
-                              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "prewarm_steps_untimed": prewarm_l,
                               "config": {"workload": "%d x PNASimpleLayer(F=%d) stacked, |V|=%d |E|=%d per GPU" % (L, F, args.nodes_per_gpu, args.edges_per_gpu),
                                          "layers": L, "row_blocks": args.blocks if world > 1 else None,
                                          "exchange": "block-pipelined point-to-point (pna_amd.shard.BlockPipeline)" if world > 1 else None,
