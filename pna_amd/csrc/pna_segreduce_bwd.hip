@@ -295,6 +295,95 @@ __global__ __launch_bounds__(kBlock) void k_bwd_rowprep(const PArgs a) {
   }
 }
 
+// The same pass with FOUR features per thread (F >= 4; 16-byte accesses, the row's last window slides back to [F - 4, F) and rewrites
+// the columns it shares with its neighbour with the same values): the one-element kernel above issues 14 dword memory
+// instructions per element and ran at 4.0 TB/s on the 3.9 GB of the packed C3 pass (0.97 ms); the same arithmetic, op by op.
+__global__ __launch_bounds__(kBlock) void k_bwd_rowprep4(const PArgs a) {
+  const int nch = (a.F + 3) / 4, TC = a.T * nch;
+  const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= (long)a.V * TC) return;
+  const int v = (int)(i / TC), ct = (int)(i - (long)v * TC);
+  const int t = ct / nch, f = min((ct - t * nch) * 4, a.F - 4);
+  const int TF = a.T * a.F, c = t * a.F + f;
+  struct __attribute__((packed, aligned(4))) i4u { i4 v; };
+  typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+  struct __attribute__((packed, aligned(2))) us4u { us4 v; };
+  auto ld = [](const float* p) -> f4 { return reinterpret_cast<const f4u*>(p)->v; };
+  auto st = [](float* p, f4 x) { reinterpret_cast<f4u*>(p)->v = x; };
+  const float D = (float)(a.rowptr[v + 1] - a.rowptr[v]);
+  const size_t og = (size_t)v * a.ld_g + (size_t)t * a.ts_g + f;
+  const f4 zero = {0.f, 0.f, 0.f, 0.f};
+  f4 base = zero;
+  if (D > 0.f) {
+    if (a.g[PNA_AGG_MEAN]) { const f4 gm = ld(a.g[PNA_AGG_MEAN] + og); for (int q = 0; q < 4; ++q) base[q] = gm[q] / D; }
+    if (a.g[PNA_AGG_SUM]) { const f4 gs = ld(a.g[PNA_AGG_SUM] + og); for (int q = 0; q < 4; ++q) base[q] = base[q] + gs[q]; }
+  }
+  f4 r1 = base;
+  if (a.has_var) {
+    f4 cvar = zero;
+    const size_t os = (size_t)v * a.ld_stat + (size_t)t * a.ts_stat + f;
+    if (D > 0.f) {
+      const f4 one = {1.f, 1.f, 1.f, 1.f};
+      const f4 sd = a.stdv ? ld(a.stdv + os) : one;
+      f4 vr;
+      if (a.var) vr = ld(a.var + os);
+      else for (int q = 0; q < 4; ++q) vr[q] = sd[q] * sd[q] - 1e-5f;
+      f4 gs = a.g[PNA_AGG_VAR] ? ld(a.g[PNA_AGG_VAR] + og) : zero;
+      if (a.g[PNA_AGG_STD]) { const f4 gd = ld(a.g[PNA_AGG_STD] + og); for (int q = 0; q < 4; ++q) gs[q] = gs[q] + gd[q] / (2.f * sd[q]); }
+      const f4 dt = a.dst_term ? ld(a.dst_term + (size_t)v * a.ld_dst + (size_t)t * a.ts_in + f) : zero;
+      const f4 mean = ld(a.mean + os);
+      for (int q = 0; q < 4; ++q) {
+        cvar[q] = vr[q] > 0.f ? gs[q] * (2.f / D) : 0.f;
+        r1[q] = base[q] + cvar[q] * (dt[q] - mean[q]);
+      }
+    }
+    st(a.table + (size_t)v * a.ld_table + TF + c, cvar);
+  }
+  st(a.table + (size_t)v * a.ld_table + c, r1);
+  f4 gmx = zero, gmn = zero;
+  if (a.g[PNA_AGG_MAX] && (a.gcopy || (a.grad_dst && D > 0.f))) gmx = ld(a.g[PNA_AGG_MAX] + og);
+  if (a.g[PNA_AGG_MIN] && (a.gcopy || (a.grad_dst && D > 0.f))) gmn = ld(a.g[PNA_AGG_MIN] + og);
+  if (a.grad_dst) {
+    f4 gd;
+    for (int q = 0; q < 4; ++q) {
+      gd[q] = D * base[q];
+      if (D > 0.f) {
+        if (a.g[PNA_AGG_MAX]) gd[q] = gd[q] + gmx[q];
+        if (a.g[PNA_AGG_MIN]) gd[q] = gd[q] + gmn[q];
+      }
+    }
+    st(a.grad_dst + (size_t)v * a.ld_gd + c, gd);
+  }
+  if (a.gcopy) {
+    st(a.gcopy + (size_t)v * a.ld_table + c, gmx);
+    st(a.gcopy + (size_t)v * a.ld_table + TF + c, gmn);
+  }
+  if (a.ranks) {
+    const size_t oa = (size_t)v * a.ld_arg + (size_t)t * a.ts_in + f;
+    const int beg = a.rowptr[v];
+    const i4 none = {-1, -1, -1, -1};
+    const i4 ex = a.argmax ? reinterpret_cast<const i4u*>(a.argmax + oa)->v : none;
+    const i4 en = a.argmin ? reinterpret_cast<const i4u*>(a.argmin + oa)->v : none;
+    us4 kx, kn;
+    for (int q = 0; q < 4; ++q) {
+      kx[q] = ex[q] < 0 ? (unsigned short)0xFFFF : (unsigned short)(ex[q] - beg);
+      kn[q] = en[q] < 0 ? (unsigned short)0xFFFF : (unsigned short)(en[q] - beg);
+    }
+    reinterpret_cast<us4u*>(a.ranks + (size_t)v * a.ld_rank + c)->v = kx;
+    reinterpret_cast<us4u*>(a.ranks + (size_t)v * a.ld_rank + TF + c)->v = kn;
+  }
+}
+
+void launch_rowprep(const PArgs& k, hipStream_t st) {
+  if (k.F >= 4) {
+    const long n = (long)k.V * k.T * ((k.F + 3) / 4);
+    hipLaunchKernelGGL(k_bwd_rowprep4, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, k);
+  } else {
+    const long n = (long)k.V * k.T * k.F;
+    hipLaunchKernelGGL(k_bwd_rowprep, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, k);
+  }
+}
+
 // grad_x[col[arg[v,c]]][c] += G[v,c] for max and min: V*T*F atomics each instead of E*T*F
 __global__ __launch_bounds__(kBlock) void k_bwd_argscatter(const PArgs a) {
   const int TF = a.T * a.F;
@@ -496,7 +585,7 @@ extern "C" int pna_segreduce_bwd_rowprep_f32(const pna_segreduce_bwd_args* p, fl
   if (p->edge_term) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_rowprep_f32: the pull formulation has no per-edge term");
   k.table = table; k.ld_table = ld_table;
   const long n = (long)k.V * TF;
-  hipLaunchKernelGGL(k_bwd_rowprep, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, k);
+  launch_rowprep(k, (hipStream_t)stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
   return PNA_OK;
@@ -524,7 +613,7 @@ extern "C" int pna_segreduce_bwd_pull_f32(const pna_segreduce_bwd_pull_args* q, 
   if (q->run_rowprep) {              // rowprep (table, grad_dst) and the ranks in ONE pass over the rows
     k.table = const_cast<float*>(q->table); k.ld_table = q->ld_table; k.ranks = q->ranks; k.ld_rank = q->ld_rank;
     k.gcopy = packed ? const_cast<float*>(q->table) + 2L * TF : nullptr;
-    hipLaunchKernelGGL(k_bwd_rowprep, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, k);
+    launch_rowprep(k, st);
   } else {
     hipLaunchKernelGGL(k_bwd_ranks, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, p->rowptr, p->argmax, p->argmin, (long)p->ld_arg,
                        (long)k.ts_in, p->V, F, T, q->ranks, (long)q->ld_rank);
