@@ -39,7 +39,8 @@ while time.time() - t0 < budget:
     g = Graph(src, dst, V)
     scalers = rnd.choice(["identity amplification attenuation", "identity amplification attenuation", "identity amplification", "amplification attenuation"])
     torch.manual_seed(rnd.randint(0, 10 ** 6))
-    pitch = 128 if F > 96 else (F + 7) // 8 * 8
+    # round 4: any row pitch >= F takes the kernel -- the 32-byte aligned pitch of rounds 2-3, the 16-byte one, or none (contiguous rows)
+    pitch = rnd.choice([128 if F > 96 else (F + 7) // 8 * 8, (F + 3) // 4 * 4, F])
     h = torch.randn(V, pitch, device=dev)[:, :F]
     if tower:
         scalers = "identity amplification attenuation"
@@ -79,5 +80,5 @@ while time.time() - t0 < budget:
     assert torch.isfinite(y_f).all() and err <= bar, ("output differs", V, E, F, N, tower, err)
     worst = max(worst, err)
     n_ok += 1
-    print(f"ok  {'tower' if tower else 'wide ' if wide else 'plain'} V={V} E={src.numel()} F={F} N={N} scalers={len(scalers.split())} err={err:.1e}", flush=True)
+    print(f"ok  {'tower' if tower else 'wide ' if wide else 'plain'} V={V} E={src.numel()} F={F} N={N} pitch={pitch} scalers={len(scalers.split())} err={err:.1e}", flush=True)
 print(f"SUMMARY {n_ok} cases passed ({n_beside} with the rest rows beside the kernel), {n_skip} skipped (path did not apply), worst relative difference {worst:.2e}, {time.time() - t0:.0f} s")
