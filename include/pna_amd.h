@@ -271,6 +271,8 @@ typedef struct pna_segreduce_bwd_args {
   const int32_t* heavy_rows;
   const int32_t* heavy_segptr;
   const int32_t* seg_heavy;
+  const int32_t* stat_row_of;  /* nullable [V] (pna_segreduce_bwd_rowprep_f32 / _pull_f32 only): mean / stdv / var / argmax / argmin hold node
+                                * v's values in row stat_row_of[v] -- a forward that wrote them in a degree plan's row order */
 } pna_segreduce_bwd_args;
 
 int pna_segreduce_bwd_f32(const pna_segreduce_bwd_args* args, pna_stream_t stream);
@@ -802,6 +804,8 @@ typedef struct pna_posttrans_dw_grouped_args {
   float* grad_b;           /* nullable [N] */
   void* workspace;
   int64_t workspace_bytes; /* >= pna_posttrans_dw_grouped_workspace_bytes(N, K, Kh, n_entries) */
+  int32_t a_plan_order;    /* != 0: `a` is already in the plan's row order (row r of `a` = virtual row r): read in sequence, not through row_perm */
+  int32_t _pad;
 } pna_posttrans_dw_grouped_args;
 
 int64_t pna_posttrans_dw_grouped_workspace_bytes(int32_t N, int32_t K, int32_t Kh, int32_t n_entries);

@@ -79,6 +79,7 @@ class PnaSegreduceBwdArgs(_Args):
         ("heavy_threshold", ctypes.c_int32), ("seg_len", ctypes.c_int32), ("n_heavy", ctypes.c_int32),
         ("n_seg", ctypes.c_int32),
         ("heavy_rows", ctypes.c_void_p), ("heavy_segptr", ctypes.c_void_p), ("seg_heavy", ctypes.c_void_p),
+        ("stat_row_of", ctypes.c_void_p),
     ]
 
 
@@ -193,7 +194,7 @@ class PnaPosttransDwGroupedArgs(_Args):
         ("row_perm", ctypes.c_void_p), ("tile_group", ctypes.c_void_p), ("wg_range", ctypes.c_void_p), ("wg_entry", ctypes.c_void_p),
         ("n_workgroups", ctypes.c_int32), ("n_entries", ctypes.c_int32), ("entry_group", ctypes.c_void_p), ("group_scale", ctypes.c_void_p),
         ("grad_w", ctypes.c_void_p), ("ldw", ctypes.c_int64), ("grad_b", ctypes.c_void_p),
-        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64), ("a_plan_order", ctypes.c_int32), ("_pad", ctypes.c_int32),
     ]
 
 

@@ -261,7 +261,7 @@ def _argscatter_sorted(gx, col, amx, amn, gagg, aggs, T, F):
     flat[uniq] = flat[uniq] + sums
 
 
-def _backward_pull(graph, x, dst_term, ident, amx, amn, gagg, aggs, all_aggs, T, F, need_x, need_d):
+def _backward_pull(graph, x, dst_term, ident, amx, amn, gagg, aggs, all_aggs, T, F, need_x, need_d, row_of=None):
     """Gradient of the aggregation w.r.t. the source table / destination term WITHOUT one atomic per edge and feature
     (the scatter kernel: 750 M atomics = 11.4 ms on the roofline workload).  With messages m_k = x[u_k] + dst_term[v]:
 
@@ -275,10 +275,12 @@ def _backward_pull(graph, x, dst_term, ident, amx, amn, gagg, aggs, all_aggs, T,
     from .graph import Graph
     csr = graph.csr
     dev = x.device
-    V, TF = ident.shape[0], T * F
+    V, TF = gagg.shape[0], T * F                            # (row_of: ident / amx / amn hold node v's row at row_of[v] -- plan order)
     A, A2 = len(aggs), len(all_aggs)
     has_var = any(a in _STAT_AGGS for a in aggs)
     b = _lib.PnaSegreduceBwdArgs()
+    if row_of is not None:
+        b.stat_row_of = _lib.dev_ptr(row_of, torch.int32, "stat_row_of")
     b.rowptr = _lib.dev_ptr(csr.rowptr, torch.int32, "rowptr")
     b.col = _lib.dev_ptr(csr.col, torch.int32, "col")
     b.V, b.F = V, F
@@ -302,6 +304,9 @@ def _backward_pull(graph, x, dst_term, ident, amx, amn, gagg, aggs, all_aggs, T,
     if need_d:
         gd = torch.empty(V, TF, dtype=torch.float32, device=dev)
         b.grad_dst, b.ld_gd = _lib.dev_ptr(gd, torch.float32, "grad_dst"), gd.stride(0)
+    if row_of is not None and not (need_x and amx is not None and has_var and "max" in aggs and "min" in aggs and 4 <= F <= 256
+                                   and csr.max_degree < 65535 and x.stride(1) == 1):
+        raise RuntimeError("_backward_pull: row_of needs the ranked pull (mean, max, min, std; 4 <= F <= 256; degrees < 65535)")
     ranked = (need_x and amx is not None and has_var and "max" in aggs and "min" in aggs and 4 <= F <= 256 and csr.max_degree < 65535
               and x.stride(1) == 1 and os.environ.get("PNA_AMD_BWD_ARGS", "pull") == "pull")
     if ranked and PULL_PACKED:
@@ -383,6 +388,85 @@ PULL_PACKED = os.environ.get("PNA_AMD_PULL_PACKED", "1") != "0"   # 0: table, ag
 DW_KERNEL = os.environ.get("PNA_AMD_DW_KERNEL", "1") != "0"    # 0: the library route (slab-batched GEMM) for the weight gradient
 DW_GROUPED = os.environ.get("PNA_AMD_DW_GROUPED", "1") != "0"  # 0: per-row scalers (three scaled copies of gy inside the kernel)
 DW_MIN_ROWS = int(os.environ.get("PNA_AMD_DW_MIN_ROWS", "4096"))  # below: a molecule batch's product is one small library GEMM
+
+
+class SimpleLayerPlanFn(torch.autograd.Function):
+    """Gather + posttrans contraction of PNASimpleLayer in TRAINING on a large whole graph, in the graph's DEGREE-PLAN row order
+    (models/dgl/pna_layer.py:197-206; round 4).  Forward: the arg-tracking gather writes the aggregate and the arg indices in plan
+    order (the work list's rows), so the contraction is the grouped one -- ONE combined block W_D per degree tile instead of three
+    scaler blocks (a third of the multiply-adds: 0.72 -> ~0.3 ms at C3) -- and scatters y to node order.  Backward: the weight
+    gradient reads the aggregate in sequence (pna_posttrans_dw_grouped_f32, a_plan_order), d agg is the three-block contraction in
+    node order as before, rowprep finds a node's mean / std / arg indices through the plan's row map (stat_row_of), the pull is
+    unchanged.  Same arithmetic per row as the node-order route up to the combined weight's rounding (the inference paths' relation)."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, layer, graph):
+        from . import degree_groups as DG, functional as PF
+        from .dgl.pna_layer import _row_scales, _avg_log_value
+        plan = DG.plan_of(graph)
+        F, N = layer.in_dim, layer.out_dim
+        K = 4 * F
+        aggs = list(layer.aggregators)
+        x = h if h.stride(1) == 1 else h.contiguous()
+        csr = graph.csr
+        dev = h.device
+        agg = torch.empty(plan.rows, DG.agg_pitch(K), dtype=torch.float32, device=dev)[:, :K]
+        agg, amx, amn = ops.segreduce(csr.rowptr, csr.col, x, F, aggs, (None,), tower_stride_in=F, out=agg, want_arg=True, arg_rows=plan.rows,
+                                      heavy=graph.heavy_schedule(), workspace=graph.workspace, items=plan.items, heavy_out=plan.heavy_out,
+                                      tune=dict(generic=2))
+        scales = _row_scales(graph, layer.scalers, layer.avg_d, dev)
+        w = weight if weight.stride(-1) == 1 else weight.contiguous()
+        y = torch.empty(h.shape[0], N, dtype=torch.float32, device=dev)
+        if plan.G:
+            img, stride = DG.combined_images(w, K, scales, plan)
+            ops.posttrans(agg[:plan.NV], K, w, [None], bias, out=y, row_perm=plan.perm, tile_image=plan.tile_image, w_img=img,
+                          image_stride=stride, n_out=N)
+        if plan.NR:
+            rest_scales = plan.rest_scales(tuple(layer.scalers) + (_avg_log_value(layer.avg_d),), scales)
+            ops.posttrans(agg[plan.NV:], K, w, rest_scales, bias, out=y, row_perm=plan.perm_rest, n_out=N)
+        ctx.graph, ctx.plan, ctx.scales, ctx.aggs, ctx.F, ctx.N = graph, plan, scales, aggs, F, N
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, agg, amx, amn)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, agg, amx, amn = ctx.saved_tensors
+        graph, plan, scales, aggs, F, N = ctx.graph, ctx.plan, ctx.scales, ctx.aggs, ctx.F, ctx.N
+        K, S = 4 * F, len(scales)
+        gy = gy if gy.stride(1) == 1 else gy.contiguous()
+        g_w = g_b = g_h = None
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_b:
+            res = ops.posttrans_dw_grouped(gy, agg, K, None, scales, plan, want_bias=want_b, a_plan_order=True)
+            if res is None:
+                raise RuntimeError("SimpleLayerPlanFn: shape outside pna_posttrans_dw_grouped_f32 (the layer checks it before taking this path)")
+            g_w, g_b = res
+        if ctx.needs_input_grad[0]:
+            wt = torch.cat([weight[:, s * K:(s + 1) * K].t() for s in range(S)], dim=1).contiguous()       # (K, S*N)
+            g_agg = ops.posttrans(gy, N, wt, scales, None, arith="bf16x3")                                  # (V, 4F), node order
+            g_h, _ = _backward_pull(graph, x, None, agg, amx, amn, g_agg, aggs, aggs, 1, F, True, False, row_of=plan.vmap32())
+        return g_h, g_w, g_b, None, None
+
+
+def simple_layer_plan_applies(layer, graph, h):
+    """Whether SimpleLayerPlanFn serves this training forward: a large whole graph with a degree plan, the four standard aggregators,
+    three scalers, one-layer posttrans, out_dim <= 80 (the grouped contraction and the weight-gradient kernel)."""
+    from . import degree_groups as DG
+    from .graph import Graph
+    F, N = layer.in_dim, layer.out_dim
+    if not (PLAN_TRAIN and h.is_cuda and h.dtype == torch.float32 and type(graph) is Graph and h.shape[1] == F and 4 <= F and N <= 80
+            and len(layer.scalers) == 3 and tuple(layer.aggregators) == ("mean", "max", "min", "std") and layer.posttrans.is_affine
+            and ops.POSTTRANS_ARITH != "f32" and graph.csr.max_degree < 65535 and 4 * F + 1 <= 384):
+        return False
+    V = h.shape[0]
+    if not DG.applies(graph, V, N, 3, layer.aggregators, F=F, n_edges=graph.csr.col.numel(), x_rows=V):
+        return False
+    plan = DG.plan_of(graph)
+    return plan.NV % 128 == 0 and plan.NRp % 192 == 0 and plan.items is not None
+
+
+PLAN_TRAIN = os.environ.get("PNA_AMD_PLAN_TRAIN", "1") != "0"   # 0: the node-order training route (AggregateFn + PosttransFn)
 
 
 class PosttransFn(torch.autograd.Function):

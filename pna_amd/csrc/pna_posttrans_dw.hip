@@ -250,6 +250,7 @@ struct GArgs {
   const int32_t* wg_range;       // [n_wg][2]: tiles [lo, hi)
   const int32_t* wg_entry;       // [n_wg]: first workspace entry of the workgroup
   int N, K, Kh, MT;
+  int a_plan;                    // `a` is in plan order: row = the virtual row
   float* part;                   // [n_entries][kGL][kMaxR]
 };
 
@@ -273,9 +274,11 @@ __global__ __launch_bounds__(kGThreads, 1) void k_posttrans_dw_grouped(const GAr
   const bool okL = nL < N;
   const float* const pL = g.gy + min(nL, N - 1);
   const float* pR[3]; unsigned ldR[3]; int kindR[3];       // 0: column of a / h, 1: the ones column, 2: padding (stays zero)
+  bool seqR[3];                                             // the column's rows are addressed by the VIRTUAL row (a in plan order)
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     const int j = 64 * (cbL + 2 * q) + lane;
+    seqR[q] = g.a_plan && j < K;
     if (j < K) { pR[q] = g.a + j; ldR[q] = (unsigned)g.lda; kindR[q] = 0; }
     else if (j < K + Kh) { pR[q] = g.h + (j - K); ldR[q] = (unsigned)g.ldh; kindR[q] = 0; }
     else { pR[q] = g.gy; ldR[q] = 0; kindR[q] = j == K + Kh ? 1 : 2; }
@@ -291,7 +294,8 @@ __global__ __launch_bounds__(kGThreads, 1) void k_posttrans_dw_grouped(const GAr
       rawL[r] = bfloat(fbits(pL[idc * (size_t)g.ldg]) & keep);
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        const float v = pR[q][idc * ldR[q]];
+        const size_t rq = seqR[q] ? (size_t)(vrow0 + 8 * kg + r) : idc;
+        const float v = pR[q][rq * ldR[q]];
         rawR[q][r] = bfloat(fbits(kindR[q] == 0 ? v : 1.f) & keep);
       }
     }
@@ -497,6 +501,7 @@ extern "C" int pna_posttrans_dw_grouped_f32(const pna_posttrans_dw_grouped_args*
   g.gy = p->gy; g.ldg = (long)p->ldg; g.a = p->a; g.lda = (long)p->lda; g.h = p->h; g.ldh = (long)p->ldh;
   g.row_perm = p->row_perm; g.tile_group = p->tile_group; g.wg_range = p->wg_range; g.wg_entry = p->wg_entry;
   g.N = p->N; g.K = p->K; g.Kh = p->Kh; g.MT = (p->N + 15) / 16; g.part = (float*)p->workspace;
+  g.a_plan = p->a_plan_order != 0;
   if (hipFuncSetAttribute((const void*)k_posttrans_dw_grouped, hipFuncAttributeMaxDynamicSharedMemorySize, kGLdsBytes) != hipSuccess)
     return pna_set_error(PNA_E_LAUNCH, "pna_posttrans_dw_grouped_f32: LDS attribute refused");
   hipLaunchKernelGGL(k_posttrans_dw_grouped, dim3((unsigned)p->n_workgroups), dim3(kGThreads), kGLdsBytes, st, g);

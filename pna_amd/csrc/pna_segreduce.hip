@@ -285,9 +285,9 @@ __device__ __forceinline__ void finalize_store(const KArgs& a, const Acc<VEC, EX
       Ld<VEC>::store(a.out + (size_t)orow * a.ldo + (size_t)(s * a.n_aggr + i) * a.block_stride + offo, o, a.nt != 0);
     }
   }
-  if constexpr (EXTRA) {
-    if (a.argmax) Ld<VEC>::store_i(a.argmax + (size_t)row * a.ld_arg + offi, acc.amx);
-    if (a.argmin) Ld<VEC>::store_i(a.argmin + (size_t)row * a.ld_arg + offi, acc.amn);
+  if constexpr (EXTRA) {                                   // (re-ordered rows: the arg indices go where the aggregate goes)
+    if (a.argmax) Ld<VEC>::store_i(a.argmax + (size_t)orow * a.ld_arg + offi, acc.amx);
+    if (a.argmin) Ld<VEC>::store_i(a.argmin + (size_t)orow * a.ld_arg + offi, acc.amn);
   }
 }
 

@@ -240,6 +240,7 @@ struct PArgs {
   const int32_t* argmax; const int32_t* argmin;
   float* table; float* grad_dst; float* grad_x;
   unsigned short* ranks;             // nullable: (V, ld_rank) [rank of argmax | rank of argmin] in the row's in-edge list (0xFFFF: none)
+  const int32_t* row_of;             // nullable: row of mean / std / argmax / argmin that belongs to node v (a forward in degree-plan order)
   float* gcopy;                      // nullable: packed table rows -- G_max | G_min copied to table[v][2 T F .. 4 T F) (pna_segreduce_bwd_pull_f32)
   long ld_g, ld_stat, ld_dst, ld_table, ld_gd, ld_arg, ld_gx, ts_in, ts_g, ts_stat, ld_rank;
   int V, F, T, has_var;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_rowprep(const PArgs a) {
   float r1 = base;
   if (a.has_var) {
     float cvar = 0.f;
-    const size_t os = (size_t)v * a.ld_stat + (size_t)t * a.ts_stat + f;
+    const size_t os = (size_t)(a.row_of ? a.row_of[v] : v) * a.ld_stat + (size_t)t * a.ts_stat + f;
     if (D > 0.f) {
       const float sd = a.stdv ? a.stdv[os] : 1.f;
       const float vr = a.var ? a.var[os] : sd * sd - 1e-5f;              // relu'(raw var): 0 at and below 0
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_rowprep(const PArgs a) {
     a.gcopy[(size_t)v * a.ld_table + TF + c] = a.g[PNA_AGG_MIN] ? a.g[PNA_AGG_MIN][og] : 0.f;
   }
   if (a.ranks) {                     // for pna_segreduce_bwd_pull_f32: where in the row's in-edge list argmax / argmin sit
-    const size_t oa = (size_t)v * a.ld_arg + (size_t)t * a.ts_in + f;
+    const size_t oa = (size_t)(a.row_of ? a.row_of[v] : v) * a.ld_arg + (size_t)t * a.ts_in + f;
     const int beg = a.rowptr[v];
     const int ex = a.argmax ? a.argmax[oa] : -1, en = a.argmin ? a.argmin[oa] : -1;
     a.ranks[(size_t)v * a.ld_rank + c] = ex < 0 ? (unsigned short)0xFFFF : (unsigned short)(ex - beg);
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_rowprep4(const PArgs a) {
   f4 r1 = base;
   if (a.has_var) {
     f4 cvar = zero;
-    const size_t os = (size_t)v * a.ld_stat + (size_t)t * a.ts_stat + f;
+    const size_t os = (size_t)(a.row_of ? a.row_of[v] : v) * a.ld_stat + (size_t)t * a.ts_stat + f;
     if (D > 0.f) {
       const f4 one = {1.f, 1.f, 1.f, 1.f};
       const f4 sd = a.stdv ? ld(a.stdv + os) : one;
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_rowprep4(const PArgs a) {
     st(a.gcopy + (size_t)v * a.ld_table + TF + c, gmn);
   }
   if (a.ranks) {
-    const size_t oa = (size_t)v * a.ld_arg + (size_t)t * a.ts_in + f;
+    const size_t oa = (size_t)(a.row_of ? a.row_of[v] : v) * a.ld_arg + (size_t)t * a.ts_in + f;
     const int beg = a.rowptr[v];
     const i4 none = {-1, -1, -1, -1};
     const i4 ex = a.argmax ? reinterpret_cast<const i4u*>(a.argmax + oa)->v : none;
@@ -518,6 +519,7 @@ int fill_pull_args(const pna_segreduce_bwd_args* p, PArgs& k, const char* who) {
   k.ld_g = p->ld_g; k.ld_stat = p->ld_stat; k.ld_dst = p->ld_dst; k.ld_gd = p->ld_gd; k.ld_arg = p->ld_arg; k.ld_gx = p->ld_gx;
   k.ts_in = T > 1 ? p->tower_stride_in : 0; k.ts_g = T > 1 ? p->tower_stride_g : 0; k.ts_stat = T > 1 ? p->tower_stride_stat : 0;
   k.V = p->V; k.F = p->F; k.T = T;
+  k.row_of = p->stat_row_of;
   return PNA_OK;
 }
 
@@ -527,6 +529,7 @@ extern "C" int pna_segreduce_bwd_f32(const pna_segreduce_bwd_args* p, pna_stream
   if (!p) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: null args");
   if (int rc_ss = pna_check_struct_size("pna_segreduce_bwd_f32", p->struct_size, sizeof(*p))) return rc_ss;
   if (p->V < 0 || p->F <= 0) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: bad V/F");
+  if (p->stat_row_of) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: stat_row_of is honoured by the rowprep / pull entry points only");
   if (p->V == 0) return PNA_OK;
   if (!p->rowptr || !p->gagg) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: rowptr/gagg must be non-null");
   if (p->n_aggr <= 0 || p->n_aggr > PNA_MAX_AGGR) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: n_aggr out of range");
@@ -638,6 +641,7 @@ extern "C" int pna_segreduce_bwd_argscatter_f32(const pna_segreduce_bwd_args* p,
   PArgs k;
   int rc = fill_pull_args(p, k, "pna_segreduce_bwd_argscatter_f32: bad arguments");
   if (rc != PNA_OK) return rc;
+  if (p->stat_row_of) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_argscatter_f32: stat_row_of is honoured by the rowprep / pull entry points only");
   if (p->V == 0 || (!k.g[PNA_AGG_MAX] && !k.g[PNA_AGG_MIN])) return PNA_OK;
   if (!p->col || !p->grad_x || (k.g[PNA_AGG_MAX] && !p->argmax) || (k.g[PNA_AGG_MIN] && !p->argmin))
     return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_argscatter_f32: col / grad_x / argmax / argmin missing");

@@ -435,9 +435,17 @@ class PNASimpleLayer(nn.Module):
             except RuntimeError as e:                        # a precondition of the hand-scheduled gather this check does not
                 if "hand-scheduled kernel was required" not in str(e):     # mirror: the ordinary path takes the call
                     raise
+        lin = self.posttrans.fully_connected[0].linear
+        y = None
+        if torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from .. import autograd as AG
+            if AG.simple_layer_plan_applies(self, graph, h):
+                # training on a large whole graph: gather + contraction in the degree plan's row order (autograd.SimpleLayerPlanFn)
+                y = AG.SimpleLayerPlanFn.apply(h, lin.weight, lin.bias, self, graph)
+        if y is not None:
+            return self._train_tail(y, h_in)
         # (V, A*F), identity scaler only; on a sharded graph the halo exchange overlaps the rows that do not need it
         agg = PF.aggregate(graph, graph.source_features(h, defer=True), self.in_dim, self.aggregators)
-        lin = self.posttrans.fully_connected[0].linear
         scales = _row_scales(graph, self.scalers, self.avg_d, h.device)
         K = len(self.aggregators) * self.in_dim
         if not self.training and self.posttrans.is_affine and not (torch.is_grad_enabled() and (
@@ -449,6 +457,10 @@ class PNASimpleLayer(nn.Module):
             return PF.posttrans(agg, K, lin.weight, lin.bias, scales, bn=self.batchnorm_h if self.batch_norm else None,
                                 relu=True, residual=h_in if self.residual else None)
         y = PF.posttrans(agg, K, lin.weight, lin.bias, scales, degree_graph=graph if type(graph) is Graph else None)
+        return self._train_tail(y, h_in)
+
+    def _train_tail(self, y, h_in):
+        """models/dgl/pna_layer.py:207-215 behind the posttrans Linear: BatchNorm, ReLU, residual, dropout."""
         y = self.posttrans.tail(y)
         if self.batch_norm:
             from ..autograd import bn_relu_residual, bn_tail_applies

@@ -43,7 +43,7 @@ def segreduce(rowptr: torch.Tensor, col: Optional[torch.Tensor], x: torch.Tensor
               tower_stride_out: Optional[int] = None, want_arg: bool = False,
               heavy: Optional[HeavySchedule] = None, workspace=None, tune: Optional[dict] = None,
               items: Optional[torch.Tensor] = None, heavy_out: Optional[torch.Tensor] = None, out_row_of: Optional[torch.Tensor] = None,
-              edge_type: Optional[torch.Tensor] = None):
+              edge_type: Optional[torch.Tensor] = None, arg_rows: Optional[int] = None):
     """out[v, t*tso + (s*A + a)*bs + f] = aggregators[a]({m_k}) [f] * row_scales[s][v]   (see pna_amd.h).
     edge_type (int32 [E], CSR order): edge_term then holds one row per edge TYPE (ABI 14).
 
@@ -84,7 +84,8 @@ def segreduce(rowptr: torch.Tensor, col: Optional[torch.Tensor], x: torch.Tensor
     a.out, a.ldo, a.block_stride = _lib.dev_ptr(out, torch.float32, "out"), _ld(out), bs
     argmax = argmin = None
     if want_arg:
-        argmax = torch.empty(V, (T - 1) * tsi + F, dtype=torch.int32, device=dev)
+        # (arg_rows: a work list that re-orders the output rows -- the degree plan's -- puts the arg indices in the same rows)
+        argmax = torch.empty(V if arg_rows is None else arg_rows, (T - 1) * tsi + F, dtype=torch.int32, device=dev)
         argmin = torch.empty_like(argmax)
         a.argmax, a.argmin, a.ld_arg = (_lib.dev_ptr(argmax, torch.int32, "argmax"),
                                         _lib.dev_ptr(argmin, torch.int32, "argmin"), _ld(argmax))
@@ -207,7 +208,7 @@ def posttrans_dw(gy: torch.Tensor, a_mat: torch.Tensor, K: int, h: Optional[torc
     return gw, gb
 
 
-def posttrans_dw_grouped(gy, a_mat, K, h, row_scales, plan, want_bias=True):
+def posttrans_dw_grouped(gy, a_mat, K, h, row_scales, plan, want_bias=True, a_plan_order=False):
     """posttrans_dw over the rows of a degree plan, in plan order (pna_posttrans_dw_grouped_f32: one unscaled copy of gy, a third of
     the multiply-adds, the scalers applied per degree run in the reduction) + the plan's few rest rows through small library
     products.  `row_scales` must be the plan's graph's DEGREE scalers (functions of the in-degree).  None: shape outside the kernel."""
@@ -251,10 +252,12 @@ def posttrans_dw_grouped(gy, a_mat, K, h, row_scales, plan, want_bias=True):
     if gb is not None:
         a.grad_b = _lib.dev_ptr(gb, torch.float32, "grad_b")
     a.workspace, a.workspace_bytes = ws.data_ptr(), nb
+    a.a_plan_order = 1 if a_plan_order else 0              # (a: (plan.rows, >= K) in the plan's row order -- a forward that gathered in it)
     _lib.check(L.pna_posttrans_dw_grouped_f32(ctypes.byref(a), _lib.stream_ptr(dev)), "pna_posttrans_dw_grouped_f32")
     if plan.NR:                                            # hub rows and rare degrees: a few thousand rows, plain products
         rr = plan.rest_rows
-        g_r, a_r = gy.index_select(0, rr), a_mat.index_select(0, rr)[:, :K]
+        g_r = gy.index_select(0, rr)
+        a_r = a_mat[plan.NV:plan.NV + plan.NR, :K] if a_plan_order else a_mat.index_select(0, rr)[:, :K]
         parts = [g_r.t() @ h.index_select(0, rr)] if Kh else []
         for rs in rest_scales:
             parts.append((g_r if rs is None else g_r * rs).t() @ a_r)

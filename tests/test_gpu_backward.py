@@ -444,6 +444,54 @@ def test_simple_layer_training_step_uses_the_bn_tail_and_matches_the_library_rou
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("V,E,F,bn", [(40_000, 400_000, 75, True), (30_000, 240_000, 20, False), (50_000, 600_000, 64, True)])
+def test_simple_layer_training_step_in_degree_plan_order(cuda_device, monkeypatch, V, E, F, bn):
+    """autograd.SimpleLayerPlanFn (round 4): the training forward gathers in the degree plan's row order (aggregate AND arg indices,
+    hub rows included), multiplies ONE combined block per degree tile, and the backward finds a node's statistics through the plan's
+    row map -- against the node-order route (AggregateFn + PosttransFn): output, input gradient, every parameter gradient, running
+    statistics; and both against nothing looser than the routes' own relation in inference (the combined weight rounds once more)."""
+    from pna_amd import autograd as AG, degree_groups as DG
+    from pna_amd.synth import powerlaw_graph
+    monkeypatch.setattr(DG, "MIN_ROWS", 1)
+    monkeypatch.setattr(DG, "MIN_OUT", 1)
+    src, dst = powerlaw_graph(V, E, seed=17)
+    keep = dst >= 50                                           # some rows without in-edges
+    g = Graph(src[keep], dst[keep], V).to(cuda_device)
+    assert int((g.in_degrees() > 128).sum()) > 0              # hub rows: cut into segments, their arg indices finished by the finalize pass
+    avg = {"log": float(torch.log(g.in_degrees().float() + 1).mean())}
+    res = {}
+    for plan_route in (True, False):
+        monkeypatch.setattr(AG, "PLAN_TRAIN", plan_route)
+        torch.manual_seed(0)
+        layer = PNASimpleLayer(F, F, "mean max min std", "identity amplification attenuation", avg, 0.0, bn, True).to(cuda_device).train()
+        with torch.no_grad():
+            for p in layer.parameters():
+                if p.dim() == 2:
+                    p.copy_(torch.randn_like(p) / p.shape[1] ** 0.5)
+        h = torch.randn(V, F, generator=torch.Generator().manual_seed(1)).to(cuda_device).requires_grad_(True)
+        used = []
+        real = AG.SimpleLayerPlanFn.apply
+        monkeypatch.setattr(AG.SimpleLayerPlanFn, "apply", lambda *a: (used.append(1), real(*a))[1])
+        out = layer(g, h)
+        monkeypatch.setattr(AG.SimpleLayerPlanFn, "apply", real)
+        assert bool(used) == plan_route
+        (out * torch.linspace(0.5, 1.5, F, device=cuda_device)).sum().backward()
+        lin = layer.posttrans.fully_connected[0].linear
+        res[plan_route] = (out.detach(), h.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone(),
+                           layer.batchnorm_h.running_mean.clone() if bn else None)
+    rel = lambda a, b: (a - b).abs().max().item() / max(1e-30, b.abs().max().item())
+    (o1, gh1, gw1, gb1, rm1), (o0, gh0, gw0, gb0, rm0) = res[True], res[False]
+    assert rel(o1, o0) <= 2e-6, rel(o1, o0)
+    if bn:
+        assert rel(rm1, rm0) <= 2e-6
+        # (a pre-activation within fp32 rounding of 0 takes the other ReLU branch on one route: a handful of elements, a whole unit)
+        off = ((gh1 - gh0).abs() > 1e-4 * gh0.abs().max()).float().mean().item()
+        assert off <= 1e-3 and rel(gw1, gw0) <= 5e-3, (off, rel(gw1, gw0))
+    else:
+        off = ((gh1 - gh0).abs() > 1e-4 * gh0.abs().max()).float().mean().item()
+        assert off <= 1e-3 and rel(gw1, gw0) <= 2e-3 and rel(gb1, gb0) <= 2e-3, (off, rel(gw1, gw0), rel(gb1, gb0))
+
+
 @pytest.mark.parametrize("route", ["degree plan order", "per-row scalers"])
 def test_simple_layer_training_step_weight_gradient_kernels_match_the_library_route(cuda_device, monkeypatch, route):
     """The layer's training step with the posttrans weight / bias gradient on pna_posttrans_dw_grouped_f32 (the rows in the graph's
