@@ -273,6 +273,10 @@ typedef struct pna_segreduce_bwd_args {
   const int32_t* seg_heavy;
   const int32_t* stat_row_of;  /* nullable [V] (pna_segreduce_bwd_rowprep_f32 / _pull_f32 only): mean / stdv / var / argmax / argmin hold node
                                 * v's values in row stat_row_of[v] -- a forward that wrote them in a degree plan's row order */
+  const int32_t* stat_node_of; /* nullable [stat_rows], the inverse map (takes precedence): the rowprep pass then WALKS the statistics' rows in
+                                * their own order -- row r belongs to node stat_node_of[r], < 0 = a padding row -- and touches the per-node
+                                * tensors (gagg, the table) at node rows: sequential reads of the big tensors, every node exactly once */
+  int64_t stat_rows;
 } pna_segreduce_bwd_args;
 
 int pna_segreduce_bwd_f32(const pna_segreduce_bwd_args* args, pna_stream_t stream);
@@ -302,6 +306,9 @@ int pna_segreduce_bwd_argscatter_f32(const pna_segreduce_bwd_args* args, pna_str
  * workspace (V, ld_rank >= 2 T F) of uint16 -- in-degrees up to 65534.  4 <= F <= 256.  * PACKED rows (round 4): with run_rowprep != 0, ld_table >= 5 T F and ranks == (uint16_t*)(table + 4 T F), the rowprep pass also
  * copies G_max | G_min to table[v][2 T F .. 4 T F) and the pull reads ONE contiguous row [R1 | R2 | G_max | G_min | ranks] per
  * out-edge (12 cache lines at F = 75 with a 1536-byte pitch instead of ~14.7 for three separate pieces); ld_rank then = 2 ld_table.
+ * IN PLACE: packed rows with base->gagg == table, one tower and base->aggr[] = {mean, std, max, min} (ld_g == ld_table): the caller's
+ * d agg contraction has written [G_mean | G_std | G_max | G_min] straight into the rows; rowprep overwrites the first two blocks
+ * with R1 | R2 and copies nothing.
  */
 typedef struct pna_segreduce_bwd_pull_args {
   uint32_t struct_size;    /* sizeof(pna_segreduce_bwd_pull_args) of the CALLER's header (ABI 19): a shorter struct is refused with PNA_E_INVALID */

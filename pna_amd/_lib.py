@@ -79,7 +79,7 @@ class PnaSegreduceBwdArgs(_Args):
         ("heavy_threshold", ctypes.c_int32), ("seg_len", ctypes.c_int32), ("n_heavy", ctypes.c_int32),
         ("n_seg", ctypes.c_int32),
         ("heavy_rows", ctypes.c_void_p), ("heavy_segptr", ctypes.c_void_p), ("seg_heavy", ctypes.c_void_p),
-        ("stat_row_of", ctypes.c_void_p),
+        ("stat_row_of", ctypes.c_void_p), ("stat_node_of", ctypes.c_void_p), ("stat_rows", ctypes.c_int64),
     ]
 
 

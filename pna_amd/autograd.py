@@ -261,7 +261,7 @@ def _argscatter_sorted(gx, col, amx, amn, gagg, aggs, T, F):
     flat[uniq] = flat[uniq] + sums
 
 
-def _backward_pull(graph, x, dst_term, ident, amx, amn, gagg, aggs, all_aggs, T, F, need_x, need_d, row_of=None):
+def _backward_pull(graph, x, dst_term, ident, amx, amn, gagg, aggs, all_aggs, T, F, need_x, need_d, row_of=None, packed_rows=None, node_of=None):
     """Gradient of the aggregation w.r.t. the source table / destination term WITHOUT one atomic per edge and feature
     (the scatter kernel: 750 M atomics = 11.4 ms on the roofline workload).  With messages m_k = x[u_k] + dst_term[v]:
 
@@ -281,6 +281,8 @@ def _backward_pull(graph, x, dst_term, ident, amx, amn, gagg, aggs, all_aggs, T,
     b = _lib.PnaSegreduceBwdArgs()
     if row_of is not None:
         b.stat_row_of = _lib.dev_ptr(row_of, torch.int32, "stat_row_of")
+    if node_of is not None:                                 # (the inverse map: rowprep walks ident's rows in sequence)
+        b.stat_node_of, b.stat_rows = _lib.dev_ptr(node_of, torch.int32, "stat_node_of"), node_of.numel()
     b.rowptr = _lib.dev_ptr(csr.rowptr, torch.int32, "rowptr")
     b.col = _lib.dev_ptr(csr.col, torch.int32, "col")
     b.V, b.F = V, F
@@ -309,11 +311,14 @@ def _backward_pull(graph, x, dst_term, ident, amx, amn, gagg, aggs, all_aggs, T,
         raise RuntimeError("_backward_pull: row_of needs the ranked pull (mean, max, min, std; 4 <= F <= 256; degrees < 65535)")
     ranked = (need_x and amx is not None and has_var and "max" in aggs and "min" in aggs and 4 <= F <= 256 and csr.max_degree < 65535
               and x.stride(1) == 1 and os.environ.get("PNA_AMD_BWD_ARGS", "pull") == "pull")
-    if ranked and PULL_PACKED:
+    if packed_rows is not None and not ranked:
+        raise RuntimeError("_backward_pull: packed_rows (in place) needs the ranked pull")
+    if ranked and (PULL_PACKED or packed_rows is not None):
         # one row [R1 | R2 | G_max | G_min | 16-bit ranks] per node at a 128-byte aligned pitch: an out-edge of the pull reads 12 cache
-        # lines at F = 75 instead of ~14.7 for three separate pieces (pna_segreduce_bwd_pull_f32, packed rows)
+        # lines at F = 75 instead of ~14.7 for three separate pieces (pna_segreduce_bwd_pull_f32, packed rows).  packed_rows: the
+        # caller's buffer, whose first 4 T F columns ARE gagg (aggs = mean, std, max, min): rowprep works in place
         pitch = (5 * TF + 31) // 32 * 32
-        packed = torch.empty(V, pitch, dtype=torch.float32, device=dev)
+        packed = torch.empty(V, pitch, dtype=torch.float32, device=dev) if packed_rows is None else packed_rows
         table = packed[:, :2 * TF]
         ranks = packed.view(torch.int16)[:, 8 * TF:10 * TF]
     else:
@@ -443,9 +448,17 @@ class SimpleLayerPlanFn(torch.autograd.Function):
                 raise RuntimeError("SimpleLayerPlanFn: shape outside pna_posttrans_dw_grouped_f32 (the layer checks it before taking this path)")
             g_w, g_b = res
         if ctx.needs_input_grad[0]:
-            wt = torch.cat([weight[:, s * K:(s + 1) * K].t() for s in range(S)], dim=1).contiguous()       # (K, S*N)
-            g_agg = ops.posttrans(gy, N, wt, scales, None, arith="bf16x3")                                  # (V, 4F), node order
-            g_h, _ = _backward_pull(graph, x, None, agg, amx, amn, g_agg, aggs, aggs, 1, F, True, False, row_of=plan.vmap32())
+            # d agg = sum_s scale_s (.) (gy W_s), node order, written STRAIGHT into the pull's packed table rows with the aggregator
+            # blocks in the order [mean | std | max | min]: rowprep then turns the first two blocks into R1 | R2 in place -- no
+            # separate (V, 4F) gradient tensor, no copy of G_max | G_min (rowprep 0.95 -> ~0.65 ms at C3)
+            V = gy.shape[0]
+            order = torch.cat([torch.arange(a * F, (a + 1) * F, device=gy.device) for a in (0, 3, 1, 2)])       # rows of W^T: mean, std, max, min
+            wt = torch.cat([weight[:, s * K:(s + 1) * K].t().index_select(0, order) for s in range(S)], dim=1).contiguous()     # (K, S*N)
+            pitch = (5 * F + 31) // 32 * 32
+            packed = torch.empty(V, pitch, dtype=torch.float32, device=gy.device)
+            g_agg = ops.posttrans(gy, N, wt, scales, None, arith="bf16x3", out=packed[:, :K])
+            g_h, _ = _backward_pull(graph, x, None, agg, amx, amn, g_agg, ["mean", "std", "max", "min"], aggs, 1, F, True, False,
+                                    row_of=plan.vmap32(), packed_rows=packed, node_of=plan.node_of_rows())
         return g_h, g_w, g_b, None, None
 
 

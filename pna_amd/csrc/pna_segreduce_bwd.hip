@@ -241,17 +241,15 @@ struct PArgs {
   float* table; float* grad_dst; float* grad_x;
   unsigned short* ranks;             // nullable: (V, ld_rank) [rank of argmax | rank of argmin] in the row's in-edge list (0xFFFF: none)
   const int32_t* row_of;             // nullable: row of mean / std / argmax / argmin that belongs to node v (a forward in degree-plan order)
+  const int32_t* node_of; long n_rows;   // nullable: the pass walks the n_rows rows of mean / std / arg* IN THEIR ORDER, row r = node node_of[r] (< 0: padding)
+  int in_place;                      // gagg == table (pna_segreduce_bwd_pull_f32, in place)
   float* gcopy;                      // nullable: packed table rows -- G_max | G_min copied to table[v][2 T F .. 4 T F) (pna_segreduce_bwd_pull_f32)
   long ld_g, ld_stat, ld_dst, ld_table, ld_gd, ld_arg, ld_gx, ts_in, ts_g, ts_stat, ld_rank;
   int V, F, T, has_var;
 };
 
-__global__ __launch_bounds__(kBlock) void k_bwd_rowprep(const PArgs a) {
-  const int TF = a.T * a.F;
-  const long i = (long)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= (long)a.V * TF) return;
-  const int v = (int)(i / TF), c = (int)(i - (long)v * TF);
-  const int t = c / a.F, f = c - t * a.F;
+__device__ __forceinline__ void rowprep_elem(const PArgs& a, int v, long vs, int t, int f) {      // vs: the row of the statistics / arg indices
+  const int TF = a.T * a.F, c = t * a.F + f;
   const float D = (float)(a.rowptr[v + 1] - a.rowptr[v]);
   const size_t og = (size_t)v * a.ld_g + (size_t)t * a.ts_g + f;
   float base = 0.f;
@@ -262,7 +260,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_rowprep(const PArgs a) {
   float r1 = base;
   if (a.has_var) {
     float cvar = 0.f;
-    const size_t os = (size_t)(a.row_of ? a.row_of[v] : v) * a.ld_stat + (size_t)t * a.ts_stat + f;
+    const size_t os = (size_t)vs * a.ld_stat + (size_t)t * a.ts_stat + f;
     if (D > 0.f) {
       const float sd = a.stdv ? a.stdv[os] : 1.f;
       const float vr = a.var ? a.var[os] : sd * sd - 1e-5f;              // relu'(raw var): 0 at and below 0
@@ -288,12 +286,25 @@ __global__ __launch_bounds__(kBlock) void k_bwd_rowprep(const PArgs a) {
     a.gcopy[(size_t)v * a.ld_table + TF + c] = a.g[PNA_AGG_MIN] ? a.g[PNA_AGG_MIN][og] : 0.f;
   }
   if (a.ranks) {                     // for pna_segreduce_bwd_pull_f32: where in the row's in-edge list argmax / argmin sit
-    const size_t oa = (size_t)(a.row_of ? a.row_of[v] : v) * a.ld_arg + (size_t)t * a.ts_in + f;
+    const size_t oa = (size_t)vs * a.ld_arg + (size_t)t * a.ts_in + f;
     const int beg = a.rowptr[v];
     const int ex = a.argmax ? a.argmax[oa] : -1, en = a.argmin ? a.argmin[oa] : -1;
     a.ranks[(size_t)v * a.ld_rank + c] = ex < 0 ? (unsigned short)0xFFFF : (unsigned short)(ex - beg);
     a.ranks[(size_t)v * a.ld_rank + TF + c] = en < 0 ? (unsigned short)0xFFFF : (unsigned short)(en - beg);
   }
+}
+
+__global__ __launch_bounds__(kBlock) void k_bwd_rowprep(const PArgs a) {
+  const int TF = a.T * a.F;
+  const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+  const long R = a.node_of ? a.n_rows : (long)a.V;
+  if (i >= R * TF) return;
+  const long r = i / TF;
+  const int c = (int)(i - r * TF);
+  const int v = a.node_of ? a.node_of[r] : (int)r;
+  if (v < 0) return;
+  const int t = c / a.F;
+  rowprep_elem(a, v, a.node_of ? r : (a.row_of ? (long)a.row_of[v] : (long)v), t, c - t * a.F);
 }
 
 // The same pass with FOUR features per thread (F >= 4; 16-byte accesses, the row's last window slides back to [F - 4, F) and rewrites
@@ -302,9 +313,20 @@ __global__ __launch_bounds__(kBlock) void k_bwd_rowprep(const PArgs a) {
 __global__ __launch_bounds__(kBlock) void k_bwd_rowprep4(const PArgs a) {
   const int nch = (a.F + 3) / 4, TC = a.T * nch;
   const long i = (long)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= (long)a.V * TC) return;
-  const int v = (int)(i / TC), ct = (int)(i - (long)v * TC);
+  const long R = a.node_of ? a.n_rows : (long)a.V;
+  if (i >= R * TC) return;
+  const long r = i / TC;
+  const int ct = (int)(i - r * TC);
+  const int v = a.node_of ? a.node_of[r] : (int)r;
+  if (v < 0) return;
+  const long vs = a.node_of ? r : (a.row_of ? (long)a.row_of[v] : (long)v);
   const int t = ct / nch, f = min((ct - t * nch) * 4, a.F - 4);
+  if (a.in_place && (ct - t * nch) * 4 + 4 > a.F) {
+    // in place (gagg == table) the sliding last window would read columns its neighbour has already overwritten: the tail's own
+    // 1..3 columns one by one instead
+    for (int ff = (ct - t * nch) * 4; ff < a.F; ++ff) rowprep_elem(a, v, vs, t, ff);
+    return;
+  }
   const int TF = a.T * a.F, c = t * a.F + f;
   struct __attribute__((packed, aligned(4))) i4u { i4 v; };
   typedef unsigned short us4 __attribute__((ext_vector_type(4)));
@@ -322,7 +344,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_rowprep4(const PArgs a) {
   f4 r1 = base;
   if (a.has_var) {
     f4 cvar = zero;
-    const size_t os = (size_t)(a.row_of ? a.row_of[v] : v) * a.ld_stat + (size_t)t * a.ts_stat + f;
+    const size_t os = (size_t)vs * a.ld_stat + (size_t)t * a.ts_stat + f;
     if (D > 0.f) {
       const f4 one = {1.f, 1.f, 1.f, 1.f};
       const f4 sd = a.stdv ? ld(a.stdv + os) : one;
@@ -360,7 +382,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_rowprep4(const PArgs a) {
     st(a.gcopy + (size_t)v * a.ld_table + TF + c, gmn);
   }
   if (a.ranks) {
-    const size_t oa = (size_t)(a.row_of ? a.row_of[v] : v) * a.ld_arg + (size_t)t * a.ts_in + f;
+    const size_t oa = (size_t)vs * a.ld_arg + (size_t)t * a.ts_in + f;
     const int beg = a.rowptr[v];
     const i4 none = {-1, -1, -1, -1};
     const i4 ex = a.argmax ? reinterpret_cast<const i4u*>(a.argmax + oa)->v : none;
@@ -375,12 +397,15 @@ __global__ __launch_bounds__(kBlock) void k_bwd_rowprep4(const PArgs a) {
   }
 }
 
-void launch_rowprep(const PArgs& k, hipStream_t st) {
+void launch_rowprep(PArgs k, hipStream_t st, bool in_place = false) {
+  k.in_place = in_place ? 1 : 0;
+  const long R = k.node_of ? k.n_rows : (long)k.V;
+  if (R <= 0) return;
   if (k.F >= 4) {
-    const long n = (long)k.V * k.T * ((k.F + 3) / 4);
+    const long n = R * k.T * ((k.F + 3) / 4);
     hipLaunchKernelGGL(k_bwd_rowprep4, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, k);
   } else {
-    const long n = (long)k.V * k.T * k.F;
+    const long n = R * k.T * k.F;
     hipLaunchKernelGGL(k_bwd_rowprep, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, k);
   }
 }
@@ -520,6 +545,8 @@ int fill_pull_args(const pna_segreduce_bwd_args* p, PArgs& k, const char* who) {
   k.ts_in = T > 1 ? p->tower_stride_in : 0; k.ts_g = T > 1 ? p->tower_stride_g : 0; k.ts_stat = T > 1 ? p->tower_stride_stat : 0;
   k.V = p->V; k.F = p->F; k.T = T;
   k.row_of = p->stat_row_of;
+  k.node_of = p->stat_node_of; k.n_rows = (long)p->stat_rows;
+  if (p->stat_node_of && p->stat_rows < 0) return pna_set_error(PNA_E_INVALID, who);
   return PNA_OK;
 }
 
@@ -529,7 +556,7 @@ extern "C" int pna_segreduce_bwd_f32(const pna_segreduce_bwd_args* p, pna_stream
   if (!p) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: null args");
   if (int rc_ss = pna_check_struct_size("pna_segreduce_bwd_f32", p->struct_size, sizeof(*p))) return rc_ss;
   if (p->V < 0 || p->F <= 0) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: bad V/F");
-  if (p->stat_row_of) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: stat_row_of is honoured by the rowprep / pull entry points only");
+  if (p->stat_row_of || p->stat_node_of) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: stat_row_of / stat_node_of are honoured by the rowprep / pull entry points only");
   if (p->V == 0) return PNA_OK;
   if (!p->rowptr || !p->gagg) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: rowptr/gagg must be non-null");
   if (p->n_aggr <= 0 || p->n_aggr > PNA_MAX_AGGR) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_f32: n_aggr out of range");
@@ -615,8 +642,15 @@ extern "C" int pna_segreduce_bwd_pull_f32(const pna_segreduce_bwd_pull_args* q, 
   const bool packed = q->run_rowprep && q->ld_table >= 5L * TF && (const void*)q->ranks == (const void*)(q->table + 4L * TF);
   if (q->run_rowprep) {              // rowprep (table, grad_dst) and the ranks in ONE pass over the rows
     k.table = const_cast<float*>(q->table); k.ld_table = q->ld_table; k.ranks = q->ranks; k.ld_rank = q->ld_rank;
-    k.gcopy = packed ? const_cast<float*>(q->table) + 2L * TF : nullptr;
-    launch_rowprep(k, st);
+    // IN PLACE: base->gagg == table with aggr[] = {mean, std, max, min} -- the caller's d agg contraction wrote its output straight
+    // into the packed rows ([G_mean | G_std | G_max | G_min] at [0, 4 T F)): rowprep overwrites the first two blocks with R1 | R2,
+    // nothing is copied (one-tower layers; every thread reads its own columns before it writes them)
+    const bool in_place = packed && p->gagg == q->table;
+    if (in_place && !(T == 1 && p->n_aggr == 4 && p->aggr[0] == PNA_AGG_MEAN && p->aggr[1] == PNA_AGG_STD && p->aggr[2] == PNA_AGG_MAX &&
+                      p->aggr[3] == PNA_AGG_MIN && p->ld_g == q->ld_table))
+      return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_pull_f32: gagg == table (in place) needs one tower, aggr[] = {mean, std, max, min} and ld_g == ld_table");
+    k.gcopy = (packed && !in_place) ? const_cast<float*>(q->table) + 2L * TF : nullptr;
+    launch_rowprep(k, st, in_place);
   } else {
     hipLaunchKernelGGL(k_bwd_ranks, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, p->rowptr, p->argmax, p->argmin, (long)p->ld_arg,
                        (long)k.ts_in, p->V, F, T, q->ranks, (long)q->ld_rank);
@@ -641,7 +675,7 @@ extern "C" int pna_segreduce_bwd_argscatter_f32(const pna_segreduce_bwd_args* p,
   PArgs k;
   int rc = fill_pull_args(p, k, "pna_segreduce_bwd_argscatter_f32: bad arguments");
   if (rc != PNA_OK) return rc;
-  if (p->stat_row_of) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_argscatter_f32: stat_row_of is honoured by the rowprep / pull entry points only");
+  if (p->stat_row_of || p->stat_node_of) return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_argscatter_f32: stat_row_of / stat_node_of are honoured by the rowprep / pull entry points only");
   if (p->V == 0 || (!k.g[PNA_AGG_MAX] && !k.g[PNA_AGG_MIN])) return PNA_OK;
   if (!p->col || !p->grad_x || (k.g[PNA_AGG_MAX] && !p->argmax) || (k.g[PNA_AGG_MIN] && !p->argmin))
     return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_argscatter_f32: col / grad_x / argmax / argmin missing");

@@ -264,6 +264,13 @@ class DegreePlan:
             self._vmap32 = self._vmap.to(torch.int32).contiguous()
         return self._vmap32
 
+    def node_of_rows(self):
+        """int32 [rows]: node of every row of the plan-ordered buffer, -1 for padding rows (pna_segreduce_bwd_args.stat_node_of)."""
+        hit = self.__dict__.get("_node_of_rows")
+        if hit is None:
+            hit = self.__dict__["_node_of_rows"] = torch.cat([self.perm, self.perm_rest]).contiguous()
+        return hit
+
     def perm_all(self):
         """int32 [rows]: node of every row of the plan-ordered buffer (degree tiles, then the rest), padding rows -> node 0."""
         if self._perm_all is None:
