@@ -238,7 +238,9 @@ def posttrans_dw_grouped(gy, a_mat, K, h, row_scales, plan, want_bias=True, a_pl
     gw = torch.empty(N, Kh + S * K, dtype=torch.float32, device=dev)
     gb = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
     nb = L.pna_posttrans_dw_grouped_workspace_bytes(N, K, Kh, n_entries)
-    ws = torch.empty(nb // 4, dtype=torch.float32, device=dev)
+    ws = plan.__dict__.get("_dw_ws")                         # (live only inside this call: kept on the plan, like the pull's packed rows)
+    if ws is None or ws.numel() * 4 < nb or ws.device != dev:
+        ws = plan.__dict__["_dw_ws"] = torch.empty(nb // 4, dtype=torch.float32, device=dev)
     a = _lib.PnaPosttransDwGroupedArgs()
     a.gy, a.ldg, a.N, a.n_scaler = _lib.dev_ptr(gy, torch.float32, "gy"), gy.stride(0), N, S
     a.a, a.lda, a.K, a.Kh = _lib.dev_ptr(a_mat, torch.float32, "a"), a_mat.stride(0), K, Kh
