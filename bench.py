@@ -497,6 +497,28 @@ def main():
             y_c = layer(g, h_c)
             contig_same_bits = bool(torch.equal(y_c, layer(g, h)))
         del h_c
+    # ---- the same step replayed from a hipGraph (pna_amd.capture.GraphedForward: the kernel, the fork / join to the second stream and
+    # the rest rows' chain as ONE graph launch): what the host side of the eager step costs.  Informative; `value` stays the eager step.
+    ms_per_step_hipgraph = None
+    if world == 1:
+        try:
+            from pna_amd.capture import GraphedForward
+            with torch.no_grad():
+                gf = GraphedForward(lambda x: layer(g, x), h, alias_inputs=True)
+                for _ in range(max(args.warmup, 3)):
+                    gf.graph.replay()
+                sync()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    gf.graph.replay()
+                sync()
+                ms_per_step_hipgraph = (time.perf_counter() - t1) / args.steps * 1e3
+                if not torch.equal(gf.static_out, layer(g, h)):
+                    ms_per_step_hipgraph = None
+            del gf
+        except Exception as ex:   # noqa: BLE001  (never sinks the line)
+            print(f"[bench] hipGraph leg skipped: {ex}", file=sys.stderr)
+            ms_per_step_hipgraph = None
 
     # the same step with the contraction forced onto the exact f32-input MFMA (reported beside the headline number)
     from pna_amd import ops as _ops
@@ -727,6 +749,7 @@ def main():
         "halo_exchange": halo_rate,
         "ms_per_step_exact_f32_mfma": ms_per_step_f32, "value_exact_f32_mfma": E / (ms_per_step_f32 * 1e-3),
         "ms_per_step_contiguous_input": ms_per_step_contig,
+        "ms_per_step_hipgraph_replay": ms_per_step_hipgraph,
         "contiguous_input": ({"what": "the same K steps with h a CONTIGUOUS (V, F) tensor (row pitch F floats = 300 bytes at F = 75): the reference API's input",
                               "takes_the_one_kernel_layer": contig_one_kernel, "output_bits_equal_the_aligned_step": contig_same_bits,
                               "value": E / (ms_per_step_contig * 1e-3), "ratio_to_headline": ms_per_step_contig / ms_per_step}
