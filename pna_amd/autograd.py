@@ -452,7 +452,9 @@ class SimpleLayerPlanFn(torch.autograd.Function):
             # blocks in the order [mean | std | max | min]: rowprep then turns the first two blocks into R1 | R2 in place -- no
             # separate (V, 4F) gradient tensor, no copy of G_max | G_min (rowprep 0.95 -> ~0.65 ms at C3)
             V = gy.shape[0]
-            order = torch.cat([torch.arange(a * F, (a + 1) * F, device=gy.device) for a in (0, 3, 1, 2)])       # rows of W^T: mean, std, max, min
+            order = plan.__dict__.get("_dagg_order")                                                           # rows of W^T: mean, std, max, min
+            if order is None or order.numel() != K or order.device != gy.device:
+                order = plan.__dict__["_dagg_order"] = torch.cat([torch.arange(a * F, (a + 1) * F, device=gy.device) for a in (0, 3, 1, 2)])
             wt = torch.cat([weight[:, s * K:(s + 1) * K].t().index_select(0, order) for s in range(S)], dim=1).contiguous()     # (K, S*N)
             pitch = (5 * F + 31) // 32 * 32
             # (1.5 GB at C3, live only inside this call: kept on the plan -- allocated per step it makes the caching allocator split and
