@@ -492,6 +492,53 @@ def test_simple_layer_training_step_in_degree_plan_order(cuda_device, monkeypatc
         assert off <= 1e-3 and rel(gw1, gw0) <= 2e-3 and rel(gb1, gb0) <= 2e-3, (off, rel(gw1, gw0), rel(gb1, gb0))
 
 
+def test_simple_layer_training_step_in_degree_plan_order_vs_the_float64_oracle(cuda_device, monkeypatch):
+    """The plan-order training step against oracle/torch_oracle.simple_layer_train_step (the restatement pinned to the reference's
+    own training-step goldens, tests/test_oracle_golden.py) evaluated in FLOAT64 on a graph with degree tiles, hub rows and rows
+    without in-edges: output, running statistics, input gradient and every parameter gradient."""
+    from oracle import torch_oracle as O
+    from pna_amd import autograd as AG, degree_groups as DG
+    from pna_amd.synth import powerlaw_graph
+    monkeypatch.setattr(DG, "MIN_ROWS", 1)
+    monkeypatch.setattr(DG, "MIN_OUT", 1)
+    V, E, F = 9000, 80_000, 32
+    src, dst = powerlaw_graph(V, E, seed=23)
+    keep = dst >= 30
+    src, dst = src[keep], dst[keep]
+    g = Graph(src, dst, V).to(cuda_device)
+    assert int((g.in_degrees() > 128).sum()) > 0
+    avg_log = torch.log(g.in_degrees().double().cpu() + 1).mean().float()
+    torch.manual_seed(0)
+    layer = PNASimpleLayer(F, F, "mean max min std", "identity amplification attenuation", {"log": avg_log}, 0.0, True, True)
+    with torch.no_grad():
+        for p in layer.parameters():
+            if p.dim() == 2:
+                p.copy_(torch.randn_like(p) / p.shape[1] ** 0.5)
+    sd = {k: v.clone() for k, v in layer.state_dict().items()}
+    h = torch.randn(V, F, generator=torch.Generator().manual_seed(1))
+    R = torch.linspace(0.5, 1.5, F)
+    layer = layer.to(cuda_device).train()
+    hd = h.to(cuda_device).requires_grad_(True)
+    used = []
+    real = AG.SimpleLayerPlanFn.apply
+    monkeypatch.setattr(AG.SimpleLayerPlanFn, "apply", lambda *a: (used.append(1), real(*a))[1])
+    out = layer(g, hd)
+    (out * R.to(cuda_device)).sum().backward()
+    assert used
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    o64, gh64, gp64, rm64, rv64 = O.simple_layer_train_step(sd64, src, dst, V, h.double(), ["mean", "max", "min", "std"],
+                                                             ["identity", "amplification", "attenuation"], avg_log.double(), R.double())
+    rel = lambda a, b: (a.double().cpu() - b).abs().max().item() / max(1e-30, b.abs().max().item())
+    assert rel(out.detach(), o64) <= 1e-5 and rel(layer.batchnorm_h.running_mean, rm64) <= 1e-5 and rel(layer.batchnorm_h.running_var, rv64) <= 1e-5
+    # (a pre-activation within fp32 rounding of 0 takes the other ReLU branch: a handful of entries carry a whole unit)
+    off = ((hd.grad.double().cpu() - gh64).abs() > 1e-4 * gh64.abs().max()).double().mean().item()
+    assert off <= 2e-3, off
+    for name, p in layer.named_parameters():
+        if name.endswith("posttrans.fully_connected.0.linear.bias"):
+            continue                                         # (in front of batch-statistics BatchNorm: true gradient 0, rounding noise)
+        assert rel(p.grad, gp64[name]) <= 2e-2, (name, rel(p.grad, gp64[name]))
+
+
 @pytest.mark.parametrize("route", ["degree plan order", "per-row scalers"])
 def test_simple_layer_training_step_weight_gradient_kernels_match_the_library_route(cuda_device, monkeypatch, route):
     """The layer's training step with the posttrans weight / bias gradient on pna_posttrans_dw_grouped_f32 (the rows in the graph's
