@@ -86,7 +86,11 @@ class PNANet(nn.Module):
         graph = as_graph(g)
         h = self.in_feat_dropout(embed(self.embedding_h, h) if isinstance(self.embedding_h, nn.Embedding) else self.embedding_h(h))
         if self.edge_feat:
+            e_idx = e
             e = embed(self.embedding_e, e)
+            if e_idx.dim() == 1 and not torch.is_floating_point(e_idx) and hasattr(graph, "register_edge_types"):
+                # the layers' edge-type fast paths (<= 4 bond types: ZINC) get the types they would otherwise have to FIND in e's rows
+                graph.register_edge_types(e, e_idx, self.embedding_e.weight)
         for i, conv in enumerate(self.layers):
             h_t = conv(graph, h, e, snorm_n)
             if self.gru_enable and i != len(self.layers) - 1:

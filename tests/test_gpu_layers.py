@@ -299,6 +299,31 @@ def test_molecules_net_golden(cuda_device, name):
     torch.testing.assert_close(out, a["out"], **TOL)
 
 
+def test_molecules_net_hands_its_bond_types_to_the_layers(cuda_device, monkeypatch):
+    """PNANet with --edge_feat: `e = embedding_e(bond_type)`.  The net registers the types on the graph (Graph.register_edge_types), so
+    the layers' edge-type fast path does not have to FIND them in e's rows (a sort of E doubles + two host syncs per fresh batch,
+    ADVICE r3): no torch.unique during the forward, the one-call kernel takes every layer, the reference's output comes out."""
+    from pna_amd import functional as PF
+    from pna_amd.nets import PNANet
+    from test_host_logic import _net_params
+    meta, a, sd = load_golden("net_zinc_sum_edgefeat")
+    params = _net_params(meta, a)
+    if params["num_bond_type"] > Graph.MAX_EDGE_TYPES:
+        pytest.skip("more bond types than the register table holds")
+    net = PNANet(params)
+    net.load_state_dict(sd)
+    net = net.to(cuda_device).eval()
+    g = Graph(a["src"], a["dst"], meta["N"], meta["sizes"]).to(cuda_device)
+    seen = []
+    run = PF._SmallTowerPlan.run
+    monkeypatch.setattr(PF._SmallTowerPlan, "run", lambda self, *args, **kw: (seen.append(args[-1] if len(args) >= 6 else kw.get("etab")), run(self, *args, **kw))[1])
+    monkeypatch.setattr(torch, "unique", lambda *a_, **k_: (_ for _ in ()).throw(AssertionError("the edge types were searched for")))
+    with torch.no_grad():
+        out = net(g, a["atoms"].to(cuda_device), a["bonds"].to(cuda_device), a["snorm_n"].to(cuda_device), None).cpu()
+    torch.testing.assert_close(out, a["out"], **TOL)
+    assert len(seen) == len(net.layers) and all(t is not None for t in seen)
+
+
 @pytest.mark.parametrize("name", golden_names("net_hiv"))
 def test_hiv_net_golden(cuda_device, name):
     """PNANetHIV against the output of the reference's OWN HIV net (README.md:45 configuration: hidden = out = 80, L = 4, mean
