@@ -231,6 +231,29 @@ out["molhiv_net_4_layers"] = dict(graphs=2048, V=V, E=E, hidden=80, L=4, inferen
                                   graphs_per_s_inference=2048 / net_eager * 1e3, train_step_ms=net_train,
                                   graphs_per_s_training=2048 / net_train * 1e3)
 
+# ---- the whole ZINC net of the reference's README with --edge_feat True (PNALayer x 4, hidden 75, 5 towers, edge_dim 50, sum
+#      readout; realworld_benchmark/README.md:62), a 128-molecule batch: FRESH edge-feature tensors every call (e = embedding_e(bonds)),
+#      the bond types handed to the graph by the net (Graph.register_edge_types) ----
+from pna_amd.nets import PNANet  # noqa: E402
+srcz, dstz, sizesz = molecule_batch(128, seed=41)
+Vz, Ez = sum(sizesz), srcz.numel()
+gz = Graph(srcz, dstz, Vz, sizesz).to(dev)
+avgz = {"log": torch.log(gz.in_degrees().double() + 1).mean().float().cpu()}
+znet = PNANet(dict(num_atom_type=28, num_bond_type=4, hidden_dim=75, out_dim=70, in_feat_dropout=0.0, dropout=0.0, L=4, readout="sum",
+                   graph_norm=True, batch_norm=True, residual=True, aggregators=AGG, scalers=SCA, avg_d=avgz, towers=5,
+                   divide_input_first=False, divide_input_last=True, edge_feat=True, edge_dim=50, pretrans_layers=1, posttrans_layers=1,
+                   gru=False, device=dev)).to(dev).eval()
+genz = torch.Generator().manual_seed(2)
+atomsz = torch.randint(0, 28, (Vz,), generator=genz).to(dev)
+bondsz = torch.randint(0, 4, (Ez,), generator=genz).to(dev)
+snz = gz.snorm_n()
+with torch.no_grad():
+    znet_eager = gpu_ms(lambda: znet(gz, atomsz, bondsz, snz, None))
+out["zinc_net_4_layers_edge_feat"] = dict(graphs=128, V=Vz, E=Ez, hidden=75, towers=5, L=4, edge_dim=50, bond_types=4, inference_eager_ms=znet_eager,
+                                          graphs_per_s_inference=128 / znet_eager * 1e3,
+                                          note="fresh e = embedding_e(bonds) every call; layers 1-3 on the one-call kernel with the edge-type table, the last "
+                                               "layer (divide_input_last) too")
+
 # ---- configs[0]: multitask dense layer, B=128 graphs of N=50 nodes, hidden 16, 4 towers ----
 gen = torch.Generator().manual_seed(1234)
 B, N = 128, 50
