@@ -171,7 +171,7 @@ def _towers_forward(towers, graph, h, e, snorm_n, divide_input):
         # e with host syncs, a replay with other values would gather through the captured example's types; the per-edge product
         # below is captured as kernels and replays correctly -- ADVICE r3)
         if (no_grad and e.is_cuda and type(graph) is Graph and all(t.pretrans.is_affine for t in towers)
-                and not torch.cuda.is_current_stream_capturing()):
+                and (not torch.cuda.is_current_stream_capturing() or graph.edge_types_registered(e))):
             etab = graph.edge_type_table(e)                   # edge features that are an embedding of <= 4 edge types: a table
         e_csr = e[csr.eid] if etab is None else None          # per-edge features in CSR (dst-sorted) order
     hs = [h[:, t * Fi:(t + 1) * Fi] if divide_input else h for t in range(T)]
@@ -323,8 +323,8 @@ class PNALayer(nn.Module):
                 # table is read from the VALUES of e with host syncs; the general route below is captured instead)
                 if e is None:
                     raise ValueError("edge_features=True but no edge features were given")
-                if e.is_cuda and not e.requires_grad and not torch.cuda.is_current_stream_capturing():
-                    etab = graph.edge_type_table(e)
+                if e.is_cuda and not e.requires_grad and (not torch.cuda.is_current_stream_capturing() or graph.edge_types_registered(e)):
+                    etab = graph.edge_type_table(e)          # (registered types -- PNANet -- are device-side results: capture-safe)
             if etab is not None or not self.edge_features:
                 return PF.tower_layer_small(self, list(self.towers), self.mixing_network, graph, h, snorm_n,
                                             _row_scales(graph, t0.scalers, t0.avg_d, h.device), self.divide_input, self.residual, etab)

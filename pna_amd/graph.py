@@ -319,7 +319,14 @@ class Graph:
         with torch.no_grad():
             res = (types.reshape(-1)[self.csr.eid.long()].to(torch.int32).contiguous(), rows.detach())
         key = (e.data_ptr(), e._version, tuple(e.shape), str(e.device))
-        self.__dict__["_edge_types"] = (key, res, weakref.ref(e))
+        self.__dict__["_edge_types"] = (key, res, weakref.ref(e), True)
+
+    def edge_types_registered(self, e):
+        """Whether edge_type_table(e) would answer from register_edge_types: types and rows that were COMPUTED on the device from the
+        caller's tensors (no values read on the host) -- safe while a hipGraph is being captured, and a replay recomputes them."""
+        hit = self.__dict__.get("_edge_types")
+        return (hit is not None and len(hit) > 3 and hit[3] and hit[2]() is e
+                and hit[0] == (e.data_ptr(), e._version, tuple(e.shape), str(e.device)))
 
     def edge_type_table(self, e):
         """(types int32 [E] in CSR order, rows (n_types, edge_dim)) when the per-edge feature rows `e` take at most

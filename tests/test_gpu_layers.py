@@ -324,6 +324,47 @@ def test_molecules_net_hands_its_bond_types_to_the_layers(cuda_device, monkeypat
     assert len(seen) == len(net.layers) and all(t is not None for t in seen)
 
 
+def test_molecules_net_under_hipgraph_capture_with_varying_bond_types(cuda_device):
+    """The whole ZINC-style net (edge features = an embedding of 4 bond types) captured as one hipGraph with the atom AND bond types as
+    inputs: the net registers the types on the graph from device-side ops, so the capture takes the one-call kernel's edge-type
+    table, and a replay with OTHER bond types recomputes it (the replay equals the eager result for the new inputs)."""
+    from pna_amd import functional as PF
+    from pna_amd.capture import GraphedForward
+    from pna_amd.nets import PNANet
+    from pna_amd.synth import molecule_batch
+    src, dst, sizes = molecule_batch(64, seed=9)
+    V, E = int(sum(sizes)), src.numel()
+    g = Graph(src, dst, V, sizes).to(cuda_device)
+    torch.manual_seed(3)
+    net = PNANet(dict(num_atom_type=28, num_bond_type=4, hidden_dim=75, out_dim=70, in_feat_dropout=0.0, dropout=0.0, L=3, readout="sum",
+                      graph_norm=True, batch_norm=True, residual=True, aggregators="mean max min std", scalers="identity amplification attenuation",
+                      avg_d={"log": torch.tensor(1.1)}, towers=5, divide_input_first=False, divide_input_last=True, edge_feat=True, edge_dim=50,
+                      pretrans_layers=1, posttrans_layers=1, gru=False, device=cuda_device)).to(cuda_device).eval()
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() == 2:
+                p.copy_(torch.randn_like(p) / p.shape[1] ** 0.5)
+    gen = torch.Generator().manual_seed(1)
+    atoms = [torch.randint(0, 28, (V,), generator=gen).to(cuda_device) for _ in range(2)]
+    bonds = [torch.randint(0, 4, (E,), generator=gen).to(cuda_device) for _ in range(2)]
+    sn = g.snorm_n()
+    seen = []
+    run = PF._SmallTowerPlan.run
+    PF._SmallTowerPlan.run = lambda self, *args, **kw: (seen.append(args[-1] if len(args) >= 6 else kw.get("etab")), run(self, *args, **kw))[1]
+    try:
+        with torch.no_grad():
+            want = [net(g, a_, b_, sn, None).clone() for a_, b_ in zip(atoms, bonds)]
+            seen.clear()
+            gf = GraphedForward(lambda a_, b_: net(g, a_, b_, sn, None), atoms[0], bonds[0])
+            assert seen and all(t is not None for t in seen)          # warm-up and capture took the table
+            got = [gf(a_, b_).clone() for a_, b_ in zip(atoms, bonds)]
+    finally:
+        PF._SmallTowerPlan.run = run
+    assert (want[0] - want[1]).abs().max() > 1e-3
+    for w, o in zip(want, got):
+        torch.testing.assert_close(o, w, rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("name", golden_names("net_hiv"))
 def test_hiv_net_golden(cuda_device, name):
     """PNANetHIV against the output of the reference's OWN HIV net (README.md:45 configuration: hidden = out = 80, L = 4, mean

@@ -249,8 +249,11 @@ bondsz = torch.randint(0, 4, (Ez,), generator=genz).to(dev)
 snz = gz.snorm_n()
 with torch.no_grad():
     znet_eager = gpu_ms(lambda: znet(gz, atomsz, bondsz, snz, None))
+    gfz = GraphedForward(lambda a_, b_: znet(gz, a_, b_, snz, None), atomsz, bondsz)      # atom AND bond types are inputs of the graph
+    znet_graphed = gpu_ms(lambda: gfz(atomsz, bondsz))
 out["zinc_net_4_layers_edge_feat"] = dict(graphs=128, V=Vz, E=Ez, hidden=75, towers=5, L=4, edge_dim=50, bond_types=4, inference_eager_ms=znet_eager,
-                                          graphs_per_s_inference=128 / znet_eager * 1e3,
+                                          graphs_per_s_inference=128 / znet_eager * 1e3, inference_hipgraph_ms=znet_graphed,
+                                          graphs_per_s_hipgraph=128 / znet_graphed * 1e3,
                                           note="fresh e = embedding_e(bonds) every call; layers 1-3 on the one-call kernel with the edge-type table, the last "
                                                "layer (divide_input_last) too")
 
