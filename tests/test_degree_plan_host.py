@@ -118,3 +118,80 @@ def test_rest_rows_run_beside_the_kernel_only_on_large_graphs(graph_and_plan, mo
     assert plan.rest_overlap_applies(75) and plan.rest_overlap_applies(128) and not plan.rest_overlap_applies(40)
     monkeypatch.setattr(DG, "FUSED_SPARE_WGS", 0)
     assert not plan.rest_overlap_applies(75)
+
+
+@pytest.mark.parametrize("n_blocks", [1, 3, 8])
+def test_block_plans_partition_the_nodes(n_blocks):
+    """The per-block plans of shard.BlockPipeline's row blocks (round 4: DegreePlan(row_range, with_heavy, extra_rows, drop_rest), as
+    functional.SimpleLayerRows.block_plan builds them): blocks 1.. hold only rows of their own range in single-degree tiles and no
+    rest rows; block 0 takes its range, the hub rows of the WHOLE graph and every block's leftovers; together: every node once."""
+    V, E = 40_000, 400_000
+    src, dst = powerlaw_graph(V, E, seed=11)
+    g = Graph(src, dst, V)
+    deg = g.in_degrees().long()
+    hs = g.heavy_schedule()
+    heavy = deg > hs.threshold
+    assert int(heavy.sum()) > 0
+    bounds = [(V * i) // n_blocks for i in range(n_blocks + 1)]
+    plans, left = {}, []
+    for i in range(1, n_blocks):
+        plans[i] = DG.DegreePlan(g, row_range=(bounds[i], bounds[i + 1]), with_heavy=False, drop_rest=True)
+        left.append(plans[i].dropped_rest)
+    plans[0] = DG.DegreePlan(g, row_range=(bounds[0], bounds[1]), with_heavy=True, extra_rows=torch.cat(left) if left else None)
+    seen = []
+    for i, plan in plans.items():
+        rows_g = plan.perm[plan.perm >= 0].long()
+        rows_r = plan.perm_rest[plan.perm_rest >= 0].long()
+        seen += [rows_g, rows_r]
+        tiles = plan.perm.view(-1, DG.TILE).long()
+        d = torch.where(tiles >= 0, deg[tiles.clamp(min=0)], torch.full_like(tiles, -1))
+        assert bool(((d == d.max(dim=1, keepdim=True).values) | (d < 0)).all())             # one in-degree per tile
+        assert not bool(heavy[rows_g].any())                                                 # hub rows are never group rows
+        assert plan.items is None and plan.row_range == (bounds[i], bounds[i + 1])
+        if i > 0:
+            assert plan.NR == 0 and not plan.with_heavy
+            assert bool(((rows_g >= bounds[i]) & (rows_g < bounds[i + 1])).all())
+            dr = plan.dropped_rest.long()
+            assert bool(((dr >= bounds[i]) & (dr < bounds[i + 1]) & ~heavy[dr]).all())
+            items, hout, hsched = plan.rest_items(g)
+            assert items.shape[0] == 0 and hout is None and hsched is None
+        else:
+            assert bool(heavy[rows_r].sum() == heavy.sum())                                  # all hub rows, wherever they lie
+            items, hout, hsched = plan.rest_items(g)
+            n_seg = hsched.n_seg if hsched.n_heavy > 0 else 0
+            assert items.shape[0] - n_seg == int((~heavy[rows_r]).sum())                     # one whole-row record per light rest row
+            assert bool((items[n_seg:, 0] >= 0).all()) and int(items[n_seg:, 0].max()) < plan.NR
+    allrows = torch.cat(seen)
+    assert allrows.numel() == V and torch.equal(torch.sort(allrows).values, torch.arange(V))
+    e_total = sum(sum(p.edge_split()) for p in plans.values())
+    assert e_total == int(deg.sum())
+
+
+def test_weight_gradient_tables_of_the_plan(graph_and_plan):
+    """DegreePlan.dw_tables (pna_posttrans_dw_grouped_f32): contiguous, equally long tile ranges per workgroup; one workspace entry per
+    run of equal degree groups inside a range, numbered in tile order; replaying the kernel's walk reproduces entry_group."""
+    g, plan = graph_and_plan
+    nt = plan.NV // DG.TILE
+    for n_wgs in (1, 7, 64, nt + 5):
+        tg, wg_range, wg_entry, entry_group, n_entries = plan.dw_tables(n_wgs)
+        assert tg.numel() == nt and wg_range.shape == (n_wgs, 2) and wg_entry.shape == (n_wgs,)
+        lo, hi = wg_range[:, 0].long(), wg_range[:, 1].long()
+        assert int(lo[0]) == 0 and int(hi[-1]) == nt and torch.equal(lo[1:], hi[:-1])
+        assert int((hi - lo).max() - (hi - lo).min()) <= 1
+        walked = []
+        for w in range(n_wgs):
+            a, b = int(lo[w]), int(hi[w])
+            if a >= b:
+                continue
+            e = int(wg_entry[w])
+            cur = int(tg[a])
+            runs = [cur]
+            for t in range(a, b):
+                if int(tg[t]) != cur:
+                    cur = int(tg[t]); runs.append(cur)
+            assert e == len(walked)                                                          # entries are numbered in tile order
+            walked += runs
+        assert n_entries == len(walked) == entry_group.numel()
+        assert walked == entry_group.tolist()
+    node_of = plan.node_of_rows()
+    assert node_of.numel() == plan.rows and torch.equal(plan.vmap32()[node_of[node_of >= 0].long()].long(), torch.nonzero(node_of >= 0).flatten())
