@@ -305,3 +305,30 @@ def test_bench_child_leg_never_sinks_the_line(monkeypatch):
         raise subprocess.TimeoutExpired(cmd="bench.py", timeout=1)
     monkeypatch.setattr(subprocess, "run", boom)
     assert "TimeoutExpired" in bench.other_workload_leg(["--workload", "c5"])["error"]
+
+
+def test_registered_edge_types_answer_without_a_search(monkeypatch):
+    """Graph.register_edge_types (PNANet: e = embedding_e(bond_type) IS rows[types]): edge_type_table(e) answers from the registration
+    for THAT tensor object only, in CSR edge order, without torch.unique; another tensor is searched for (and found) as before."""
+    gen = torch.Generator().manual_seed(3)
+    V, E = 40, 200
+    src, dst = torch.randint(0, V, (E,), generator=gen), torch.randint(0, V, (E,), generator=gen)
+    g = Graph(src, dst, V)
+    rows = torch.randn(4, 6, generator=gen)
+    types = torch.randint(0, 4, (E,), generator=gen)
+    e = rows[types]
+    g.register_edge_types(e, types, rows)
+    assert g.edge_types_registered(e)
+    real_unique = torch.unique
+    monkeypatch.setattr(torch, "unique", lambda *a, **k: (_ for _ in ()).throw(AssertionError("searched")))
+    t_csr, r = g.edge_type_table(e)
+    monkeypatch.setattr(torch, "unique", real_unique)
+    assert torch.equal(r, rows) and torch.equal(t_csr.long(), types[g.csr.eid.long()])
+    assert torch.equal(r[t_csr.long()], e[g.csr.eid.long()])
+    e2 = e.clone()
+    assert not g.edge_types_registered(e2)
+    found = g.edge_type_table(e2)                                  # the verified search still works for a caller of the bare layer
+    assert found is not None and torch.equal(found[1][found[0].long()], e2[g.csr.eid.long()])
+    assert not g.edge_types_registered(e)                          # (one cache slot: the search replaced the registration)
+    g.register_edge_types(e, types, torch.randn(9, 6))             # more rows than the register table holds: nothing registered
+    assert not g.edge_types_registered(e)
