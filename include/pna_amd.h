@@ -27,7 +27,11 @@ extern "C" {
 #endif
 
 #define PNA_ABI_VERSION 19 /* 19: + pna_fused_roles_{supported,grid,f32}: the one-kernel layer with gather / multiply wavefront roles;
-                                  every args struct of ABI 19 on carries struct_size first.
+                                  every args struct of ABI 19 on carries struct_size first.  Added inside 19 (new entry points and
+                                  trailing fields only): pna_posttrans_dw_f32 / pna_posttrans_dw_grouped_f32 (+ _workspace_bytes),
+                                  pna_tower_layer_args.{edge_type, edge_table, ld_edge_table, n_edge_types, no_self_panel},
+                                  pna_segreduce_bwd_args.{stat_row_of, stat_node_of, stat_rows}, the packed / in-place rows of
+                                  pna_segreduce_bwd_pull_f32, 64-bit source-row addressing (x_rows < 2^32, any pitch >= F).
                               18: + pna_bn_tail_{workspace_bytes,fwd_f32,bwd_f32}: batch-statistics BatchNorm + ReLU + residual of the training path.
                               17: + pna_fused_degree_args.spare_workgroups (the rest-row launches beside the persistent kernel).
                               16: + pna_segreduce_bwd_pull_f32 (the backward's max / min terms inside the pull: no scatter atomics).
