@@ -333,6 +333,39 @@ def main():
     layer = layer.to(dev).eval()
     g.degree_scalers(float(avg_log))
 
+    # ---- per-graph / per-weight set-up of the one-kernel layer, timed on its own BEFORE any step (set-up reported
+    #      separately).  Once per graph: the degree plan (row order, tile-major id records, descriptors) and the
+    #      rest rows' work list; once per (weights, graph): the packed bf16x3 weight images W_D.  Neither is part of a step.
+    setup = None
+    if world == 1 and hasattr(layer, "_degree_grouped_path"):
+        from pna_amd import degree_groups as _DGs
+        with torch.no_grad():
+            if layer._degree_grouped_path(g, h) and _DGs.fused_applies(g, h, F, F):
+                from pna_amd.dgl.pna_layer import _row_scales
+                torch.cuda.synchronize()
+                t_s = time.perf_counter()
+                plan_s = _DGs.plan_of(g)
+                tabs = plan_s.fused_tables()
+                if plan_s.NR:
+                    plan_s.rest_items(g)
+                torch.cuda.synchronize()
+                t_plan = (time.perf_counter() - t_s) * 1e3
+                t_s = time.perf_counter()
+                img_s, _ = _DGs.fused_images(layer.posttrans.fully_connected[0].linear.weight, F, _row_scales(g, layer.scalers, layer.avg_d, dev), plan_s)
+                torch.cuda.synchronize()
+                t_img = (time.perf_counter() - t_s) * 1e3
+                nbytes = lambda t: 0 if t is None else int(t.numel() * t.element_size())   # noqa: E731
+                rest = plan_s.rest_items(g) if plan_s.NR else (None, None, None)
+                setup = {"degree_plan_build_ms": t_plan, "weight_image_pack_ms": t_img, "csr_build_ms": csr_build_ms,
+                         "plan_device_bytes": {"row_perm": nbytes(plan_s.perm) + nbytes(plan_s.perm_rest), "tile_desc": nbytes(tabs[0]),
+                                               "tile_ids": nbytes(tabs[1]), "rest_work_list": nbytes(rest[0]) + nbytes(rest[1]),
+                                               "node_to_plan_row": nbytes(plan_s._vmap), "two_kernel_work_list": nbytes(plan_s.items)},
+                         "weight_images_bytes": nbytes(img_s), "degree_groups": plan_s.G,
+                         "note": "host wall-clock around the first build, device idle before and synchronised after; once per graph (plan) / "
+                                 "once per (weights, graph) (images), amortised over layers, steps and epochs; a one-shot forward on a fresh "
+                                 "graph pays csr + plan + images + one step"}
+                setup["plan_device_bytes"]["total"] = sum(setup["plan_device_bytes"].values())
+
     def step():
         with torch.no_grad():
             return layer(g, h)
@@ -749,6 +782,8 @@ def main():
         "halo_exchange": halo_rate,
         "ms_per_step_exact_f32_mfma": ms_per_step_f32, "value_exact_f32_mfma": E / (ms_per_step_f32 * 1e-3),
         "ms_per_step_contiguous_input": ms_per_step_contig,
+        "value_contiguous_input": (E / (ms_per_step_contig * 1e-3)) if ms_per_step_contig else None,
+        "per_graph_setup": setup,
         "ms_per_step_hipgraph_replay": ms_per_step_hipgraph,
         "contiguous_input": ({"what": "the same K steps with h a CONTIGUOUS (V, F) tensor (row pitch F floats = 300 bytes at F = 75): the reference API's input",
                               "takes_the_one_kernel_layer": contig_one_kernel, "output_bits_equal_the_aligned_step": contig_same_bits,

@@ -235,6 +235,25 @@ def golden_dense_registry(name, seed, B=3, N=7, F=5):
     save(name, meta, arrays, torch.nn.Module())
 
 
+def golden_dgl_registry(name, seed, n=6, d=5, F=7):
+    """Every entry of the DGL operator registries (models/dgl/aggregators.py:54-56, scalers.py:22) evaluated by the reference
+    itself on one random mailbox -- the moment entries included, whole-tensor mean and all."""
+    from models.dgl.aggregators import AGGREGATORS as REF_AGG
+    from models.dgl.scalers import SCALERS as REF_SCA
+    gen = torch.Generator().manual_seed(seed)
+    h = torch.randn(n, d, F, generator=gen) * 1.5 + 0.3
+    avg_d = dict(log=torch.tensor(1.37))
+    arrays = dict(h=h, avg_log=avg_d["log"], out=torch.zeros(1))
+    for k, f in REF_AGG.items():
+        arrays[f"agg/{k}"] = f(h)
+    m = torch.randn(n, 2 * F, generator=gen)
+    arrays["m"] = m
+    for k, f in REF_SCA.items():
+        arrays[f"sca/{k}"] = f(m, d, avg_d)
+    meta = dict(kind="dgl_registry", seed=seed, n=n, d=d, F=F, aggregators=list(REF_AGG), scalers=list(REF_SCA))
+    save(name, meta, arrays, torch.nn.Module())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
@@ -263,6 +282,7 @@ def main():
     golden_net("net_zinc_mean_gru", 42, hidden=16, out_dim=16, L=2, towers=4, edge_dim=0, readout="mean", gru=True)
     golden_net("net_zinc_max", 43, hidden=12, out_dim=8, L=2, towers=2, edge_dim=0, readout="max")
     golden_dense_registry("dense_registry_all", 9)
+    golden_dgl_registry("dgl_registry_all", 11)
     # --- dense variant (multitask path, models/pytorch/pna/layer.py) ---
     golden_dense("dense_multitask_mid", 1234, B=6, N=14, in_f=16, out_f=16, towers=4, divide_input=True,
                  scalers=("identity",))

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to the HI
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpna_amd.so")
 
-PNA_ABI_VERSION = 19
+PNA_ABI_VERSION = 20
 PNA_MAX_AGGR = 8
 PNA_MAX_SCALER = 8
 
@@ -135,19 +135,6 @@ class PnaFusedDegreeArgs(_Args):
         ("agg_out", ctypes.c_void_p), ("ld_agg", ctypes.c_int64),
         ("x_dst", ctypes.c_void_p), ("ld_xdst", ctypes.c_int64), ("h_self", ctypes.c_void_p), ("ld_h", ctypes.c_int64), ("row_post", ctypes.c_void_p),
         ("spare_workgroups", ctypes.c_int32), ("_pad4", ctypes.c_int32),
-    ]
-
-
-class PnaFusedRolesArgs(_Args):
-    _fields_ = [
-        ("struct_size", ctypes.c_uint32), ("F", ctypes.c_int32), ("N", ctypes.c_int32), ("relu", ctypes.c_int32),
-        ("tile_desc", ctypes.c_void_p), ("tile_ids", ctypes.c_void_p), ("ids_stride", ctypes.c_int64), ("n_records", ctypes.c_int64),
-        ("n_tiles", ctypes.c_int64), ("wg_range", ctypes.c_void_p), ("n_workgroups", ctypes.c_int32), ("act_slope", ctypes.c_float),
-        ("x", ctypes.c_void_p), ("ldx", ctypes.c_int64), ("x_rows", ctypes.c_int64),
-        ("row_perm", ctypes.c_void_p), ("n_nodes", ctypes.c_int64), ("w_img", ctypes.c_void_p), ("image_stride", ctypes.c_int64),
-        ("bias", ctypes.c_void_p), ("col_scale", ctypes.c_void_p), ("col_shift", ctypes.c_void_p),
-        ("residual", ctypes.c_void_p), ("ld_res", ctypes.c_int64), ("y", ctypes.c_void_p), ("ldy", ctypes.c_int64),
-        ("agg_out", ctypes.c_void_p), ("ld_agg", ctypes.c_int64), ("err", ctypes.c_void_p),
     ]
 
 
@@ -291,14 +278,6 @@ def lib():
         L.pna_fused_tower_pack_f32.restype = ctypes.c_int
         L.pna_fused_degree_f32.argtypes = [ctypes.POINTER(PnaFusedDegreeArgs), ctypes.c_void_p]
         L.pna_fused_degree_f32.restype = ctypes.c_int
-        L.pna_fused_roles_f32.argtypes = [ctypes.POINTER(PnaFusedRolesArgs), ctypes.c_void_p]
-        L.pna_fused_roles_f32.restype = ctypes.c_int
-        L.pna_fused_roles_supported.argtypes = [ctypes.c_int32, ctypes.c_int32]
-        L.pna_fused_roles_supported.restype = ctypes.c_int32
-        L.pna_fused_roles_grid.argtypes = [ctypes.c_int32]
-        L.pna_fused_roles_grid.restype = ctypes.c_int32
-        L.pna_fused_roles_image_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32]
-        L.pna_fused_roles_image_bytes.restype = ctypes.c_int64
         L.pna_posttrans_packed_floats.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                   ctypes.POINTER(ctypes.c_int64)]
         L.pna_posttrans_packed_floats.restype = ctypes.c_int64

@@ -222,7 +222,7 @@ def _column_sums(t):
 def _tall_tn(p, q, chunks=256):
     """p^T q for tall (M, a), (M, b) operands: the reduction runs over M.  As ONE library GEMM the 1e6-long reduction of the C3
     weight gradient ((225 x 1e6)(1e6 x 300)) runs at 44 TF/s -- the output has only 24 tiles; cut into 256 row slabs as a batched
-    GEMM + a sum over the slabs it takes 1.27 instead of 3.06 ms (tools/exp_dw_gemm.py), and the slab-wise summation is the more
+    GEMM + a sum over the slabs it takes 1.27 instead of 3.06 ms (tools/exp_dw_gemm.py [removed in round 5: git history]), and the slab-wise summation is the more
     accurate order."""
     M = p.shape[0]
     if not p.is_cuda or M < 64 * chunks:
@@ -459,9 +459,13 @@ class SimpleLayerPlanFn(torch.autograd.Function):
             pitch = (5 * F + 31) // 32 * 32
             # (1.5 GB at C3, live only inside this call: kept on the plan -- allocated per step it makes the caching allocator split and
             # re-grow its largest block as soon as the training loop frees its gradients every iteration: +1.8 ms per step measured)
-            packed = plan.__dict__.get("_pull_rows")
-            if packed is None or packed.shape != (V, pitch) or packed.device != gy.device:
-                packed = plan.__dict__["_pull_rows"] = torch.empty(V, pitch, dtype=torch.float32, device=gy.device)
+            # One flat buffer sized for the widest layer seen on this graph, viewed at this layer's pitch: a net whose layers differ
+            # in F does not reallocate it in every layer's backward.  One backward at a time per Graph (the buffer, the
+            # plan's weight-gradient workspace and graph.workspace are shared: the one-caller-per-Graph rule of functional.py).
+            flat = plan.__dict__.get("_pull_rows")
+            if flat is None or flat.numel() < V * pitch or flat.device != gy.device:
+                flat = plan.__dict__["_pull_rows"] = torch.empty(V * pitch, dtype=torch.float32, device=gy.device)
+            packed = flat[:V * pitch].view(V, pitch)
             g_agg = ops.posttrans(gy, N, wt, scales, None, arith="bf16x3", out=packed[:, :K])
             g_h, _ = _backward_pull(graph, x, None, agg, amx, amn, g_agg, ["mean", "std", "max", "min"], aggs, 1, F, True, False,
                                     row_of=plan.vmap32(), packed_rows=packed, node_of=plan.node_of_rows())
@@ -546,10 +550,15 @@ class PosttransFn(torch.autograd.Function):
             if DW_KERNEL and gy.is_cuda and M_rows(gy) >= DW_MIN_ROWS:
                 dg = ctx.degree_graph
                 if dg is not None and DW_GROUPED and dg.num_nodes == M_rows(gy):
-                    # the rows in the graph's degree-plan order: 32 consecutive rows share their scaler values (ops.posttrans_dw_grouped)
+                    # the rows in the graph's degree-plan order: 32 consecutive rows share their scaler values (ops.posttrans_dw_grouped).
+                    # Only for a graph that HAS a plan or is large enough for the forward to build one (DG.MIN_ROWS): a per-batch graph
+                    # of a few thousand nodes -- a fresh Graph every training step -- must not pay the plan's sorts and host syncs inside
+                    # every backward and then throw it away; it takes pna_posttrans_dw_f32 below, which needs no plan
                     from . import degree_groups as DG
-                    plan = DG.plan_of(dg)
-                    if plan.G > 0 and plan.NR <= DG.MAX_REST_FRACTION * dg.num_nodes:
+                    plan = dg.__dict__.get("_pna_amd_degree_plan")
+                    if plan is None and dg.num_nodes >= DG.MIN_ROWS:
+                        plan = DG.plan_of(dg)
+                    if plan is not None and plan.G > 0 and plan.NR <= DG.MAX_REST_FRACTION * dg.num_nodes:
                         res = ops.posttrans_dw_grouped(gy, a, K, h_self, scales, plan, want_bias=want_b)
                 if res is None:
                     res = ops.posttrans_dw(gy, a, K, h_self, scales, want_bias=want_b)

@@ -531,7 +531,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_posttrans_x3(const XArgs g) {
     load_step(nxt[D - 1], D - 1);
     __syncthreads();
 #ifdef PNA_AMD_EXPERIMENTS
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // phase timers, tools/x3_timers.py
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // phase timers, tools/x3_timers.py [removed in round 5: git history]
 #endif
     auto step = [&](auto par_c, int k) __attribute__((always_inline)) {
       constexpr int PAR = decltype(par_c)::value;           // k % D

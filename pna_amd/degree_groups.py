@@ -26,7 +26,7 @@ TILE = 128                 # rows of a workgroup tile of the one-block grouped k
 TILE_REST = 192            # ... of the three-block kernel that takes the rest (12 wavefronts x 16 rows)
 MIN_ROWS = 1 << 17         # graphs smaller than this keep the ordinary path (the grouping is worth it when launches are long)
 ENABLED = True
-# Where the grouping pays (tools/dg_shapes_time.py, 1 M nodes / 10 M edges, one run, grouped vs ordinary layer, ms): 3 scalers
+# Where the grouping pays (tools/dg_shapes_time.py [removed in round 5: git history], 1 M nodes / 10 M edges, one run, grouped vs ordinary layer, ms): 3 scalers
 # F = 20: 0.524 / 0.497, 32: 0.524 / 0.519, 50: 0.973 / 1.017, 64: 0.908 / 1.058, 75: 1.296 / 1.441, 96: 1.426 / 1.998;
 # 2 scalers F = 75: 1.297 / 1.288, 128: 1.880 / 2.277.
 MIN_OUT = 40               # narrower outputs keep the ordinary path (no gain measured at 20 and 32)
@@ -129,7 +129,6 @@ class DegreePlan:
         self._rest_scales = {}
         self._fused, self._rest_items, self._vmap32, self._perm_all, self._rest_items_node, self._ones_rows = None, None, None, None, None, None
         self._edge_split = None
-        self._roles, self._roles_err = None, None
         self._deg, self._csr = deg, csr
 
     def fused_tables(self):
@@ -168,66 +167,6 @@ class DegreePlan:
             self._fused = (desc, ids, total)
         return self._fused
 
-    def roles_tables(self, n_wgs, tile_cost=None):
-        """Tables of pna_fused_roles_f32 (include/pna_amd.h), built once per graph and grid on the device:
-        (tile_desc [nt][4] = {first record, in-degree, weight image, 0} per 64-row tile of the virtual order; tile_ids = FOUR
-        arrays (one per 16-row block of a tile) of 16-id records, max(D, 1) records per tile, tiles back to back, 24 padding records
-        behind; ids_stride in bytes; n_records; wg_range [n_wgs][2] = the tiles [lo, hi) of every workgroup, a partition balanced by
-        `records + tile_cost` (the gather's packets plus the multiply side's constant per tile))."""
-        tile_cost = ROLES_TILE_COST if tile_cost is None else tile_cost
-        key = (int(n_wgs), float(tile_cost), ROLES_XCD_INTERLEAVE)
-        if self._roles is not None and self._roles[0] == key:
-            return self._roles[1]
-        dev = self.perm.device
-        nt = self.NV // 64
-        if nt == 0:
-            out = (torch.zeros(0, 4, dtype=torch.int32, device=dev), torch.zeros(4, 24, 16, dtype=torch.int32, device=dev), 24 * 64, 0,
-                   torch.zeros(n_wgs, 2, dtype=torch.int32, device=dev))
-            self._roles = (key, out)
-            return out
-        p64 = self.perm.view(nt, 64).long()
-        first = p64[:, :1]
-        live = first[:, 0] >= 0                                              # (a tile of padding rows only: D = 0, one record of row 0)
-        rows = torch.where(p64 >= 0, p64, first.clamp(min=0))                 # a padding row repeats the tile's first row
-        D = torch.where(live, self._deg[rows[:, 0]], torch.zeros_like(first[:, 0]))
-        nrec = D.clamp(min=1)
-        rec0 = torch.cumsum(nrec, 0) - nrec
-        total = int(nrec.sum().item())
-        if (total + 24) * 64 >= (1 << 32):
-            self._roles = (key, None)                                        # the kernel addresses records with 32-bit byte offsets
-            return None
-        tile = torch.repeat_interleave(torch.arange(nt, device=dev), nrec)
-        e = torch.arange(total, device=dev) - rec0[tile]
-        rp = self._csr.rowptr.long()
-        n_col = self._csr.col.numel()
-        ids = torch.zeros(4, total + 24, 16, dtype=torch.int32, device=dev)
-        has = (D[tile] > 0)[:, None]
-        for b in range(4):
-            pos = rp[rows[tile, 16 * b:16 * b + 16]] + e[:, None]            # (total, 16) positions in col[]
-            v = self._csr.col[pos.clamp(max=max(n_col - 1, 0))] if n_col else torch.zeros_like(pos, dtype=torch.int32)
-            ids[b, :total] = torch.where(has, v, torch.zeros_like(v)).to(torch.int32)
-        image = torch.repeat_interleave(self.tile_image.long(), TILE // 64)
-        desc = torch.stack([rec0, D, image, torch.zeros_like(D)], dim=1).to(torch.int32).contiguous()
-        # workgroup ranges: equal shares of sum(records + tile_cost)
-        cost = nrec.double() + float(tile_cost)
-        cum = torch.cumsum(cost, 0)
-        tot = float(cum[-1].item())
-        n_wgs = int(n_wgs)
-        bounds = torch.arange(1, n_wgs, device=dev, dtype=torch.float64) * (tot / n_wgs)
-        cut = torch.searchsorted(cum, bounds, right=False) + 1                 # tile index where workgroup b + 1 starts
-        rng = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), cut.clamp(max=nt), torch.full((1,), nt, dtype=torch.long, device=dev)])
-        rng = torch.cummax(rng, 0).values
-        pairs = torch.stack([rng[:-1], rng[1:]], dim=1)
-        if ROLES_XCD_INTERLEAVE and n_wgs % 8 == 0:
-            # workgroup b runs on XCD b % 8 (observed; for speed only).  The identity order gives every XCD ranges from all over the
-            # degree spectrum; this order gives XCD x the contiguous eighth x: the weight images of few degree groups per L2
-            b = torch.arange(n_wgs, device=dev)
-            pairs = pairs[(b % 8) * (n_wgs // 8) + b // 8]
-        wg_range = pairs.to(torch.int32).contiguous()
-        out = (desc, ids.contiguous(), (total + 24) * 64, total, wg_range)
-        self._roles = (key, out)
-        return out
-
     def dw_tables(self, n_wgs):
         """Tables of pna_posttrans_dw_grouped_f32 (the weight gradient over the group rows in plan order), once per plan and grid:
         (tile_group [nt], wg_range [n_wgs][2] -- equally long contiguous tile ranges --, wg_entry [n_wgs], entry_group [n_entries]):
@@ -251,12 +190,6 @@ class DegreePlan:
                tg[starts].contiguous(), int(starts.numel()))
         self.__dict__["_dw_tables"] = (n_wgs, out)
         return out
-
-    def roles_err(self):
-        """int32 [1], zero: the give-up flag of pna_fused_roles_f32 (checked by the tests and by bench.py, never on the hot path)."""
-        if self._roles_err is None:
-            self._roles_err = torch.zeros(1, dtype=torch.int32, device=self.perm.device)
-        return self._roles_err
 
     def vmap32(self):
         """int32 [V]: row of the plan-ordered aggregate buffer that holds node v (pna_segreduce_args.out_row_of)."""
@@ -367,7 +300,7 @@ class DegreePlan:
 def agg_pitch(K):
     """Row pitch (floats) of the plan-ordered aggregate.  The contraction reads a row as 128-byte strips, one per chunk of 32
     columns; with packed rows of 4F = 300 floats (1200 bytes) 7 strips in 8 straddle two 128-byte lines.  Measured on the
-    one-block kernel, 1 M rows (tools/x3_pitch_time.py, one run, best of 5 x 20 launches): pitch 300 / 304 / 320 / 352 floats
+    one-block kernel, 1 M rows (tools/x3_pitch_time.py [removed in round 5: git history], one run, best of 5 x 20 launches): pitch 300 / 304 / 320 / 352 floats
     -> 0.457 / 0.434 / 0.422 / 0.419 ms (the three-block kernel, bound by its matrix work, does not care: 0.75 ms at all four)."""
     a = max(1, int(AGG_ALIGN))
     return (K + a - 1) // a * a
@@ -469,11 +402,6 @@ def fused_images(weight, F, row_scales, plan, tower=False):
     return img, stride
 
 
-ROLES = os.environ.get("PNA_AMD_ROLES", "0") != "0"   # the one-kernel layer with gather / multiply wavefront roles (pna_fused_roles_f32): parity-green but
-                                                      # 2.4x slower than pna_fused_degree_f32 at C3: an experiment, off by default
-ROLES_TILE_COST = float(os.environ.get("PNA_AMD_ROLES_TILE_COST", "3"))   # a tile's constant cost in the workgroup partition, in edge packets
-ROLES_XCD_INTERLEAVE = False
-ROLES_SPARE_UNITS = int(os.environ.get("PNA_AMD_ROLES_SPARE", "16"))      # CUs left to the rest-row launches beside the kernel (cf. FUSED_SPARE_WGS)
 REST_SEG_LEN = 128         # edges per hub-row segment in the rest launch of the one-kernel layer (see DegreePlan.rest_items)
 REST_ROWS_PER_GROUP = 1    # work items per lane group in that launch (the full-graph gather: 4): a few thousand items must spread over 256 CUs
 TOWERS = True              # the tower layers (PNALayer) through the degree-grouped contraction with collapsed posttrans / mixing weights

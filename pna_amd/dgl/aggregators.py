@@ -11,6 +11,8 @@ import torch
 
 from .. import ops
 
+EPS = 1e-5  # models/dgl/aggregators.py:3
+
 
 def _mailbox_reduce(h, name):
     if h.dim() != 3:
@@ -45,7 +47,31 @@ def aggregate_sum(h):
     return _mailbox_reduce(h, "sum")
 
 
-# moment3/4/5 of the reference (aggregators.py:29-47) reduce over the WHOLE tensor by mistake
-# (torch.mean without dim, :33) and are unused by every shipped config -- not provided.
+def aggregate_moment(h, n=3):
+    """models/dgl/aggregators.py:29-36, QUIRK INCLUDED: the reference centres per node (`torch.mean(h, dim=1, keepdim=True)`, :32) but
+    then takes `torch.mean(torch.pow(h - h_mean, n))` WITHOUT a dim (:33) -- the n-th central moment averaged over the whole
+    mailbox tensor -- and returns the signed n-th root of that as a 0-dim tensor.  (So it cannot be concatenated in reduce_func,
+    pna_layer.py:48, and no shipped config names it; it is an entry the reference's registry exports, reproduced as it behaves.)
+    The per-node mean runs on the segment-reduce kernel; the whole-tensor power mean is two device-side torch reductions."""
+    if h.dim() != 3:
+        raise ValueError("mailbox must be (n, d, F)")
+    h_mean = _mailbox_reduce(h, "mean").unsqueeze(1)
+    h_n = torch.mean(torch.pow(h - h_mean, n))
+    return torch.sign(h_n) * torch.pow(torch.abs(h_n) + EPS, 1. / n)
+
+
+def aggregate_moment_3(h):
+    return aggregate_moment(h, n=3)
+
+
+def aggregate_moment_4(h):
+    return aggregate_moment(h, n=4)
+
+
+def aggregate_moment_5(h):
+    return aggregate_moment(h, n=5)
+
+
 AGGREGATORS = {"mean": aggregate_mean, "sum": aggregate_sum, "max": aggregate_max, "min": aggregate_min,
-               "std": aggregate_std, "var": aggregate_var}
+               "std": aggregate_std, "var": aggregate_var, "moment3": aggregate_moment_3, "moment4": aggregate_moment_4,
+               "moment5": aggregate_moment_5}

@@ -339,6 +339,16 @@ def degree_grouped_aggregate(layer, graph, h, plan, out=None, x=None):
     return out
 
 
+def _simple_layer_state(layer):
+    """(version, address) of every tensor a cached FusedDegreeCall of `layer` snapshots: the posttrans Linear and the BatchNorm."""
+    lin = layer.posttrans.fully_connected[0].linear
+    ts = [lin.weight, lin.bias]
+    if layer.batch_norm:
+        bn = layer.batchnorm_h
+        ts += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+    return tuple((t._version, t.data_ptr()) for t in ts if t is not None)
+
+
 def _layer_tail_operands(layer, h):
     """(column scale, column shift, residual) of the simple layer's epilogue: eval BatchNorm folded, the input as residual."""
     cs = ct = None
@@ -728,91 +738,6 @@ class FusedDegreeCall:
         return self.y
 
 
-class FusedRolesCall(FusedDegreeCall):
-    """FusedDegreeCall with the group rows on pna_fused_roles_f32 (gather / multiply wavefront roles): the same
-    statistics, weight images and epilogue, other tables (DegreePlan.roles_tables) and no pitch / alignment / 4 GiB conditions on
-    the source table.  `spare` CUs are left to the rest-row launches when they run beside the kernel (run_fused_call)."""
-
-    def __init__(self, layer, graph, h, x=None, out=None, agg_out=None):
-        from . import _lib, degree_groups as DG
-        from .dgl.pna_layer import _row_scales
-        import ctypes
-        F, N = layer.in_dim, layer.out_dim
-        self.layer, self.graph, self.plan = layer, graph, DG.plan_of(graph)
-        plan = self.plan
-        self.x = x = graph.source_features(h) if x is None else x
-        lin = layer.posttrans.fully_connected[0].linear
-        self.scales = scales = _row_scales(graph, layer.scalers, layer.avg_d, h.device)
-        V = h.shape[0]
-        self.y = y = torch.empty(V, (N + 3) // 4 * 4, dtype=torch.float32, device=h.device)[:, :N] if out is None else out
-        self.cs, self.ct, self.res = cs, ct, res = _layer_tail_operands(layer, h)
-        self.img, self.stride = DG.fused_images(lin.weight, F, scales, plan)
-        self.err = plan.roles_err()
-        self.lin, self.agg_out, self.h = lin, agg_out, h
-        self.lib, self.check, self.stream = _lib.lib(), _lib.check, _lib.stream_ptr(h.device)
-        self.fn = self.lib.pna_fused_roles_f32
-        self.spare = 0
-        self.args = None
-        self._grid_args = {}
-        self._bind()
-
-    def _bind(self):
-        """The argument block for the current `spare` (the tables depend on the grid)."""
-        from . import _lib
-        import ctypes
-        hit = self._grid_args.get(self.spare)
-        if hit is None:
-            plan, layer, x, y = self.plan, self.layer, self.x, self.y
-            F, N = layer.in_dim, layer.out_dim
-            n_wgs = self.lib.pna_fused_roles_grid(self.spare)
-            tabs = plan.roles_tables(n_wgs)
-            if tabs is None:
-                raise RuntimeError("pna_fused_roles: the graph's id records exceed 4 GiB")
-            desc, ids, ids_stride, n_rec, wg_range = tabs
-            a = _lib.PnaFusedRolesArgs()
-            a.F, a.N, a.relu, a.act_slope = F, N, 1, 0.0
-            a.tile_desc, a.tile_ids = _lib.dev_ptr(desc, torch.int32, "tile_desc"), _lib.dev_ptr(ids, torch.int32, "tile_ids")
-            a.ids_stride, a.n_records, a.n_tiles = ids_stride, n_rec, desc.shape[0]
-            a.wg_range, a.n_workgroups = _lib.dev_ptr(wg_range, torch.int32, "wg_range"), n_wgs
-            a.x, a.ldx, a.x_rows = _lib.dev_ptr(x, torch.float32, "x"), x.stride(0), x.shape[0]
-            a.row_perm, a.n_nodes = _lib.dev_ptr(plan.perm, torch.int32, "row_perm"), y.shape[0]
-            a.w_img, a.image_stride = _lib.dev_ptr(self.img, torch.float32, "w_img"), self.stride
-            a.bias = _lib.dev_ptr(self.lin.bias, torch.float32, "bias")
-            a.col_scale, a.col_shift = _lib.dev_ptr(self.cs, torch.float32, "col_scale"), _lib.dev_ptr(self.ct, torch.float32, "col_shift")
-            if self.res is not None:
-                a.residual, a.ld_res = _lib.dev_ptr(self.res, torch.float32, "residual"), self.res.stride(0)
-            a.y, a.ldy = _lib.dev_ptr(y, torch.float32, "y"), y.stride(0)
-            if self.agg_out is not None:
-                a.agg_out, a.ld_agg = _lib.dev_ptr(self.agg_out, torch.float32, "agg_out"), self.agg_out.stride(0)
-            a.err = _lib.dev_ptr(self.err, torch.int32, "err")
-            hit = self._grid_args[self.spare] = (a, ctypes.byref(a), tabs)
-        self.args, self.ref = hit[0], hit[1]
-
-    def set_spare(self, on):
-        from . import degree_groups as DG
-        units = (DG.ROLES_SPARE_UNITS if on is True else 0) if isinstance(on, bool) else int(on)
-        if units != self.spare:
-            self.spare = units
-            self._bind()
-
-    def group_rows(self):
-        self.check(self.fn(self.ref, self.stream), "pna_fused_roles_f32")
-        return self.y
-
-
-def roles_applies(graph, x, F, N):
-    """Whether pna_fused_roles_f32 serves this call (whole-graph inference path already chosen by `applies`): a shape it is
-    instantiated for and a unit-stride source table.  No pitch, alignment or size conditions (64-bit lane addresses, no read leaves a
-    row): a contiguous (V, F) tensor qualifies."""
-    from . import _lib, degree_groups as DG
-    if not (DG.FUSED and DG.ROLES) or not _lib.lib().pna_fused_roles_supported(F, N):
-        return False
-    if x.dim() != 2 or x.stride(1) != 1 or x.stride(0) < F or x.data_ptr() % 4 != 0 or x.shape[0] < 1:
-        return False
-    plan = DG.plan_of(graph)
-    return plan.G > 0
-
-
 def simple_layer_degree_fused(layer, graph, h, x=None, out=None, agg_out=None):
     """PNASimpleLayer.forward (eval) with the group rows in ONE kernel (pna_fused_degree_f32): gather, the four
     aggregators, the combined scaler block W_D and the posttrans contraction with its BatchNorm / ReLU / residual epilogue; the
@@ -820,8 +745,6 @@ def simple_layer_degree_fused(layer, graph, h, x=None, out=None, agg_out=None):
     graph's rows, 5 % of its edges) take the two-kernel path over their compact list.  `x`: the source table (halo in place on
     a sharded graph); `agg_out` (verification): (plan.NV, >= 4F) receives the statistics the contraction consumed."""
     src = graph.source_features(h) if x is None else x
-    if roles_applies(graph, src, layer.in_dim, layer.out_dim):
-        return run_fused_call(FusedRolesCall(layer, graph, h, x=src, out=out, agg_out=agg_out))
     return run_fused_call(FusedDegreeCall(layer, graph, h, x=src, out=out, agg_out=agg_out))
 
 
@@ -833,7 +756,7 @@ def simple_layer_degree_grouped(layer, graph, h):
     from . import degree_groups as DG
     plan = DG.plan_of(graph)
     from .graph import Graph
-    if type(graph) is Graph and (roles_applies(graph, h, layer.in_dim, layer.out_dim) or DG.fused_applies(graph, h, layer.in_dim, layer.out_dim)):
+    if type(graph) is Graph and DG.fused_applies(graph, h, layer.in_dim, layer.out_dim):
         return simple_layer_degree_fused(layer, graph, h, x=h)
     # A shard (HaloGraph).  The two-kernel path cuts its gather into the rows that read only local sources -- aggregated while
     # the halo exchange is in flight -- and the rest; the one-kernel path needs the whole [local | halo] table first.  Which one
@@ -844,7 +767,7 @@ def simple_layer_degree_grouped(layer, graph, h):
     if (isinstance(graph, HaloGraph) and DG.FUSED and graph._resident(h) and graph._pending is None
             and graph.interior_fraction() < DG.FUSED_HALO_MAX_INTERIOR):
         x_ext = graph._ext[:, : h.shape[1]]
-        if roles_applies(graph, x_ext, layer.in_dim, layer.out_dim) or DG.fused_applies(graph, x_ext, layer.in_dim, layer.out_dim):
+        if DG.fused_applies(graph, x_ext, layer.in_dim, layer.out_dim):
             return simple_layer_degree_fused(layer, graph, h, x=graph.source_features(h))
     return degree_grouped_posttrans(layer, graph, h, degree_grouped_aggregate(layer, graph, h, plan), plan)
 
@@ -979,7 +902,10 @@ class SimpleLayerRows:
             if plan is not None:
                 # the block through the one-kernel layer: its own degree groups (pna_fused_degree_f32) + its rest rows; rows are
                 # scattered to their node ids in the next table (1.47 -> ~0.85 ms / layer of compute at C3 shape)
-                key = (l, b, table.data_ptr(), out.data_ptr())
+                # the cached call snapshots the packed weight images and the folded BatchNorm scale / shift: the parameters' (version,
+                # address) belong in the key, or an optimizer step / load_state_dict between two runs leaves the group rows on stale
+                # weights while the rest rows read the live ones
+                key = (l, b, table.data_ptr(), out.data_ptr()) + _simple_layer_state(layer)
                 call = self._calls.get(key)
                 if call is None:
                     if len(self._calls) > 4 * len(self.layers) * self.n_blocks:

@@ -17,7 +17,7 @@ from . import _lib
 
 # Rows with more in-edges than this are cut into SEG_LEN-edge segments reduced by separate lane
 # groups (see include/pna_amd.h "Heavy rows"); 128/128 measured best on the 10 M-edge power-law graph
-# (tools/sweep.py, profiles/).
+# (tools/sweep.py [removed in round 5: git history], profiles/).
 HEAVY_THRESHOLD = 128
 SEG_LEN = 128
 
@@ -250,7 +250,7 @@ class Graph:
         windows of `window` rows; order="natural" (default): ascending row id, which keeps whatever locality the
         node numbering has (neighbouring rows tend to share source rows and then hit in L1/L2).  On the 10 M-edge
         power-law benchmark graph natural order is fastest although degree sorting removes a third of the
-        instructions -- the gather is bound by cache misses, not by issue (tools/sweep.py, profiles/)."""
+        instructions -- the gather is bound by cache misses, not by issue (tools/sweep.py [removed in round 5: git history], profiles/)."""
         hs = self.heavy_schedule(threshold, seg_len)
         key = ("items", hs.threshold, hs.seg_len, order, window)
         if key not in self._heavy:

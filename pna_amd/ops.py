@@ -22,7 +22,7 @@ from .graph import HeavySchedule
 POSTTRANS_ARITH = os.environ.get("PNA_AMD_POSTTRANS", "auto")
 X3_MIN_ROWS = 16384
 
-_TUNE = {}   # process-wide tuning overrides (set by tools/sweep.py and bench.py), see set_tuning()
+_TUNE = {}   # process-wide tuning overrides (set by tools/sweep.py [removed in round 5: git history] and bench.py), see set_tuning()
 
 
 def set_tuning(**kw):

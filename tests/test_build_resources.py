@@ -23,7 +23,7 @@ CSRC = os.path.join(ROOT, "pna_amd", "csrc")
                                                                                         "k_segreduce_fastILi4ELb0ELb0ELb1ELi0E": 104, "k_segreduce_fastILi4ELb1ELb0ELb1ELi0E": 104,
                                                                                         "k_segreduce_fastILi4ELb1ELb0ELb0ELi1E": 104, "k_segreduce_fastILi4ELb1ELb0ELb0ELi2E": 104}),
                                           ("pna_posttrans.hip", {}), ("pna_pack.hip", {}), ("pna_tower_fused.hip", {}), ("pna_fused.hip", {}),
-                                          ("pna_segreduce_bwd.hip", {}), ("pna_fused_roles.hip", {"k_fused_roles": 256}),
+                                          ("pna_segreduce_bwd.hip", {}),
                                           # the weight-gradient kernels: two 4-wavefront workgroups / one 8-wavefront workgroup per CU
                                           ("pna_posttrans_dw.hip", {"k_posttrans_dw": 256}),
                                           # the one-kernel layer: two 4-wavefront workgroups per CU (the production instantiations: DUMP = false)

@@ -453,6 +453,24 @@ def test_dense_registry_every_entry_vs_reference_golden(cuda_device):
         torch.testing.assert_close(got, a[f"sca/{name}"], rtol=1e-6, atol=1e-7)
 
 
+def test_dgl_registry_every_entry_vs_reference_golden(cuda_device):
+    """All 9 aggregators (moment3/4/5 with the reference's whole-tensor mean: 0-dim results) and the 3 scalers of the DGL
+    registries against the values the reference's own functions produced (tests/golden/dgl_registry_all.npz)."""
+    meta, a, _ = load_golden("dgl_registry_all")
+    h = a["h"].to(cuda_device)
+    assert set(meta["aggregators"]) == set(DGL_AGG) and set(meta["scalers"]) == set(DGL_SCALERS)
+    for name in meta["aggregators"]:
+        got, ref = DGL_AGG[name](h).cpu(), a[f"agg/{name}"]
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        if name in ("max", "min"):
+            assert torch.equal(got, ref), name
+        else:
+            torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-6, msg=lambda m: f"{name}: {m}")
+    avg_d = {"log": a["avg_log"].to(cuda_device)}
+    for name in meta["scalers"]:
+        assert torch.equal(DGL_SCALERS[name](a["m"].to(cuda_device), meta["d"], avg_d).cpu(), a[f"sca/{name}"]), name
+
+
 def test_dense_layer_with_exotic_aggregators(cuda_device):
     from oracle import torch_oracle as O
     gen = torch.Generator().manual_seed(2)

@@ -6,7 +6,7 @@ to 1e-6, the oracle-autograd gradients of its parameters to 5e-4 and every step'
 
 Only the PNA layers run on the GPU; the recurrent / readout modules around them stay on the CPU, where they execute the very ops
 the reference run executed.  With those on the GPU as well the trace drifts by 1e-3 .. 1e-2 within eight Adam steps -- for the
-plain-torch restatement of the layer (oracle/torch_oracle.py on the GPU) exactly as for the HIP layer (tools/train_trace_diag.py,
+plain-torch restatement of the layer (oracle/torch_oracle.py on the GPU) exactly as for the HIP layer (tools/train_trace_diag.py [removed in round 5: git history],
 profiles/r03_train_trace_diag.txt): MIOpen's GRU / LSTM gradients differ from the CPU's at 1e-4 .. 5e-3 relative and Adam's
 normalised update amplifies that; the step-1 loss (forward only) agrees to 1e-7 either way.  That drift says nothing about the
 layer under test, so it is kept out of the comparison.
@@ -117,7 +117,7 @@ def test_two_epoch_loss_trace_matches_the_reference(cuda_device, name):
     autograd through the oracle's plain-torch restatement of the layer: 5e-4 of the parameter's largest gradient; (3) the eight-step
     Adam trace: 1e-3 per step.  Why not 1e-4 for (3): Adam's update g / (|g| + eps) turns fp32-level differences in small
     gradients into lr-sized parameter differences; the plain-torch restatement of the layer run on the GPU in this same harness
-    drifts from the CPU trace just as far (tools/train_trace_diag.py: 2e-5 .. 3e-4 per step over the eight steps for both).
+    drifts from the CPU trace just as far (tools/train_trace_diag.py [removed in round 5: git history]: 2e-5 .. 3e-4 per step over the eight steps for both).
     Round 3 held 5e-3: the dense variant's narrow towers (F = 2 / 4) summed the max / min gradient terms with hardware atomics whose
     order varied from run to run (2.8e-3 in 2 of 31 runs).  Round 4 sums them in a fixed order (autograd._argscatter_sorted): ten
     repeats of this test gave 3.2e-4 .. 4.7e-4 (the rest of the spread: library GEMM / reduction orders outside the layer)."""

@@ -59,12 +59,12 @@ def test_the_stub_has_gccs_layout(tmp_path):
 
 
 def test_a_short_args_struct_is_refused():
-    """ABI 19: struct_size first in every args struct; an entry point checks it before it looks at anything else (no GPU needed)."""
+    """ABI 19 on: struct_size first in every args struct; an entry point checks it before it looks at anything else (no GPU needed)."""
     from pna_amd import _lib
     L = _lib.lib()
     L.pna_last_error.restype = ctypes.c_char_p
     cases = [(_lib.PnaSegreduceArgs, L.pna_segreduce_fwd_f32), (_lib.PnaPosttransArgs, L.pna_posttrans_f32), (_lib.PnaPosttransArgs, L.pna_posttrans_x3_f32),
-             (_lib.PnaFusedDegreeArgs, L.pna_fused_degree_f32), (_lib.PnaFusedRolesArgs, L.pna_fused_roles_f32), (_lib.PnaFusedSimpleArgs, L.pna_fused_simple_f32),
+             (_lib.PnaFusedDegreeArgs, L.pna_fused_degree_f32), (_lib.PnaFusedSimpleArgs, L.pna_fused_simple_f32),
              (_lib.PnaSmallLinearArgs, L.pna_small_linear_f32), (_lib.PnaTowerLayerArgs, L.pna_tower_layer_f32), (_lib.PnaBnTailArgs, L.pna_bn_tail_fwd_f32),
              (_lib.PnaSegreduceBwdArgs, L.pna_segreduce_bwd_f32), (_lib.PnaPosttransDwArgs, L.pna_posttrans_dw_f32),
              (_lib.PnaPosttransDwGroupedArgs, L.pna_posttrans_dw_grouped_f32)]

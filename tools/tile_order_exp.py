@@ -1,0 +1,152 @@
+#!/usr/bin/env python
+"""an L2 / XCD-aware TILE ORDER for the one-kernel layer at C3 -- the experiment, with its counters.
+
+The shipped plan orders the 64-row workgroup tiles of pna_fused_degree_f32 by (in-degree, row id); the persistent kernel deals tile
+t to workgroup t % G, i.e. to XCD (t % G) % 8: at any moment all eight L2s work on the same one or two degree groups (ONE 150 KB
+weight image live per L2) and the rows v-1, v, v+1 -- which share source lines on the benchmark graph (its ring: 2 of every 10
+in-edges come from v-1 / v+1, pna_amd/synth.py:33-36) -- sit in different degree groups, far apart in time and on different XCDs.
+
+This tool re-orders the SAME tiles (no row changes tile: the kernel's statistics are bit-identical by construction, checked) and
+times the kernel / runs it under rocprofv3 --pmc:
+
+  ORDER=ascending        the shipped order
+  ORDER=idmajor          tiles sorted by the median row id of their rows; consecutive COHORTS of G/8 tiles go to one XCD and one
+                         round of its workgroups (position = round * G + 8 * slot + xcd), tiles inside a cohort are dealt to the
+                         XCD's workgroups longest-first against their accumulated cost (static LPT: every workgroup's total stays level)
+  ORDER=idmajor_rr       the same sorted list dealt round-robin (no XCD cohorts): the control
+  ORDER=band<k>          degrees cut into k bands of equal row counts, bands in ascending order, id-major cohorts INSIDE a band
+                         (fewer weight images live per L2 than idmajor, less mixing of degrees)
+
+    ORDER=idmajor python tools/tile_order_exp.py [json-out]          # timing, parity vs the shipped order
+    ORDER=idmajor rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum -- python tools/tile_order_exp.py --pmc
+"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pna_amd import _lib  # noqa: E402
+from pna_amd import Graph, degree_groups as DG, functional as PF  # noqa: E402
+from pna_amd.dgl.pna_layer import PNASimpleLayer  # noqa: E402
+from pna_amd.synth import powerlaw_graph  # noqa: E402
+
+
+def tile_order(plan, order, G, tile_cost=10.0):
+    """-> long [nt]: new position p holds shipped tile src[p] (64-row tiles of the plan's virtual order)."""
+    dev = plan.perm.device
+    nt = plan.NV // 64
+    p64 = plan.perm.view(nt, 64).long()
+    live = p64 >= 0
+    first = p64[:, 0].clamp(min=0)
+    D = torch.where(live[:, 0], plan._deg[first], torch.zeros_like(first))
+    big = torch.iinfo(torch.int64).max
+    key = torch.where(live, p64, torch.full_like(p64, big)).sort(dim=1).values
+    n_live = live.sum(1).clamp(min=1)
+    med = key.gather(1, ((n_live - 1) // 2)[:, None])[:, 0]                     # median row id of the tile's live rows
+    med = torch.where(live.any(1), med, torch.zeros_like(med))
+    if order == "ascending":
+        return torch.arange(nt, device=dev)
+    band = torch.zeros(nt, dtype=torch.long, device=dev)
+    if order.startswith("band"):
+        k = int(order[4:])
+        rows_cum = torch.cumsum(torch.full((nt,), 64, device=dev), 0)         # tiles are already in ascending degree
+        band = ((rows_cum - 1) * k // (nt * 64)).clamp(max=k - 1)
+        # a degree value never straddles two bands: take the band of the degree's first tile
+        ud, inv = torch.unique_consecutive(D, return_inverse=True)
+        firstpos = torch.full((ud.numel(),), nt, dtype=torch.long, device=dev).scatter_reduce(0, inv, torch.arange(nt, device=dev), "amin")
+        band = band[firstpos[inv]]
+    seq = torch.argsort(band * (1 << 40) + med, stable=True)                     # (band, median id)
+    if order == "idmajor_rr":
+        return seq
+    # XCD cohorts + LPT inside a cohort, on the host (15 k tiles: milliseconds)
+    seq_c, cost = seq.cpu().tolist(), (D.double() + tile_cost).cpu().tolist()
+    assert G % 8 == 0
+    src = [-1] * nt
+    load = [0.0] * G                                                            # accumulated cost of workgroup w (w % 8 = its XCD)
+    pos = 0
+    r = 0
+    while pos < nt:
+        n_r = min(G, nt - r * G)                                                # workgroups that have a tile in round r
+        for x in range(8):
+            wgs = [w for w in range(x, n_r, 8)]
+            if not wgs:
+                continue
+            tiles = seq_c[pos:pos + len(wgs)]
+            pos += len(tiles)
+            tiles.sort(key=lambda t: -cost[t])
+            wgs.sort(key=lambda w: load[w])
+            for t, w in zip(tiles, wgs):
+                src[r * G + w] = t
+                load[w] += cost[t]
+        r += 1
+    assert all(s >= 0 for s in src)
+    return torch.tensor(src, dtype=torch.long, device=dev)
+
+
+def permuted_tables(plan, src):
+    desc, ids, n_rec = plan.fused_tables()
+    nt = plan.NV // 64
+    d2 = desc.view(nt, 4, 4)[src].reshape(-1, 4).contiguous()
+    perm2 = plan.perm.view(nt, 64)[src].reshape(-1).contiguous()
+    return d2, ids, n_rec, perm2
+
+
+def main():
+    dev = torch.device("cuda:0")
+    V, E, F = int(os.environ.get("FD_V", 1_000_000)), int(os.environ.get("FD_E", 10_000_000)), int(os.environ.get("FD_F", 75))
+    order = os.environ.get("ORDER", "ascending")
+    pmc = "--pmc" in sys.argv
+    src_e, dst_e = powerlaw_graph(V, E, seed=1234, device=dev)
+    g = Graph(src_e, dst_e, V)
+    avg = {"log": torch.log(g.in_degrees().double() + 1).mean().float().cpu()}
+    torch.manual_seed(0)
+    layer = PNASimpleLayer(F, F, "mean max min std", "identity amplification attenuation", avg, 0.0, True, True).to(dev).eval()
+    h = torch.randn(V, (F + 7) // 8 * 8, device=dev)[:, :F]
+    plan = DG.plan_of(g)
+    props = torch.cuda.get_device_properties(0)
+    with torch.no_grad():
+        call = PF.FusedDegreeCall(layer, g, h, x=h)
+        call.set_spare(True)
+        G = props.multi_processor_count * 2 - int(call.args.spare_workgroups)
+        y0 = call.group_rows().clone()
+        src = tile_order(plan, order, G)
+        d2, ids, n_rec, perm2 = permuted_tables(plan, src)
+        call.keep = call.keep + (d2, perm2)
+        call.args.tile_desc = _lib.dev_ptr(d2, torch.int32, "tile_desc")
+        call.args.row_perm = _lib.dev_ptr(perm2, torch.int32, "row_perm")
+        call.y = torch.zeros_like(y0)
+        call.args.y = _lib.dev_ptr(call.y, torch.float32, "y")
+        y1 = call.group_rows().clone()
+        same = bool(torch.equal(y0, y1))
+        if pmc:
+            for _ in range(30):
+                call.group_rows()
+            torch.cuda.synchronize()
+            print(f"PMC order={order} G={G} same_bits={same}")
+            return
+
+        def ev(fn, n=20, reps=5):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(reps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(n):
+                    fn()
+                b.record()
+                torch.cuda.synchronize()
+                best = min(best, a.elapsed_time(b) / n)
+            return best
+        out = {"order": order, "G": G, "tiles": plan.NV // 64, "same_bits_as_shipped_order": same, "group_rows_ms": ev(call.group_rows)}
+    print("RESULT " + json.dumps(out), flush=True)
+    if len(sys.argv) > 1 and not sys.argv[1].startswith("--"):
+        json.dump(out, open(sys.argv[1], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

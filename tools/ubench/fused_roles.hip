@@ -1,3 +1,6 @@
+// ARCHIVED in round 5 (ABI 20): no longer part of libpna_amd.so.  Build as a standalone library with
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Iinclude -Ipna_amd/csrc -Itools/ubench tools/ubench/fused_roles.hip pna_amd/csrc/pna_common.hip -o tools/ubench/libfused_roles.so
+// Result: parity-green, 2.1-2.7x slower than pna_fused_degree_f32 (profiles/r04_roles_*).
 // pna_fused_roles.hip -- PNASimpleLayer forward (models/dgl/pna_layer.py:186-216) as ONE kernel of SPECIALISED wavefronts on
 // degree-ordered rows (round 4; the successor of pna_fused_degree.hip for its main shapes).  Implements
 // pna_fused_roles_f32; the weight images are pna_fused_degree_pack_f32's.
@@ -30,7 +33,7 @@
 #include <string.h>
 #include <type_traits>
 
-#include "pna_amd.h"
+#include "fused_roles_abi.h"   // (includes pna_amd.h)
 #include "pna_internal.h"
 #include "pna_rowstats.h"
 #include "pna_x3_split.h"
