@@ -155,6 +155,28 @@ def _projection_cache_padded(tower, Fi, P):
     return hit[1], hit[2]
 
 
+def _projection_cache_padded_div(towers, Fi, P):
+    """_projection_cache_padded for T towers with divide_input=True (models/dgl/pna_layer.py:133-136): tower t projects the input
+    slice [t Fi, (t+1) Fi) -- ONE block-diagonal GEMM gives x_cat = [x_src (T Fi) | 0 | x_dst (T Fi) | 0] with tower t's rows in
+    columns [t Fi, (t+1) Fi) of each half."""
+    lins = [t.pretrans.fully_connected[0].linear for t in towers]
+    key = tuple((p._version, p.data_ptr(), str(p.device)) for l in lins for p in (l.weight, l.bias)) + (P,)
+    hit = towers[0].__dict__.get("_pna_amd_proj_pad_div")
+    if hit is None or hit[0] != key:
+        T = len(lins)
+        with torch.no_grad():
+            W = torch.zeros(2 * P, T * Fi, dtype=lins[0].weight.dtype, device=lins[0].weight.device)
+            b = torch.zeros(2 * P, dtype=W.dtype, device=W.device)
+            for t, lin in enumerate(lins):
+                r = slice(t * Fi, (t + 1) * Fi)
+                W[r, r] = lin.weight[:, :Fi]
+                W[P + t * Fi:P + (t + 1) * Fi, r] = lin.weight[:, Fi:2 * Fi]
+                b[P + t * Fi:P + (t + 1) * Fi] = lin.bias
+        hit = (key, W.contiguous(), b.contiguous())
+        towers[0].__dict__["_pna_amd_proj_pad_div"] = hit
+    return hit[1], hit[2]
+
+
 def _towers_forward(towers, graph, h, e, snorm_n, divide_input):
     """Shared body of PNATower.forward / PNALayer.forward: all towers through one gather kernel."""
     t0 = towers[0]
@@ -334,8 +356,12 @@ class PNALayer(nn.Module):
             towers = list(self.towers)
             T, Fi = len(towers), towers[0].in_dim
             if PF.tower_layer_degree_fused_applies(self, graph, h):
-                # one tower: everything after the projection in ONE kernel (functional.tower_layer_degree_fused)
-                Wpad, bpad = _projection_cache_padded(towers[0], Fi, PF.tower_projection_pitch(Fi))
+                # one tower, or T towers over slices of the input (divide_input): everything after the projection in ONE kernel
+                # (functional.tower_layer_degree_fused)
+                if T == 1:
+                    Wpad, bpad = _projection_cache_padded(towers[0], Fi, PF.tower_projection_pitch(Fi))
+                else:
+                    Wpad, bpad = _projection_cache_padded_div(towers, Fi, PF.tower_projection_pitch(T * Fi))
                 return PF.tower_layer_degree_fused(self, graph, h, snorm_n, PF.linear_act(h, Wpad, bpad))
             if self.divide_input:
                 W = torch.stack([t.pretrans.fully_connected[0].linear.weight for t in towers])

@@ -532,16 +532,44 @@ def tower_projection_pitch(Fi):
 
 
 def tower_layer_degree_fused_applies(layer, graph, h):
-    """Whether the grouped tower path runs its group rows through pna_fused_degree_f32's tower mode: ONE tower of 49..80
-    features, at most 80 outputs, features the kernel can read in 16-byte pieces."""
+    """Whether the grouped tower path runs its group rows through pna_fused_degree_f32's tower mode: ONE gather of 49..80
+    message features, at most 80 outputs, features the kernel can read in 16-byte pieces.  That is a layer with one tower, or --
+    round 5 -- T towers with divide_input=True (models/dgl/pna_layer.py:133-136: tower t sees the input slice [t Fi, (t+1) Fi), so
+    all towers' messages together are in_dim = T Fi wide: ONE gather over the block-diagonal projection, and the collapsed
+    posttrans . BatchNorm . mixing weight is dense anyway).  T towers with divide_input=False have T DIFFERENT projections of the
+    whole input (T x in_dim message features per edge, T gathers' worth of bytes): they stay on the two-kernel path."""
     from . import degree_groups as DG
     towers = list(layer.towers)
-    Fi = towers[0].in_dim
-    if not (DG.FUSED and len(towers) == 1 and 49 <= Fi <= 80 and layer.in_dim == Fi and 4 <= layer.out_dim <= 80):
+    Fe = len(towers) * towers[0].in_dim                    # message features per edge, all towers
+    if not (DG.FUSED and (len(towers) == 1 or layer.divide_input) and 49 <= Fe <= 80 and layer.in_dim == Fe and 4 <= layer.out_dim <= 80):
         return False
-    if not DG.fused_applies(graph, h, Fi, layer.out_dim):
+    if not DG.fused_applies(graph, h, Fe, layer.out_dim):
         return False
-    return h.shape[0] * 2 * tower_projection_pitch(Fi) * 4 < (1 << 32)
+    return h.shape[0] * 2 * tower_projection_pitch(Fe) * 4 < (1 << 32)
+
+
+def _tower_flat_weights(layer, towers, mix):
+    """_tower_collapsed_weights for the one-kernel tower layer: the same collapsed weight with the columns of every scaler block
+    re-ordered from tower-major [t: mean | max | min | std] (Fi each) to aggregator-major over ALL towers' features
+    [mean (T Fi) | max | min | std | h panel] -- the layout of ONE tower of Fe = T Fi features, which is what the gather over the
+    block-diagonal projection produces (divide_input=True; one tower: the identity)."""
+    Wv, d, c, ones, K = _tower_collapsed_weights(layer, towers, mix, layer.divide_input)
+    T, Fi = len(towers), towers[0].in_dim
+    if T == 1:
+        return Wv, d, c, ones, K
+    hit = layer.__dict__.get("_pna_amd_flat")
+    if hit is not None and hit[0] is Wv:
+        return hit[1], d, c, ones, K
+    S = Wv.shape[1] // K
+    Fe = T * Fi
+    a_ = torch.arange(4, device=Wv.device).view(4, 1, 1)
+    t_ = torch.arange(T, device=Wv.device).view(1, T, 1)
+    f_ = torch.arange(Fi, device=Wv.device).view(1, 1, Fi)
+    cols = torch.cat([(t_ * 4 * Fi + a_ * Fi + f_).reshape(-1), torch.arange(4 * Fe, K, device=Wv.device)])      # new column -> old column
+    idx = torch.cat([s_ * K + cols for s_ in range(S)])
+    Wp = Wv.index_select(1, idx).contiguous()
+    layer.__dict__["_pna_amd_flat"] = (Wv, Wp)
+    return Wp, d, c, ones, K
 
 
 _SIDE_STREAMS = {}
@@ -591,7 +619,7 @@ def run_fused_call(call):
 
 
 class FusedTowerCall:
-    """One PNALayer forward (ONE tower; eval) on the one-kernel path after the node-level projection, cut into its launches like
+    """One PNALayer forward (one tower, or T towers with divide_input=True; eval) on the one-kernel path after the node-level projection, cut into its launches like
     FusedDegreeCall: `group_rows()` = pna_fused_degree_f32 in tower mode, `rest_rows()` = gather with the destination term + the
     rows' own features + three-block contraction over the compact list of the rows no degree group holds."""
 
@@ -601,11 +629,11 @@ class FusedTowerCall:
         import ctypes
         towers, mix = list(layer.towers), layer.mixing_network
         t0 = towers[0]
-        Fi, V, dev = t0.in_dim, h.shape[0], h.device
+        Fi, V, dev = len(towers) * t0.in_dim, h.shape[0], h.device          # (Fi: message features per edge, ALL towers -- see _tower_flat_weights)
         P = x_cat.shape[1] // 2
-        self.layer, self.graph, self.plan, self.t0 = layer, graph, DG.plan_of(graph), t0
+        self.layer, self.graph, self.plan, self.t0, self.Fe = layer, graph, DG.plan_of(graph), t0, Fi
         plan = self.plan
-        self.Wv, self.d, self.c, self.ones, self.K = Wv, d, c, ones, K = _tower_collapsed_weights(layer, towers, mix, layer.divide_input)
+        self.Wv, self.d, self.c, self.ones, self.K = Wv, d, c, ones, K = _tower_flat_weights(layer, towers, mix)
         N = Wv.shape[0]
         self.x_src, self.x_dst, self.h = x_cat[:, :Fi], x_cat[:, P:P + Fi], h
         self.scales = scales = _row_scales(graph, t0.scalers, t0.avg_d, dev)
@@ -652,7 +680,7 @@ class FusedTowerCall:
         if plan.NR:
             from . import degree_groups as DG
             from .dgl.pna_layer import _avg_log_value
-            Fi, K, N = t0.in_dim, self.K, self.Wv.shape[0]
+            Fi, K, N = self.Fe, self.K, self.Wv.shape[0]
             items, orow, hout, hs = plan.rest_items_by_node(graph)
             agg = torch.empty(plan.NRp, DG.agg_pitch(K), dtype=torch.float32, device=self.y.device)
             csr = graph.csr

@@ -332,3 +332,37 @@ def test_registered_edge_types_answer_without_a_search(monkeypatch):
     assert not g.edge_types_registered(e)                          # (one cache slot: the search replaced the registration)
     g.register_edge_types(e, types, torch.randn(9, 6))             # more rows than the register table holds: nothing registered
     assert not g.edge_types_registered(e)
+
+
+def test_flat_tower_weights_and_block_diagonal_projection():
+    """Round 5: T towers with divide_input=True on the one-kernel tower layer (functional._tower_flat_weights, pna_layer.
+    _projection_cache_padded_div).  Host algebra on CPU tensors: the collapsed weight with aggregator-major columns over ALL towers'
+    features times [mean | max | min | std | h] equals the tower-major form, and ONE block-diagonal GEMM gives every tower's
+    source / destination projection of its input slice (models/dgl/pna_layer.py:133-136, :35-40)."""
+    import torch
+    from pna_amd import functional as PF
+    from pna_amd.dgl.pna_layer import PNALayer, _projection_cache_padded_div
+    torch.manual_seed(0)
+    T, Fi, S, V = 4, 16, 3, 9
+    layer = PNALayer(T * Fi, 64, "mean max min std", "identity amplification attenuation", {"log": torch.tensor(1.3)}, 0.0, True, True, towers=T,
+                     pretrans_layers=1, posttrans_layers=1, divide_input=True, residual=True, edge_features=False, edge_dim=0).eval()
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.copy_(torch.randn_like(p) * 0.3)
+    towers, mix = list(layer.towers), layer.mixing_network
+    Wv, d, c, ones, K = PF._tower_collapsed_weights(layer, towers, mix, True)
+    Wp = PF._tower_flat_weights(layer, towers, mix)[0]
+    assert K == 5 * T * Fi and Wp.shape == Wv.shape
+    a, h = torch.randn(V, T, 4, Fi, dtype=torch.float64), torch.randn(V, T * Fi, dtype=torch.float64)
+    old = torch.cat([a.reshape(V, -1), h], 1)                                    # [t: mean | max | min | std] per tower, then h
+    new = torch.cat([a.permute(0, 2, 1, 3).reshape(V, -1), h], 1)                # [mean (all towers) | max | min | std], then h
+    for s in range(S):
+        torch.testing.assert_close(new @ Wp[:, s * K:(s + 1) * K].double().t(), old @ Wv[:, s * K:(s + 1) * K].double().t(), rtol=1e-12, atol=1e-12)
+    P = PF.tower_projection_pitch(T * Fi)
+    W, b = _projection_cache_padded_div(towers, Fi, P)
+    x = h.float() @ W.t() + b
+    for t, tw in enumerate(towers):
+        lin = tw.pretrans.fully_connected[0].linear
+        hs = h.float()[:, t * Fi:(t + 1) * Fi]
+        torch.testing.assert_close(x[:, t * Fi:(t + 1) * Fi], hs @ lin.weight[:, :Fi].t(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(x[:, P + t * Fi:P + (t + 1) * Fi], hs @ lin.weight[:, Fi:].t() + lin.bias, rtol=1e-5, atol=1e-6)
