@@ -247,6 +247,17 @@ def sampled_check(g, h_ext, y, layer_sd, avg_log, n_rows, lo=0):
             "tolerance": "per element 1e-5 |ref| + 2e-6 sum_k |w_k a_k| |bn scale| (fp32 layer vs float64 contraction of the fp32 oracle aggregate)"}
 
 
+def _finite(x):
+    """The record with every non-finite float replaced by None (a failed diagnostic leaves inf / nan behind: not JSON)."""
+    if isinstance(x, dict):
+        return {k: _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    if isinstance(x, float) and not (x == x and abs(x) != float("inf")):
+        return None
+    return x
+
+
 def F_of(layer_sd):
     return layer_sd["posttrans.fully_connected.0.linear.weight"].shape[1] // 12
 
@@ -485,6 +496,14 @@ def main():
             check = {"ok": False, "error": repr(ex)}
         if not check.get("ok"):
             print(f"[bench] rank {rank}: sampled parity check FAILED: {check}", file=sys.stderr, flush=True)
+    # N > 1: every rank's verdict in the line (rank 0 prints it; a failed check on ANY rank is visible and never costs the line)
+    check_ranks = None
+    if world > 1:
+        mine = torch.tensor([1.0 if (check or {}).get("ok") else 0.0, float((check or {}).get("worst_err_over_tolerance", float("nan")))],
+                            device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        check_ranks = [{"rank": i, "ok": bool(t[0].item() == 1.0), "worst_err_over_tolerance": float(t[1].item())} for i, t in enumerate(allr)]
 
     # ---- cold-cache leg: 3 rotating copies of the feature table and of the graph's index arrays, so that no
     # step finds its 300 MB of features / 40 MB of source ids in the 256 MiB Infinity Cache from the previous step --------
@@ -574,6 +593,14 @@ def main():
     csr = g.csr
     with torch.no_grad():
         x_ext = g.source_features(h)                                   # (synchronous form: the halo has landed)
+        # (the two collectives of this section first, on every rank: whatever the rank-local diagnostics below do -- they are caught --
+        # no rank can leave another waiting in an all-to-all, and rank 0 always prints its line: VERDICT r4 item 5a)
+        t_halo = event_time_ms(lambda: g.source_features(h), args.kernel_iters) if world > 1 else 0.0
+    diag_error = None
+    t_seg = t_post = t_post_f32 = float("inf")
+    grouped = fused = power = halo_rate = None
+    try:
+      with torch.no_grad():
         t_seg = event_time_ms(lambda: PF.aggregate(g, x_ext, F, AGGREGATORS.split()), args.kernel_iters)
         agg = PF.aggregate(g, x_ext, F, AGGREGATORS.split())
         lin = layer.posttrans.fully_connected[0].linear
@@ -618,7 +645,6 @@ def main():
                          "padded_rows": plan.NV, "id_records": plan.fused_tables()[2],
                          "rest_rows_beside_kernel": bool(beside), "spare_workgroups": int(call.args.spare_workgroups),
                          "ms_group_rows_kernel_full_grid": t_fused_full}
-        t_halo = event_time_ms(lambda: g.source_features(h), args.kernel_iters) if world > 1 else 0.0
         # N > 1: the exchange priced against the links it crosses.  Rank 0's received + sent halo bytes (whole rows of the resident
         # table, pitch ldx floats) over the standalone exchange time, beside ONE xGMI link's ~153 GB/s per direction: the all-to-all
         # spreads over world - 1 peers (one link each on an 8-GPU node), so the per-link rate is the total / (world - 1).
@@ -641,6 +667,11 @@ def main():
                      "segment_reduce": power_probe(lambda: PF.aggregate(g, x_ext, F, AGGREGATORS.split()))}
             if grouped is not None:
                 power["contraction_degree_grouped"] = power_probe(lambda: PF.degree_grouped_posttrans(layer, g, h, agg_g, plan, out=y_g))
+    except Exception as ex:                                         # noqa: BLE001  (reported in the line, never instead of it)
+        diag_error = repr(ex)
+        print(f"[bench] rank {rank}: per-kernel diagnostics failed: {diag_error}", file=sys.stderr, flush=True)
+        if not (t_seg < float("inf")):
+            grouped = fused = None
     alg_read = e_local * (4 * F + 4) + 4 * (n_local + 1)
     alg_write = n_local * 16 * F
     alg_bytes = alg_read + alg_write
@@ -770,11 +801,14 @@ def main():
                                        "(tests/test_gpu_posttrans_x3.py)") if arith == "bf16x3" else "f32 (v_mfma_f32_16x16x4_f32)",
                    "max_in_degree": int(csr.max_degree), "halo_rows_rank0": getattr(g, "n_halo", 0),
                    "interior_rows_rank0": int(g.interior_mask().sum().item()) if world > 1 else None,
-                   "local_rows_rank0": n_local, "local_edges_rank0": e_local, "partition_balance": args.balance if world > 1 else None},
+                   "local_rows_rank0": n_local, "local_edges_rank0": e_local, "partition_balance": args.balance if world > 1 else None,
+                   "halo_exchange_in_step": ("every timed step runs the halo all-to-all of the source rows (pack + all_to_all_single over RCCL) before its "
+                                             "kernel, although this benchmark's features do not change between steps: it is the cost a multi-layer net "
+                                             "pays once per layer; nothing is prefetched or reused across steps") if world > 1 else None},
         "roofline": roofline, "roofline_segreduce_standalone": roofline_segreduce, "roofline_posttrans": roofline_post, "roofline_layer": roofline_layer,
         "power_probe": power,
         "ms_per_step_cold": ms_per_step_cold, "value_cold": (E / (ms_per_step_cold * 1e-3)) if ms_per_step_cold else None,
-        "parity_check": check,
+        "parity_check": check, "parity_check_all_ranks": check_ranks,
         "kernel_ms": {"fused_degree_group_rows": fused["ms_group_rows_kernel"] if fused else None,
                       "fused_degree_rest_rows": fused["ms_rest_rows_two_kernel_path"] if fused else None,
                       "segreduce": t_seg, "posttrans": t_post, "posttrans_exact_f32_mfma": t_post_f32, "halo_all_to_all": t_halo,
@@ -809,7 +843,8 @@ def main():
         rec["configs4_per_gpu_shape"] = other_workload_leg(["--workload", "c5", "--no-cpu-baseline", "--no-cold", "--no-power-probe",
                                                             "--steps", "10", "--warmup", "3"])
     if rank == 0:
-        print(json.dumps(rec), flush=True)
+        rec["diagnostics_error"] = diag_error
+        print(json.dumps(_finite(rec)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

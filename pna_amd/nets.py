@@ -3,7 +3,9 @@
 `PNANet` mirrors realworld_benchmark/nets/molecules_graph_regression/pna_net.py:16-96 (same `net_params`
 dict, forward signature and state_dict keys): atom/bond embeddings -> L x PNALayer -> per-graph readout ->
 MLPReadout.  `PNANetHIV` mirrors nets/HIV_graph_classification/pna_net.py:9-64 with an in-tree stand-in for
-ogb's AtomEncoder (a sum of per-feature embeddings; ogb is not available offline).
+ogb's AtomEncoder (a sum of per-feature embeddings; ogb is not available offline).  `PNANetSuperpixels` mirrors
+nets/superpixels_graph_classification/pna_net.py:17-104 (CIFAR10 / MNIST: Linear embeddings of float node / edge features,
+MLPReadout to n_classes, cross-entropy).
 
 The per-graph readout (`dgl.sum_nodes` / `mean_nodes` / `max_nodes`, pna_net.py:83-90) is the same HIP
 segment-reduce kernel as the message passing: segments = batch_num_nodes, messages = the node rows themselves.
@@ -101,6 +103,50 @@ class PNANet(nn.Module):
 
     def loss(self, scores, targets):
         return nn.L1Loss()(scores, targets)
+
+
+class PNANetSuperpixels(nn.Module):
+    """nets/superpixels_graph_classification/pna_net.py:17-104: the same stack as the molecules net behind LINEAR embeddings of the
+    float node features (mean colour | position: in_dim 3 for MNIST, 5 for CIFAR10) and edge features, `n_classes` outputs and a
+    cross-entropy loss.  (Like the reference's forward :72-98, `in_feat_dropout` is read from the params and never applied.)
+    Same `net_params` keys, forward signature and state_dict keys."""
+
+    def __init__(self, net_params):
+        super().__init__()
+        p = net_params
+        hidden_dim, out_dim, n_layers = p["hidden_dim"], p["out_dim"], p["L"]
+        self.readout = p["readout"]
+        self.edge_feat = p["edge_feat"]
+        self.gru_enable = p["gru"]
+        self.embedding_h = nn.Linear(p["in_dim"], hidden_dim)
+        if self.edge_feat:
+            self.embedding_e = nn.Linear(p["in_dim_edge"], p["edge_dim"])
+        common = dict(dropout=p["dropout"], graph_norm=p["graph_norm"], batch_norm=p["batch_norm"], residual=p["residual"],
+                      aggregators=p["aggregators"], scalers=p["scalers"], avg_d=p["avg_d"], towers=p["towers"],
+                      edge_features=self.edge_feat, edge_dim=p["edge_dim"], pretrans_layers=p["pretrans_layers"],
+                      posttrans_layers=p["posttrans_layers"])
+        self.layers = nn.ModuleList([PNALayer(in_dim=hidden_dim, out_dim=hidden_dim, divide_input=p["divide_input_first"],
+                                              **common) for _ in range(n_layers - 1)])
+        self.layers.append(PNALayer(in_dim=hidden_dim, out_dim=out_dim, divide_input=p["divide_input_last"], **common))
+        if self.gru_enable:
+            self.gru = GRU(hidden_dim, hidden_dim, p["device"])
+        self.MLP_layer = MLPReadout(out_dim, p["n_classes"])
+
+    def forward(self, g, h, e, snorm_n, snorm_e=None):
+        graph = as_graph(g)
+        h = self.embedding_h(h)
+        if self.edge_feat:
+            e = self.embedding_e(e)
+        for i, conv in enumerate(self.layers):
+            h_t = conv(graph, h, e, snorm_n)
+            if self.gru_enable and i != len(self.layers) - 1:
+                h_t = self.gru(h, h_t)
+            h = h_t
+        hg = readout_nodes(graph, h, self.readout if self.readout in ("sum", "max", "mean") else "mean")
+        return self.MLP_layer(hg)
+
+    def loss(self, pred, label):
+        return nn.CrossEntropyLoss()(pred, label)
 
 
 class _SmallTableEmbedding(torch.autograd.Function):

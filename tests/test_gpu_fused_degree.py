@@ -435,3 +435,56 @@ def test_source_table_beyond_4_gib_and_2_pow_24_rows(cuda_device):
         y3 = c3.rest_rows().clone()
         y2 = c2.rest_rows().clone()
         assert torch.equal(y2[plan0.rest_rows], y3[plan0.rest_rows])
+
+
+# WHICH path a shape takes is part of the contract -- a shape outside the one-kernel layer's instantiations must
+# land on the two-kernel grouped path (or, beyond 128 outputs, on the ordinary kernels) visibly, not silently; and whatever ran
+# must match the oracle.  "one" = pna_fused_degree_f32 over the group rows, "two" = gather in degree order + grouped contraction,
+# "ordinary" = gather + three-block contraction in node order.
+@pytest.mark.parametrize("F,N,path", [
+    (75, 75, "one"), (64, 64, "one"), (80, 80, "one"), (17, 40, "one"), (40, 72, "one"),             # one gather pass, one panel
+    (128, 128, "one"), (120, 100, "one"), (113, 81, "one"), (128, 64, "one"),                        # two gather passes
+    (64, 96, "one"), (50, 128, "one"),                                                               # one pass of two full blocks, two panels
+    (96, 96, "two"), (100, 100, "two"), (112, 112, "two"), (81, 64, "two"),                          # 81 <= F <= 112: unequal passes, not built
+    (75, 96, "two"), (80, 128, "two"), (40, 100, "two"),                                             # N > 80 needs exactly two full blocks per pass
+    (16, 64, "two"),                                                                                 # F < 17
+    (75, 160, "ordinary"), (128, 192, "ordinary"),                                                   # N > 128: no grouped contraction
+])
+def test_which_path_a_shape_takes_and_that_it_matches_the_oracle(cuda_device, F, N, path):
+    from oracle import torch_oracle as O
+    from pna_amd import Graph, degree_groups as DG, functional as PF
+    from pna_amd.synth import powerlaw_graph
+    V, E = 6000, 48_000
+    src, dst = powerlaw_graph(V, E, seed=F + N)
+    g = Graph(src, dst, V).to(cuda_device)
+    layer = _layer(F, N, "cpu", residual=(F == N), seed=N)
+    sd = {k: v.clone() for k, v in layer.state_dict().items()}
+    layer = layer.to(cuda_device)
+    h = _features(V, F, cuda_device, seed=F)
+    ran = []
+    keep = (PF.run_fused_call, PF.degree_grouped_posttrans)
+    PF.run_fused_call = lambda call: (ran.append("one"), keep[0](call))[1]
+    PF.degree_grouped_posttrans = lambda *a, **k: (ran.append("two"), keep[1](*a, **k))[1]
+    try:
+        with torch.no_grad(), _Knobs(fused=True, small_graphs=True):
+            assert (_lib_image_bytes(F, N) > 0) == (path == "one")
+            y = layer(g, h).cpu()
+    finally:
+        PF.run_fused_call, PF.degree_grouped_posttrans = keep
+    assert (ran or ["ordinary"]) == [path], (F, N, ran)
+    # the north star's bar per element against the float64 evaluation of the reference's formulas: 1e-5 relative + the fp32 rounding
+    # floor of a K = 12 F sum in another order, 2e-6 x sum_k |w_k a_k| carried through BatchNorm's scale (bench.py's parity_check)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    ref, agg = O.simple_layer_forward(sd64, src, dst, V, h.cpu().double().contiguous(), ["mean", "max", "min", "std"],
+                                      ["identity", "amplification", "attenuation"], torch.tensor(2.3, dtype=torch.float64), residual=(F == N),
+                                      return_aggregate=True)
+    W, b = sd64["posttrans.fully_connected.0.linear.weight"], sd64["posttrans.fully_connected.0.linear.bias"]
+    bn_scale = sd64["batchnorm_h.weight"] / torch.sqrt(sd64["batchnorm_h.running_var"] + 1e-5)
+    mass = (agg.abs() @ W.abs().t() + b.abs()) * bn_scale.abs()
+    err, tol = (y.double() - ref).abs(), 1e-5 * ref.abs() + 2e-6 * mass
+    assert bool((err <= tol).all()), (F, N, path, (err / tol).max().item())
+
+
+def _lib_image_bytes(F, N):
+    from pna_amd import _lib
+    return _lib.lib().pna_fused_degree_image_bytes(F, N)

@@ -299,6 +299,30 @@ def test_molecules_net_golden(cuda_device, name):
     torch.testing.assert_close(out, a["out"], **TOL)
 
 
+def _superpixels_params(meta, a, device="cpu"):
+    return dict(in_dim=meta["in_dim"], in_dim_edge=1, hidden_dim=meta["hidden_dim"], out_dim=meta["out_dim"], n_classes=meta["n_classes"],
+                in_feat_dropout=0.0, dropout=0.0, L=meta["L"], readout=meta["readout"], graph_norm=True, batch_norm=True, residual=True,
+                aggregators=meta["aggregators"], scalers=meta["scalers"], avg_d={"log": a["avg_log"]}, towers=meta["towers"],
+                divide_input_first=meta["divide_input_first"], divide_input_last=meta["divide_input_last"], edge_feat=meta["edge_feat"],
+                edge_dim=meta["edge_dim"], pretrans_layers=1, posttrans_layers=1, gru=meta["gru"], device=device)
+
+
+@pytest.mark.parametrize("name", golden_names("net_superpixels"))
+def test_superpixels_net_golden(cuda_device, name):
+    """Whole superpixels PNANet (Linear embeddings, L tower layers incl. divide_input_first, GRU, readout, MLPReadout to n_classes) against
+    the output of the reference's own net (nets/superpixels_graph_classification/pna_net.py), state_dict loaded strictly."""
+    from pna_amd.nets import PNANetSuperpixels
+    meta, a, sd = load_golden(name)
+    net = PNANetSuperpixels(_superpixels_params(meta, a))
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.load_state_dict(sd, strict=True)
+    net = net.to(cuda_device).eval()
+    g = Graph(a["src"], a["dst"], meta["N"], meta["sizes"]).to(cuda_device)
+    with torch.no_grad():
+        out = net(g, a["x"].to(cuda_device), a["e"].to(cuda_device), a["snorm_n"].to(cuda_device), None).cpu()
+    torch.testing.assert_close(out, a["out"], **TOL)
+
+
 def test_molecules_net_hands_its_bond_types_to_the_layers(cuda_device, monkeypatch):
     """PNANet with --edge_feat: `e = embedding_e(bond_type)`.  The net registers the types on the graph (Graph.register_edge_types), so
     the layers' edge-type fast path does not have to FIND them in e's rows (a sort of E doubles + two host syncs per fresh batch,
