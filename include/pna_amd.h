@@ -504,7 +504,7 @@ int pna_fused_simple_f32(const pna_fused_simple_args* args, pna_stream_t stream)
  *   y[perm[v]]  = residual[perm[v]] + act((bias + W_D(v) . a[v]) * col_scale + col_shift)   (bf16x3 arithmetic of pna_posttrans_x3_f32)
  *
  * The caller (pna_amd/degree_groups.py) orders the rows by in-degree into VIRTUAL rows v in [0, M):
- *   row_perm[v]   node of virtual row v, or -1 = padding (nothing is stored); M a multiple of 64; every aligned block of 16
+ *   row_perm[v]   node of virtual row v, or -1 = padding (nothing is stored); M a multiple of pna_fused_degree_tile_rows(F, N) (64 or 128); every aligned block of 16
  *                 virtual rows holds rows of ONE in-degree (padding aside), every aligned block of 64 rows uses ONE weight image;
  *   tile_desc     [M / 16][4] = {first record, in-degree D, weight image, 0} of every 16-row block;
  *   tile_ids      n_records records of 16 int32: record (first + e)[i] = source row (row of x) of the e-th in-edge of the block's
@@ -577,6 +577,9 @@ typedef struct pna_fused_degree_args {
 } pna_fused_degree_args;
 
 int64_t pna_fused_degree_image_bytes(int32_t F, int32_t N);   /* 0 = unsupported shape */
+int32_t pna_fused_degree_tile_rows(int32_t F, int32_t N);     /* rows of a workgroup tile for the shape (M must be a multiple; all of
+                                                                  one degree and one weight image): 64, or 128 for the wide shapes when the
+                                                                  library runs them as 8-wavefront workgroups; 0 = unsupported shape */
 int pna_fused_degree_pack_f32(const float* w_ref, int64_t ldw_ref, int32_t N, int32_t F, int32_t n_scaler, const float* scale,
                               int32_t n_img, void* img, pna_stream_t stream);
 int pna_fused_degree_f32(const pna_fused_degree_args* args, pna_stream_t stream);

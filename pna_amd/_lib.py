@@ -10,7 +10,8 @@ import os
 import torch  # noqa: F401  (must be imported first: the library binds to the HIP runtime torch loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpna_amd.so")
+# (PNA_AMD_LIB_PATH: another build of the same ABI -- tools/build_variant.sh, the -DPNA_AMD_EXPERIMENTS build -- for same-box A/B runs)
+LIB_PATH = os.environ.get("PNA_AMD_LIB_PATH") or os.path.join(_HERE, "lib", "libpna_amd.so")
 
 PNA_ABI_VERSION = 20
 PNA_MAX_AGGR = 8
@@ -254,6 +255,8 @@ def lib():
         L.pna_fused_simple_f32.restype = ctypes.c_int
         L.pna_fused_degree_image_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32]
         L.pna_fused_degree_image_bytes.restype = ctypes.c_int64
+        L.pna_fused_degree_tile_rows.argtypes = [ctypes.c_int32, ctypes.c_int32]
+        L.pna_fused_degree_tile_rows.restype = ctypes.c_int32
         L.pna_fused_degree_pack_f32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                 ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
         L.pna_fused_degree_pack_f32.restype = ctypes.c_int

@@ -67,11 +67,24 @@ struct FDArgs {
   int abl;                     // experiments build only: parts skipped for timing (bit 0 MFMAs, 1 fragment maths after the first chunk,
 };                             // 2 the fold, 3 the y stores, 4 the B-fragment reads): results are then meaningless
 
-constexpr int kNW = 80, kNT = 5, kWaves = 4, kThreads = 64 * kWaves;
-constexpr int kNBuf = 5;                                  // LDS weight buffers: a chunk image is requested kNBuf - 1 steps before it is read
-constexpr int kAhead = kNBuf - 1;
+constexpr int kNW = 80, kNT = 5;
+#ifndef FD_WIDE_WAVES
+#define FD_WIDE_WAVES 4
+#endif
+// Wavefronts per workgroup (template parameter WAVES of the kernel; a workgroup tile = 16 WAVES rows of ONE degree = one weight
+// image): 4, two workgroups per CU, for the shapes of one gather pass and one panel -- while one workgroup multiplies the other
+// gathers, and the launch is bound by the memory system.  The WIDE shapes are not: their time is a per-workgroup
+// chain of latencies (4.8.13), and the weight image is streamed once per tile -- FD_WIDE_WAVES wavefronts per workgroup there.
+constexpr int waves_for(int gp, int npan) { return (gp == 2 || npan == 2) ? FD_WIDE_WAVES : 4; }
+constexpr int kWavesMax = 8;
+// LDS weight buffers (template parameter NBUF of the kernel): a step's image is requested NBUF - 1 steps before it is read.  Five
+// buffers of 15 KB (one panel of 80 columns) are what two workgroups per CU can hold; the wide shapes' panels of 64 columns are
+// 12 KB, so SIX fit (2 x (72 + 1.5) KB of the CU's 160 KB) -- round 5: their multiply phase is paced by the COPY LATENCY, not by the
+// matrix pipe (phase timers at BASELINE configs[4]'s shape: 73 % of a wavefront's time in the multiply phase against 21 % of
+// matrix-pipe time; skipping every MFMA, fragment and B read leaves 2.55 of 3.26 ms), and a copy that has four steps to land instead
+// of three shortens every paced step by a quarter.
+constexpr int buffers_for(int gp, int npan) { return waves_for(gp, npan) == 8 ? 10 : npan == 2 ? 6 : 5; }
 constexpr int kChunkV = 3 * 4 * kNW;                      // 16-byte pieces of one chunk image: [term][lane group][80 cols][8 k] bf16
-constexpr int kNI = (kChunkV + kThreads - 1) / kThreads;  // global_load_lds instructions per wavefront per chunk
 constexpr int kRing = 4;                                  // edge packets in the register ring
 constexpr int kNRes = kNT;                                // residual loads per lane (16 bytes each: 4 consecutive columns of one row)
 
@@ -185,8 +198,10 @@ __device__ __forceinline__ unsigned long long now() {
 // its chunks, gather 1 (the ids of the tile's edges a second time, its source rows' second half), its chunks, epilogue.  NPAN = 2:
 // 81..128 output columns as two PANELS of 64 (4 column tiles each): a step multiplies one chunk's A fragment against one panel's
 // image (12 KB: the five-buffer pipeline still fits two workgroups per CU), the fragment is formed once per chunk.
-template <int NFBF, bool HALF, bool DUMP, bool TOWER = false, bool RESPF = !DUMP && !TOWER, int GP = 1, int NPAN = 1>
-__global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const FDArgs g) {
+template <int NFBF, bool HALF, bool DUMP, bool TOWER = false, bool RESPF = !DUMP && !TOWER, int GP = 1, int NPAN = 1, int WAVES = waves_for(GP, NPAN),
+          int NBUF = buffers_for(GP, NPAN)>
+__global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fused_degree(const FDArgs g) {
+  constexpr int kNBuf = NBUF, kAhead = NBUF - 1, kWaves = WAVES, kThreads = 64 * WAVES;
   static_assert(!TOWER || (NFBF == 2 && !DUMP), "tower mode: two full feature blocks (49 <= F <= 80), production only");
   static_assert((GP == 1 || (GP == 2 && !HALF && !TOWER)) && (NPAN == 1 || (NPAN == 2 && !TOWER)), "wide shapes: full blocks, no tower mode");
   constexpr int NB = NFBF + (HALF ? 1 : 0);               // feature blocks of one gather pass
@@ -570,7 +585,7 @@ __global__ __launch_bounds__(kThreads, DUMP ? 1 : 2) void k_fused_degree(const F
   long ib_cur = (long)td_cur.z * g.img_stride, ib_next = (long)td_nxt.z * g.img_stride;
   int buf = 0;
 #pragma unroll
-  for (int c = 0; c < kAhead; ++c) stage(c, c, ib_cur);   // (every shape has at least 4 steps)
+  for (int c = 0; c < kAhead; ++c) stage(c, c, ib_cur);   // (every shape has at least kAhead steps)
   // the ids of the first tile's edges 0..3 (later tiles: fetched by the previous tile's last packets)
 #pragma unroll
   for (int j = 0; j < kRing; ++j) ld4_ws(idr[j], g.ids, (unsigned)td_cur.x * 64u + (unsigned)j * 64u + lib);
@@ -780,10 +795,12 @@ __host__ __device__ constexpr bool shape_wide_n(int N) { return N > kNW && N <= 
 template <int NFBF, bool HALF, bool DUMP, bool TOWER = false, int GP = 1, int NPAN = 1>
 int launch(const FDArgs& g, int wgs, hipStream_t st) {
   constexpr int NWP = NPAN == 1 ? kNW : 64;
-  const size_t lds = (size_t)kNBuf * (3 * 4 * NWP) * 16 + (size_t)(3 * NWP * NPAN) * sizeof(float);
-  auto* fn = k_fused_degree<NFBF, HALF, DUMP, TOWER, !DUMP && !TOWER, GP, NPAN>;
+  constexpr int NBUF = buffers_for(GP, NPAN), WAVES = waves_for(GP, NPAN);
+  const size_t lds = (size_t)NBUF * (3 * 4 * NWP) * 16 + (size_t)(3 * NWP * NPAN) * sizeof(float);
+  auto* fn = k_fused_degree<NFBF, HALF, DUMP, TOWER, !DUMP && !TOWER, GP, NPAN, WAVES, NBUF>;
   if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-  hipLaunchKernelGGL(fn, dim3((unsigned)wgs), dim3(kThreads), lds, st, g);
+  if (WAVES == 8) wgs = (wgs + 1) / 2;                    // (the caller counts 4-wavefront workgroups, two per CU)
+  hipLaunchKernelGGL(fn, dim3((unsigned)wgs), dim3(64 * WAVES), lds, st, g);
   return 0;
 }
 template <bool DUMP>
@@ -807,6 +824,11 @@ int launch_shape(const FDArgs& g, int wgs, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int32_t pna_fused_degree_tile_rows(int32_t F, int32_t N) {
+  if (pna_fused_degree_image_bytes(F, N) == 0) return 0;
+  return 16 * waves_for(shape_wide_f(F) ? 2 : 1, shape_wide_n(N) ? 2 : 1);
+}
 
 extern "C" int64_t pna_fused_degree_image_bytes(int32_t F, int32_t N) {
   // F: 17..80 (one gather pass) or 113..128 (two passes of two full blocks; 81..112 would need unequal passes: not built);
@@ -868,8 +890,9 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: x must be 4-byte aligned with a row pitch >= F (< 2^29 floats)");
   if (p->x_rows < 1 || p->x_rows >= (1ll << 32))
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: the source table must have 1 <= x_rows < 2^32");
-  if (p->M < 0 || p->M % (kWaves * 16) != 0 || p->M >= (1ll << 31))
-    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: M must be a multiple of 64");
+  const int tile_rows = 16 * waves_for(shape_wide_f(p->F) ? 2 : 1, shape_wide_n(p->N) ? 2 : 1);
+  if (p->M < 0 || p->M % tile_rows != 0 || p->M >= (1ll << 31))
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: M must be a multiple of pna_fused_degree_tile_rows(F, N) (64, or 128 for the wide shapes)");
   if (p->n_records < 4 || p->n_records * 64 >= (1ll << 32))
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: tile_ids must hold 4 <= n_records < 2^26 records");
   if (p->n_nodes < 1 || p->ldy < p->N || p->n_nodes * p->ldy * 4 >= (1ll << 32) ||
@@ -904,7 +927,7 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
   if (const char* e = getenv("PNA_FD_DBG_PTR")) g.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // device buffer: 4 counters per wavefront
   if (const char* e = getenv("PNA_FD_ABL")) g.abl = atoi(e);
 #endif
-  const int ntiles = (int)(p->M / (kWaves * 16));
+  const int ntiles = (int)(p->M / 64);                     // in 64-row units: launch() halves the grid for 8-wavefront workgroups
   int per_cu = 2;
 #ifdef PNA_AMD_EXPERIMENTS
   if (const char* e = getenv("PNA_FD_WGS")) per_cu = atoi(e) > 0 ? atoi(e) : 2;

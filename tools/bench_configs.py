@@ -257,6 +257,47 @@ out["zinc_net_4_layers_edge_feat"] = dict(graphs=128, V=Vz, E=Ez, hidden=75, tow
                                           note="fresh e = embedding_e(bonds) every call; layers 1-3 on the one-call kernel with the edge-type table, the last "
                                                "layer (divide_input_last) too")
 
+# ---- the superpixels net of the reference's CIFAR10 config (configs/superpixels_graph_classification_pna_CIFAR10.json: batch 128, L 4,
+#      hidden 75 -> out 70, 5 towers, divide_input_first=True / _last=False, sum readout, no edge features): 128 graphs x ~117 superpixels x
+#      8 nearest neighbours = ~15 k nodes / ~120 k edges -- the MID-SIZE regime between the one-call small-batch kernel
+#      (functional.SMALL_TOWER_ROWS) and the degree-planned paths (VERDICT r4 missing #6) ----
+import numpy as np  # noqa: E402
+from pna_amd.nets import PNANetSuperpixels  # noqa: E402
+rng_c = np.random.default_rng(41)
+srcs_c, dsts_c, sizes_c, off_c = [], [], [], 0
+for _ in range(128):
+    n_c = int(np.clip(round(rng_c.normal(117.6, 4.0)), 85, 150))
+    pos_c = rng_c.random((n_c, 2))
+    d2_c = ((pos_c[:, None, :] - pos_c[None, :, :]) ** 2).sum(-1)
+    np.fill_diagonal(d2_c, np.inf)
+    nb_c = np.argsort(d2_c, axis=1)[:, :8]
+    dsts_c.append(np.repeat(np.arange(n_c), 8) + off_c)
+    srcs_c.append(nb_c.reshape(-1) + off_c)
+    sizes_c.append(n_c)
+    off_c += n_c
+src_c, dst_c = torch.from_numpy(np.concatenate(srcs_c)), torch.from_numpy(np.concatenate(dsts_c))
+Vs, Es = int(sum(sizes_c)), int(src_c.numel())
+gs = Graph(src_c, dst_c, Vs, sizes_c).to(dev)
+avgs = {"log": torch.log(gs.in_degrees().double() + 1).mean().float().cpu()}
+snet = PNANetSuperpixels(dict(in_dim=5, in_dim_edge=1, hidden_dim=75, out_dim=70, n_classes=10, in_feat_dropout=0.0, dropout=0.0, L=4, readout="sum",
+                              graph_norm=True, batch_norm=True, residual=True, aggregators=AGG, scalers=SCA, avg_d=avgs, towers=5,
+                              divide_input_first=True, divide_input_last=False, edge_feat=False, edge_dim=0, pretrans_layers=1, posttrans_layers=1,
+                              gru=False, device=dev)).to(dev).eval()
+xs_c = torch.rand(Vs, 5, device=dev)
+sns = gs.snorm_n()
+with torch.no_grad():
+    snet_eager = gpu_ms(lambda: snet(gs, xs_c, None, sns, None))
+    gfs = GraphedForward(lambda x_: snet(gs, x_, None, sns, None), xs_c)
+    snet_graphed = gpu_ms(lambda: gfs(xs_c))
+    hs_c = torch.randn(Vs, 75, device=dev)
+    first_eager = gpu_ms(lambda: snet.layers[0](gs, hs_c, None, sns))
+    last_eager = gpu_ms(lambda: snet.layers[-1](gs, hs_c, None, sns))
+out["cifar10_superpixels_net_4_layers"] = dict(graphs=128, V=Vs, E=Es, in_dim=5, hidden=75, out_dim=70, towers=5, L=4, divide_input_first=True,
+                                               divide_input_last=False, inference_eager_ms=snet_eager, inference_hipgraph_ms=snet_graphed,
+                                               graphs_per_s_hipgraph=128 / snet_graphed * 1e3, edges_per_s_per_layer_hipgraph=4 * Es / snet_graphed * 1e3,
+                                               first_layer_eager_ms=first_eager, last_layer_eager_ms=last_eager,
+                                               small_batch_kernel_rows_limit=PF.SMALL_TOWER_ROWS)
+
 # ---- configs[0]: multitask dense layer, B=128 graphs of N=50 nodes, hidden 16, 4 towers ----
 gen = torch.Generator().manual_seed(1234)
 B, N = 128, 50
@@ -312,4 +353,26 @@ with torch.no_grad():
     t_agg_simple = gpu_ms(lambda: PF.aggregate(g3, xs, Fc, AGG.split()), iters=20)
 out["c3_tower_layer"] = dict(V=Vc, E=Ec, F=Fc, towers=1, layer_ms=t_tower, simple_layer_ms=t_simple, aggregate_tower_ms=t_agg_tower,
                              aggregate_simple_ms=t_agg_simple, edges_per_s_layer=Ec / t_tower * 1e3)
+# ---- the reference's 5-tower layers at the same scale.  divide_input=True (CIFAR10 / MNIST first layers, ZINC's last:
+#      tower t reads the input slice [15 t, 15 t + 15)): all towers' messages are 75 features per edge -- ONE gather, the one-kernel tower
+#      layer (round 5).  divide_input=False (ZINC's first layers): five different 150 -> 75 projections = 375 message features per edge,
+#      5 x the gather bytes (15.2 GB per layer: >= 3 ms at the 5 TB/s the gather sustains) -- the two-kernel grouped path. ----
+from pna_amd import degree_groups as DGc  # noqa: E402
+res5 = {}
+for div in (True, False):
+    t5 = PNALayer(Fc, Fc, AGG, SCA, avg3, 0.0, True, True, towers=5, divide_input=div, residual=True).eval()
+    randomise(t5)
+    t5 = t5.to(dev)
+    with torch.no_grad():
+        one = bool(PF.tower_layer_degree_grouped_applies(t5, g3, h3) and PF.tower_layer_degree_fused_applies(t5, g3, h3))
+        ms5 = gpu_ms(lambda: t5(g3, h3, None, sn3), iters=10, warmup=3)
+        entry = dict(layer_ms=ms5, one_kernel_path=one, message_features_per_edge=75 if div else 375, edges_per_s_layer=Ec / ms5 * 1e3)
+        if one:
+            keep_f = DGc.FUSED
+            DGc.FUSED = False
+            entry["two_kernel_grouped_path_ms"] = gpu_ms(lambda: t5(g3, h3, None, sn3), iters=10, warmup=3)
+            DGc.FUSED = keep_f
+    res5["divide_input" if div else "whole_input"] = entry
+    del t5
+out["c3_tower_layer_5_towers"] = dict(V=Vc, E=Ec, F=Fc, towers=5, **res5)
 print(json.dumps(out, indent=1))

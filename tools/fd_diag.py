@@ -65,6 +65,17 @@ with torch.no_grad():
     out = {"V": V, "E": E, "F": F, "groups": plan.G, "rest_rows": plan.NR, "padded_rows": plan.NV, "rows": rows_g, "edges": e_g,
            "spare_workgroups": int(call.args.spare_workgroups), "lib": os.path.basename(_lib.LIB_PATH)}
     out["group_rows_ms"] = ev(call.group_rows)
+    if os.environ.get("FD_PARITY"):                          # the kernel's rows against the two-kernel grouped path (same statistics, same weights)
+        y1 = call.group_rows().clone()
+        live = plan.perm[plan.perm >= 0].long()
+        DG.FUSED = False
+        y2 = layer(g, h)
+        DG.FUSED = True
+        s_ = y2.abs().max().item()
+        out["max_diff_vs_two_kernel_of_max"] = (y1[live] - y2[live]).abs().max().item() / s_
+        out["rows_differing_over_2e-6"] = int(((y1[live] - y2[live]).abs().max(dim=1).values > 2e-6 * s_).sum())
+        print(f"parity vs two-kernel grouped path: {out['max_diff_vs_two_kernel_of_max']:.2e} of max|y|, {out['rows_differing_over_2e-6']} rows over 2e-6", flush=True)
+        del y2
     alg = e_g * (4 * F + 4) + plan.NV + rows_g * (8 * F + 4)
     out["algorithmic_bytes"] = alg
     out["frac_of_8TBps"] = alg / (out["group_rows_ms"] * 1e-3) / 8e12

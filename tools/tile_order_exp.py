@@ -117,7 +117,8 @@ def main():
         call.keep = call.keep + (d2, perm2)
         call.args.tile_desc = _lib.dev_ptr(d2, torch.int32, "tile_desc")
         call.args.row_perm = _lib.dev_ptr(perm2, torch.int32, "row_perm")
-        call.y = torch.zeros_like(y0)
+        y_buf = torch.zeros(V, int(call.args.ldy), device=dev)          # (the SAME row pitch as the call's own y: ldy stays as bound)
+        call.y = y_buf[:, :F]
         call.args.y = _lib.dev_ptr(call.y, torch.float32, "y")
         y1 = call.group_rows().clone()
         same = bool(torch.equal(y0, y1))
