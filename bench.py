@@ -194,7 +194,8 @@ def other_workload_leg(extra, timeout_s=150):
         return {"command": "python " + " ".join(os.path.relpath(c, ROOT) if os.path.isabs(c) else c for c in cmd[1:]),
                 "workload": (d.get("config") or {}).get("workload"), "ms_per_step": d.get("ms_per_step"), "value": d.get("value"), "unit": d.get("unit"),
                 "steps": d.get("steps"), "warmup": d.get("warmup"), "prewarm_steps_untimed": d.get("prewarm_steps_untimed"),
-                "roofline": {k: r.get(k) for k in ("kernel", "frac", "ms_per_launch", "achieved", "unit", "rest_rows_beside_kernel", "full_grid")},
+                "roofline": {k: r.get(k) for k in ("kernel", "frac", "ms_per_launch", "achieved", "unit", "rest_rows_beside_kernel", "full_grid", "traffic",
+                                                     "traffic_source", "traffic_over_algorithmic", "traffic_GB_per_s", "algorithmic_bytes_per_launch", "read_only_frac")},
                 "roofline_layer_frac": (d.get("roofline_layer") or {}).get("frac"), "parity_check": d.get("parity_check")}
     except Exception as ex:                                         # (timeout, JSON, OS): never the parent's problem
         return {"error": repr(ex), "command": " ".join(cmd[1:])}
@@ -725,12 +726,15 @@ def main():
                             + (" -- in the step on a second stream BESIDE this kernel, which leaves spare_workgroups of its 2-per-CU workgroups out for them"
                                " (both timed alone here)" if fused["rest_rows_beside_kernel"] else "")}
         ftp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(ftp) and args.workload == "c3" and world == 1 and args.nodes_per_gpu == V_PER_GPU and args.edges_per_gpu == E_PER_GPU:
+        default_c3 = args.workload == "c3" and args.nodes_per_gpu == V_PER_GPU and args.edges_per_gpu == E_PER_GPU
+        default_c5 = args.workload == "c5" and args.nodes_per_gpu == 2_000_000 and args.edges_per_gpu == 20_000_000
+        if os.path.exists(ftp) and world == 1 and (default_c3 or default_c5):
             try:
-                tj = json.load(open(ftp)).get("pna_fused_degree_c3")
+                tj = json.load(open(ftp)).get("pna_fused_degree_c3" if default_c3 else "pna_fused_degree_c5")
                 if tj:
                     roofline["traffic"] = tj.get("hbm_bytes_per_launch")
-                    roofline["traffic_source"] = "profiles/hbm_traffic.json (pna_fused_degree_c3): " + tj.get("collected", "") + "; NOT measured in this run"
+                    roofline["traffic_source"] = ("profiles/hbm_traffic.json (pna_fused_degree_" + ("c3" if default_c3 else "c5") + "): " + tj.get("collected", "")
+                                                  + "; NOT measured in this run")
                     # the counters' bytes over THIS run's launch time: what the memory system delivered.  traffic > algorithmic here is line
                     # granularity, not re-reads (a 300-byte row lies on three 128-byte lines: hbm_traffic.json line_granular_floor)
                     roofline["traffic_over_algorithmic"] = roofline["traffic"] / fused_bytes

@@ -65,7 +65,7 @@ struct FDArgs {
   int F, M, N, relu;
   float slope;
   int abl;                     // experiments build only: parts skipped for timing (bit 0 MFMAs, 1 fragment maths after the first chunk,
-};                             // 2 the fold, 3 the y stores, 4 the B-fragment reads): results are then meaningless
+};                             // 2 the fold, 3 the y stores, 4 the B-fragment reads, 7 the weight copies, 8 gather from row 0): results are then meaningless
 
 constexpr int kNW = 80, kNT = 5;
 #ifndef FD_WIDE_WAVES
@@ -239,6 +239,7 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
 
   // ---- weight chunks: global -> LDS, asynchronously (every wavefront issues exactly kNI copies per chunk) ----------------
   auto stage = [&](int c, int buf, long ib) __attribute__((always_inline)) {
+    if (FD_ABL(7)) return;                               // (experiments: no weight copies at all -- what the L2 -> LDS stream costs)
     const unsigned char* src = g.w_img + ib + (size_t)c * CHV * 16;
     unsigned char* dst = lds + (size_t)buf * CHV * 16;
 #pragma unroll
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
       constexpr bool LASTP = P == GP - 1;                 // the pass that holds the row's last block
       constexpr int NFA = LASTP ? NB - 1 : NB;             // blocks addressed through A (never past F)
       constexpr int PO = P * NFBF * 128;                    // byte offset of the pass's features inside a row
-      const size_t ro = (size_t)(unsigned)idr[j] * ldb;
+      const size_t ro = FD_ABL(8) ? (size_t)0 : (size_t)(unsigned)idr[j] * ldb;   // (experiments, bit 8: every packet reads row 0)
       if constexpr (NFA > 0) {
         const char* const pa = xA + ro;
         ldx16<PO>(sl[j][0], pa); ldx16<PO + 16>(sl[j][1], pa);
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
     if constexpr (RES_NOW) {
       const unsigned rrow = (unsigned)max(prow(), 0) * g.ldrb;
 #pragma unroll
-      for (int n = 0; n < NTA; ++n) ld16(res[n], resb, rrow + res_col(n));
+      for (int n = 0; n < NTA; ++n) ld16_ws(res[n], resb, rrow + res_col(n));   // (_ws: under SGPR pressure the base is reloaded right in front)
     }
     wait_slot<2 * LB + NR, NL>(sl[1], idr[1]); fold(J1{}, e0 + 1 < D);
     wait_slot<1 * LB + NR, NL>(sl[2], idr[2]); fold(J2{}, e0 + 2 < D);
@@ -582,6 +583,7 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
   //      multiply phase, 5x its matrix-pipe time.)  The same waits retire the residual rows requested at the end of the gather:
   //      they are older than every copy issued during the steps. ------------------------------------------------------------------
   unsigned long long tg = 0, tm = 0, te = 0, t00 = now();
+  unsigned long long tvm = 0, tb0 = 0, tbar = 0;           // experiments build: inside the multiply phase -- copy waits | first barrier of a pass | other barriers
   long ib_cur = (long)td_cur.z * g.img_stride, ib_next = (long)td_nxt.z * g.img_stride;
   int buf = 0;
 #pragma unroll
@@ -643,8 +645,20 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
     // (end of step RSTEP) into the epilogue: they are younger than the image this wait is for
     // (wide shapes: the same holds for the first steps behind the second gather)
     constexpr int young = !TOWER ? 0 : (c > PSTEP && c < PWAIT) ? NPL : c > RSTEP ? NTA : 0;
+#ifdef FD_FINE_TIMERS
+    {   // (-DPNA_AMD_EXPERIMENTS -DFD_FINE_TIMERS) the same wait and barrier, timed apart: copy wait | barrier wait (the first step of a pass: the other wavefronts' gathers)
+      const unsigned long long w0 = now();
+      if constexpr (sp >= kAhead - 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"((kAhead - 2) * NI + young) : "memory");
+      const unsigned long long w1 = now();
+      asm volatile("s_barrier" ::: "memory");
+      const unsigned long long w2 = now();
+      tvm += w1 - w0;
+      if constexpr (sp == 0) tb0 += w2 - w1; else tbar += w2 - w1;
+    }
+#else
     if constexpr (sp >= kAhead - 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"((kAhead - 2) * NI + young) : "memory");
     else asm volatile("s_barrier" ::: "memory");
+#endif
     if constexpr (TOWER && c == PWAIT) {                  // (the wait above left only the two youngest images in flight)
       static_assert(NL == 4 || NL == 5, "tower shapes");
       asm volatile("" : "+v"(rp));
@@ -738,8 +752,8 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the copies issued for steps that do not exist
 #ifdef PNA_AMD_EXPERIMENTS
   if (g.dbg && lane == 0) {
-    unsigned long long* d = g.dbg + ((size_t)blockIdx.x * kWaves + wave) * 4;
-    d[0] = tg; d[1] = tm; d[2] = te; d[3] = now() - t00;
+    unsigned long long* d = g.dbg + ((size_t)blockIdx.x * kWaves + wave) * 8;
+    d[0] = tg; d[1] = tm; d[2] = te; d[3] = now() - t00; d[4] = tvm; d[5] = tb0; d[6] = tbar; d[7] = 0;
   }
 #endif
 }
@@ -924,7 +938,7 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
   g.agg_out = p->agg_out; g.ld_agg = p->ld_agg;
   g.xd = p->x_dst; g.xh = p->h_self; g.row_post = p->row_post; g.lddb = (unsigned)(p->ld_xdst * 4); g.ldhb = (unsigned)(p->ld_h * 4);
 #ifdef PNA_AMD_EXPERIMENTS
-  if (const char* e = getenv("PNA_FD_DBG_PTR")) g.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // device buffer: 4 counters per wavefront
+  if (const char* e = getenv("PNA_FD_DBG_PTR")) g.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // device buffer: 8 counters per wavefront
   if (const char* e = getenv("PNA_FD_ABL")) g.abl = atoi(e);
 #endif
   const int ntiles = (int)(p->M / 64);                     // in 64-row units: launch() halves the grid for 8-wavefront workgroups

@@ -551,6 +551,12 @@ def test_simple_layer_training_step_weight_gradient_kernels_match_the_library_ro
     g = Graph(src, dst, V).to(cuda_device)
     avg = {"log": float(torch.log(g.in_degrees().float() + 1).mean())}
     monkeypatch.setattr(AG, "DW_GROUPED", route == "degree plan order")
+    if route == "degree plan order":
+        # the grouped route is for graphs that HAVE a degree plan (or are large enough for the forward to build one, DG.MIN_ROWS): a
+        # per-batch graph of a few thousand nodes must not pay a plan inside every backward -- this one gets its plan here
+        from pna_amd import degree_groups as DG
+        assert g.__dict__.get("_pna_amd_degree_plan") is None and V < DG.MIN_ROWS
+        DG.plan_of(g)
     res = {}
     for kind in ("kernel", "kernel again", "library"):
         monkeypatch.setattr(AG, "DW_KERNEL", kind != "library")
@@ -602,13 +608,48 @@ def test_simple_layer_training_step_golden(cuda_device, name):
     torch.testing.assert_close(layer.batchnorm_h.running_mean.cpu(), a["running_mean_after"], rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(layer.batchnorm_h.running_var.cpu(), a["running_var_after"], rtol=1e-5, atol=1e-6)
     assert int(layer.batchnorm_h.num_batches_tracked) == int(sd["batchnorm_h.num_batches_tracked"]) + 1
-    scale = lambda t: max(1.0, t.abs().max().item())
-    assert (h.grad.cpu() - a["grad_h"]).abs().max().item() <= 1e-4 * scale(a["grad_h"])
-    wscale = scale(a["grad/posttrans.fully_connected.0.linear.weight"])
+    # ---- gradients: PER ELEMENT against the float64 evaluation of the reference's formulas (the forward tests'
+    # form).  tol = 1e-5 |ref64|  +  4 x the REFERENCE's own fp32 error on the element's row (its golden fp32 gradient against
+    # the float64 value: how ill-conditioned the entry is -- E[x^2] - E[x]^2 in fp32, sums that cancel)  +  2e-6 x the tensor's largest
+    # entry (the fp32 floor of a sum over all rows in another order).  Entries a ReLU FLIP can reach are excluded EXPLICITLY and counted:
+    # where the float64 BatchNorm output in front of the ReLU (:211) is within 1e-5 of zero its sign is decided by rounding, and a flip
+    # moves the whole weight-gradient row of that output column, the column's BatchNorm gradients and the input gradient of the
+    # node and its in-neighbours by O(R) -- there the reference's fp32 value is no more right than the product's.
+    from oracle import torch_oracle as O
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    _, gh64, gp64, _, _, z64 = O.simple_layer_train_step(sd64, a["src"], a["dst"], meta["N"], a["h"].double(), meta["aggregators"].split(),
+                                                         meta["scalers"].split(), a["avg_log"].double(), a["R"].double(), residual=meta["residual"],
+                                                         return_pre_relu=True)
+    risk = z64.abs() < 1e-5 * max(1.0, z64.abs().max().item())                     # (rows v, output columns n) a flip could happen at
+    risk_cols = risk.any(0)
+    risk_nodes = risk.any(1)
+    nb = torch.zeros(meta["N"], dtype=torch.bool)
+    nb[a["src"].long()[risk_nodes[a["dst"].long()]]] = True                        # in-neighbours of the nodes at risk (their features reach z)
+    risk_rows_h = risk_nodes | nb
+    n_risk = int(risk.sum())
+    assert n_risk <= max(2, 2e-4 * risk.numel()), f"{n_risk} pre-ReLU values within 1e-5 of zero: the fixture is degenerate"
+
+    def close(got, ref32, ref64, what, exclude_rows=None):
+        got, ref32 = got.double().cpu(), ref32.double()
+        ref_err = (ref32 - ref64).abs()
+        ref_err = ref_err.max(dim=1, keepdim=True).values if ref_err.dim() == 2 else ref_err
+        tol = 1e-5 * ref64.abs() + 4.0 * ref_err + 2e-6 * ref64.abs().max().clamp(min=1e-30)
+        bad = (got - ref64).abs() > tol
+        if exclude_rows is not None and bool(exclude_rows.any()):
+            bad[exclude_rows] = False
+            # (the excluded entries keep the old, loose bar: 1e-4 of the tensor's largest entry against the reference's fp32 value)
+            assert ((got - ref32).abs()[exclude_rows].max().item() <= 1e-4 * max(1.0, ref32.abs().max().item())), what
+        assert not bool(bad.any()), (what, int(bad.sum()), ((got - ref64).abs() / tol).max().item(), n_risk)
+    close(h.grad, a["grad_h"], gh64, "grad_h", risk_rows_h)
     for k, p in layer.named_parameters():
-        ref = a["grad/" + k]
-        # (the posttrans bias sits in front of the batch-statistics BatchNorm: its true gradient is 0, the reference stores rounding noise)
-        assert (p.grad.cpu() - ref).abs().max().item() <= 1e-4 * max(scale(ref), wscale if k.endswith("linear.bias") else 0.0), k
+        if k.endswith("posttrans.fully_connected.0.linear.bias"):
+            # (the bias sits in front of the batch-statistics BatchNorm: its true gradient is 0 -- float64 says ~1e-17 --, the reference
+            # stores fp32 rounding noise: bound by the noise level of the weight gradient's bar instead)
+            wmax = gp64["posttrans.fully_connected.0.linear.weight"].abs().max().item()
+            assert p.grad.abs().max().item() <= 1e-4 * wmax, k
+            continue
+        excl = risk_cols if p.dim() <= 2 and p.shape[0] == risk_cols.numel() else None
+        close(p.grad, a["grad/" + k], gp64[k], k, excl)
 
 
 @pytest.mark.gpu

@@ -472,17 +472,29 @@ def test_which_path_a_shape_takes_and_that_it_matches_the_oracle(cuda_device, F,
     finally:
         PF.run_fused_call, PF.degree_grouped_posttrans = keep
     assert (ran or ["ordinary"]) == [path], (F, N, ran)
-    # the north star's bar per element against the float64 evaluation of the reference's formulas: 1e-5 relative + the fp32 rounding
-    # floor of a K = 12 F sum in another order, 2e-6 x sum_k |w_k a_k| carried through BatchNorm's scale (bench.py's parity_check)
+    # the north star's bar per element (bench.py's parity_check): the oracle's fp32 aggregate (reduce_func in fp32, like the reference:
+    # a float64 std would part from BOTH at rows whose variance cancels, E[x^2] - E[x]^2), contracted in float64 -- 1e-5 relative + the
+    # fp32 rounding floor of a K = 12 F sum in another order, 2e-6 x sum_k |w_k a_k| carried through BatchNorm's scale
+    hc = h.cpu().contiguous()
+    agg = O.reduce_bucketed(hc[src], src, dst, V, ["mean", "max", "min", "std"], ["identity", "amplification", "attenuation"], torch.tensor(2.3)).double()
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
-    ref, agg = O.simple_layer_forward(sd64, src, dst, V, h.cpu().double().contiguous(), ["mean", "max", "min", "std"],
-                                      ["identity", "amplification", "attenuation"], torch.tensor(2.3, dtype=torch.float64), residual=(F == N),
-                                      return_aggregate=True)
     W, b = sd64["posttrans.fully_connected.0.linear.weight"], sd64["posttrans.fully_connected.0.linear.bias"]
     bn_scale = sd64["batchnorm_h.weight"] / torch.sqrt(sd64["batchnorm_h.running_var"] + 1e-5)
+    z = ((agg @ W.t() + b) - sd64["batchnorm_h.running_mean"]) * bn_scale + sd64["batchnorm_h.bias"]
+    ref = torch.relu(z) + (hc.double() if F == N else 0.0)
     mass = (agg.abs() @ W.abs().t() + b.abs()) * bn_scale.abs()
-    err, tol = (y.double() - ref).abs(), 1e-5 * ref.abs() + 2e-6 * mass
-    assert bool((err <= tol).all()), (F, N, path, (err / tol).max().item())
+    # ... plus the fp32 rounding of the epilogue's own operands (4 ulp of |BatchNorm shift| + |residual|: a column whose BatchNorm
+    # scale is tiny has next to no mass, its output is the shift -- rounded in fp32 like everything else)
+    shift = (sd64["batchnorm_h.bias"] - sd64["batchnorm_h.running_mean"] * bn_scale).abs()
+    eps_floor = 2.4e-7 * (shift + (hc.double().abs() if F == N else 0.0) + ref.abs())
+    err, tol = (y.double() - ref).abs(), 1e-5 * ref.abs() + 2e-6 * mass + eps_floor
+    if not bool((err <= tol).all()):
+        ratio = err / tol
+        r, c = divmod(int(ratio.argmax()), ratio.shape[1])
+        deg = torch.bincount(dst, minlength=V)
+        raise AssertionError(f"F={F} N={N} path={path}: worst err/tol {ratio.max().item():.3f} at row {r} (in-degree {int(deg[r])}) col {c}: got {y[r, c].item():.8g} "
+                             f"ref {ref[r, c].item():.8g} tol {tol[r, c].item():.3g}; rows over: {int((ratio > 1).any(1).sum())}, their in-degrees "
+                             f"{sorted(set(deg[(ratio > 1).any(1)].tolist()))[:12]}")
 
 
 def _lib_image_bytes(F, N):

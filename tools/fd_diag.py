@@ -83,20 +83,27 @@ with torch.no_grad():
     if "exp" in os.path.basename(_lib.LIB_PATH):
         props = torch.cuda.get_device_properties(0)
         nw = props.multi_processor_count * 2 * 4
-        dbg = torch.zeros(nw * 4, dtype=torch.int64, device=dev)
+        dbg = torch.zeros(nw * 8, dtype=torch.int64, device=dev)
         os.environ["PNA_FD_DBG_PTR"] = hex(dbg.data_ptr())
         call.group_rows()
         torch.cuda.synchronize()
         del os.environ["PNA_FD_DBG_PTR"]
-        d = dbg.view(nw, 4).double()
+        d = dbg.view(nw, 8).double()
         d = d[d[:, 3] > 0]
         out["phase_timers"] = {"wavefronts": int(d.shape[0]), "total_cycles_mean": d[:, 3].mean().item(), "gather_frac": (d[:, 0] / d[:, 3]).mean().item(),
                                "multiply_frac": (d[:, 1] / d[:, 3]).mean().item(), "epilogue_frac": (d[:, 2] / d[:, 3]).mean().item(),
-                               "total_cycles_min": d[:, 3].min().item(), "total_cycles_max": d[:, 3].max().item()}
+                               "total_cycles_min": d[:, 3].min().item(), "total_cycles_max": d[:, 3].max().item(),
+                               "inside_multiply": {"copy_wait_frac": (d[:, 4] / d[:, 3]).mean().item(),
+                                                   "first_barrier_of_a_pass_frac": (d[:, 5] / d[:, 3]).mean().item(),
+                                                   "other_barriers_frac": (d[:, 6] / d[:, 3]).mean().item()}}
         print("phase timers:", json.dumps(out["phase_timers"]), flush=True)
         for abl, what in [(0, "nothing skipped"), (1, "no MFMAs"), (16, "no B-fragment reads"), (17, "no MFMAs, no B-fragment reads"),
                           (19, "no MFMA / fragment maths / B reads"), (4, "no fold (loads still issued and waited for)"), (8, "no y stores"),
                           (64, "no s_setprio"), (23, "no MFMA / fragment maths / B reads / fold: loads, waits, barriers, weight copies, epilogue"),
+                          (128, "no weight copies (L2 -> LDS stream gone)"), (151, "no weight copies, no MFMA / fragment / B reads / fold"),
+                          (256, "every gather packet reads row 0 (no HBM gather traffic)"), (384, "no weight copies, gather from row 0"),
+                          (407, "no compute, no weight copies, gather from row 0: barriers, waits, descriptors, epilogue"),
+                          (415, "... and no y stores"),
                           (0, "nothing skipped (again)")]:
             os.environ["PNA_FD_ABL"] = str(abl)
             out[f"ablation_{abl}_ms"] = ev(call.group_rows, n=5, reps=2)
