@@ -74,6 +74,11 @@ def segreduce(rowptr: torch.Tensor, col: Optional[torch.Tensor], x: torch.Tensor
     a.n_tower, a.tower_stride_in, a.tower_stride_out = T, tsi, tso
     a.n_aggr = A
     for i, name in enumerate(aggregators):
+        if name in ("moment3", "moment4", "moment5"):
+            # the reference's DGL moment aggregators return a 0-dim tensor (models/dgl/aggregators.py:33: mean over the WHOLE mailbox), which
+            # its reduce_func cannot concatenate (pna_layer.py:48 raises there too): registry entries, not per-node aggregators of a layer
+            raise RuntimeError(f"zero-dimensional tensor cannot be concatenated: '{name}' of the DGL registry reduces the whole mailbox to one "
+                               f"number (models/dgl/aggregators.py:29-36) and cannot be a layer's aggregator -- the reference fails at the same place")
         a.aggr[i] = _lib.AGG_CODES[name]          # KeyError on unknown names, like the reference's dict lookup
     a.n_scaler = S
     for i, rs in enumerate(row_scales):
