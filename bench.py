@@ -631,20 +631,21 @@ def main():
                 # (the kernel as the step launches it: on a large graph it leaves DG.FUSED_SPARE_WGS workgroups out and the rest
                 # rows' launches run beside it on a second stream -- functional.run_fused_call; timed alone here, each on its own)
                 beside = plan.rest_overlap_applies(F)
-                call.args.spare_workgroups = DG.FUSED_SPARE_WGS if beside else 0
+                call.set_spare(beside)                    # (also binds the tile list balanced for THAT grid: DegreePlan.fused_balance)
                 t_fused = event_time_ms(call.group_rows, args.kernel_iters)
                 t_rest = event_time_ms(call.rest_rows, args.kernel_iters)
                 t_fused_full = t_fused
                 if beside:                                # ... and on the whole device (what the step launched before ABI 17)
-                    call.args.spare_workgroups = 0
+                    call.set_spare(False)
                     t_fused_full = event_time_ms(call.group_rows, args.kernel_iters)
-                    call.args.spare_workgroups = DG.FUSED_SPARE_WGS
+                    call.set_spare(True)
                 rows_g = grouped["rows_in_groups"]
                 deg_l = (csr.rowptr[1:] - csr.rowptr[:-1]).long()
                 e_g = int(deg_l[plan.perm[plan.perm >= 0].long()].sum().item())
                 fused = {"ms_group_rows_kernel": t_fused, "ms_rest_rows_two_kernel_path": t_rest, "rows": rows_g, "edges": e_g,
                          "padded_rows": plan.NV, "id_records": plan.fused_tables()[2],
                          "rest_rows_beside_kernel": bool(beside), "spare_workgroups": int(call.args.spare_workgroups),
+                         "tile_order": DG.FUSED_BALANCE if plan.fused_balance(PF._fused_grid(dev, int(call.args.spare_workgroups), plan.NV // 64)) is not None else "plan order",
                          "ms_group_rows_kernel_full_grid": t_fused_full}
         # N > 1: the exchange priced against the links it crosses.  Rank 0's received + sent halo bytes (whole rows of the resident
         # table, pitch ldx floats) over the standalone exchange time, beside ONE xGMI link's ~153 GB/s per direction: the all-to-all
@@ -718,6 +719,7 @@ def main():
                     "rest_rows_two_kernel_path_ms": fused["ms_rest_rows_two_kernel_path"],
                     "mfma_frac_executed_flops": 2.0 * plan.NV * (4 * F) * F / tf / (MFMA_BF16_PEAK / 6),
                     "rest_rows_beside_kernel": fused["rest_rows_beside_kernel"], "spare_workgroups": fused["spare_workgroups"],
+                    "tile_order": fused["tile_order"],
                     "full_grid": {"ms_per_launch": fused["ms_group_rows_kernel_full_grid"],
                                   "frac": fused_bytes / (fused["ms_group_rows_kernel_full_grid"] * 1e-3) / HBM_PEAK,
                                   "note": "the same kernel on every workgroup slot of the device (spare_workgroups = 0): its own ceiling; the step "

@@ -29,6 +29,7 @@ extern "C" {
 #define PNA_ABI_VERSION 20 /* 20: - pna_fused_roles_{supported,image_bytes,grid,f32} (ABI 19's one-kernel layer with gather / multiply wavefront
                                   roles: parity-green, 2.1-2.7x slower than pna_fused_degree_f32, never on a product path -- removed from the
                                   library in round 5; the source lives on as tools/ubench/fused_roles.hip, the result in DESIGN.md 4.9).
+                                  + pna_fused_degree_args.tile_counter (dynamic tile schedule), pna_fused_degree_tile_rows.
                                   The trailing fields added "inside 19" are part of 20's structs: a binding that knows them no longer
                                   passes the version check of a library that does not.  Every args struct carries struct_size first.
                               19: struct_size first in every args struct; + pna_posttrans_dw_f32 / pna_posttrans_dw_grouped_f32
@@ -574,6 +575,11 @@ typedef struct pna_fused_degree_args {
                              * persistent and books every register of a CU, so launches on another stream wait until it retires;
                              * with a few workgroups left out they run beside it (the caller's rest-row launches: DESIGN.md 4.8.9). */
   int32_t _pad4;
+  int32_t* tile_counter;  /* ABI 20, nullable: one device int32 the CALL owns while it runs (the library sets it on `stream` before the
+                           * launch).  Non-null: DYNAMIC tile schedule -- a workgroup's first four tiles are b, b + G, b + 2 G, b + 3 G
+                           * (G = the launch's grid), every later tile index is claimed from this counter, so a workgroup that falls
+                           * behind simply takes fewer tiles; tiles are started in tile_desc order device-wide.  Null: the static
+                           * schedule b, b + G, b + 2 G, ...  The results do not depend on it (bit-identical). */
 } pna_fused_degree_args;
 
 int64_t pna_fused_degree_image_bytes(int32_t F, int32_t N);   /* 0 = unsupported shape */

@@ -135,7 +135,7 @@ class PnaFusedDegreeArgs(_Args):
         ("y", ctypes.c_void_p), ("ldy", ctypes.c_int64), ("relu", ctypes.c_int32), ("act_slope", ctypes.c_float),
         ("agg_out", ctypes.c_void_p), ("ld_agg", ctypes.c_int64),
         ("x_dst", ctypes.c_void_p), ("ld_xdst", ctypes.c_int64), ("h_self", ctypes.c_void_p), ("ld_h", ctypes.c_int64), ("row_post", ctypes.c_void_p),
-        ("spare_workgroups", ctypes.c_int32), ("_pad4", ctypes.c_int32),
+        ("spare_workgroups", ctypes.c_int32), ("_pad4", ctypes.c_int32), ("tile_counter", ctypes.c_void_p),
     ]
 
 

@@ -59,6 +59,7 @@ struct FDArgs {
   float* agg_out; long ld_agg; // optional: the statistics as the contraction sees them, [mean | max | min | std] x F per virtual row
   const float* xd; const float* xh; const float* row_post;   // tower layers: the rows' own projections / features, the per-row factor
   unsigned lddb, ldhb;         // row pitch of xd / xh in bytes
+  int* counter;                // dynamic tile schedule (round 5): device int32, = 4 x grid at launch; nullptr: tile b, b + G, b + 2 G, ...
   unsigned long long* dbg;     // experiments build only: per-wavefront phase timers
   unsigned ldb;                // row pitch of x in bytes
   unsigned ldyb, ldrb;         // row pitch of y / residual in bytes (ldrb = 0 without a residual: every load reads y's first row)
@@ -261,6 +262,19 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
   sld16(td_cur, g.tdesc, desc_off(t));
   sld16(td_nxt, g.tdesc, desc_off(t + G));
   td_n2 = td_nxt;
+  // DYNAMIC TILE SCHEDULE (round 5, g.counter != nullptr).  Statically a workgroup walks tiles b, b + G, b + 2 G, ...; the phase timers
+  // show the slowest workgroup 9 % behind the mean even when the tile list is cost-balanced (the memory system does not serve every CU
+  // alike).  Dynamically the first FOUR tiles are the static ones and every later tile index comes from a device-wide counter (= 4 G at
+  // launch): wavefront 0 claims an index at the start of a multiply phase (one atomic, never waited for: it is older than every load
+  // the next gather waits on), hands it to the workgroup through one of two LDS words in that gather's drain, and everybody reads the
+  // word behind the next multiply phase's barriers -- a claim is used four tiles after it was made, which is what the descriptor
+  // prefetch (two tiles ahead) and the id prefetch (the previous tile's last packets) need.  Indices grow monotonically, so tiles
+  // are still STARTED in list order device-wide: the list's degree order is the time order, one weight image live per L2.
+  const bool dyn = g.counter != nullptr;
+  int t_n1 = t + G, t_n2 = t + 2 * G;                     // the workgroup's next tile and the one after
+  int claimed = t + 3 * G;                                // (wavefront 0, lane 0) the index claimed last: the tile after t_n2
+  int par = 0;                                            // which LDS word the current tile's hand-over uses
+  const unsigned slot_b = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(kNBuf * CHV * 16) + (unsigned)(3 * NWA * 4);
   const unsigned lib = (unsigned)li * 4u;
   int idr[kRing];
   int pr = -1;                                            // the node (row of y / residual) of tile row li (-1: padding)
@@ -361,7 +375,7 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
     // the packets of edges 0..3; each refills its id with the next group's, or -- after the last group -- the NEXT tile's edge j
     const unsigned n0 = 1 < ng ? rb + 4u * 64u : rbn;
     issue(J0{}, n0); issue(J1{}, n0); issue(J2{}, n0); issue(J3{}, n0);
-    if constexpr (P == 0) sld16(td_n2, g.tdesc, desc_off(t + 2 * G));   // (the descriptor after next: its latency sits behind the packets just issued)
+    if constexpr (P == 0) sld16(td_n2, g.tdesc, desc_off(t_n2));        // (the descriptor after next: its latency sits behind the packets just issued)
     // steady state: slot j holds edge 4 gi + j; behind it in flight: the three younger packets.  Every edge here is a real one.
     for (int gi = 0; gi + 1 < ng; ++gi) {
       const unsigned nr = gi + 2 < ng ? rb + (unsigned)(4 * gi + 8) * 64u : rbn;
@@ -387,6 +401,14 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
     wait_slot<2 * LB + NR, NL>(sl[1], idr[1]); fold(J1{}, e0 + 1 < D);
     wait_slot<1 * LB + NR, NL>(sl[2], idr[2]); fold(J2{}, e0 + 2 < D);
     wait_slot<NR, NL>(sl[3], idr[3]);          fold(J3{}, e0 + 3 < D);
+    if constexpr (P == 0) {
+      if (dyn && wave == 0) {                             // the claim made a multiply phase ago has landed (older than every load waited for above)
+        asm volatile("" : "+v"(claimed));
+        if (__builtin_amdgcn_readfirstlane(claimed) < 0)  // (belt and braces: the register was set to -1 when the claim was issued;
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(claimed) : : "memory");       //  never seen -- returns are in order)
+        if (lane == 0) asm volatile("ds_write_b32 %0, %1" : : "v"(slot_b + (unsigned)par * 4u), "v"(claimed) : "memory");
+      }
+    }
     // FAST tiles (round 4): every sum of squares of the lane's features finite (then every message was: the terms are >= 0) and
     // in-edges present -- all but pathological inputs.  Their statistics are finished without the special-value selects (frag()).
     {
@@ -721,6 +743,10 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
     // wavefront mostly waits for memory and its fold hides behind that (skipping the fold entirely changes nothing).  Measured in
     // the experiments build on the C3 layer: 0.873 -> 0.790 ms.
     if (!FD_ABL(6)) __builtin_amdgcn_s_setprio(1);
+    if (dyn && wave == 0 && lane == 0) {                  // claim the tile three after the next one (result harvested in the next gather's drain)
+      const int one = 1;
+      asm volatile("v_mov_b32 %0, -1\n\ts_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=&v"(claimed) : "v"(0u), "v"(one), "s"(g.counter) : "memory");
+    }
     pass_steps(std::integral_constant<int, 0>{});
     if constexpr (GP == 2) {                              // the second half of the features: gather again, multiply on
       if (!FD_ABL(6)) __builtin_amdgcn_s_setprio(0);
@@ -740,7 +766,16 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
     if (!FD_ABL(6)) __builtin_amdgcn_s_setprio(0);
     const unsigned long long t2 = now();
     tm += t1 - t0; te += t2 - t1;
-    t += G;
+    {
+      int t_n3 = t_n2 + G;
+      if (dyn) {                                          // the word wavefront 0 wrote in this tile's first gather: read behind the multiply phase's barriers
+        int v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(slot_b + (unsigned)par * 4u) : "memory");
+        t_n3 = __builtin_amdgcn_readfirstlane(v);
+        par ^= 1;
+      }
+      t = t_n1; t_n1 = t_n2; t_n2 = t_n3;
+    }
     if (t >= ntiles) break;                               // (wave-uniform)
     td_cur = td_nxt; td_nxt = td_n2;
     ib_cur = ib_next;
@@ -810,10 +845,11 @@ template <int NFBF, bool HALF, bool DUMP, bool TOWER = false, int GP = 1, int NP
 int launch(const FDArgs& g, int wgs, hipStream_t st) {
   constexpr int NWP = NPAN == 1 ? kNW : 64;
   constexpr int NBUF = buffers_for(GP, NPAN), WAVES = waves_for(GP, NPAN);
-  const size_t lds = (size_t)NBUF * (3 * 4 * NWP) * 16 + (size_t)(3 * NWP * NPAN) * sizeof(float);
+  const size_t lds = (size_t)NBUF * (3 * 4 * NWP) * 16 + (size_t)(3 * NWP * NPAN) * sizeof(float) + 16;    // (+ the two hand-over words of the dynamic schedule)
   auto* fn = k_fused_degree<NFBF, HALF, DUMP, TOWER, !DUMP && !TOWER, GP, NPAN, WAVES, NBUF>;
   if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
   if (WAVES == 8) wgs = (wgs + 1) / 2;                    // (the caller counts 4-wavefront workgroups, two per CU)
+  if (g.counter && hipMemsetD32Async((hipDeviceptr_t)g.counter, 4 * wgs, 1, st) != hipSuccess) return -3;
   hipLaunchKernelGGL(fn, dim3((unsigned)wgs), dim3(64 * WAVES), lds, st, g);
   return 0;
 }
@@ -937,6 +973,7 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
   g.M = (int)p->M; g.N = p->N; g.relu = p->relu; g.slope = p->relu == 2 ? p->act_slope : 0.f;
   g.agg_out = p->agg_out; g.ld_agg = p->ld_agg;
   g.xd = p->x_dst; g.xh = p->h_self; g.row_post = p->row_post; g.lddb = (unsigned)(p->ld_xdst * 4); g.ldhb = (unsigned)(p->ld_h * 4);
+  g.counter = p->tile_counter;
 #ifdef PNA_AMD_EXPERIMENTS
   if (const char* e = getenv("PNA_FD_DBG_PTR")) g.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // device buffer: 8 counters per wavefront
   if (const char* e = getenv("PNA_FD_ABL")) g.abl = atoi(e);
@@ -952,7 +989,7 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
   if (ntiles < wgs) wgs = ntiles;
   hipStream_t st = (hipStream_t)stream;
   const int rc = p->agg_out ? launch_shape<true>(g, wgs, st) : launch_shape<false>(g, wgs, st);
-  if (rc != 0) return pna_set_error(PNA_E_LAUNCH, rc == -2 ? "pna_fused_degree_f32: no instantiation for this F" : "pna_fused_degree_f32: hipFuncSetAttribute failed");
+  if (rc != 0) return pna_set_error(PNA_E_LAUNCH, rc == -2 ? "pna_fused_degree_f32: no instantiation for this F" : rc == -3 ? "pna_fused_degree_f32: hipMemsetD32Async of tile_counter failed" : "pna_fused_degree_f32: hipFuncSetAttribute failed");
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
   return PNA_OK;

@@ -167,6 +167,67 @@ class DegreePlan:
             self._fused = (desc, ids, total)
         return self._fused
 
+    def fused_balance(self, G):
+        """(tile_desc, row_perm, src) of pna_fused_degree_f32 for a grid of G workgroups with its 64-row tiles LOAD-BALANCED (round 5), or
+        None when the balance is off / does not apply.  The persistent kernel gives workgroup w the tiles at positions w, w + G, w + 2 G, ..;
+        the plan lists tiles in ascending degree, and the number of tiles is not a multiple of G: the LAST round is partial and holds
+        the most expensive tiles (hub-side degrees: 6-10x a mean tile), handed to the first nt % G workgroups on top of a full share --
+        on the benchmark graph the slowest workgroup carries 7.5 % more than the mean (phase timers: 1.88 M cycles against 1.72 M).
+        Here (FUSED_BALANCE = "lpt"): the partial round holds the nt % G CHEAPEST tiles instead, and inside every full round the tiles are
+        dealt longest-first to the workgroups with the least accumulated cost, rounds processed from the heaviest down -- each workgroup
+        still gets one tile per round in ascending degree over time, so the device stays degree-synchronous (one weight image live per
+        L2: the id-major order of tools/tile_order_exp.py lost exactly that).  The SAME tiles in another order: no row changes its
+        16-row block, the statistics and outputs are bit-identical.  cost(tile) = in-degree + FUSED_TILE_COST (the multiply / epilogue /
+        control share in edge units).  One host round trip per (plan, G)."""
+        if FUSED_BALANCE not in ("lpt", "cheap_last", "dynamic") or self.NV == 0:
+            return None
+        tabs = self.fused_tables()
+        if tabs is False:
+            return None
+        key = (int(G), FUSED_BALANCE, float(FUSED_TILE_COST), int(FUSED_DYNAMIC_TAIL))
+        hit = self.__dict__.setdefault("_fused_bal", {}).get(key)
+        if hit is not None:
+            return hit
+        import numpy as np
+        desc = tabs[0]
+        nt = self.NV // 64
+        G = int(G)
+        D = desc.view(nt, 4, 4)[:, :, 1].max(dim=1).values.cpu().numpy().astype(np.float64)     # (a tile's blocks: one degree, or 0 = padding)
+        cost = D + float(FUSED_TILE_COST)
+        rem, n_full = nt % G, nt // G
+        seq = np.arange(nt)
+        if FUSED_BALANCE == "dynamic":
+            # the list the DYNAMIC schedule walks (pna_fused_degree_args.tile_counter: every workgroup claims its next tile when it
+            # is ready for one): the G most expensive tiles FIRST, one per workgroup while everybody starts anyway (longest first:
+            # none of them can become the tail), then ascending degree (the device stays degree-synchronous), and the G cheapest
+            # tiles LAST -- whoever is still running at the end runs a tile of a few microseconds.  FUSED_DYNAMIC_TAIL x G of them,
+            # cheapest last: a workgroup holds claims four tiles ahead, so the tail it can be left with is its last four tiles
+            tail = int(FUSED_DYNAMIC_TAIL) * G
+            if nt > 2 * (G + tail):
+                order = np.argsort(cost, kind="stable")                                       # ascending cost (= plan order up to padding tiles)
+                seq = np.concatenate([order[nt - G:][::-1], order[tail:nt - G], order[:tail][::-1]])
+            src = seq.copy()
+        elif rem:
+            seq = np.concatenate([np.arange(rem, nt), np.arange(rem)])                       # the partial round: the cheapest tiles
+        src = seq.copy()
+        if FUSED_BALANCE == "lpt" and n_full > 0 and G > 1:
+            load = np.zeros(G)
+            if rem:
+                load[:rem] += cost[seq[n_full * G:]]
+            for r in range(n_full - 1, -1, -1):
+                tiles = seq[r * G:(r + 1) * G]
+                tiles = tiles[np.argsort(-cost[tiles], kind="stable")]
+                wgs = np.argsort(load, kind="stable")
+                src[r * G + wgs] = tiles
+                load[wgs] += cost[tiles]
+        src_t = torch.from_numpy(src).to(desc.device)
+        out = (desc.view(nt, 4, 4)[src_t].reshape(-1, 4).contiguous(), self.perm.view(nt, 64)[src_t].reshape(-1).contiguous(), src_t)
+        cache = self.__dict__["_fused_bal"]
+        if len(cache) >= 4:
+            cache.clear()
+        cache[key] = out
+        return out
+
     def dw_tables(self, n_wgs):
         """Tables of pna_posttrans_dw_grouped_f32 (the weight gradient over the group rows in plan order), once per plan and grid:
         (tile_group [nt], wg_range [n_wgs][2] -- equally long contiguous tile ranges --, wg_entry [n_wgs], entry_group [n_entries]):
@@ -402,6 +463,11 @@ def fused_images(weight, F, row_scales, plan, tower=False):
     return img, stride
 
 
+# Load balance of the one-kernel layer (DegreePlan.fused_balance): "dynamic" (tiles claimed from a device counter, heaviest first / cheapest
+# last) | "lpt" | "cheap_last" (static schedules over a cost-balanced list) | "off" (the plan's ascending order, static)
+FUSED_BALANCE = os.environ.get("PNA_AMD_FUSED_BALANCE", "dynamic")
+FUSED_DYNAMIC_TAIL = int(os.environ.get("PNA_AMD_FUSED_DYNAMIC_TAIL", "4"))   # "dynamic": this many x G of the cheapest tiles end the list
+FUSED_TILE_COST = float(os.environ.get("PNA_AMD_FUSED_TILE_COST", "10"))   # a tile's constant cost in edge units (multiply + epilogue + control)
 REST_SEG_LEN = 128         # edges per hub-row segment in the rest launch of the one-kernel layer (see DegreePlan.rest_items)
 REST_ROWS_PER_GROUP = 1    # work items per lane group in that launch (the full-graph gather: 4): a few thousand items must spread over 256 CUs
 TOWERS = True              # the tower layers (PNALayer) through the degree-grouped contraction with collapsed posttrans / mixing weights

@@ -618,6 +618,50 @@ def run_fused_call(call):
     return call.y
 
 
+def _fused_grid(device, spare, n_tiles64):
+    """Workgroups pna_fused_degree_f32 launches for the 4-wavefront shapes (pna_fused_degree.hip: two per CU, less the spare ones, never
+    below one per CU, never more than tiles)."""
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    wgs = 2 * cus
+    if spare > 0:
+        wgs = wgs - spare if wgs - spare > cus else cus
+    return max(1, min(wgs, n_tiles64))
+
+
+def _bind_tile_order(call, spare):
+    """Point the call's argument block at the plan's tile list for the grid `spare` gives: the load-balanced order
+    (DegreePlan.fused_balance) for the production instantiations of the 64-row-tile shapes, the plan's own order otherwise (the
+    verification instantiation writes agg_out in plan order; the 8-wavefront build of the wide shapes has 128-row tiles)."""
+    from . import _lib
+    plan, a = call.plan, call.args
+    a.spare_workgroups = int(spare)
+    bal = None
+    if not a.agg_out and plan.NV and _lib.lib().pna_fused_degree_tile_rows(a.F, a.N) == 64:
+        bal = plan.fused_balance(_fused_grid(call.y.device, int(spare), plan.NV // 64))
+    if bal is None:
+        desc, perm, post = plan.fused_tables()[0], plan.perm, getattr(call, "post_g", None)
+    else:
+        desc, perm, src = bal
+        post = getattr(call, "post_g", None)
+        if post is not None and post is not plan.ones_rows():
+            key = ("post", src.data_ptr())
+            hit = call.__dict__.setdefault("_post_b", {}).get(key)
+            if hit is None:
+                hit = call._post_b[key] = post.view(plan.NV // 64, 64)[src].reshape(-1).contiguous()
+            post = hit
+    from . import degree_groups as DG
+    counter = None
+    if bal is not None and DG.FUSED_BALANCE == "dynamic":
+        counter = call.__dict__.get("_tile_counter")
+        if counter is None:
+            counter = call._tile_counter = torch.zeros(1, dtype=torch.int32, device=call.y.device)
+    a.tile_counter = None if counter is None else _lib.dev_ptr(counter, torch.int32, "tile_counter")
+    call._order_keep = (desc, perm, post, counter)
+    a.tile_desc, a.row_perm = _lib.dev_ptr(desc, torch.int32, "tile_desc"), _lib.dev_ptr(perm, torch.int32, "row_perm")
+    if post is not None and a.row_post:
+        a.row_post = _lib.dev_ptr(post, torch.float32, "row_post")
+
+
 class FusedTowerCall:
     """One PNALayer forward (one tower, or T towers with divide_input=True; eval) on the one-kernel path after the node-level projection, cut into its launches like
     FusedDegreeCall: `group_rows()` = pna_fused_degree_f32 in tower mode, `rest_rows()` = gather with the destination term + the
@@ -663,13 +707,14 @@ class FusedTowerCall:
         a.y, a.ldy, a.relu, a.act_slope = _lib.dev_ptr(y, torch.float32, "y"), y.stride(0), 2, self.slope
         self.args, self.ref = a, ctypes.byref(a)
         self.fn, self.check, self.stream = _lib.lib().pna_fused_degree_f32, _lib.check, _lib.stream_ptr(dev)
+        _bind_tile_order(self, 0)
 
     def layer_F(self):
         return self.args.F
 
     def set_spare(self, on):
         from . import degree_groups as DG
-        self.args.spare_workgroups = DG.FUSED_SPARE_WGS if on else 0
+        _bind_tile_order(self, DG.FUSED_SPARE_WGS if on else 0)
 
     def group_rows(self):
         self.check(self.fn(self.ref, self.stream), "pna_fused_degree_f32")
@@ -738,13 +783,14 @@ class FusedDegreeCall:
             a.agg_out, a.ld_agg = _lib.dev_ptr(agg_out, torch.float32, "agg_out"), agg_out.stride(0)
         self.args, self.ref = a, ctypes.byref(a)
         self.fn, self.check, self.stream = _lib.lib().pna_fused_degree_f32, _lib.check, _lib.stream_ptr(h.device)
+        _bind_tile_order(self, 0)
 
     def layer_F(self):
         return self.layer.in_dim
 
     def set_spare(self, on):
         from . import degree_groups as DG
-        self.args.spare_workgroups = DG.FUSED_SPARE_WGS if on else 0
+        _bind_tile_order(self, DG.FUSED_SPARE_WGS if on else 0)
 
     def group_rows(self):
         self.check(self.fn(self.ref, self.stream), "pna_fused_degree_f32")

@@ -195,3 +195,46 @@ def test_weight_gradient_tables_of_the_plan(graph_and_plan):
         assert walked == entry_group.tolist()
     node_of = plan.node_of_rows()
     assert node_of.numel() == plan.rows and torch.equal(plan.vmap32()[node_of[node_of >= 0].long()].long(), torch.nonzero(node_of >= 0).flatten())
+
+
+def test_fused_balance_is_a_permutation_of_tiles_round_by_round(graph_and_plan):
+    """Round 5: the one-kernel layer's LOAD-BALANCED tile lists (DegreePlan.fused_balance).  Always the same 64-row tiles in another order
+    (every 16-row descriptor and its rows move together).  "lpt" (static schedule): the partial last round holds the cheapest tiles, every
+    full round holds exactly the tiles the ascending order put there (the device stays degree-synchronous), the heaviest workgroup comes
+    closer to the mean.  "dynamic" (tiles claimed from a counter): the G most expensive tiles first, longest first, the G cheapest last,
+    ascending cost in between."""
+    g, plan = graph_and_plan
+    desc, ids, n_rec = plan.fused_tables()
+    nt = plan.NV // 64
+    cost = desc.view(nt, 4, 4)[:, :, 1].max(dim=1).values.double() + DG.FUSED_TILE_COST
+    keep = DG.FUSED_BALANCE
+    try:
+        for mode in ("lpt", "dynamic"):
+            DG.FUSED_BALANCE = mode
+            for G in (8, 24, 40):
+                d2, p2, src = plan.fused_balance(G)
+                assert torch.equal(torch.sort(src).values, torch.arange(nt))
+                assert torch.equal(d2.view(nt, 4, 4), desc.view(nt, 4, 4)[src]) and torch.equal(p2.view(nt, 64), plan.perm.view(nt, 64)[src])
+                assert plan.fused_balance(G)[2] is src                                           # cached per (grid, mode)
+                if mode == "lpt":
+                    rem, n_full = nt % G, nt // G
+                    if rem:
+                        assert torch.equal(torch.sort(src[n_full * G:]).values, torch.arange(rem))    # the partial round: tiles 0 .. rem - 1 (cheapest)
+                    for r in range(n_full):
+                        assert torch.equal(torch.sort(src[r * G:(r + 1) * G]).values, torch.arange(rem + r * G, rem + (r + 1) * G))
+                    wg = torch.arange(nt) % G
+                    before = torch.zeros(G, dtype=torch.double).index_add_(0, wg, cost)
+                    after = torch.zeros(G, dtype=torch.double).index_add_(0, wg, cost[src])
+                    assert after.max() <= before.max() + 1e-9 and abs(after.sum() - before.sum()) < 1e-6
+                else:
+                    tail = DG.FUSED_DYNAMIC_TAIL * G
+                    assert nt > 2 * (G + tail)
+                    c = cost[src]
+                    assert bool((c[:G - 1] >= c[1:G]).all()) and c[:G].min() >= c[G:].max() - 1e-9          # the G heaviest, longest first
+                    assert c[nt - tail:].max() <= c[:nt - tail].min() + 1e-9                                # the cheapest tiles last ...
+                    assert bool((c[nt - tail:-1] >= c[nt - tail + 1:]).all())                               # ... the very cheapest at the very end
+                    assert bool((c[G:nt - tail - 1] <= c[G + 1:nt - tail]).all())                           # ascending in between
+        DG.FUSED_BALANCE = "off"
+        assert plan.fused_balance(8) is None
+    finally:
+        DG.FUSED_BALANCE = keep

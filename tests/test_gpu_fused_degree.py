@@ -500,3 +500,49 @@ def test_which_path_a_shape_takes_and_that_it_matches_the_oracle(cuda_device, F,
 def _lib_image_bytes(F, N):
     from pna_amd import _lib
     return _lib.lib().pna_fused_degree_image_bytes(F, N)
+
+
+@pytest.mark.parametrize("F,N", [(75, 75), (128, 128), (40, 72)])
+def test_balanced_tile_order_gives_the_same_bits(cuda_device, F, N):
+    """Round 5: the load-balanced tile list (DegreePlan.fused_balance: the same tiles dealt to the persistent workgroups in another
+    order) against the plan's own order -- identical output BITS, simple layer and (F = 75) the one-tower layer with graph norm (its
+    per-row factor travels with the rows)."""
+    from pna_amd import Graph, degree_groups as DG, functional as PF
+    from pna_amd.synth import powerlaw_graph
+    V, E = 140_000, 1_200_000
+    src, dst = powerlaw_graph(V, E, seed=11, device=cuda_device)
+    layer = _layer(F, N, cuda_device, residual=(F == N), seed=3)
+    h = _features(V, F, cuda_device, seed=2)
+    outs = {}
+    keep = DG.FUSED_BALANCE
+    try:
+        for mode in ("off", "lpt", "cheap_last", "dynamic"):
+            DG.FUSED_BALANCE = mode
+            g = Graph(src, dst, V)                               # (a fresh plan per mode)
+            with torch.no_grad(), _Knobs(fused=True, small_graphs=True):
+                assert DG.fused_applies(g, h, F, N)
+                call = PF.FusedDegreeCall(layer, g, h, x=h)
+                assert (DG.plan_of(g).fused_balance(PF._fused_grid(cuda_device, 0, DG.plan_of(g).NV // 64)) is not None) == (mode != "off")
+                assert bool(call.args.tile_counter) == (mode == "dynamic")
+                outs[mode] = PF.run_fused_call(call).clone()
+                for _ in range(3):                               # (the counter is re-armed by every launch)
+                    assert torch.equal(PF.run_fused_call(call), outs[mode])
+            if F == 75:
+                from pna_amd.dgl.pna_layer import PNALayer
+                torch.manual_seed(5)
+                tl = PNALayer(F, F, "mean max min std", "identity amplification attenuation", {"log": torch.tensor(2.3)}, 0.0, True, True, towers=1,
+                              divide_input=False, residual=True).to(cuda_device).eval()
+                sn = torch.rand(V, 1, device=cuda_device) + 0.5
+                with torch.no_grad(), _Knobs(fused=True, small_graphs=True):
+                    keep_t, PF.SMALL_TOWER_ROWS = PF.SMALL_TOWER_ROWS, 0
+                    try:
+                        assert PF.tower_layer_degree_fused_applies(tl, g, h)
+                        outs["tower " + mode] = tl(g, h, None, sn).clone()
+                    finally:
+                        PF.SMALL_TOWER_ROWS = keep_t
+    finally:
+        DG.FUSED_BALANCE = keep
+    assert torch.equal(outs["off"], outs["lpt"]) and torch.equal(outs["off"], outs["cheap_last"]) and torch.equal(outs["off"], outs["dynamic"])
+    if F == 75:
+        assert torch.equal(outs["tower off"], outs["tower lpt"]) and torch.equal(outs["tower off"], outs["tower cheap_last"])
+        assert torch.equal(outs["tower off"], outs["tower dynamic"])

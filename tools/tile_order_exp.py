@@ -9,7 +9,10 @@ in-edges come from v-1 / v+1, pna_amd/synth.py:33-36) -- sit in different degree
 This tool re-orders the SAME tiles (no row changes tile: the kernel's statistics are bit-identical by construction, checked) and
 times the kernel / runs it under rocprofv3 --pmc:
 
-  ORDER=ascending        the shipped order
+  ORDER=ascending        the plan's order, static schedule (rounds 3-4)
+  ORDER=dynamic          the round-5 product path: tiles claimed from a device counter, list = heaviest first / ascending / cheapest last
+  ORDER=dynamic_plan_order   the counter on the plan's ascending list (heaviest tiles claimed last)
+  ORDER=lpt | cheap_last     static schedules over cost-balanced lists (balanced_order below)
   ORDER=idmajor          tiles sorted by the median row id of their rows; consecutive COHORTS of G/8 tiles go to one XCD and one
                          round of its workgroups (position = round * G + 8 * slot + xcd), tiles inside a cohort are dealt to the
                          XCD's workgroups longest-first against their accumulated cost (static LPT: every workgroup's total stays level)
@@ -49,6 +52,8 @@ def tile_order(plan, order, G, tile_cost=10.0):
     med = torch.where(live.any(1), med, torch.zeros_like(med))
     if order == "ascending":
         return torch.arange(nt, device=dev)
+    if order in ("cheap_last", "lpt", "lpt_only"):
+        return balanced_order(D.cpu().tolist(), G, order, tile_cost).to(dev)
     band = torch.zeros(nt, dtype=torch.long, device=dev)
     if order.startswith("band"):
         k = int(order[4:])
@@ -86,6 +91,40 @@ def tile_order(plan, order, G, tile_cost=10.0):
     return torch.tensor(src, dtype=torch.long, device=dev)
 
 
+def balanced_order(D, G, order, tile_cost):
+    """LOAD BALANCE of the persistent kernel (workgroup w takes positions w, w + G, w + 2 G, ...; tiles arrive in ascending degree):
+    nt is not a multiple of G, so the LAST round is partial -- and in ascending order it holds the most expensive tiles (hub-side degrees:
+    6-10x a mean tile), handed to the first nt % G workgroups ON TOP of a full share.
+      cheap_last: the partial round holds the nt % G CHEAPEST tiles instead (order = tiles [rem, nt) ascending, then tiles [0, rem));
+      lpt:        cheap_last + inside every full round the tiles are dealt longest-first to the workgroups with the least accumulated cost,
+                  rounds processed from the heaviest down (static LPT by rounds: each workgroup still gets one tile per round, in ascending
+                  degree over time -- the device stays degree-synchronous, one weight image live per L2);
+      lpt_only:   LPT by rounds on the shipped order (partial round last, heaviest).
+    cost of a tile = its in-degree + tile_cost (the multiply / epilogue / control share, in edge units)."""
+    nt = len(D)
+    cost = [d + tile_cost for d in D]
+    rem = nt % G
+    seq = list(range(nt))
+    if order in ("cheap_last", "lpt") and rem:
+        seq = list(range(rem, nt)) + list(range(rem))
+    if order == "cheap_last":
+        return torch.tensor(seq, dtype=torch.long)
+    n_full = nt // G
+    src = list(seq)
+    load = [0.0] * G
+    if rem:                                                  # the partial round's tiles sit at positions n_full * G + w, w < rem
+        for w in range(rem):
+            load[w] += cost[seq[n_full * G + w]]
+    for r in range(n_full - 1, -1, -1):
+        tiles = sorted(seq[r * G:(r + 1) * G], key=lambda t: -cost[t])
+        wgs = sorted(range(G), key=lambda w: load[w])
+        for t, w in zip(tiles, wgs):
+            src[r * G + w] = t
+            load[w] += cost[t]
+    print(f"[balanced_order] {order}: workgroup cost min {min(load):.0f} mean {sum(load) / G:.0f} max {max(load):.0f}", flush=True)
+    return torch.tensor(src, dtype=torch.long)
+
+
 def permuted_tables(plan, src):
     desc, ids, n_rec = plan.fused_tables()
     nt = plan.NV // 64
@@ -112,11 +151,16 @@ def main():
         call.set_spare(True)
         G = props.multi_processor_count * 2 - int(call.args.spare_workgroups)
         y0 = call.group_rows().clone()
-        src = tile_order(plan, order, G)
-        d2, ids, n_rec, perm2 = permuted_tables(plan, src)
-        call.keep = call.keep + (d2, perm2)
-        call.args.tile_desc = _lib.dev_ptr(d2, torch.int32, "tile_desc")
-        call.args.row_perm = _lib.dev_ptr(perm2, torch.int32, "row_perm")
+        if order == "dynamic":
+            pass                                             # the product path as bound: DegreePlan.fused_balance("dynamic") + tile_counter
+        else:
+            dyn_counter = call.args.tile_counter
+            src = tile_order(plan, "ascending" if order == "dynamic_plan_order" else order, G)
+            d2, ids, n_rec, perm2 = permuted_tables(plan, src)
+            call.keep = call.keep + (d2, perm2)
+            call.args.tile_desc = _lib.dev_ptr(d2, torch.int32, "tile_desc")
+            call.args.row_perm = _lib.dev_ptr(perm2, torch.int32, "row_perm")
+            call.args.tile_counter = dyn_counter if order == "dynamic_plan_order" else None     # static schedule for the list orders
         y_buf = torch.zeros(V, int(call.args.ldy), device=dev)          # (the SAME row pitch as the call's own y: ldy stays as bound)
         call.y = y_buf[:, :F]
         call.args.y = _lib.dev_ptr(call.y, torch.float32, "y")
