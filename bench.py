@@ -352,14 +352,16 @@ def main():
     if world == 1 and hasattr(layer, "_degree_grouped_path"):
         from pna_amd import degree_groups as _DGs
         with torch.no_grad():
+            torch.cuda.synchronize()
+            t_s = time.perf_counter()                         # (the path check below is what builds the plan: inside the clock)
             if layer._degree_grouped_path(g, h) and _DGs.fused_applies(g, h, F, F):
                 from pna_amd.dgl.pna_layer import _row_scales
-                torch.cuda.synchronize()
-                t_s = time.perf_counter()
                 plan_s = _DGs.plan_of(g)
                 tabs = plan_s.fused_tables()
                 if plan_s.NR:
                     plan_s.rest_items(g)
+                for sp in (0, _DGs.FUSED_SPARE_WGS):            # the tile lists of the two grids the step and the diagnostics launch
+                    plan_s.fused_balance(PF._fused_grid(dev, sp, plan_s.NV // 64))
                 torch.cuda.synchronize()
                 t_plan = (time.perf_counter() - t_s) * 1e3
                 t_s = time.perf_counter()
@@ -371,7 +373,8 @@ def main():
                 setup = {"degree_plan_build_ms": t_plan, "weight_image_pack_ms": t_img, "csr_build_ms": csr_build_ms,
                          "plan_device_bytes": {"row_perm": nbytes(plan_s.perm) + nbytes(plan_s.perm_rest), "tile_desc": nbytes(tabs[0]),
                                                "tile_ids": nbytes(tabs[1]), "rest_work_list": nbytes(rest[0]) + nbytes(rest[1]),
-                                               "node_to_plan_row": nbytes(plan_s._vmap), "two_kernel_work_list": nbytes(plan_s.items)},
+                                               "node_to_plan_row": nbytes(plan_s._vmap), "two_kernel_work_list": nbytes(plan_s.items),
+                                               "balanced_tile_lists": sum(nbytes(x) for v_ in plan_s.__dict__.get("_fused_bal", {}).values() for x in v_)},
                          "weight_images_bytes": nbytes(img_s), "degree_groups": plan_s.G,
                          "note": "host wall-clock around the first build, device idle before and synchronised after; once per graph (plan) / "
                                  "once per (weights, graph) (images), amortised over layers, steps and epochs; a one-shot forward on a fresh "
