@@ -575,11 +575,13 @@ typedef struct pna_fused_degree_args {
                              * persistent and books every register of a CU, so launches on another stream wait until it retires;
                              * with a few workgroups left out they run beside it (the caller's rest-row launches: DESIGN.md 4.8.9). */
   int32_t _pad4;
-  int32_t* tile_counter;  /* ABI 20, nullable: one device int32 the CALL owns while it runs (the library sets it on `stream` before the
-                           * launch).  Non-null: DYNAMIC tile schedule -- a workgroup's first four tiles are b, b + G, b + 2 G, b + 3 G
-                           * (G = the launch's grid), every later tile index is claimed from this counter, so a workgroup that falls
-                           * behind simply takes fewer tiles; tiles are started in tile_desc order device-wide.  Null: the static
-                           * schedule b, b + G, b + 2 G, ...  The results do not depend on it (bit-identical). */
+  int32_t* tile_counter;  /* ABI 20, nullable: TWO device int32 the call owns while it runs, ZERO before the first launch (the kernel
+                           * leaves them zero: the last workgroup to finish resets them, so back-to-back launches on one stream need
+                           * nothing in between).  Non-null: DYNAMIC tile schedule -- a workgroup's first four tiles are b, b + G,
+                           * b + 2 G, b + 3 G (G = the launch's grid), every later tile index is 4 G + a claim from the first word,
+                           * so a workgroup that falls behind simply takes fewer tiles; tiles are started in tile_desc order
+                           * device-wide.  Null: the static schedule b, b + G, b + 2 G, ...  The results do not depend on it
+                           * (bit-identical). */
 } pna_fused_degree_args;
 
 int64_t pna_fused_degree_image_bytes(int32_t F, int32_t N);   /* 0 = unsupported shape */

@@ -59,7 +59,7 @@ struct FDArgs {
   float* agg_out; long ld_agg; // optional: the statistics as the contraction sees them, [mean | max | min | std] x F per virtual row
   const float* xd; const float* xh; const float* row_post;   // tower layers: the rows' own projections / features, the per-row factor
   unsigned lddb, ldhb;         // row pitch of xd / xh in bytes
-  int* counter;                // dynamic tile schedule (round 5): device int32, = 4 x grid at launch; nullptr: tile b, b + G, b + 2 G, ...
+  int* counter;                // dynamic tile schedule (round 5): two device int32, zero at launch (claims | finished workgroups); nullptr: tile b, b + G, b + 2 G, ...
   unsigned long long* dbg;     // experiments build only: per-wavefront phase timers
   unsigned ldb;                // row pitch of x in bytes
   unsigned ldyb, ldrb;         // row pitch of y / residual in bytes (ldrb = 0 without a residual: every load reads y's first row)
@@ -264,8 +264,8 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
   td_n2 = td_nxt;
   // DYNAMIC TILE SCHEDULE (round 5, g.counter != nullptr).  Statically a workgroup walks tiles b, b + G, b + 2 G, ...; the phase timers
   // show the slowest workgroup 9 % behind the mean even when the tile list is cost-balanced (the memory system does not serve every CU
-  // alike).  Dynamically the first FOUR tiles are the static ones and every later tile index comes from a device-wide counter (= 4 G at
-  // launch): wavefront 0 claims an index at the start of a multiply phase (one atomic, never waited for: it is older than every load
+  // alike).  Dynamically the first FOUR tiles are the static ones and every later tile index is 4 G + a claim from a device-wide counter
+  // (zero at launch, zeroed again by the last workgroup to finish): wavefront 0 claims an index at the start of a multiply phase (one atomic, never waited for: it is older than every load
   // the next gather waits on), hands it to the workgroup through one of two LDS words in that gather's drain, and everybody reads the
   // word behind the next multiply phase's barriers -- a claim is used four tiles after it was made, which is what the descriptor
   // prefetch (two tiles ahead) and the id prefetch (the previous tile's last packets) need.  Indices grow monotonically, so tiles
@@ -274,6 +274,7 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
   int t_n1 = t + G, t_n2 = t + 2 * G;                     // the workgroup's next tile and the one after
   int claimed = t + 3 * G;                                // (wavefront 0, lane 0) the index claimed last: the tile after t_n2
   int par = 0;                                            // which LDS word the current tile's hand-over uses
+  bool first_claim = true;                                // (wavefront 0) `claimed` still holds the static index t + 3 G
   const unsigned slot_b = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(kNBuf * CHV * 16) + (unsigned)(3 * NWA * 4);
   const unsigned lib = (unsigned)li * 4u;
   int idr[kRing];
@@ -406,7 +407,10 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
         asm volatile("" : "+v"(claimed));
         if (__builtin_amdgcn_readfirstlane(claimed) < 0)  // (belt and braces: the register was set to -1 when the claim was issued;
           asm volatile("s_waitcnt vmcnt(0)" : "+v"(claimed) : : "memory");       //  never seen -- returns are in order)
-        if (lane == 0) asm volatile("ds_write_b32 %0, %1" : : "v"(slot_b + (unsigned)par * 4u), "v"(claimed) : "memory");
+        // (a claim returns the counter's value, 0, 1, 2, ..: tile index = 4 G + that; the first write hands over the static fourth tile)
+        const int idx = first_claim ? claimed : claimed + 4 * G;
+        if (lane == 0) asm volatile("ds_write_b32 %0, %1" : : "v"(slot_b + (unsigned)par * 4u), "v"(idx) : "memory");
+        first_claim = false;
       }
     }
     // FAST tiles (round 4): every sum of squares of the lane's features finite (then every message was: the terms are >= 0) and
@@ -785,6 +789,14 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
     tg += now() - t2;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the copies issued for steps that do not exist
+  // the dynamic schedule leaves its two words as it found them: the LAST workgroup to get here (every claim of the launch has been
+  // made by then) zeroes them for the next launch on the stream -- no memset node in front of every launch
+  if (dyn && wave == 0 && lane == 0) {
+    if (__hip_atomic_fetch_add(g.counter + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1) {
+      __hip_atomic_store(g.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(g.counter + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 #ifdef PNA_AMD_EXPERIMENTS
   if (g.dbg && lane == 0) {
     unsigned long long* d = g.dbg + ((size_t)blockIdx.x * kWaves + wave) * 8;
@@ -849,7 +861,6 @@ int launch(const FDArgs& g, int wgs, hipStream_t st) {
   auto* fn = k_fused_degree<NFBF, HALF, DUMP, TOWER, !DUMP && !TOWER, GP, NPAN, WAVES, NBUF>;
   if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
   if (WAVES == 8) wgs = (wgs + 1) / 2;                    // (the caller counts 4-wavefront workgroups, two per CU)
-  if (g.counter && hipMemsetD32Async((hipDeviceptr_t)g.counter, 4 * wgs, 1, st) != hipSuccess) return -3;
   hipLaunchKernelGGL(fn, dim3((unsigned)wgs), dim3(64 * WAVES), lds, st, g);
   return 0;
 }
@@ -989,7 +1000,7 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
   if (ntiles < wgs) wgs = ntiles;
   hipStream_t st = (hipStream_t)stream;
   const int rc = p->agg_out ? launch_shape<true>(g, wgs, st) : launch_shape<false>(g, wgs, st);
-  if (rc != 0) return pna_set_error(PNA_E_LAUNCH, rc == -2 ? "pna_fused_degree_f32: no instantiation for this F" : rc == -3 ? "pna_fused_degree_f32: hipMemsetD32Async of tile_counter failed" : "pna_fused_degree_f32: hipFuncSetAttribute failed");
+  if (rc != 0) return pna_set_error(PNA_E_LAUNCH, rc == -2 ? "pna_fused_degree_f32: no instantiation for this F" : "pna_fused_degree_f32: hipFuncSetAttribute failed");
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
   return PNA_OK;

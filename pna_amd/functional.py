@@ -634,6 +634,13 @@ def _bind_tile_order(call, spare):
     verification instantiation writes agg_out in plan order; the 8-wavefront build of the wide shapes has 128-row tiles)."""
     from . import _lib
     plan, a = call.plan, call.args
+    memo = call.__dict__.setdefault("_orders", {})
+    hit = memo.get((int(spare), DG_balance_key()))
+    if hit is not None:                                   # (per call and grid: the pointers only -- this runs in front of every launch)
+        a.spare_workgroups, a.tile_desc, a.row_perm, a.tile_counter = int(spare), hit[0], hit[1], hit[2]
+        if hit[3] is not None:
+            a.row_post = hit[3]
+        return
     a.spare_workgroups = int(spare)
     bal = None
     if not a.agg_out and plan.NV and _lib.lib().pna_fused_degree_tile_rows(a.F, a.N) == 64:
@@ -652,14 +659,24 @@ def _bind_tile_order(call, spare):
     from . import degree_groups as DG
     counter = None
     if bal is not None and DG.FUSED_BALANCE == "dynamic":
-        counter = call.__dict__.get("_tile_counter")
-        if counter is None:
-            counter = call._tile_counter = torch.zeros(1, dtype=torch.int32, device=call.y.device)
+        # ONE counter pair per plan (zero between launches: the kernel's last workgroup resets it; launches over one Graph are one caller's,
+        # one stream's at a time -- the rule graph.workspace and the side stream already impose): a per-call tensor would put an
+        # allocation and a fill kernel in front of every forward
+        counter = plan.__dict__.get("_tile_counter")
+        if counter is None or counter.device != call.y.device:
+            counter = plan.__dict__["_tile_counter"] = torch.zeros(2, dtype=torch.int32, device=call.y.device)     # (claims | finished: the kernel leaves them zero)
     a.tile_counter = None if counter is None else _lib.dev_ptr(counter, torch.int32, "tile_counter")
     call._order_keep = (desc, perm, post, counter)
     a.tile_desc, a.row_perm = _lib.dev_ptr(desc, torch.int32, "tile_desc"), _lib.dev_ptr(perm, torch.int32, "row_perm")
+    rp = None
     if post is not None and a.row_post:
-        a.row_post = _lib.dev_ptr(post, torch.float32, "row_post")
+        rp = a.row_post = _lib.dev_ptr(post, torch.float32, "row_post")
+    memo[(int(spare), DG_balance_key())] = (a.tile_desc, a.row_perm, a.tile_counter, rp, call._order_keep)
+
+
+def DG_balance_key():
+    from . import degree_groups as DG
+    return (DG.FUSED_BALANCE, DG.FUSED_TILE_COST, DG.FUSED_DYNAMIC_TAIL)
 
 
 class FusedTowerCall:
