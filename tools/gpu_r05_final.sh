@@ -32,3 +32,6 @@ rm -rf $O/pmc/*/*/*.db 2>/dev/null
 timeout 500 python tools/bench_train.py > $O/train_step.json 2> $O/train_step.err; echo "train rc=$?"
 timeout 700 python tools/bench_configs.py > $O/configs.json 2> $O/configs.err; echo "configs rc=$?"
 tail -3 $O/configs.err
+timeout 200 python tools/fuzz_fused.py 90 51 > $O/fuzz_fused.log 2>&1; echo "fuzz fused rc=$?"; tail -3 $O/fuzz_fused.log
+timeout 200 python tools/fuzz_fused.py 60 53 big > $O/fuzz_fused_big.log 2>&1; echo "fuzz fused big rc=$?"; tail -3 $O/fuzz_fused_big.log
+timeout 200 python tools/fuzz_train.py 60 9 > $O/fuzz_train.log 2>&1; echo "fuzz train rc=$?"; tail -3 $O/fuzz_train.log
