@@ -468,6 +468,7 @@ def fused_images(weight, F, row_scales, plan, tower=False):
 FUSED_BALANCE = os.environ.get("PNA_AMD_FUSED_BALANCE", "dynamic")
 FUSED_DYNAMIC_TAIL = int(os.environ.get("PNA_AMD_FUSED_DYNAMIC_TAIL", "4"))   # "dynamic": this many x G of the cheapest tiles end the list
 FUSED_TILE_COST = float(os.environ.get("PNA_AMD_FUSED_TILE_COST", "10"))   # a tile's constant cost in edge units (multiply + epilogue + control)
+OUT_PITCH_ALIGN = int(os.environ.get("PNA_AMD_OUT_PITCH_ALIGN", "32"))   # floats: row pitch of the one-kernel layers' own output (functional.out_pitch)
 REST_SEG_LEN = 128         # edges per hub-row segment in the rest launch of the one-kernel layer (see DegreePlan.rest_items)
 REST_ROWS_PER_GROUP = 1    # work items per lane group in that launch (the full-graph gather: 4): a few thousand items must spread over 256 CUs
 TOWERS = True              # the tower layers (PNALayer) through the degree-grouped contraction with collapsed posttrans / mixing weights

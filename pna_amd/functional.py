@@ -618,6 +618,17 @@ def run_fused_call(call):
     return call.y
 
 
+def out_pitch(N):
+    """Row pitch (floats) of the output the one-kernel layers allocate: whole 128-byte lines (N = 75 -> 96 floats).  The kernel
+    stores a row as 64-byte pieces (16 columns: four lanes x 16 bytes); at a line-aligned pitch every piece is one aligned half
+    line of a line no other row shares, at the smallest 16-byte aligned pitch (76 floats) most pieces straddle two sectors and
+    neighbouring rows share lines.  Measured at C3 (one box, kernel ms): pitch 76 0.745, 80 0.735, 96 0.732.  A multi-layer net
+    reads the rows back as the next layer's source table: three whole lines per 300-byte row instead of 3.4."""
+    from . import degree_groups as DG
+    a = max(4, int(DG.OUT_PITCH_ALIGN))
+    return (N + a - 1) // a * a
+
+
 def _fused_grid(device, spare, n_tiles64):
     """Workgroups pna_fused_degree_f32 launches for the 4-wavefront shapes (pna_fused_degree.hip: two per CU, less the spare ones, never
     below one per CU, never more than tiles)."""
@@ -698,7 +709,7 @@ class FusedTowerCall:
         N = Wv.shape[0]
         self.x_src, self.x_dst, self.h = x_cat[:, :Fi], x_cat[:, P:P + Fi], h
         self.scales = scales = _row_scales(graph, t0.scalers, t0.avg_d, dev)
-        self.y = y = torch.empty(V, (N + 3) // 4 * 4, dtype=torch.float32, device=dev)[:, :N]
+        self.y = y = torch.empty(V, out_pitch(N), dtype=torch.float32, device=dev)[:, :N]
         self.res = res = h if layer.residual else None
         self.slope = float(mix.activation.negative_slope)
         if t0.graph_norm and snorm_n is not None:
@@ -781,7 +792,7 @@ class FusedDegreeCall:
         self.scales = scales = _row_scales(graph, layer.scalers, layer.avg_d, h.device)
         V = h.shape[0]
         # (rows at a 16-byte aligned pitch: the next layer of a stack can read them in 16-byte strips, i.e. stay on this path)
-        self.y = y = torch.empty(V, (N + 3) // 4 * 4, dtype=torch.float32, device=h.device)[:, :N] if out is None else out
+        self.y = y = torch.empty(V, out_pitch(N), dtype=torch.float32, device=h.device)[:, :N] if out is None else out
         self.cs, self.ct, self.res = cs, ct, res = _layer_tail_operands(layer, h)
         desc, ids, n_rec = plan.fused_tables()
         img, stride = DG.fused_images(lin.weight, F, scales, plan)
