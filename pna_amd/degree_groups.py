@@ -477,8 +477,9 @@ MAX_REST_FRACTION = 0.5    # more rest rows than this: the grouping is overhead,
 FUSED_HALO_MAX_INTERIOR = 0.5   # shards: below this fraction of rows without remote sources, exchange first and run ONE kernel
 # The rest-row launches BESIDE the one-kernel layer (functional.run_fused_call): the persistent kernel leaves this
 # many of its 2-per-CU workgroups out and the rest rows' gather / finalize / contraction run on a second stream in the slots left
-# free (measured on the benchmark graph: 24 is too few -- the chain of small launches then outlasts the kernel -- 32..40 hide it).
-FUSED_SPARE_WGS = int(os.environ.get("PNA_AMD_FUSED_SPARE_WGS", "32"))   # (0: the rest rows behind the kernel, as before ABI 17)
+# free (measured on the benchmark graph: 24 is too few -- the chain of small launches then outlasts the kernel -- 32..40 hide it;
+# round 5: the kernel got 6 % faster, the chain did not -- at 32 it outlasts the kernel on some boxes (step 0.745-0.762), at 40 it does not (0.745-0.748)).
+FUSED_SPARE_WGS = int(os.environ.get("PNA_AMD_FUSED_SPARE_WGS", "40"))   # (0: the rest rows behind the kernel, as before ABI 17)
 FUSED_OVERLAP_MIN_ROWS = 1 << 19   # smaller graphs: the kernel is too short to hide a chain of launches confined to a few CUs
 FUSED_OVERLAP_MIN_F = 64           # ... and so it is with few features (the chain is latency, the kernel's time follows F); measured: 75, 128
 FUSED_OVERLAP_MAX_REST_EDGES = 1.0 / 12   # ... and so it is when the rest rows hold more than this fraction of the group rows' edges
