@@ -646,7 +646,8 @@ def _bind_tile_order(call, spare):
     from . import _lib
     plan, a = call.plan, call.args
     memo = call.__dict__.setdefault("_orders", {})
-    hit = memo.get((int(spare), DG_balance_key()))
+    mkey = (int(spare), DG_balance_key(), int(torch.cuda.current_stream(call.y.device).cuda_stream))      # (the counter pair belongs to the stream)
+    hit = memo.get(mkey)
     if hit is not None:                                   # (per call and grid: the pointers only -- this runs in front of every launch)
         a.spare_workgroups, a.tile_desc, a.row_perm, a.tile_counter = int(spare), hit[0], hit[1], hit[2]
         if hit[3] is not None:
@@ -670,19 +671,23 @@ def _bind_tile_order(call, spare):
     from . import degree_groups as DG
     counter = None
     if bal is not None and DG.FUSED_BALANCE == "dynamic":
-        # ONE counter pair per plan (zero between launches: the kernel's last workgroup resets it; launches over one Graph are one caller's,
-        # one stream's at a time -- the rule graph.workspace and the side stream already impose): a per-call tensor would put an
-        # allocation and a fill kernel in front of every forward
-        counter = plan.__dict__.get("_tile_counter")
-        if counter is None or counter.device != call.y.device:
-            counter = plan.__dict__["_tile_counter"] = torch.zeros(2, dtype=torch.int32, device=call.y.device)     # (claims | finished: the kernel leaves them zero)
+        # ONE counter pair per (plan, stream) (zero between launches: the kernel's last workgroup resets it; launches on one stream are
+        # ordered, launches on different streams get different pairs): a per-call tensor would put an allocation and a fill kernel in
+        # front of every forward
+        ckey = (str(call.y.device), int(torch.cuda.current_stream(call.y.device).cuda_stream))
+        counters = plan.__dict__.setdefault("_tile_counters", {})
+        counter = counters.get(ckey)
+        if counter is None:                                  # (claims | finished: the kernel leaves them zero)
+            if len(counters) > 16:
+                counters.clear()
+            counter = counters[ckey] = torch.zeros(2, dtype=torch.int32, device=call.y.device)
     a.tile_counter = None if counter is None else _lib.dev_ptr(counter, torch.int32, "tile_counter")
     call._order_keep = (desc, perm, post, counter)
     a.tile_desc, a.row_perm = _lib.dev_ptr(desc, torch.int32, "tile_desc"), _lib.dev_ptr(perm, torch.int32, "row_perm")
     rp = None
     if post is not None and a.row_post:
         rp = a.row_post = _lib.dev_ptr(post, torch.float32, "row_post")
-    memo[(int(spare), DG_balance_key())] = (a.tile_desc, a.row_perm, a.tile_counter, rp, call._order_keep)
+    memo[mkey] = (a.tile_desc, a.row_perm, a.tile_counter, rp, call._order_keep)
 
 
 def DG_balance_key():
