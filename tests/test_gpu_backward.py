@@ -657,8 +657,9 @@ def test_simple_layer_training_step_golden(cuda_device, name):
 def test_tower_layer_training_step_golden(cuda_device, name):
     """One training step of PNALayer with towers against the REFERENCE's own (models/dgl/pna_layer.py:130-148 over :55-76 in
     train mode, oracle/make_golden_simple_train.py): output, gradients w.r.t. node features, edge features and every parameter,
-    the towers' running statistics.  Bar per element: 3e-4 of the tensor's largest entry (1e-5 for the output) + 4 x the reference's OWN fp32 error
-    on the row (its value against the oracle's float64 evaluation of the same step): the reference takes the std of `a_u + b_v` as
+    the towers' running statistics.  Bar per element, AGAINST THE FLOAT64 VALUE of the step (the oracle evaluated in float64 on the
+    fixture's inputs): 1e-5 of the tensor's largest entry (3e-5 node / edge gradients, 1e-4 pretrans weights) + 4 x the reference's OWN fp32
+    error on the row (its stored value against that float64 value): the reference takes the std of `a_u + b_v` as
     E[m^2] - E[m]^2 in fp32, which loses the variance's low digits when the destination's term dwarfs the spread of its
     neighbours (fixture t4_div: six rows, gradient entries off by 1e-3 of the largest) -- the product takes the std of `a_u`
     alone and lands on the float64 value."""
@@ -681,23 +682,26 @@ def test_tower_layer_training_step_golden(cuda_device, name):
     out = layer(g, h, e, a["snorm_n"].to(cuda_device))
     (out * a["R"].to(cuda_device)).sum().backward()
 
-    def close(got, ref, exact, what, base, by_row=True, scale=None):
+    def close(got, ref, exact, what, base, by_row=True, scale=None, spare=2):
+        # measured against the FLOAT64 value of the step; the reference's own fp32 error on the row says where the step is ill-conditioned
         ref_err = (ref.double() - exact).abs()
         # (the ill-conditioned entries share a ROW of the node tensors -- one destination -- and spread over a whole weight matrix)
         ref_err = ref_err.max(dim=1, keepdim=True).values if by_row and ref_err.dim() == 2 else ref_err.max()
-        diff, scale = (got.double().cpu() - ref.double()).abs(), scale or max(1.0, ref.abs().max().item())
+        diff, scale = (got.double().cpu() - exact).abs(), scale or max(1.0, exact.abs().max().item())
         bad = diff > base * scale + 4.0 * ref_err
         # ... and the product has such entries of its own (it takes the std of a_u alone: other destinations, the same size of
-        # error): a few entries may sit outside the bar, none further than 5e-3 of the largest entry
-        assert int(bad.sum()) <= max(2, 5e-3 * bad.numel()) and diff.max().item() <= 5e-3 * scale, (what, int(bad.sum()), diff.max().item(), ref_err.max().item())
+        # error): a few entries may sit outside the bar, none further than 2e-3 of the largest entry (measured: 6e-4, the reference's 1.1e-3)
+        assert int(bad.sum()) <= max(spare, 5e-3 * bad.numel()) and diff.max().item() <= 2e-3 * scale, (what, int(bad.sum()), diff.max().item(), ref_err.max().item())
     close(out.detach(), a["out"], out64, "out", 1e-5)
-    # (3e-4: the same ill-conditioning in the product's own fp32 arithmetic -- other rows than the reference's, the same size)
-    close(h.grad, a["grad_h"], gh64, "grad_h", 3e-4)
+    # (3e-5 / 1e-4 where the std's backward runs -- node and edge gradients, the pretrans weights --, 1e-5 elsewhere; measured round 5:
+    # every entry of t3_edgefeat inside 1e-5, t4_div's 11 entries of grad_h and 4 of towers.0's 72 pretrans weights are the ill-conditioned ones)
+    close(h.grad, a["grad_h"], gh64, "grad_h", 3e-5)
     if ef:
-        close(e.grad, a["grad_e"], ge64, "grad_e", 3e-4)
+        close(e.grad, a["grad_e"], ge64, "grad_e", 3e-5)
     wscale = max(v.abs().max().item() for k, v in a.items() if k.startswith("grad/"))       # (one scale for all parameters: the
     for k, p in layer.named_parameters():                                                     # noise of those entries reaches each)
-        close(p.grad, a["grad/" + k], gp64[k], k, 3e-4, by_row=False, scale=wscale)
+        pre = "pretrans" in k and k.endswith("weight")
+        close(p.grad, a["grad/" + k], gp64[k], k, 1e-4 if pre else 1e-5, by_row=False, scale=wscale, spare=4 if pre else 2)
     for k, b in layer.named_buffers():
         if "running" in k:
             torch.testing.assert_close(b.cpu(), a["after/" + k], rtol=1e-5, atol=1e-6)
