@@ -84,8 +84,19 @@ constexpr int kWavesMax = 8;
 // matrix pipe (phase timers at BASELINE configs[4]'s shape: 73 % of a wavefront's time in the multiply phase against 21 % of
 // matrix-pipe time; skipping every MFMA, fragment and B read leaves 2.55 of 3.26 ms), and a copy that has four steps to land instead
 // of three shortens every paced step by a quarter.
-constexpr int buffers_for(int gp, int npan) { return waves_for(gp, npan) == 8 ? 10 : npan == 2 ? 6 : 5; }
-constexpr int kChunkV = 3 * 4 * kNW;                      // 16-byte pieces of one chunk image: [term][lane group][80 cols][8 k] bf16
+#ifndef FD_NBUF_REG
+#define FD_NBUF_REG 5
+#endif
+#ifndef FD_NBUF_WIDE
+#define FD_NBUF_WIDE 6
+#endif
+// (nc: chunks of one gather pass -- a tile must have at least NBUF - 1 steps; tower: bf16 x 3 images of 15 KB, five)
+constexpr int buffers_for(int gp, int npan, int nc = 4, bool tower = true) {
+  return waves_for(gp, npan) == 8 ? 10 : tower ? 5 : npan == 2 ? FD_NBUF_WIDE : (nc * gp >= FD_NBUF_REG - 1 + 2) ? FD_NBUF_REG : 5;
+}
+constexpr int kChunkV = 3 * 4 * kNW;                      // 16-byte pieces of one chunk image, tower mode: [term][lane group][80 cols][8 k] bf16 x 3
+constexpr int kChunkVH = 2 * 4 * kNW;                     // ... of the layer proper (round 5): two fp16 terms (pna_x3_split.h)
+constexpr int kTailBytes = 512;                           // behind every fp16 image: 128 floats, 2^-s_n of the columns' power-of-two scales
 constexpr int kRing = 4;                                  // edge packets in the register ring
 constexpr int kNRes = kNT;                                // residual loads per lane (16 bytes each: 4 consecutive columns of one row)
 
@@ -200,7 +211,7 @@ __device__ __forceinline__ unsigned long long now() {
 // 81..128 output columns as two PANELS of 64 (4 column tiles each): a step multiplies one chunk's A fragment against one panel's
 // image (12 KB: the five-buffer pipeline still fits two workgroups per CU), the fragment is formed once per chunk.
 template <int NFBF, bool HALF, bool DUMP, bool TOWER = false, bool RESPF = !DUMP && !TOWER, int GP = 1, int NPAN = 1, int WAVES = waves_for(GP, NPAN),
-          int NBUF = buffers_for(GP, NPAN)>
+          int NBUF = buffers_for(GP, NPAN, 4 * NFBF + (HALF ? 2 : 0), TOWER)>
 __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fused_degree(const FDArgs g) {
   constexpr int kNBuf = NBUF, kAhead = NBUF - 1, kWaves = WAVES, kThreads = 64 * WAVES;
   static_assert(!TOWER || (NFBF == 2 && !DUMP), "tower mode: two full feature blocks (49 <= F <= 80), production only");
@@ -211,7 +222,15 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
   constexpr int NWP = NPAN == 1 ? kNW : 64;               // columns of one panel
   constexpr int NT = NWP / 16, NTA = NT * NPAN;           // column tiles per panel / accumulator tiles
   constexpr int NWA = NWP * NPAN;                         // all (padded) output columns
-  constexpr int CHV = 3 * 4 * NWP;                        // 16-byte pieces of one step's image: [term][lane group][NWP cols][8 k] bf16
+  // ARITHMETIC (round 5).  H2: statistics and weights as TWO fp16 terms each, three partial products per multiply (pna_x3_split.h):
+  // half the MFMAs, two thirds of the weight stream and of the B-fragment reads of the bf16 x 3 form (six products), the same accuracy
+  // class -- the row of statistics is scaled by a power of two so that its bound sits in [2^13, 2^14) (rscl below), the weights'
+  // columns likewise at pack time (their 2^-s in the image's tail), the accumulator is scaled back in the epilogue.  Tower mode keeps
+  // bf16 x 3: its node panels enter the contraction as they come from memory, mid-tile.
+  constexpr bool H2 = !TOWER;
+  constexpr int NTERM = H2 ? 2 : 3, NPROD = H2 ? 3 : 6, NCC = H2 ? 4 : 3;
+  using frag_t = std::conditional_t<H2, h8, bf8>;
+  constexpr int CHV = NTERM * 4 * NWP;                    // 16-byte pieces of one step's image: [term][lane group][NWP cols][8 k]
   constexpr int NI = (CHV + kThreads - 1) / kThreads;     // global_load_lds instructions per wavefront per step
   constexpr int NSP = NC * NPAN;                          // steps of one gather pass
   constexpr int NCT = NSP * GP + NPC;                     // steps per tile
@@ -229,11 +248,12 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
   const int ntiles = g.M / (kWaves * 16);
   const int G = (int)gridDim.x;
 
-  float* const colc = reinterpret_cast<float*>(lds + (size_t)kNBuf * CHV * 16);           // [3][NWA]: bias | scale | shift
+  float* const colc = reinterpret_cast<float*>(lds + (size_t)kNBuf * CHV * 16);           // [NCC][NWA]: bias | scale | shift | (H2) 2^-s of the column
   for (int i = tid; i < NWA; i += kThreads) {
     colc[i] = (g.bias && i < g.N) ? g.bias[i] : 0.f;
     colc[NWA + i] = (g.col_scale && i < g.N) ? g.col_scale[i] : 1.f;
     colc[2 * NWA + i] = (g.col_shift && i < g.N) ? g.col_shift[i] : 0.f;
+    if constexpr (H2) colc[3 * NWA + i] = reinterpret_cast<const float*>(g.w_img + (size_t)NCT * CHV * 16)[i];   // (the first image's tail: the same in all)
   }
 
   f4 acc[NTA];
@@ -275,7 +295,7 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
   int claimed = t + 3 * G;                                // (wavefront 0, lane 0) the index claimed last: the tile after t_n2
   int par = 0;                                            // which LDS word the current tile's hand-over uses
   bool first_claim = true;                                // (wavefront 0) `claimed` still holds the static index t + 3 G
-  const unsigned slot_b = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(kNBuf * CHV * 16) + (unsigned)(3 * NWA * 4);
+  const unsigned slot_b = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(kNBuf * CHV * 16) + (unsigned)(NCC * NWA * 4);
   const unsigned lib = (unsigned)li * 4u;
   int idr[kRing];
   int pr = -1;                                            // the node (row of y / residual) of tile row li (-1: padding)
@@ -287,6 +307,8 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
   float S_[NB][8], Q_[NB][8], MX[NB][8], MN[NB][8];       // (a half block uses [0..3])
   int deg = 0;                                            // in-degree of the tile's rows (wave-uniform)
   bool fast_tile = false;                                 // the tile's statistics are all finite and it has in-edges (set by gather())
+  int sA = 0;                                             // H2: the power of two row li's statistics are multiplied by (set by gather()) ...
+  float rscl = 1.f, runs = 1.f;                           // ... 2^sA and 2^-sA
   // The lane's strip of feature block fb starts at feature 32 fb + 8 lg (a half block: + 4 lg) -- except in the row's LAST block,
   // where a window that would reach past F slides back to end at F (round 4): no read ever leaves the row (rows of any pitch >= F,
   // the table's last row included), no statistic is ever made of padding.  A feature the slide covers twice counts once: the
@@ -424,11 +446,45 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
       // (not in the tower instantiation with a half block: 256 registers are taken there)
       fast_tile = !(TOWER && HALF) && D > 0 && __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(qs) < INFINITY)) == 0;
     }
+    // H2: the row's power-of-two scale.  Every statistic of a feature is bounded by its largest message magnitude m (mean and min
+    // inside [min, max]; std <= sqrt(mean of squares + 1e-5) <= m + 0.0032): bound = 2 max(m, 0.0032) over the row's features -- the
+    // lane's own, then the row's other three lanes (li + 16 k: two ds_bpermute, no LDS memory touched) --, clamped to FLT_MAX (a row
+    // that holds an infinite message is non-finite in every output column anyway).  2^sA puts the bound into [2^13, 2^14).
+    if constexpr (H2) {
+      float m = 0.f;
+#pragma unroll
+      for (int fb = 0; fb < NB; ++fb)
+#pragma unroll
+        for (int j = 0; j < ((HALF && fb == NFBF) ? 4 : 8); ++j)
+          asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(m) : "v"(m), "v"(MX[fb][j]), "v"(MN[fb][j]));
+      float o;
+      asm volatile("ds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"((unsigned)((lane ^ 16) * 4)), "v"(m) : "memory");
+      asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(o));
+      asm volatile("ds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"((unsigned)((lane ^ 32) * 4)), "v"(m) : "memory");
+      asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(o));
+      const float bound = __builtin_fminf(__builtin_fmaxf(m + m, 0.0064f), 3.4028234663852886e38f);
+      const int s1 = h2_scale_exp(bound);
+      if constexpr (P == 0) {
+        sA = s1;
+      } else {
+        // the second gather pass of a wide shape: ONE scale per row for both passes' products -- the smaller of the two; the accumulator
+        // (in units of the first pass's scale) follows it down: a power of two <= 1, exact
+        const int sN = min(sA, s1);
+        const float fac = __builtin_ldexpf(1.0f, max(sN - sA, -126));
+#pragma unroll
+        for (int n = 0; n < NTA; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) asm("v_mul_f32 %0, %1, %2" : "=v"(acc[n][r]) : "v"(acc[n][r]), "v"(fac));
+        sA = sN;
+      }
+      rscl = __builtin_ldexpf(1.0f, sA);
+      runs = __builtin_ldexpf(1.0f, -sA);
+    }
   };
 
   // ---- chunk c: the lane's eight A values, split into three bf16 terms.  Full block fb, chunk 4 fb + a: aggregator a (0 mean,
   //      1 max, 2 min, 3 std) of the lane's 8 features; half block, chunk 4 NFBF + h: aggregators 2h | 2h + 1 of its 4 features ----
-  bf8 A[3];
+  frag_t A[NTERM];
   // (single VALU instructions through inline asm, like the fold: written as plain C++ hipcc packs two features' chains into
   // v_pk_fma_f32 / v_pk_mul_f32 with op_sel swizzles -- the form that drops results beside MFMA wavefronts)
   auto mul1 = [](float a, float b) __attribute__((always_inline)) -> float { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
@@ -503,7 +559,7 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
     constexpr int c = decltype(c_c)::value;               // chunk within the gather pass P
     constexpr int P = decltype(p_c)::value;
     if ((c > 0 || P > 0) && FD_ABL(1)) { asm volatile("" : "+v"(A[0])); return; }
-    if constexpr (c >= NC) {                              // a node panel: the strips are the A operand as they come
+    if constexpr (!H2) if constexpr (c >= NC) {           // a node panel (tower mode): the strips are the A operand as they come
       constexpr int pc = c - NC;
       constexpr bool halfc = pc >= 2 * NFBF;
       constexpr int p = halfc ? 0 : pc / NFBF, fb = halfc ? NFBF : pc % NFBF;
@@ -529,7 +585,8 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
           if (!is_dup(P, fb, f)) g.agg_out[(size_t)((t * kWaves + wave) * 16 + li) * g.ld_agg + a * g.F + f] = v[j];
         }
       }
-      split8((f4){v[0], v[1], v[2], v[3]}, (f4){v[4], v[5], v[6], v[7]}, A[0], A[1], A[2]);
+      if constexpr (H2) split8_h2((f4){v[0], v[1], v[2], v[3]}, (f4){v[4], v[5], v[6], v[7]}, rscl, A[0], A[1]);
+      else split8((f4){v[0], v[1], v[2], v[3]}, (f4){v[4], v[5], v[6], v[7]}, A[0], A[1], A[2]);
       return;
     }
 #pragma unroll
@@ -543,8 +600,13 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
       }
     }
     const f4 lo4 = (f4){v[0], v[1], v[2], v[3]}, hi4 = (f4){v[4], v[5], v[6], v[7]};
-    if (__builtin_amdgcn_ballot_w64(absmax8(lo4, hi4) == INFINITY) != 0) split8_inf(lo4, hi4, A[0], A[1], A[2]);
-    else split8(lo4, hi4, A[0], A[1], A[2]);
+    if constexpr (H2) {
+      if (__builtin_amdgcn_ballot_w64(absmax8(lo4, hi4) == INFINITY) != 0) split8_h2_inf(lo4, hi4, rscl, A[0], A[1]);
+      else split8_h2(lo4, hi4, rscl, A[0], A[1]);
+    } else {
+      if (__builtin_amdgcn_ballot_w64(absmax8(lo4, hi4) == INFINITY) != 0) split8_inf(lo4, hi4, A[0], A[1], A[2]);
+      else split8(lo4, hi4, A[0], A[1], A[2]);
+    }
   };
 
   // ---- epilogue: BatchNorm / ReLU / residual, rows scattered to node order through perm -----------------------------------
@@ -570,11 +632,20 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
       asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(cb) : "v"(colc_b), "n"(n * 64) : "memory");
       asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(cs) : "v"(colc_b), "n"(NWA * 4 + n * 64) : "memory");
       asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ct) : "v"(colc_b), "n"(2 * NWA * 4 + n * 64) : "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cb), "+v"(cs), "+v"(ct) : : "memory");
+      [[maybe_unused]] f4 cu;
+      if constexpr (H2) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(cu) : "v"(colc_b), "n"(3 * NWA * 4 + n * 64) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cb), "+v"(cs), "+v"(ct), "+v"(cu) : : "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cb), "+v"(cs), "+v"(ct) : : "memory");
+      }
       float z[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = acc[n][r] + cb[r];
+        // (H2: the accumulator is in units of 2^(sA + s_n): back by the row's and the column's powers of two, exact, in the bias' fma)
+        float v;
+        if constexpr (H2) v = __builtin_fmaf(acc[n][r], runs * cu[r], cb[r]);
+        else v = acc[n][r] + cb[r];
         if constexpr (TOWER) v = v * rp;
         v = __builtin_fmaf(v, cs[r], ct[r]);
         z[r] = v < lo ? (leaky ? v * g.slope : 0.f) : v;  // ReLU / LeakyReLU / none (lo = -inf); NaN < lo is false: NaN is kept
@@ -631,8 +702,13 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
     constexpr int c = sp / NPAN, pan = sp % NPAN, a0 = pan * NT;
     const unsigned ba0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(buf * CHV + lg * NWP + li) * 16u;
     const int buf2 = buf == 0 ? kNBuf - 1 : buf - 1;     // (k + kAhead) % kNBuf
-    bf8 B[2][3];                                         // B fragments of column tile n (slot n & 1): one ds_read_b128 per term
-    constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
+    frag_t B[2][NTERM];                                  // B fragments of column tile n (slot n & 1): one ds_read_b128 per term
+    // partial products, smallest first: (statistics' term TA, weights' term TB)
+    constexpr int TA[6] = {H2 ? 1 : 2, H2 ? 0 : 1, 0, 1, 0, 0}, TB[6] = {0, 1, H2 ? 0 : 2, 0, 1, 0};
+    auto mma = [](const frag_t& w_, const frag_t& a_, f4 c_) __attribute__((always_inline)) -> f4 {
+      if constexpr (H2) return __builtin_amdgcn_mfma_f32_16x16x32_f16(w_, a_, c_, 0, 0, 0);
+      else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_, a_, c_, 0, 0, 0);
+    };
     if constexpr (sg == 0) {
 #pragma unroll
       for (int n = 0; n < NTA; ++n) acc[n] = (f4){0.f, 0.f, 0.f, 0.f};
@@ -645,7 +721,7 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
     // address register per step, the (term, column tile) displacement in the instruction's offset field: as "v" operands the
     // 45 distinct addresses were hoisted out of the tile loop and spilled.
 #define FD_READ_B(slot, n)                                                                                                                  \
-    _Pragma("unroll") for (int tm_ = 0; tm_ < 3; ++tm_)                                                                                     \
+    _Pragma("unroll") for (int tm_ = 0; tm_ < NTERM; ++tm_)                                                                                 \
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(B[slot][tm_]) : "v"(ba0), "n"(tm_ * 4 * NWP * 16 + (n) * 256) : "memory")
 #ifdef FD_SCHED_FENCE
 #define FD_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -653,14 +729,16 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
 #define FD_FENCE()
 #endif
 #define FD_WAIT_B()                                                                                                                         \
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(B[0][0]), "+v"(B[0][1]), "+v"(B[0][2]), "+v"(B[1][0]), "+v"(B[1][1]), "+v"(B[1][2]) : : "memory"); FD_FENCE()
+    if constexpr (H2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(B[0][0]), "+v"(B[0][1]), "+v"(B[1][0]), "+v"(B[1][1]) : : "memory");          \
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(B[0][0]), "+v"(B[0][1]), "+v"(B[0][NTERM - 1]), "+v"(B[1][0]), "+v"(B[1][1]), "+v"(B[1][NTERM - 1]) : : "memory"); \
+    FD_FENCE()
     if (!FD_ABL(4)) { FD_READ_B(0, 0); FD_READ_B(1, 1); }
     FD_WAIT_B();
     if (!FD_ABL(0))
 #pragma unroll
-    for (int pp = 0; pp < 6; ++pp) {
-      acc[a0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[0][TB[pp]], A[TA[pp]], acc[a0], 0, 0, 0);
-      acc[a0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[1][TB[pp]], A[TA[pp]], acc[a0 + 1], 0, 0, 0);
+    for (int pp = 0; pp < NPROD; ++pp) {
+      acc[a0] = mma(B[0][TB[pp]], A[TA[pp]], acc[a0]);
+      acc[a0 + 1] = mma(B[1][TB[pp]], A[TA[pp]], acc[a0 + 1]);
     }
     FD_FENCE();
     if (!FD_ABL(4)) { FD_READ_B(0, 2); FD_READ_B(1, 3); }
@@ -698,9 +776,9 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
     else stage(sg + kAhead - NCT, buf2, ib_next);
     if (!FD_ABL(0))
 #pragma unroll
-    for (int pp = 0; pp < 6; ++pp) {
-      acc[a0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[0][TB[pp]], A[TA[pp]], acc[a0 + 2], 0, 0, 0);
-      acc[a0 + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[1][TB[pp]], A[TA[pp]], acc[a0 + 3], 0, 0, 0);
+    for (int pp = 0; pp < NPROD; ++pp) {
+      acc[a0 + 2] = mma(B[0][TB[pp]], A[TA[pp]], acc[a0 + 2]);
+      acc[a0 + 3] = mma(B[1][TB[pp]], A[TA[pp]], acc[a0 + 3]);
     }
     FD_FENCE();
     if constexpr (NT == 5) {
@@ -708,7 +786,7 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
       FD_WAIT_B();
       if (!FD_ABL(0))
 #pragma unroll
-      for (int pp = 0; pp < 6; ++pp) acc[a0 + 4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[0][TB[pp]], A[TA[pp]], acc[a0 + 4], 0, 0, 0);
+      for (int pp = 0; pp < NPROD; ++pp) acc[a0 + 4] = mma(B[0][TB[pp]], A[TA[pp]], acc[a0 + 4]);
       FD_FENCE();
     }
 #undef FD_READ_B
@@ -810,18 +888,43 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
 //      Tower images (tower != 0): scaler blocks of K = 5 F columns [4 F aggregators | F self panel (block 0 only)], followed by
 //      the chunks of the two node panels: x_dst against W_D,mean + W_D,max + W_D,min, h against the self panel.
 //      Wide shapes (npan = 2): [chunk][panel][term][lane group][64 cols][8 k], panel p = output columns 64 p .. 64 p + 64.
+//      Round 5, the layer proper (tower = 0): TWO fp16 terms of W_D[n][.] * 2^s_n, s_n the power of two that puts the largest |W_D[n][k]| over
+//      k and over ALL images into [2^13, 2^14) (colmax: the maxima's bit patterns, k_fused_colmax; pna_x3_split.h); images `stride`
+//      elements apart, each followed by the tail of the columns' 2^-s_n (k_fused_tails).
+__device__ __forceinline__ float colmax_bound(unsigned bits) {   // (NaN / Inf / 0 maxima: any finite positive bound will do)
+  return __builtin_fminf(__builtin_fmaxf(__builtin_bit_cast(float, bits), 1e-30f), 3.4028234663852886e38f);
+}
+__global__ void k_fused_colmax(const float* w_ref, long ldw, int N, int F, int S, const float* scale, int n_img, unsigned* colmax) {
+  const int K = 4 * F;
+  const long total = (long)n_img * N * K;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(i % K);
+    const int n = (int)((i / K) % N), im = (int)(i / ((long)K * N));
+    const float* row = w_ref + (long)n * ldw + col;
+    float w = scale ? scale[(long)im * S] * row[0] : row[0];
+    for (int s = 1; s < S; ++s) w = w + (scale ? scale[(long)im * S + s] * row[(long)s * K] : row[(long)s * K]);
+    atomicMax(colmax + n, __builtin_bit_cast(unsigned, __builtin_fabsf(w)));      // (|w| as bits: ordered like the floats; NaN above all)
+  }
+}
+__global__ void k_fused_tails(unsigned char* img, long payload, long stride_bytes, int n_img, int N) {
+  const int n = threadIdx.x;                              // 128 threads
+  const unsigned bits = reinterpret_cast<const unsigned*>(img + payload)[n];
+  const float u = n < N ? __builtin_ldexpf(1.0f, -h2_scale_exp(colmax_bound(bits))) : 1.0f;
+  __syncthreads();
+  for (int im = 0; im < n_img; ++im) reinterpret_cast<float*>(img + (long)im * stride_bytes + payload)[n] = u;
+}
 __global__ void k_pack_fused_degree(const float* w_ref, long ldw, int N, int F, int S, const float* scale, int n_img, unsigned short* img, int tower,
-                                    int nwp, int npan) {
+                                    int nwp, int npan, int nterm, const unsigned* colmax, long stride) {
   const int nfull = shape_full(F), NCS = shape_chunks(F), K = tower ? 5 * F : 4 * F;
   const int NC = NCS + (tower ? 2 * nfull + (shape_half(F) ? 1 : 0) : 0);
-  const long per = (long)NC * npan * 3 * 4 * nwp * 8;
+  const long per = (long)NC * npan * nterm * 4 * nwp * 8;
   const long total = per * n_img;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     long r = i;
     const int e = r % 8; r /= 8;
     const int nn = r % nwp; r /= nwp;
     const int lgp = r % 4; r /= 4;
-    const int term = r % 3; r /= 3;
+    const int term = r % nterm; r /= nterm;
     const int pan = r % npan; r /= npan;
     const int c = r % NC; r /= NC;
     const int im = (int)r;
@@ -845,7 +948,8 @@ __global__ void k_pack_fused_degree(const float* w_ref, long ldw, int N, int F, 
     };
     float w = 0.f;
     if (n < N && f < F && !dup) w = a < 5 ? combined(a * F + f) : (combined(f) + combined(F + f)) + combined(2 * F + f);
-    img[i] = weight_term(w, term);
+    if (nterm == 3) img[(long)im * stride + i % per] = weight_term(w, term);
+    else img[(long)im * stride + i % per] = weight_term_h2(w * __builtin_ldexpf(1.0f, h2_scale_exp(colmax_bound(colmax[n < N ? n : 0]))), term);
   }
 }
 
@@ -856,8 +960,9 @@ __host__ __device__ constexpr bool shape_wide_n(int N) { return N > kNW && N <= 
 template <int NFBF, bool HALF, bool DUMP, bool TOWER = false, int GP = 1, int NPAN = 1>
 int launch(const FDArgs& g, int wgs, hipStream_t st) {
   constexpr int NWP = NPAN == 1 ? kNW : 64;
-  constexpr int NBUF = buffers_for(GP, NPAN), WAVES = waves_for(GP, NPAN);
-  const size_t lds = (size_t)NBUF * (3 * 4 * NWP) * 16 + (size_t)(3 * NWP * NPAN) * sizeof(float) + 16;    // (+ the two hand-over words of the dynamic schedule)
+  constexpr int NBUF = buffers_for(GP, NPAN, 4 * NFBF + (HALF ? 2 : 0), TOWER), WAVES = waves_for(GP, NPAN);
+  constexpr int NTERM = TOWER ? 3 : 2, NCC = TOWER ? 3 : 4;                                                  // (the kernel's H2 = !TOWER)
+  const size_t lds = (size_t)NBUF * (NTERM * 4 * NWP) * 16 + (size_t)(NCC * NWP * NPAN) * sizeof(float) + 16;   // (+ the two hand-over words of the dynamic schedule)
   auto* fn = k_fused_degree<NFBF, HALF, DUMP, TOWER, !DUMP && !TOWER, GP, NPAN, WAVES, NBUF>;
   if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
   if (WAVES == 8) wgs = (wgs + 1) / 2;                    // (the caller counts 4-wavefront workgroups, two per CU)
@@ -897,7 +1002,7 @@ extern "C" int64_t pna_fused_degree_image_bytes(int32_t F, int32_t N) {
   // (49 <= F <= 64 or 113..128: with a half block on top, 80 statistics + the ring + 32 accumulators + the residual spill)
   const bool f_ok = (F >= 17 && F <= 80) || shape_wide_f(F), n_ok = (N >= 4 && N <= kNW) || shape_wide_n(N);
   if (!f_ok || !n_ok || (shape_wide_n(N) && !shape_wide_f(F) && !(shape_full(F) == 2 && !shape_half(F)))) return 0;
-  return (int64_t)shape_chunks(F) * (shape_wide_n(N) ? 2 * (3 * 4 * 64) : kChunkV) * 16;
+  return (int64_t)shape_chunks(F) * (shape_wide_n(N) ? 2 * (2 * 4 * 64) : kChunkVH) * 16 + kTailBytes;
 }
 
 static int64_t tower_image_bytes(int F, int N) {
@@ -914,7 +1019,7 @@ extern "C" int pna_fused_tower_pack_f32(const float* w_ref, int64_t ldw, int32_t
   const int64_t elems = tower_image_bytes(F, N) / 2 * n_img;
   const int blocks = (int)((elems + 255) / 256 > 8192 ? 8192 : (elems + 255) / 256);
   hipLaunchKernelGGL(k_pack_fused_degree, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ref, (long)ldw, N, F, n_scaler, scale, n_img,
-                     (unsigned short*)img, 1, kNW, 1);
+                     (unsigned short*)img, 1, kNW, 1, 3, (const unsigned*)nullptr, (long)(tower_image_bytes(F, N) / 2));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
   return PNA_OK;
@@ -925,11 +1030,19 @@ extern "C" int pna_fused_degree_pack_f32(const float* w_ref, int64_t ldw, int32_
   if (!w_ref || !img || n_img < 1 || n_scaler < 1 || n_scaler > PNA_MAX_SCALER || pna_fused_degree_image_bytes(F, N) == 0 ||
       ldw < (int64_t)n_scaler * 4 * F || (n_scaler > 1 && !scale))
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_pack_f32: bad arguments (F in 17..80 or 113..128, N in 4..128, N > 80 needs F in 49..64 or 113..128; scale required for n_scaler > 1)");
-  const int64_t elems = pna_fused_degree_image_bytes(F, N) / 2 * n_img;
+  const int64_t stride = pna_fused_degree_image_bytes(F, N), payload = stride - kTailBytes;
+  const int64_t elems = payload / 2 * n_img;
   const int blocks = (int)((elems + 255) / 256 > 8192 ? 8192 : (elems + 255) / 256);
   const bool wide = shape_wide_n(N);
-  hipLaunchKernelGGL(k_pack_fused_degree, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ref, (long)ldw, N, F, n_scaler, scale, n_img,
-                     (unsigned short*)img, 0, wide ? 64 : kNW, wide ? 2 : 1);
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* const colmax = reinterpret_cast<unsigned*>((unsigned char*)img + payload);       // the first image's tail: scratch until k_fused_tails
+  if (hipMemsetAsync(colmax, 0, kTailBytes, st) != hipSuccess) return pna_set_error(PNA_E_LAUNCH, "pna_fused_degree_pack_f32: hipMemsetAsync failed");
+  const int64_t welems = (int64_t)n_img * N * 4 * F;
+  hipLaunchKernelGGL(k_fused_colmax, dim3((unsigned)((welems + 255) / 256 > 4096 ? 4096 : (welems + 255) / 256)), dim3(256), 0, st, w_ref, (long)ldw, N, F,
+                     n_scaler, scale, n_img, colmax);
+  hipLaunchKernelGGL(k_pack_fused_degree, dim3(blocks), dim3(256), 0, st, w_ref, (long)ldw, N, F, n_scaler, scale, n_img,
+                     (unsigned short*)img, 0, wide ? 64 : kNW, wide ? 2 : 1, 2, (const unsigned*)colmax, (long)(stride / 2));
+  hipLaunchKernelGGL(k_fused_tails, dim3(1), dim3(128), 0, st, (unsigned char*)img, (long)payload, (long)stride, n_img, N);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
   return PNA_OK;

@@ -1,5 +1,5 @@
 // pna_x3_split.h -- the exact fp32 -> 3 x bf16 operand split shared by the bf16x3 contraction kernels
-// (pna_posttrans_x3.hip, pna_fused_degree.hip).
+// (pna_posttrans_x3.hip, pna_fused_degree.hip's tower mode), and the fp32 -> 2 x fp16 split of the one-kernel layer (below).
 //   x = x0 + x1 + x2,   x0 = top 16 bits of x,  x1 = top 16 bits of (x - x0),  x2 = top 16 bits of (x - x0 - x1)
 // by truncation, so every term is exact and finite inputs never overflow.  See include/pna_amd.h for the non-finite rules.
 #ifndef PNA_X3_SPLIT_H
@@ -87,6 +87,66 @@ __device__ __forceinline__ unsigned short weight_term(float w, int term) {
   const float r1 = wf - top16(wf), r2 = winf ? w : r1 - top16(r1);
   const float t = term == 0 ? wf : term == 1 ? r1 : r2;
   return (unsigned short)(fbits(t) >> 16);
+}
+
+
+// ---- fp16 x 2 (round 5; the one-kernel layer's contraction, pna_fused_degree.hip) ---------------------------------------------
+// x = h0 + h1 + r,  h0 = fp16(x), h1 = fp16(x - h0) (round to nearest, both), |r| <= 2^-22 |x|: two terms carry 22-23 of fp32's 24
+// significand bits, and THREE partial products (h1 w0, h0 w1, h0 w0; the dropped h1 w1 is 2^-22 of the product) do what bf16 x 3
+// needs six for -- provided the operand sits high in fp16's narrow range: the caller scales a row of statistics / a column of
+// weights by a power of two (exact) so that its largest magnitude lands in [2^13, 2^14), and scales the accumulator back.  Measured
+// against float64 on the benchmark layer's shapes: 1.25x the bf16 x 3 error, a fifth of an fp32 GEMM's.
+// gfx950 MFMAs do not flush fp16 subnormals: an element 2^-28 below its row's largest still contributes what it can.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));     // 8 fp16 = one MFMA A/B fragment
+
+__device__ __forceinline__ unsigned cvt_pk_h(float lo, float hi) { unsigned r; asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r; }
+__device__ __forceinline__ float h_lo(unsigned p) { float r; asm("v_cvt_f32_f16 %0, %1" : "=v"(r) : "v"(p)); return r; }
+__device__ __forceinline__ float h_hi(unsigned p) {
+  float r; asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(p)); return r;
+}
+__device__ __forceinline__ float sub_1(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float mul_1(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// 8 floats x scl (a power of two: exact) -> the two fp16 fragments.  Single VALU instructions through inline asm, like split8's
+// callers: hipcc would pack the chains into v_pk_*_f32 with op_sel swizzles.
+__device__ __forceinline__ void split8_h2(const f4 lo, const f4 hi, float scl, h8& t0, h8& t1) {
+  const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  u4 p0, p1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float xe = mul_1(x[2 * j], scl), xo = mul_1(x[2 * j + 1], scl);
+    p0[j] = cvt_pk_h(xe, xo);
+    p1[j] = cvt_pk_h(sub_1(xe, h_lo(p0[j])), sub_1(xo, h_hi(p0[j])));
+  }
+  t0 = __builtin_bit_cast(h8, p0); t1 = __builtin_bit_cast(h8, p1);
+}
+// The same for a fragment that holds +-Inf: an infinite element is carried by its LOWER term alone (t0 = 0, t1 = +-Inf): of the three
+// partial products only h1 w0 sees it, and w0 = 0 only where the weight is zero (fp32: Inf * 0 = NaN too) or 2^-39 below its column's largest.
+__device__ __forceinline__ void split8_h2_inf(const f4 lo, const f4 hi, float scl, h8& t0, h8& t1) {
+  const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  u4 p0, p1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float xe = mul_1(x[2 * j], scl), xo = mul_1(x[2 * j + 1], scl);
+    const bool ie = __builtin_fabsf(xe) == INFINITY, io = __builtin_fabsf(xo) == INFINITY;
+    const float fe = ie ? 0.f : xe, fo = io ? 0.f : xo;
+    p0[j] = cvt_pk_h(fe, fo);
+    const float re = sub_1(fe, h_lo(p0[j])), ro = sub_1(fo, h_hi(p0[j]));
+    p1[j] = cvt_pk_h(ie ? xe : re, io ? xo : ro);
+  }
+  t0 = __builtin_bit_cast(h8, p0); t1 = __builtin_bit_cast(h8, p1);
+}
+
+// power-of-two scale that puts a magnitude bound into [2^13, 2^14): the exponent s (bound * 2^s); bound in (0, FLT_MAX]
+__device__ __forceinline__ int h2_scale_exp(float bound) { return 14 - __builtin_amdgcn_frexp_expf(bound); }
+
+// one weight (already multiplied by its column's power of two) -> its fp16 term `term`; an infinite weight is carried by its lower term alone
+__device__ __forceinline__ unsigned short weight_term_h2(float w, int term) {
+  const bool winf = __builtin_fabsf(w) == INFINITY;
+  const float wf = winf ? 0.f : w;
+  const _Float16 t0 = (_Float16)wf;
+  const _Float16 t1 = winf ? (_Float16)w : (_Float16)(wf - (float)t0);
+  return __builtin_bit_cast(unsigned short, term == 0 ? t0 : t1);
 }
 
 }  // namespace pna_x3

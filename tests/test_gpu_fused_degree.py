@@ -319,7 +319,7 @@ def test_fused_entry_point_rejects_bad_arguments(cuda_device):
     a.M = 64
     assert L.pna_fused_degree_f32(ctypes.byref(a), None) == -1 and b"non-null" in L.pna_last_error()
     assert L.pna_fused_degree_image_bytes(96, 80) == 0 and L.pna_fused_degree_image_bytes(75, 81) == 0 and L.pna_fused_degree_image_bytes(16, 16) == 0
-    assert L.pna_fused_degree_image_bytes(75, 75) == 10 * 15360 and L.pna_fused_degree_image_bytes(64, 80) == 8 * 15360
+    assert L.pna_fused_degree_image_bytes(75, 75) == 10 * 10240 + 512 and L.pna_fused_degree_image_bytes(64, 80) == 8 * 10240 + 512   # (chunks of two fp16 terms + the columns' scales)
 
 
 def test_tower_mode_rows_vs_float64_and_100_identical_runs_at_full_size(cuda_device, c3):
