@@ -30,6 +30,8 @@ extern "C" {
                                   roles: parity-green, 2.1-2.7x slower than pna_fused_degree_f32, never on a product path -- removed from the
                                   library in round 5; the source lives on as tools/ubench/fused_roles.hip, the result in DESIGN.md 4.9).
                                   + pna_fused_degree_args.tile_counter (dynamic tile schedule), pna_fused_degree_tile_rows.
+                                  pna_fused_degree_{image_bytes,pack_f32,f32}: images of two fp16 terms + a 512-byte tail of column scales
+                                  (an opaque format between the pack function and the kernel of ONE library; the byte count changed).
                                   The trailing fields added "inside 19" are part of 20's structs: a binding that knows them no longer
                                   passes the version check of a library that does not.  Every args struct carries struct_size first.
                               19: struct_size first in every args struct; + pna_posttrans_dw_f32 / pna_posttrans_dw_grouped_f32
@@ -502,7 +504,20 @@ int pna_fused_simple_f32(const pna_fused_simple_args* args, pna_stream_t stream)
  *
  *   a[v]        = [mean | max | min | std] over the in-edges of x[src]                     (bit-identical to pna_segreduce_fwd_f32
  *                                                                                             for rows one lane group walks alone)
- *   y[perm[v]]  = residual[perm[v]] + act((bias + W_D(v) . a[v]) * col_scale + col_shift)   (bf16x3 arithmetic of pna_posttrans_x3_f32)
+ *   y[perm[v]]  = residual[perm[v]] + act((bias + W_D(v) . a[v]) * col_scale + col_shift)   (fp32 in and out, fp32 accumulation; see ARITHMETIC)
+ *
+ * ARITHMETIC (round 5; rounds 3-4: the bf16x3 arithmetic of pna_posttrans_x3_f32, which tower mode keeps).  Every statistic and every
+ * weight enters the matrix pipe as TWO fp16 terms, x = h0 + h1 + r with h0 = fp16(x), h1 = fp16(x - h0) (round to nearest), |r| <= 2^-22 |x|,
+ * and a product as three partial products (h1 w0, h0 w1, h0 w0; v_mfma_f32_16x16x32_f16, fp32 accumulation): half the matrix instructions
+ * and two thirds of the weight stream of bf16x3's six products.  fp16's range is narrow, so the operands are first multiplied by powers of
+ * two (exact): row v's statistics by 2^s(v), chosen in the kernel so that twice the row's largest message magnitude lies in
+ * [2^13, 2^14), and column n of the weights by 2^t(n), chosen by pna_fused_degree_pack_f32 from the largest |W_D[n][k]| over k and over all images
+ * (2^-t(n) rides in each image's 512-byte tail); the accumulator is multiplied by 2^-(s + t) in the bias' fma.  Measured against float64
+ * on BASELINE configs[2] / [4] shapes: 1.25 x the error of bf16x3, a fifth of an fp32 GEMM's.  An element more than 2^28 below its row's
+ * (column's) largest loses low bits, more than 2^38 below it vanishes -- absolute errors of 2^-39 of the row's largest product.
+ * Non-finite operands: NaN propagates; a row that holds an infinite statistic (column: an infinite weight) is non-finite in every output
+ * it reaches, as in fp32 -- but its FINITE elements are scaled against FLT_MAX and may underflow, so where fp32 gives +-Inf the result
+ * may be +-Inf or NaN, never finite garbage.
  *
  * The caller (pna_amd/degree_groups.py) orders the rows by in-degree into VIRTUAL rows v in [0, M):
  *   row_perm[v]   node of virtual row v, or -1 = padding (nothing is stored); M a multiple of pna_fused_degree_tile_rows(F, N) (64 or 128); every aligned block of 16
@@ -511,7 +526,7 @@ int pna_fused_simple_f32(const pna_fused_simple_args* args, pna_stream_t stream)
  *   tile_ids      n_records records of 16 int32: record (first + e)[i] = source row (row of x) of the e-th in-edge of the block's
  *                 i-th row, e in [0, D), in the row's edge order; a padding row repeats the block's first row; a block owns
  *                 max(4, round_up(D, 4)) records, the ones past D being copies of record D - 1 (D = 0: any valid row);
- *   w_img         n_img images, image_stride >= pna_fused_degree_image_bytes(F, N) bytes apart, from pna_fused_degree_pack_f32:
+ *   w_img         n_img images, image_stride == pna_fused_degree_image_bytes(F, N) bytes apart (the pack function's layout), from pna_fused_degree_pack_f32:
  *                 w_ref is the Linear weight (N, n_scaler * 4F) in the reference's column order [scaler][aggregator][feature]
  *                 (pna_layer.py:192-193), scale (n_img, n_scaler) the scalers' values for image i (NULL with n_scaler = 1:
  *                 the weight itself); W_D is formed in fp32 in scaler order, like the reference's blocks.

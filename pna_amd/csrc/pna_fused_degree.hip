@@ -19,8 +19,9 @@
 // order; mean = s / D correctly rounded) as single VALU instructions: the statistics are the same bits as the two-kernel path's.
 //
 // Contraction.  The statistics ARE the MFMA A operand: with K ordered (feature block, aggregator) -- the weight image is packed
-// to match -- chunk c = 4 fb + a multiplies the lane's eight values of aggregator a, split exactly into three bf16 terms
-// (pna_x3_split.h; six partial products per multiply, fp32 accumulation: the arithmetic of pna_posttrans_x3.hip).  One combined
+// to match -- chunk c = 4 fb + a multiplies the lane's eight values of aggregator a, split into TWO fp16 terms after a power-of-two
+// row scale (round 5, pna_x3_split.h: three partial products per multiply, fp32 accumulation, the accuracy of the bf16 x 3 form of
+// rounds 3-4 -- six products -- which tower mode keeps).  One combined
 // image per degree group, streamed through five LDS buffers by global_load_lds (four steps ahead, counted waits), one barrier per
 // chunk in the middle of the chunk's MFMA stream.  Workgroups of 4 wavefronts (64 rows), two per CU: while one multiplies, the
 // other gathers.  Tower mode (PNALayer with one tower) and the wide shapes (F or N up to 128) are template parameters below.
@@ -78,9 +79,11 @@ constexpr int kNW = 80, kNT = 5;
 // chain of latencies (4.8.13), and the weight image is streamed once per tile -- FD_WIDE_WAVES wavefronts per workgroup there.
 constexpr int waves_for(int gp, int npan) { return (gp == 2 || npan == 2) ? FD_WIDE_WAVES : 4; }
 constexpr int kWavesMax = 8;
-// LDS weight buffers (template parameter NBUF of the kernel): a step's image is requested NBUF - 1 steps before it is read.  Five
-// buffers of 15 KB (one panel of 80 columns) are what two workgroups per CU can hold; the wide shapes' panels of 64 columns are
-// 12 KB, so SIX fit (2 x (72 + 1.5) KB of the CU's 160 KB) -- round 5: their multiply phase is paced by the COPY LATENCY, not by the
+// LDS weight buffers (template parameter NBUF of the kernel): a step's image is requested NBUF - 1 steps before it is read.  With the
+// bf16 x 3 images of rounds 3-4 five buffers of 15 KB (one panel of 80 columns) were what two workgroups per CU could hold, and six of
+// the wide shapes' 12 KB panels of 64 columns; the fp16 x 2 images are 10 / 8 KB and more would fit -- 6 / 8 and 7 / 9 buffers measured
+// the same as 5 / 6 on both benchmark shapes (-DFD_NBUF_REG / -DFD_NBUF_WIDE; profiles/README.md), so the counts stay.  Why six for the
+// wide shapes (round 5, measured on the bf16 x 3 kernel): their multiply phase is paced by the COPY LATENCY, not by the
 // matrix pipe (phase timers at BASELINE configs[4]'s shape: 73 % of a wavefront's time in the multiply phase against 21 % of
 // matrix-pipe time; skipping every MFMA, fragment and B read leaves 2.55 of 3.26 ms), and a copy that has four steps to land instead
 // of three shortens every paced step by a quarter.

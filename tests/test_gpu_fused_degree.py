@@ -159,6 +159,59 @@ def test_fused_layer_isolated_nodes_and_nonfinite_features(cuda_device):
     assert (y_f[zero_rows][ok] - ref[ok]).abs().max().item() <= 1e-5
 
 
+@pytest.mark.parametrize("V,E,F,N", [(150_000, 1_200_000, 75, 75), (140_000, 1_000_000, 128, 128), (130_000, 700_000, 40, 72)])
+def test_fused_layer_fp16_scales_over_a_wide_dynamic_range(cuda_device, V, E, F, N):
+    """The power-of-two scales of the fp16 x 2 contraction (round 5; pna_x3_split.h): feature rows from 1e-15 to 1e+15 (a destination's
+    statistics share ONE scale, set by its largest message), six decades of spread inside a row, the two halves of a wide row six
+    decades apart either way (the second gather pass re-scales the accumulator), weight columns over eight decades (one scale per
+    column).  Checked PER ELEMENT against the float64 contraction of the kernel's own fp32 statistics (its agg_out dump): within
+    2e-6 of sum_k |a_k| |W_D[n][k]| carried through BatchNorm's scale (+ the fp32 floor of the epilogue's O(1) bias / BatchNorm terms) --
+    measured 5e-7, the two-kernel path's bf16 x 3 contraction 7e-7 on the same inputs; a lost second fp16 term would be 5e-4 of the
+    dominant product, a wrong scale a factor of two."""
+    from pna_amd import Graph, degree_groups as DG, functional as PF
+    from pna_amd.synth import powerlaw_graph
+    src, dst = powerlaw_graph(V, E, seed=11, device=cuda_device)
+    g = Graph(src, dst, V)
+    layer = _layer(F, N, cuda_device, residual=False, seed=4)
+    gen = torch.Generator(device=cuda_device).manual_seed(5)
+    h = _features(V, F, cuda_device, seed=6)
+    with torch.no_grad():
+        # rows: 30 decades (the wide rows: 20 + the halves' six either way -- sums of squares stay inside fp32)
+        h.mul_(10.0 ** torch.empty(V, 1, device=cuda_device).uniform_(-15 if F <= 96 else -10, 15 if F <= 96 else 10, generator=gen))
+        h.mul_(10.0 ** torch.empty(V, F, device=cuda_device).uniform_(-6, 0, generator=gen))            # inside a row: 6 decades
+        if F > 96:
+            h[:, 64:].mul_(10.0 ** (6.0 * torch.randint(-1, 2, (V, 1), device=cuda_device, generator=gen).float()))
+        lin, bn = layer.posttrans.fully_connected[0].linear, layer.batchnorm_h
+        lin.weight.mul_((10.0 ** (torch.arange(N, device=cuda_device) % 9 - 4).float())[:, None])       # columns: 8 decades
+        with _Knobs(fused=True, small_graphs=True):
+            assert DG.fused_applies(g, h, F, N)
+            y_f = layer(g, h)
+            plan = DG.plan_of(g)
+            dump = torch.zeros(plan.NV, 4 * F, device=cuda_device)
+            PF.simple_layer_degree_fused(layer, g, h, agg_out=dump)
+        with _Knobs(fused=False, small_graphs=True):
+            y_g = layer(g, h)
+        assert torch.isfinite(y_g).all() and torch.isfinite(y_f).all()
+        live = plan.perm >= 0
+        nodes = plan.perm[live].long()
+        assert nodes.numel() > V // 2
+        a = dump[live].double()                               # [mean | max | min | std] x F: the fp32 statistics the contraction consumed
+        amp, att = (t[nodes].double()[:, None] for t in g.degree_scalers(2.3))
+        W, b, K = lin.weight.double(), lin.bias.double(), 4 * F
+        z = a @ W[:, :K].t() + amp * (a @ W[:, K:2 * K].t()) + att * (a @ W[:, 2 * K:].t())
+        mass = a.abs() @ W[:, :K].abs().t() + amp.abs() * (a.abs() @ W[:, K:2 * K].abs().t()) + att.abs() * (a.abs() @ W[:, 2 * K:].abs().t())
+        bn_scale = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+        ref = torch.relu((z + b - bn.running_mean.double()) * bn_scale + bn.bias.double())
+        tol = 2e-6 * (mass * bn_scale.abs() + 10.0)
+        worst = {}
+        for name, y in (("one-kernel, fp16 x 2", y_f), ("two-kernel, bf16 x 3", y_g)):
+            worst[name] = ((y[nodes].double() - ref).abs() / tol).max().item()
+        assert worst["one-kernel, fp16 x 2"] <= 1.0 and worst["two-kernel, bf16 x 3"] <= 1.0, worst
+        assert worst["one-kernel, fp16 x 2"] <= 2.0 * worst["two-kernel, bf16 x 3"] + 0.1, worst     # (the same accuracy class)
+        # the bar bites: most products dwarf the O(1) floor, and the outputs are far from zero on the scale of the bar
+        assert ((mass * bn_scale.abs() > 1e3).float().mean().item() > 0.3) and ((ref > 50 * tol).float().mean().item() > 0.1)
+
+
 @pytest.fixture(scope="module")
 def c3(cuda_device):
     from pna_amd import Graph

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 measurement set (one GPU call): GPU suite, smoke, the bench line (with its configs[4]-shape child leg), its rocprofv3 kernel trace,
-# the C5-shape kernel's FETCH / WRITE counters (the six-buffer kernel), the other BASELINE configs incl. the CIFAR10 net and the 5-tower
+# the C5-shape and C3 kernels' FETCH / WRITE / L2 counters (the fp16 x 2 kernel), the other BASELINE configs incl. the CIFAR10 net and the 5-tower
 # layers, the training step.
 #   gpurun --timeout 1500 -- 'bash tools/gpu_r05_final.sh'
 export TMPDIR=/tmp
@@ -26,8 +26,15 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum
   timeout 200 rocprofv3 --pmc $set --output-format csv -d $O/pmc/c5_$i -o k -- python $P/tools/fd_diag.py --pmc > $O/pmc_c5_$i.log 2>&1; echo "c5 pmc pass $i rc=$?"
 done
 unset FD_V FD_E FD_F
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_32B_sum"; do
+  i=$((i+1))
+  timeout 200 rocprofv3 --pmc $set --output-format csv -d $O/pmc3/c3_$i -o k -- python $P/tools/fd_diag.py --pmc > $O/pmc_c3_$i.log 2>&1; echo "c3 pmc pass $i rc=$?"
+done
 cd $P
 python tools/pmc_sum.py $O/pmc | tee $O/pmc_c5.txt
+python tools/pmc_sum.py $O/pmc3 | tee $O/pmc_c3.txt
+rm -rf $O/pmc3/*/*/*.db 2>/dev/null
 rm -rf $O/pmc/*/*/*.db 2>/dev/null
 timeout 500 python tools/bench_train.py > $O/train_step.json 2> $O/train_step.err; echo "train rc=$?"
 timeout 700 python tools/bench_configs.py > $O/configs.json 2> $O/configs.err; echo "configs rc=$?"
