@@ -720,7 +720,10 @@ def main():
                     "gather_read_bytes": gather_read, "read_only_frac": gather_read / tf / HBM_PEAK,
                     "edges_per_s_kernel_only": e_g / tf, "rows": rows_g, "edges": e_g,
                     "rest_rows_two_kernel_path_ms": fused["ms_rest_rows_two_kernel_path"],
-                    "mfma_frac_executed_flops": 2.0 * plan.NV * (4 * F) * F / tf / (MFMA_BF16_PEAK / 6),
+                    # (three fp16 partial products per multiply since round 5 -- six bf16 ones before; the f16 pipe's dense peak is the bf16 pipe's)
+                    "mfma_frac_executed_flops": 2.0 * plan.NV * (4 * F) * F / tf / (MFMA_BF16_PEAK / 3),
+                    "contraction_arith": "fp16 x 2: fp32 in / out, every operand as two fp16 terms behind a power-of-two row / column scale, three partial "
+                                         "products per multiply, fp32 accumulation (DESIGN.md 4.8.15; tower mode: bf16 x 3)",
                     "rest_rows_beside_kernel": fused["rest_rows_beside_kernel"], "spare_workgroups": fused["spare_workgroups"],
                     "tile_order": fused["tile_order"],
                     "full_grid": {"ms_per_launch": fused["ms_group_rows_kernel_full_grid"],

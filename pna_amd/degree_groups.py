@@ -425,7 +425,8 @@ def fused_tower_images(weight, F, row_scales, plan):
 
 def fused_images(weight, F, row_scales, plan, tower=False):
     """Packed images of W_D = sum_s s_s(D) W_s for pna_fused_degree_f32 (K in the kernel's chunk order), one per degree group,
-    cached on the weight like combined_images.  The combination and the bf16x3 split happen in the pack kernel
+    cached on the weight like combined_images.  The combination and the operand split (two fp16 terms behind per-column power-of-two
+    scales; tower images: three bf16 terms) happen in the pack kernel
     (pna_fused_degree_pack_f32) from the (G, S) matrix of the groups' scaler values."""
     N, G, S = weight.shape[0], plan.G, len(row_scales)
     key = ("fused", tower, weight._version, weight.data_ptr(), str(weight.device), tuple(weight.shape), F, plan.serial, G,
