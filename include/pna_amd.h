@@ -506,13 +506,14 @@ int pna_fused_simple_f32(const pna_fused_simple_args* args, pna_stream_t stream)
  *                                                                                             for rows one lane group walks alone)
  *   y[perm[v]]  = residual[perm[v]] + act((bias + W_D(v) . a[v]) * col_scale + col_shift)   (fp32 in and out, fp32 accumulation; see ARITHMETIC)
  *
- * ARITHMETIC (round 5; rounds 3-4: the bf16x3 arithmetic of pna_posttrans_x3_f32, which tower mode keeps).  Every statistic and every
+ * ARITHMETIC (round 5; rounds 3-4: the bf16x3 arithmetic of pna_posttrans_x3_f32).  Every statistic and every
  * weight enters the matrix pipe as TWO fp16 terms, x = h0 + h1 + r with h0 = fp16(x), h1 = fp16(x - h0) (round to nearest), |r| <= 2^-22 |x|,
  * and a product as three partial products (h1 w0, h0 w1, h0 w0; v_mfma_f32_16x16x32_f16, fp32 accumulation): half the matrix instructions
  * and two thirds of the weight stream of bf16x3's six products.  fp16's range is narrow, so the operands are first multiplied by powers of
  * two (exact): row v's statistics by 2^s(v), chosen in the kernel so that twice the row's largest message magnitude lies in
  * [2^13, 2^14), and column n of the weights by 2^t(n), chosen by pna_fused_degree_pack_f32 from the largest |W_D[n][k]| over k and over all images
- * (2^-t(n) rides in each image's 512-byte tail); the accumulator is multiplied by 2^-(s + t) in the bias' fma.  Measured against float64
+ * (2^-t(n) rides in each image's 512-byte tail); the accumulator is multiplied by 2^-(s + t) in the bias' fma.  In tower mode the row's
+ * scale also covers its own x_dst / h_self strips: it is lowered when they arrive, mid-row, and the accumulator with it (exact).  Measured against float64
  * on BASELINE configs[2] / [4] shapes: 1.25 x the error of bf16x3, a fifth of an fp32 GEMM's.  An element more than 2^28 below its row's
  * (column's) largest loses low bits, more than 2^38 below it vanishes -- absolute errors of 2^-39 of the row's largest product.
  * Non-finite operands: NaN propagates; a row that holds an infinite statistic (column: an infinite weight) is non-finite in every output

@@ -21,7 +21,7 @@
 // Contraction.  The statistics ARE the MFMA A operand: with K ordered (feature block, aggregator) -- the weight image is packed
 // to match -- chunk c = 4 fb + a multiplies the lane's eight values of aggregator a, split into TWO fp16 terms after a power-of-two
 // row scale (round 5, pna_x3_split.h: three partial products per multiply, fp32 accumulation, the accuracy of the bf16 x 3 form of
-// rounds 3-4 -- six products -- which tower mode keeps).  One combined
+// rounds 3-4 -- six products).  One combined
 // image per degree group, streamed through five LDS buffers by global_load_lds (four steps ahead, counted waits), one barrier per
 // chunk in the middle of the chunk's MFMA stream.  Workgroups of 4 wavefronts (64 rows), two per CU: while one multiplies, the
 // other gathers.  Tower mode (PNALayer with one tower) and the wide shapes (F or N up to 128) are template parameters below.
@@ -99,6 +99,10 @@ constexpr int buffers_for(int gp, int npan, int nc = 4, bool tower = true) {
 }
 constexpr int kChunkV = 3 * 4 * kNW;                      // 16-byte pieces of one chunk image, tower mode: [term][lane group][80 cols][8 k] bf16 x 3
 constexpr int kChunkVH = 2 * 4 * kNW;                     // ... of the layer proper (round 5): two fp16 terms (pna_x3_split.h)
+#ifndef FD_TOWER_H2
+#define FD_TOWER_H2 1                                     // tower mode on the fp16 x 2 arithmetic too (0: bf16 x 3, rounds 3-4)
+#endif
+constexpr bool kTowerH2 = FD_TOWER_H2 != 0;
 constexpr int kTailBytes = 512;                           // behind every fp16 image: 128 floats, 2^-s_n of the columns' power-of-two scales
 constexpr int kRing = 4;                                  // edge packets in the register ring
 constexpr int kNRes = kNT;                                // residual loads per lane (16 bytes each: 4 consecutive columns of one row)
@@ -228,9 +232,10 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
   // ARITHMETIC (round 5).  H2: statistics and weights as TWO fp16 terms each, three partial products per multiply (pna_x3_split.h):
   // half the MFMAs, two thirds of the weight stream and of the B-fragment reads of the bf16 x 3 form (six products), the same accuracy
   // class -- the row of statistics is scaled by a power of two so that its bound sits in [2^13, 2^14) (rscl below), the weights'
-  // columns likewise at pack time (their 2^-s in the image's tail), the accumulator is scaled back in the epilogue.  Tower mode keeps
-  // bf16 x 3: its node panels enter the contraction as they come from memory, mid-tile.
-  constexpr bool H2 = !TOWER;
+  // columns likewise at pack time (their 2^-s in the image's tail), the accumulator is scaled back in the epilogue.  Tower mode too
+  // (-DFD_TOWER_H2=0: bf16 x 3 as in rounds 3-4): its node panels enter the contraction as they come from memory, mid-tile, and the
+  // row's scale is lowered to cover them when they land (panel_rescale below).
+  constexpr bool H2 = !TOWER || kTowerH2;
   constexpr int NTERM = H2 ? 2 : 3, NPROD = H2 ? 3 : 6, NCC = H2 ? 4 : 3;
   using frag_t = std::conditional_t<H2, h8, bf8>;
   constexpr int CHV = NTERM * 4 * NWP;                    // 16-byte pieces of one step's image: [term][lane group][NWP cols][8 k]
@@ -558,11 +563,38 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
       }
     }
   };
+  // Tower mode on fp16 x 2: the node panels (the row's own x_dst and h strips) land mid-tile; once they have (end of step PWAIT) the
+  // row's scale is lowered to cover them too -- the smaller exponent of the two -- and the accumulator follows it down (a power of two
+  // <= 1: exact); the chunks from PWAIT + 1 on, statistics and panels alike, are split in the new units.
+  auto panel_rescale = [&]() __attribute__((always_inline)) {
+    float m = 0.f;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(m) : "v"(m), "v"(pk[p][l].x), "v"(pk[p][l].y));
+        asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(m) : "v"(m), "v"(pk[p][l].z), "v"(pk[p][l].w));
+      }
+    float o;
+    asm volatile("ds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"((unsigned)((lane ^ 16) * 4)), "v"(m) : "memory");
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(o));
+    asm volatile("ds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"((unsigned)((lane ^ 32) * 4)), "v"(m) : "memory");
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(o));
+    const int sN = min(sA, h2_scale_exp(__builtin_fminf(__builtin_fmaxf(m, 1e-30f), 3.4028234663852886e38f)));
+    const float fac = __builtin_ldexpf(1.0f, max(sN - sA, -126));
+#pragma unroll
+    for (int n = 0; n < NTA; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) asm("v_mul_f32 %0, %1, %2" : "=v"(acc[n][r]) : "v"(acc[n][r]), "v"(fac));
+    sA = sN;
+    rscl = __builtin_ldexpf(1.0f, sA);
+    runs = __builtin_ldexpf(1.0f, -sA);
+  };
   auto frag = [&](auto c_c, auto p_c) __attribute__((always_inline)) {
     constexpr int c = decltype(c_c)::value;               // chunk within the gather pass P
     constexpr int P = decltype(p_c)::value;
     if ((c > 0 || P > 0) && FD_ABL(1)) { asm volatile("" : "+v"(A[0])); return; }
-    if constexpr (!H2) if constexpr (c >= NC) {           // a node panel (tower mode): the strips are the A operand as they come
+    if constexpr (TOWER) if constexpr (c >= NC) {         // a node panel (tower mode): the strips are the A operand as they come
       constexpr int pc = c - NC;
       constexpr bool halfc = pc >= 2 * NFBF;
       constexpr int p = halfc ? 0 : pc / NFBF, fb = halfc ? NFBF : pc % NFBF;
@@ -572,8 +604,13 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
         if ((halfc || p == 0) && deg <= 0) lo4[j] = 0.f;     // (the x_dst panel: not for rows without in-edges)
         if (!halfc && p == 0 && deg <= 0) hi4[j] = 0.f;
       }
-      if (__builtin_amdgcn_ballot_w64(absmax8(lo4, hi4) == INFINITY) != 0) split8_inf(lo4, hi4, A[0], A[1], A[2]);
-      else split8(lo4, hi4, A[0], A[1], A[2]);
+      if constexpr (H2) {                                 // (in units of the row's scale, which panel_rescale() made cover these strips)
+        if (__builtin_amdgcn_ballot_w64(absmax8(lo4, hi4) == INFINITY) != 0) split8_h2_inf(lo4, hi4, rscl, A[0], A[1]);
+        else split8_h2(lo4, hi4, rscl, A[0], A[1]);
+      } else {
+        if (__builtin_amdgcn_ballot_w64(absmax8(lo4, hi4) == INFINITY) != 0) split8_inf(lo4, hi4, A[0], A[1], A[2]);
+        else split8(lo4, hi4, A[0], A[1], A[2]);
+      }
       return;
     }
     float v[8];
@@ -796,6 +833,7 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
 #undef FD_WAIT_B
 #undef FD_FENCE
     buf = buf == kNBuf - 1 ? 0 : buf + 1;
+    if constexpr (TOWER && H2 && c == PWAIT) panel_rescale();
     // the next chunk's fragment, once the chunk's last panel is issued (tower mode: the panel chunks continue the numbering)
     if constexpr (pan == NPAN - 1 && c + 1 < NC + NPC) frag(std::integral_constant<int, c + 1>{}, p_c);
     if constexpr (TOWER && c == PSTEP) issue_panels();
@@ -897,15 +935,21 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
 __device__ __forceinline__ float colmax_bound(unsigned bits) {   // (NaN / Inf / 0 maxima: any finite positive bound will do)
   return __builtin_fminf(__builtin_fmaxf(__builtin_bit_cast(float, bits), 1e-30f), 3.4028234663852886e38f);
 }
-__global__ void k_fused_colmax(const float* w_ref, long ldw, int N, int F, int S, const float* scale, int n_img, unsigned* colmax) {
-  const int K = 4 * F;
-  const long total = (long)n_img * N * K;
+__global__ void k_fused_colmax(const float* w_ref, long ldw, int N, int F, int S, const float* scale, int n_img, unsigned* colmax, int tower) {
+  const int K = tower ? 5 * F : 4 * F;                    // columns of a scaler block
+  const int KC = tower ? 6 * F : 4 * F;                   // weights the images hold per output column: + the x_dst panel's sums (tower)
+  const long total = (long)n_img * N * KC;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int col = (int)(i % K);
-    const int n = (int)((i / K) % N), im = (int)(i / ((long)K * N));
-    const float* row = w_ref + (long)n * ldw + col;
-    float w = scale ? scale[(long)im * S] * row[0] : row[0];
-    for (int s = 1; s < S; ++s) w = w + (scale ? scale[(long)im * S + s] * row[(long)s * K] : row[(long)s * K]);
+    const int col = (int)(i % KC);
+    const int n = (int)((i / KC) % N), im = (int)(i / ((long)KC * N));
+    auto combined = [&](int c_) -> float {                // (k_pack_fused_degree's, op for op)
+      const float* row = w_ref + (long)n * ldw + c_;
+      float w = scale ? scale[(long)im * S] * row[0] : row[0];
+      for (int s = 1; s < S; ++s) w = w + (scale ? scale[(long)im * S + s] * row[(long)s * K] : row[(long)s * K]);
+      return w;
+    };
+    const int f = col - 5 * F;
+    const float w = col < 5 * F ? combined(col) : (combined(f) + combined(F + f)) + combined(2 * F + f);
     atomicMax(colmax + n, __builtin_bit_cast(unsigned, __builtin_fabsf(w)));      // (|w| as bits: ordered like the floats; NaN above all)
   }
 }
@@ -964,7 +1008,8 @@ template <int NFBF, bool HALF, bool DUMP, bool TOWER = false, int GP = 1, int NP
 int launch(const FDArgs& g, int wgs, hipStream_t st) {
   constexpr int NWP = NPAN == 1 ? kNW : 64;
   constexpr int NBUF = buffers_for(GP, NPAN, 4 * NFBF + (HALF ? 2 : 0), TOWER), WAVES = waves_for(GP, NPAN);
-  constexpr int NTERM = TOWER ? 3 : 2, NCC = TOWER ? 3 : 4;                                                  // (the kernel's H2 = !TOWER)
+  constexpr bool H2 = !TOWER || kTowerH2;                                                                      // (the kernel's)
+  constexpr int NTERM = H2 ? 2 : 3, NCC = H2 ? 4 : 3;
   const size_t lds = (size_t)NBUF * (NTERM * 4 * NWP) * 16 + (size_t)(NCC * NWP * NPAN) * sizeof(float) + 16;   // (+ the two hand-over words of the dynamic schedule)
   auto* fn = k_fused_degree<NFBF, HALF, DUMP, TOWER, !DUMP && !TOWER, GP, NPAN, WAVES, NBUF>;
   if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
@@ -1010,7 +1055,25 @@ extern "C" int64_t pna_fused_degree_image_bytes(int32_t F, int32_t N) {
 
 static int64_t tower_image_bytes(int F, int N) {
   if (F > 80 || N > kNW || pna_fused_degree_image_bytes(F, N) == 0 || shape_full(F) != 2) return 0;
-  return (int64_t)(shape_chunks(F) + 2 * shape_full(F) + (shape_half(F) ? 1 : 0)) * kChunkV * 16;
+  return (int64_t)(shape_chunks(F) + 2 * shape_full(F) + (shape_half(F) ? 1 : 0)) * (kTowerH2 ? kChunkVH : kChunkV) * 16 + (kTowerH2 ? kTailBytes : 0);
+}
+// column maxima -> fp16 x 2 images -> tails (stream-ordered; the first image's tail is the maxima's scratch until k_fused_tails)
+static int pack_h2(const char* who, const float* w_ref, int64_t ldw, int N, int F, int S, const float* scale, int n_img, void* img, int64_t stride,
+                   int tower, int nwp, int npan, hipStream_t st) {
+  const int64_t payload = stride - kTailBytes;
+  const int64_t elems = payload / 2 * n_img;
+  const int blocks = (int)((elems + 255) / 256 > 8192 ? 8192 : (elems + 255) / 256);
+  unsigned* const colmax = reinterpret_cast<unsigned*>((unsigned char*)img + payload);
+  if (hipMemsetAsync(colmax, 0, kTailBytes, st) != hipSuccess) return pna_set_error(PNA_E_LAUNCH, who);
+  const int64_t welems = (int64_t)n_img * N * (tower ? 6 : 4) * F;
+  hipLaunchKernelGGL(k_fused_colmax, dim3((unsigned)((welems + 255) / 256 > 4096 ? 4096 : (welems + 255) / 256)), dim3(256), 0, st, w_ref, (long)ldw, N, F,
+                     S, scale, n_img, colmax, tower);
+  hipLaunchKernelGGL(k_pack_fused_degree, dim3(blocks), dim3(256), 0, st, w_ref, (long)ldw, N, F, S, scale, n_img,
+                     (unsigned short*)img, tower, nwp, npan, 2, (const unsigned*)colmax, (long)(stride / 2));
+  hipLaunchKernelGGL(k_fused_tails, dim3(1), dim3(128), 0, st, (unsigned char*)img, (long)payload, (long)stride, n_img, N);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
+  return PNA_OK;
 }
 extern "C" int64_t pna_fused_tower_image_bytes(int32_t F, int32_t N) { return tower_image_bytes(F, N); }
 
@@ -1019,6 +1082,8 @@ extern "C" int pna_fused_tower_pack_f32(const float* w_ref, int64_t ldw, int32_t
   if (!w_ref || !img || n_img < 1 || n_scaler < 1 || n_scaler > PNA_MAX_SCALER || tower_image_bytes(F, N) == 0 ||
       ldw < (int64_t)n_scaler * 5 * F || (n_scaler > 1 && !scale))
     return pna_set_error(PNA_E_INVALID, "pna_fused_tower_pack_f32: bad arguments (49 <= F <= 80, 4 <= N <= 80, ldw >= n_scaler * 5 F, scale required for n_scaler > 1)");
+  if (kTowerH2) return pack_h2("pna_fused_tower_pack_f32: hipMemsetAsync failed", w_ref, ldw, N, F, n_scaler, scale, n_img, img, tower_image_bytes(F, N), 1, kNW, 1,
+                               (hipStream_t)stream);
   const int64_t elems = tower_image_bytes(F, N) / 2 * n_img;
   const int blocks = (int)((elems + 255) / 256 > 8192 ? 8192 : (elems + 255) / 256);
   hipLaunchKernelGGL(k_pack_fused_degree, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ref, (long)ldw, N, F, n_scaler, scale, n_img,
@@ -1033,22 +1098,9 @@ extern "C" int pna_fused_degree_pack_f32(const float* w_ref, int64_t ldw, int32_
   if (!w_ref || !img || n_img < 1 || n_scaler < 1 || n_scaler > PNA_MAX_SCALER || pna_fused_degree_image_bytes(F, N) == 0 ||
       ldw < (int64_t)n_scaler * 4 * F || (n_scaler > 1 && !scale))
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_pack_f32: bad arguments (F in 17..80 or 113..128, N in 4..128, N > 80 needs F in 49..64 or 113..128; scale required for n_scaler > 1)");
-  const int64_t stride = pna_fused_degree_image_bytes(F, N), payload = stride - kTailBytes;
-  const int64_t elems = payload / 2 * n_img;
-  const int blocks = (int)((elems + 255) / 256 > 8192 ? 8192 : (elems + 255) / 256);
   const bool wide = shape_wide_n(N);
-  hipStream_t st = (hipStream_t)stream;
-  unsigned* const colmax = reinterpret_cast<unsigned*>((unsigned char*)img + payload);       // the first image's tail: scratch until k_fused_tails
-  if (hipMemsetAsync(colmax, 0, kTailBytes, st) != hipSuccess) return pna_set_error(PNA_E_LAUNCH, "pna_fused_degree_pack_f32: hipMemsetAsync failed");
-  const int64_t welems = (int64_t)n_img * N * 4 * F;
-  hipLaunchKernelGGL(k_fused_colmax, dim3((unsigned)((welems + 255) / 256 > 4096 ? 4096 : (welems + 255) / 256)), dim3(256), 0, st, w_ref, (long)ldw, N, F,
-                     n_scaler, scale, n_img, colmax);
-  hipLaunchKernelGGL(k_pack_fused_degree, dim3(blocks), dim3(256), 0, st, w_ref, (long)ldw, N, F, n_scaler, scale, n_img,
-                     (unsigned short*)img, 0, wide ? 64 : kNW, wide ? 2 : 1, 2, (const unsigned*)colmax, (long)(stride / 2));
-  hipLaunchKernelGGL(k_fused_tails, dim3(1), dim3(128), 0, st, (unsigned char*)img, (long)payload, (long)stride, n_img, N);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
-  return PNA_OK;
+  return pack_h2("pna_fused_degree_pack_f32: hipMemsetAsync failed", w_ref, ldw, N, F, n_scaler, scale, n_img, img, pna_fused_degree_image_bytes(F, N), 0,
+                 wide ? 64 : kNW, wide ? 2 : 1, (hipStream_t)stream);
 }
 
 extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t stream) {

@@ -442,6 +442,42 @@ def test_tower_mode_rows_vs_float64_and_100_identical_runs_at_full_size(cuda_dev
     assert worst <= 1.0, worst
 
 
+@pytest.mark.parametrize("F", [75, 64])
+def test_tower_mode_fp16_scales_over_a_wide_dynamic_range(cuda_device, F):
+    """Tower mode on the fp16 x 2 contraction: the row's scale is set by its neighbours' statistics first and LOWERED mid-tile when the row's
+    own x_dst / h strips land (panel_rescale in pna_fused_degree.hip) -- with node rows spread over 16 decades the two bounds differ by
+    many powers of two either way on most rows.  The one-kernel layer against the two-kernel grouped path (same statistics; bf16 x 3
+    contraction, no scales), per element, normalised by the ROW's largest output: 2e-5 (a lost second term would be 5e-4, a wrong
+    scale a factor of two)."""
+    from pna_amd import Graph, degree_groups as DG, functional as PF
+    from pna_amd.dgl.pna_layer import PNALayer
+    from pna_amd.synth import powerlaw_graph
+    V, E = 150_000, 1_200_000
+    src, dst = powerlaw_graph(V, E, seed=13, device=cuda_device)
+    g = Graph(src, dst, V)
+    torch.manual_seed(12)
+    layer = PNALayer(F, F, "mean max min std", "identity amplification attenuation", {"log": torch.tensor(2.3)}, 0.0, True, True,
+                     towers=1, divide_input=False, residual=True).to(cuda_device).eval()
+    gen = torch.Generator(device=cuda_device).manual_seed(3)
+    h = _features(V, F, cuda_device, seed=8)
+    snorm = torch.rand(V, 1, device=cuda_device, generator=gen) + 0.5
+    with torch.no_grad():
+        layer.towers[0].batchnorm_h.running_mean.normal_()
+        layer.towers[0].batchnorm_h.running_var.uniform_(0.5, 2.0)
+        h.mul_(10.0 ** torch.empty(V, 1, device=cuda_device).uniform_(-8, 8, generator=gen))
+        with _Knobs(fused=True, small_graphs=True):
+            assert PF.tower_layer_degree_fused_applies(layer, g, h)
+            y_f = layer(g, h, None, snorm)
+        with _Knobs(fused=False, small_graphs=True):
+            assert PF.tower_layer_degree_grouped_applies(layer, g, h)
+            y_g = layer(g, h, None, snorm)
+    assert torch.isfinite(y_g).all() and torch.isfinite(y_f).all()
+    scale = y_g.abs().amax(1, keepdim=True)
+    ratio = ((y_f - y_g).abs() / (2e-5 * scale + 1e-5)).max().item()
+    assert ratio <= 1.0, ratio
+    assert (scale > 1e3).float().mean().item() > 0.3            # (the bar bites: a third of the rows are far above the O(1) floor)
+
+
 def test_source_table_beyond_4_gib_and_2_pow_24_rows(cuda_device):
     """VERDICT r3 item 3 / BASELINE configs[4] at 8 ranks: a shard's [local | halo] table has > 2^24 rows and > 4 GiB, which round 3's
     32-bit byte offsets (__umul24) could not address -- that configuration fell to the two-kernel path.  Here: the same graph twice,
