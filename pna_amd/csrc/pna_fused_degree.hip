@@ -177,13 +177,33 @@ __device__ __forceinline__ void wait_slot(f4 (&s)[NL], int& id) {
 }
 // one message into the running statistics of one feature: the production fold as single VALU instructions
 __device__ __forceinline__ void fold1(float& S, float& Q, float& MX, float& MN, float m, float ms) {
-  float s1, p1, q1, x1, n1;
-  asm volatile("v_add_f32 %0, %1, %2" : "=v"(s1) : "v"(S), "v"(ms));
-  asm volatile("v_mul_f32 %0, %1, %1" : "=v"(p1) : "v"(ms));
-  asm volatile("v_add_f32 %0, %1, %2" : "=v"(q1) : "v"(Q), "v"(p1));
-  asm volatile("v_max_f32 %0, %1, %2" : "=v"(x1) : "v"(MX), "v"(m));
-  asm volatile("v_min_f32 %0, %1, %2" : "=v"(n1) : "v"(MN), "v"(m));
-  S = s1; Q = q1; MX = x1; MN = n1;
+  // ONE asm statement (round 5, last): between two inline-asm statements of which the second reads a register the first wrote, hipcc for
+  // gfx940+ inserts an `s_nop 0` -- it must assume the first ended in a dst_sel write (the forwarding hazard of SDWA / op_sel
+  // destinations), and it does not count other inline-asm statements in between as wait states.  Statement by statement this fold
+  // paid one wasted issue slot per message and feature (v_mul -> v_add), the operand split three per pair of values, the means' division
+  // two per value: ~700 of the ~6 000 instructions a wavefront issues per tile, in a kernel whose wide shapes are bound by instruction
+  // issue.  Inside one statement the instructions are ours: plain VALU results forward without wait states.
+  float p1;
+  asm volatile("v_mul_f32 %4, %6, %6\n\t"
+               "v_add_f32 %0, %0, %6\n\t"
+               "v_add_f32 %1, %1, %4\n\t"
+               "v_max_f32 %2, %2, %5\n\t"
+               "v_min_f32 %3, %3, %5"
+               : "+v"(S), "+v"(Q), "+v"(MX), "+v"(MN), "=&v"(p1) : "v"(m), "v"(ms));
+}
+// The four values of one 16-byte load in ONE statement (the product temporaries of consecutive one-value statements land in the same
+// register, which hipcc reads as a dependency: a nop per value again).  S / Q / MX / MN: the four features' running statistics.
+__device__ __forceinline__ void fold4(float* S, float* Q, float* MX, float* MN, const f4 m, const f4 ms) {
+  float p0, p1, p2, p3;
+  asm volatile("v_mul_f32 %16, %24, %24\n\tv_mul_f32 %17, %25, %25\n\tv_mul_f32 %18, %26, %26\n\tv_mul_f32 %19, %27, %27\n\t"
+               "v_add_f32 %0, %0, %24\n\tv_add_f32 %1, %1, %25\n\tv_add_f32 %2, %2, %26\n\tv_add_f32 %3, %3, %27\n\t"
+               "v_add_f32 %4, %4, %16\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %18\n\tv_add_f32 %7, %7, %19\n\t"
+               "v_max_f32 %8, %8, %20\n\tv_max_f32 %9, %9, %21\n\tv_max_f32 %10, %10, %22\n\tv_max_f32 %11, %11, %23\n\t"
+               "v_min_f32 %12, %12, %20\n\tv_min_f32 %13, %13, %21\n\tv_min_f32 %14, %14, %22\n\tv_min_f32 %15, %15, %23"
+               : "+v"(S[0]), "+v"(S[1]), "+v"(S[2]), "+v"(S[3]), "+v"(Q[0]), "+v"(Q[1]), "+v"(Q[2]), "+v"(Q[3]),
+                 "+v"(MX[0]), "+v"(MX[1]), "+v"(MX[2]), "+v"(MX[3]), "+v"(MN[0]), "+v"(MN[1]), "+v"(MN[2]), "+v"(MN[3]),
+                 "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3)
+               : "v"(m.x), "v"(m.y), "v"(m.z), "v"(m.w), "v"(ms.x), "v"(ms.y), "v"(ms.z), "v"(ms.w));
 }
 
 #ifdef PNA_AMD_EXPERIMENTS
@@ -393,13 +413,12 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
       constexpr int j = decltype(jc)::value;
       if (FD_ABL(2)) { asm volatile("" : "+v"(sl[j][0])); return; }
 #pragma unroll
-      for (int l = 0; l < NL; ++l)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int fb = l >> 1, c = (l & 1) * 4 + k;
-          const float m = sl[j][l][k];
-          fold1(S_[fb][c], Q_[fb][c], MX[fb][c], MN[fb][c], m, on ? m : 0.f);
-        }
+      for (int l = 0; l < NL; ++l) {
+        const int fb = l >> 1, c0 = (l & 1) * 4;
+        const f4 m = sl[j][l];
+        const f4 ms = on ? m : (f4){0.f, 0.f, 0.f, 0.f};
+        fold4(&S_[fb][c0], &Q_[fb][c0], &MX[fb][c0], &MN[fb][c0], m, ms);
+      }
     };
     using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
     using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
@@ -463,8 +482,10 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
 #pragma unroll
       for (int fb = 0; fb < NB; ++fb)
 #pragma unroll
-        for (int j = 0; j < ((HALF && fb == NFBF) ? 4 : 8); ++j)
-          asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(m) : "v"(m), "v"(MX[fb][j]), "v"(MN[fb][j]));
+        for (int j = 0; j < ((HALF && fb == NFBF) ? 4 : 8); j += 4)                     // (one statement per four features: see fold1)
+          asm("v_max3_f32 %0, %0, |%1|, |%2|\n\tv_max3_f32 %0, %0, |%3|, |%4|\n\tv_max3_f32 %0, %0, |%5|, |%6|\n\tv_max3_f32 %0, %0, |%7|, |%8|"
+              : "+v"(m) : "v"(MX[fb][j]), "v"(MN[fb][j]), "v"(MX[fb][j + 1]), "v"(MN[fb][j + 1]), "v"(MX[fb][j + 2]), "v"(MN[fb][j + 2]),
+                "v"(MX[fb][j + 3]), "v"(MN[fb][j + 3]));
       float o;
       asm volatile("ds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"((unsigned)((lane ^ 16) * 4)), "v"(m) : "memory");
       asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(o));
@@ -534,18 +555,90 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
     return o;
   };
   auto div_fast = [&](float a, float D_, float invD_) __attribute__((always_inline)) -> float {   // div_rn without its NaN / Inf fall-back
-    const float q0 = mul1(a, invD_);
-    return fma1(fnma1(D_, q0, a), invD_, q0);
+    float q0, t, r;                                       // (one statement: see fold1)
+    asm("v_mul_f32 %0, %3, %5\n\t"
+        "v_fma_f32 %1, -%4, %0, %3\n\t"
+        "v_fma_f32 %2, %1, %5, %0"
+        : "=&v"(q0), "=&v"(t), "=&v"(r) : "v"(a), "v"(D_), "v"(invD_));
+    return r;
+  };
+  // var + 1e-5 of the std: mean = s / D, msq = q / D (div_fast twice), max(msq - mean * mean, 0) + 1e-5 -- the same ten instructions, one statement
+  auto var_eps_fast = [&](float s_, float q_, float D_, float invD_) __attribute__((always_inline)) -> float {
+    float a0, a1, mean, b0, b1, msq, r;
+    asm("v_mul_f32 %0, %7, %10\n\t"
+        "v_mul_f32 %3, %8, %10\n\t"
+        "v_fma_f32 %1, -%9, %0, %7\n\t"
+        "v_fma_f32 %4, -%9, %3, %8\n\t"
+        "v_fma_f32 %2, %1, %10, %0\n\t"
+        "v_fma_f32 %5, %4, %10, %3\n\t"
+        "v_mul_f32 %6, %2, %2\n\t"
+        "v_sub_f32 %6, %5, %6\n\t"
+        "v_max_f32 %6, %6, 0\n\t"
+        "v_add_f32 %6, %6, %11"
+        : "=&v"(a0), "=&v"(a1), "=&v"(mean), "=&v"(b0), "=&v"(b1), "=&v"(msq), "=&v"(r) : "v"(s_), "v"(q_), "v"(D_), "v"(invD_), "v"(1e-5f));
+    return r;
+  };
+  // four means / two variances per statement (consecutive one-value statements share scratch registers: a nop each, see fold1)
+  auto div_fast4 = [&](const float* a, float D_, float invD_, float* r) __attribute__((always_inline)) {
+    float q0, q1, q2, q3, t0, t1, t2, t3;
+    asm("v_mul_f32 %4, %12, %17\n\tv_mul_f32 %5, %13, %17\n\tv_mul_f32 %6, %14, %17\n\tv_mul_f32 %7, %15, %17\n\t"
+        "v_fma_f32 %8, -%16, %4, %12\n\tv_fma_f32 %9, -%16, %5, %13\n\tv_fma_f32 %10, -%16, %6, %14\n\tv_fma_f32 %11, -%16, %7, %15\n\t"
+        "v_fma_f32 %0, %8, %17, %4\n\tv_fma_f32 %1, %9, %17, %5\n\tv_fma_f32 %2, %10, %17, %6\n\tv_fma_f32 %3, %11, %17, %7"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(D_), "v"(invD_));
+  };
+  auto var_eps_fast2 = [&](const float* s_, const float* q_, float D_, float invD_, float* r) __attribute__((always_inline)) {
+    float a0, a1, m0, b0, b1, q0, c0, c1, m1, d0, d1, q1;
+    asm("v_mul_f32 %2, %14, %19\n\tv_mul_f32 %5, %16, %19\n\tv_mul_f32 %8, %15, %19\n\tv_mul_f32 %11, %17, %19\n\t"
+        "v_fma_f32 %3, -%18, %2, %14\n\tv_fma_f32 %6, -%18, %5, %16\n\tv_fma_f32 %9, -%18, %8, %15\n\tv_fma_f32 %12, -%18, %11, %17\n\t"
+        "v_fma_f32 %4, %3, %19, %2\n\tv_fma_f32 %7, %6, %19, %5\n\tv_fma_f32 %10, %9, %19, %8\n\tv_fma_f32 %13, %12, %19, %11\n\t"
+        "v_mul_f32 %0, %4, %4\n\tv_mul_f32 %1, %10, %10\n\t"
+        "v_sub_f32 %0, %7, %0\n\tv_sub_f32 %1, %13, %1\n\t"
+        "v_max_f32 %0, %0, 0\n\tv_max_f32 %1, %1, 0\n\t"
+        "v_add_f32 %0, %0, %20\n\tv_add_f32 %1, %1, %20"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(a0), "=&v"(a1), "=&v"(m0), "=&v"(b0), "=&v"(b1), "=&v"(q0), "=&v"(c0), "=&v"(c1), "=&v"(m1), "=&v"(d0),
+          "=&v"(d1), "=&v"(q1)
+        : "v"(s_[0]), "v"(s_[1]), "v"(q_[0]), "v"(q_[1]), "v"(D_), "v"(invD_), "v"(1e-5f));
+  };
+  // the eight statistics of chunk c of a FAST tile: stat_fast value by value, in wider statements
+  auto stats_fast8 = [&](auto c_c, float* v) __attribute__((always_inline)) {
+    constexpr int c = decltype(c_c)::value;
+    const float D = (float)deg, invD = 1.0f / D;
+    auto stds = [&](int fb, int j0, int n, float* o) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < n; j += 2) {
+        float x[2];
+        var_eps_fast2(&S_[fb][j0 + j], &Q_[fb][j0 + j], D, invD, x);
+        o[j] = sqrt_rn(x[0]); o[j + 1] = sqrt_rn(x[1]);
+      }
+    };
+    if constexpr (c < 4 * NFBF) {
+      constexpr int fb = c / 4, a = c % 4;
+      if constexpr (a == 0) { div_fast4(&S_[fb][0], D, invD, v); div_fast4(&S_[fb][4], D, invD, v + 4); }
+      else if constexpr (a == 3) stds(fb, 0, 8, v);
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = a == 1 ? MX[fb][j] : MN[fb][j];
+      }
+    } else {                                              // the half block: (mean | max) then (min | std) of its four features
+      constexpr int fb = NFBF, hh = c - 4 * NFBF;
+      if constexpr (hh == 0) {
+        div_fast4(&S_[fb][0], D, invD, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 + j] = MX[fb][j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = MN[fb][j];
+        stds(fb, 0, 4, v + 4);
+      }
+    }
   };
   auto stat_fast = [&](int fb, int j, int a) __attribute__((always_inline)) -> float {
     const float D = (float)deg, invD = 1.0f / D;
     if (a == 1) return MX[fb][j];
     if (a == 2) return MN[fb][j];
     if (a == 0) return div_fast(S_[fb][j], D, invD);
-    const float mean = div_fast(S_[fb][j], D, invD), msq = div_fast(Q_[fb][j], D, invD);
-    float var = sub1(msq, mul1(mean, mean));
-    var = pna_dev::vmax(var, 0.f);
-    return sqrt_rn(add1(var, 1e-5f));
+    return sqrt_rn(var_eps_fast(S_[fb][j], Q_[fb][j], D, invD));
   };
   f4 pk[2][NL];                                           // tower mode: strips of x_dst (0) and h (1) of the row's own node
   constexpr int NPL = 2 * NL + 1;                         // loads of the panel request: the strips, the rows' factors
@@ -615,12 +708,13 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
     }
     float v[8];
     if (!(TOWER && HALF) && fast_tile) {
+      if constexpr (c < NC) stats_fast8(c_c, v);           // (c >= NC: tower panel chunks, handled above)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         int fb, sj, a, f;
         if constexpr (c < 4 * NFBF) { fb = c / 4; sj = j; a = c % 4; f = feat0(P, fb) + j; }
         else { fb = NFBF; sj = j & 3; a = 2 * (c - 4 * NFBF) + (j >> 2); f = feat0(P, fb) + (j & 3); }
-        v[j] = stat_fast(fb, sj, a);
+        (void)sj;
         if constexpr (DUMP) {
           if (!is_dup(P, fb, f)) g.agg_out[(size_t)((t * kWaves + wave) * 16 + li) * g.ld_agg + a * g.F + f] = v[j];
         }

@@ -111,13 +111,20 @@ __device__ __forceinline__ float mul_1(float a, float b) { float r; asm("v_mul_f
 // callers: hipcc would pack the chains into v_pk_*_f32 with op_sel swizzles.
 __device__ __forceinline__ void split8_h2(const f4 lo, const f4 hi, float scl, h8& t0, h8& t1) {
   const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  // ONE statement for the eight values (see fold1 in pna_fused_degree.hip: statement by statement hipcc puts an `s_nop 0` behind every
+  // instruction whose result -- or whose scratch register -- the next statement touches: five per pair of values here)
   u4 p0, p1;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float xe = mul_1(x[2 * j], scl), xo = mul_1(x[2 * j + 1], scl);
-    p0[j] = cvt_pk_h(xe, xo);
-    p1[j] = cvt_pk_h(sub_1(xe, h_lo(p0[j])), sub_1(xo, h_hi(p0[j])));
-  }
+  float a, b, c, d;
+#define PNA_H2_PAIR(P0, P1, XE, XO)                                                                                   \
+  "v_mul_f32 %8, " XE ", %20\n\tv_mul_f32 %9, " XO ", %20\n\tv_cvt_pk_f16_f32 " P0 ", %8, %9\n\t"                   \
+  "v_cvt_f32_f16 %10, " P0 "\n\tv_cvt_f32_f16_sdwa %11, " P0 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t" \
+  "v_sub_f32 %8, %8, %10\n\tv_sub_f32 %9, %9, %11\n\tv_cvt_pk_f16_f32 " P1 ", %8, %9"
+  asm(PNA_H2_PAIR("%0", "%4", "%12", "%13") "\n\t" PNA_H2_PAIR("%1", "%5", "%14", "%15") "\n\t"
+      PNA_H2_PAIR("%2", "%6", "%16", "%17") "\n\t" PNA_H2_PAIR("%3", "%7", "%18", "%19")
+      : "=&v"(p0[0]), "=&v"(p0[1]), "=&v"(p0[2]), "=&v"(p0[3]), "=&v"(p1[0]), "=&v"(p1[1]), "=&v"(p1[2]), "=&v"(p1[3]),
+        "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(scl));
+#undef PNA_H2_PAIR
   t0 = __builtin_bit_cast(h8, p0); t1 = __builtin_bit_cast(h8, p1);
 }
 // The same for a fragment that holds +-Inf: an infinite element is carried by its LOWER term alone (t0 = 0, t1 = +-Inf): of the three

@@ -68,6 +68,10 @@ with torch.no_grad():
     if os.environ.get("FD_PARITY"):                          # the kernel's rows against the two-kernel grouped path (same statistics, same weights)
         y1 = call.group_rows().clone()
         live = plan.perm[plan.perm >= 0].long()
+        bits = y1[live].contiguous().view(torch.int32).long()             # a checksum of the output BITS: equal between two builds = bit-identical results
+        w = torch.arange(1, bits.numel() + 1, device=dev).view_as(bits) % 1000003
+        out["output_bits_checksum"] = [int(bits.sum()), int((bits * w).sum())]
+        print("output bits checksum:", out["output_bits_checksum"], flush=True)
         DG.FUSED = False
         y2 = layer(g, h)
         DG.FUSED = True
