@@ -175,24 +175,13 @@ __device__ __forceinline__ void wait_slot(f4 (&s)[NL], int& id) {
   else
     asm volatile("s_waitcnt vmcnt(%7)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(id) : "n"(N) : "memory");
 }
-// one message into the running statistics of one feature: the production fold as single VALU instructions
-__device__ __forceinline__ void fold1(float& S, float& Q, float& MX, float& MN, float m, float ms) {
-  // ONE asm statement (round 5, last): between two inline-asm statements of which the second reads a register the first wrote, hipcc for
-  // gfx940+ inserts an `s_nop 0` -- it must assume the first ended in a dst_sel write (the forwarding hazard of SDWA / op_sel
-  // destinations), and it does not count other inline-asm statements in between as wait states.  Statement by statement this fold
-  // paid one wasted issue slot per message and feature (v_mul -> v_add), the operand split three per pair of values, the means' division
-  // two per value: ~700 of the ~6 000 instructions a wavefront issues per tile, in a kernel whose wide shapes are bound by instruction
-  // issue.  Inside one statement the instructions are ours: plain VALU results forward without wait states.
-  float p1;
-  asm volatile("v_mul_f32 %4, %6, %6\n\t"
-               "v_add_f32 %0, %0, %6\n\t"
-               "v_add_f32 %1, %1, %4\n\t"
-               "v_max_f32 %2, %2, %5\n\t"
-               "v_min_f32 %3, %3, %5"
-               : "+v"(S), "+v"(Q), "+v"(MX), "+v"(MN), "=&v"(p1) : "v"(m), "v"(ms));
-}
-// The four values of one 16-byte load in ONE statement (the product temporaries of consecutive one-value statements land in the same
-// register, which hipcc reads as a dependency: a nop per value again).  S / Q / MX / MN: the four features' running statistics.
+// the four messages of one 16-byte load into the running statistics of four features: the production fold as single VALU instructions.
+// ONE asm statement per 16-byte load (round 5, last): between two inline-asm statements of which the second reads a register the first wrote, hipcc for
+// gfx940+ inserts an `s_nop 0` -- it must assume the first ended in a dst_sel write (the forwarding hazard of SDWA / op_sel
+// destinations), and it does not count other inline-asm statements in between as wait states.  Statement by statement this fold
+// paid one wasted issue slot per message and feature (v_mul -> v_add), the operand split three per pair of values, the means' division
+// two per value: ~700 of the ~6 000 instructions a wavefront issues per tile, in a kernel whose wide shapes are bound by instruction
+// issue.  Inside one statement the instructions are ours: plain VALU results forward without wait states.
 __device__ __forceinline__ void fold4(float* S, float* Q, float* MX, float* MN, const f4 m, const f4 ms) {
   float p0, p1, p2, p3;
   asm volatile("v_mul_f32 %16, %24, %24\n\tv_mul_f32 %17, %25, %25\n\tv_mul_f32 %18, %26, %26\n\tv_mul_f32 %19, %27, %27\n\t"
@@ -482,7 +471,7 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
 #pragma unroll
       for (int fb = 0; fb < NB; ++fb)
 #pragma unroll
-        for (int j = 0; j < ((HALF && fb == NFBF) ? 4 : 8); j += 4)                     // (one statement per four features: see fold1)
+        for (int j = 0; j < ((HALF && fb == NFBF) ? 4 : 8); j += 4)                     // (one statement per four features: see fold4)
           asm("v_max3_f32 %0, %0, |%1|, |%2|\n\tv_max3_f32 %0, %0, |%3|, |%4|\n\tv_max3_f32 %0, %0, |%5|, |%6|\n\tv_max3_f32 %0, %0, |%7|, |%8|"
               : "+v"(m) : "v"(MX[fb][j]), "v"(MN[fb][j]), "v"(MX[fb][j + 1]), "v"(MN[fb][j + 1]), "v"(MX[fb][j + 2]), "v"(MN[fb][j + 2]),
                 "v"(MX[fb][j + 3]), "v"(MN[fb][j + 3]));
@@ -554,31 +543,9 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
     o = e2 > 0.f ? rp2 : o;
     return o;
   };
-  auto div_fast = [&](float a, float D_, float invD_) __attribute__((always_inline)) -> float {   // div_rn without its NaN / Inf fall-back
-    float q0, t, r;                                       // (one statement: see fold1)
-    asm("v_mul_f32 %0, %3, %5\n\t"
-        "v_fma_f32 %1, -%4, %0, %3\n\t"
-        "v_fma_f32 %2, %1, %5, %0"
-        : "=&v"(q0), "=&v"(t), "=&v"(r) : "v"(a), "v"(D_), "v"(invD_));
-    return r;
-  };
-  // var + 1e-5 of the std: mean = s / D, msq = q / D (div_fast twice), max(msq - mean * mean, 0) + 1e-5 -- the same ten instructions, one statement
-  auto var_eps_fast = [&](float s_, float q_, float D_, float invD_) __attribute__((always_inline)) -> float {
-    float a0, a1, mean, b0, b1, msq, r;
-    asm("v_mul_f32 %0, %7, %10\n\t"
-        "v_mul_f32 %3, %8, %10\n\t"
-        "v_fma_f32 %1, -%9, %0, %7\n\t"
-        "v_fma_f32 %4, -%9, %3, %8\n\t"
-        "v_fma_f32 %2, %1, %10, %0\n\t"
-        "v_fma_f32 %5, %4, %10, %3\n\t"
-        "v_mul_f32 %6, %2, %2\n\t"
-        "v_sub_f32 %6, %5, %6\n\t"
-        "v_max_f32 %6, %6, 0\n\t"
-        "v_add_f32 %6, %6, %11"
-        : "=&v"(a0), "=&v"(a1), "=&v"(mean), "=&v"(b0), "=&v"(b1), "=&v"(msq), "=&v"(r) : "v"(s_), "v"(q_), "v"(D_), "v"(invD_), "v"(1e-5f));
-    return r;
-  };
-  // four means / two variances per statement (consecutive one-value statements share scratch registers: a nop each, see fold1)
+  // div_rn without its NaN / Inf fall-back (q0 = a / D rounded, one Newton step), and var + 1e-5 of the std: mean = s / D, msq = q / D,
+  // max(msq - mean * mean, 0) + 1e-5 -- stat()'s instructions for a FAST tile, several values per asm statement (see fold4):
+  // four means / two variances per statement (consecutive one-value statements share scratch registers: a nop each, see fold4)
   auto div_fast4 = [&](const float* a, float D_, float invD_, float* r) __attribute__((always_inline)) {
     float q0, q1, q2, q3, t0, t1, t2, t3;
     asm("v_mul_f32 %4, %12, %17\n\tv_mul_f32 %5, %13, %17\n\tv_mul_f32 %6, %14, %17\n\tv_mul_f32 %7, %15, %17\n\t"
@@ -632,13 +599,6 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
         stds(fb, 0, 4, v + 4);
       }
     }
-  };
-  auto stat_fast = [&](int fb, int j, int a) __attribute__((always_inline)) -> float {
-    const float D = (float)deg, invD = 1.0f / D;
-    if (a == 1) return MX[fb][j];
-    if (a == 2) return MN[fb][j];
-    if (a == 0) return div_fast(S_[fb][j], D, invD);
-    return sqrt_rn(var_eps_fast(S_[fb][j], Q_[fb][j], D, invD));
   };
   f4 pk[2][NL];                                           // tower mode: strips of x_dst (0) and h (1) of the row's own node
   constexpr int NPL = 2 * NL + 1;                         // loads of the panel request: the strips, the rows' factors

@@ -111,7 +111,7 @@ __device__ __forceinline__ float mul_1(float a, float b) { float r; asm("v_mul_f
 // callers: hipcc would pack the chains into v_pk_*_f32 with op_sel swizzles.
 __device__ __forceinline__ void split8_h2(const f4 lo, const f4 hi, float scl, h8& t0, h8& t1) {
   const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-  // ONE statement for the eight values (see fold1 in pna_fused_degree.hip: statement by statement hipcc puts an `s_nop 0` behind every
+  // ONE statement for the eight values (see fold4 in pna_fused_degree.hip: statement by statement hipcc puts an `s_nop 0` behind every
   // instruction whose result -- or whose scratch register -- the next statement touches: five per pair of values here)
   u4 p0, p1;
   float a, b, c, d;
