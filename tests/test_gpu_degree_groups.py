@@ -307,7 +307,7 @@ def test_grouped_tower_layer_equals_ordinary_kernels(cuda_device, T, Fi, out, di
 def test_one_kernel_tower_layer_equals_two_kernel_grouped_path(cuda_device, Fi, out, gn, bn, res):
     """pna_fused_degree_f32 in tower mode (gather over x_src, destination term and self features as extra K panels) against the
     two-kernel grouped path (gather with the destination term added per edge -> aggregate in HBM -> grouped contraction), which
-    the reference goldens pin: same collapsed weight, bf16x3 arithmetic in both; they differ in WHERE x_dst is added (after the
+    the reference goldens pin: same collapsed weight, fp32-level arithmetic in both (fp16 x 2 in the one-kernel layer since round 5, bf16x3 in the two-kernel path); they differ in WHERE x_dst is added (after the
     statistics instead of per edge) and in the summation order over K.  Every shape class: half block or not, partial column
     windows, with / without graph norm, BatchNorm, residual; isolated nodes and hub rows are in the graph."""
     from pna_amd import Graph, degree_groups as DG, functional as PF

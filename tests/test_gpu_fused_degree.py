@@ -96,7 +96,7 @@ def test_fused_layer_equals_two_kernel_paths(cuda_device, V, E, F, N, scalers, r
     assert torch.isfinite(y_f).all()
     s = y_p.abs().max().item()
     assert (y_dump - y_f).abs().max().item() <= 1e-6 * s       # (the verification instantiation runs one workgroup per CU: same arithmetic)
-    assert (y_f - y_g).abs().max().item() <= 2e-6 * s          # same W_D up to the order of its fp32 combination, same bf16x3 contraction
+    assert (y_f - y_g).abs().max().item() <= 2e-6 * s          # same W_D up to the order of its fp32 combination; fp16 x 2 against bf16 x 3 contraction: the same accuracy class
     assert (y_f - y_p).abs().max().item() <= 2e-5 * s
 
 
