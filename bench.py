@@ -39,6 +39,15 @@ AGGREGATORS = "mean max min std"
 SCALERS = "identity amplification attenuation"
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md
 MFMA_F32_PEAK = 157.3e12   # FLOP/s, f32-input MFMA (= the fp32 vector rate)
+ARITH_TEXT = {
+    "fp16x2_guarded": "fp16x2_guarded: fp32 in / out; every operand as two fp16 terms behind a power-of-two row / column scale, three partial products "
+                      "per multiply, fp32 accumulation -- with the floor-error GUARD: tiles whose outputs the bound does not certify are computed again "
+                      "in bf16x3 (componentwise fp32-accurate on every input; include/pna_amd.h ARITHMETIC, DESIGN.md 4.8.17)",
+    "fp16x2": "fp16x2 (unguarded, opt-in PNA_AMD_FUSED_ARITH=fp16x2): two fp16 terms, three partial products; normwise- but not componentwise-accurate "
+              "when a row's statistics span more than ~2^17",
+    "bf16x3": "bf16x3: fp32 in / out; each fp32 operand cut exactly into 3 bf16 terms, 6 partial products per multiply on the bf16 MFMA pipe, fp32 "
+              "accumulate; error vs float64 at the exact-f32 kernel's level (tests/test_gpu_posttrans_x3.py)",
+}
 MFMA_BF16_PEAK = 2.5e15    # FLOP/s, dense bf16 MFMA; the bf16x3 contraction spends 6 bf16 products per fp32 multiply
 
 
@@ -347,7 +356,7 @@ def main():
 
     # ---- per-graph / per-weight set-up of the one-kernel layer, timed on its own BEFORE any step (set-up reported
     #      separately).  Once per graph: the degree plan (row order, tile-major id records, descriptors) and the
-    #      rest rows' work list; once per (weights, graph): the packed bf16x3 weight images W_D.  Neither is part of a step.
+    #      rest rows' work list; once per (weights, graph): the packed weight images W_D (fp16 x 2 and bf16 x 3).  Neither is part of a step.
     setup = None
     if world == 1 and hasattr(layer, "_degree_grouped_path"):
         from pna_amd import degree_groups as _DGs
@@ -593,6 +602,42 @@ def main():
         ms_per_step_f32 = (time.perf_counter() - t1) / args.steps * 1e3
         _ops.POSTTRANS_ARITH = keep
 
+    # the same step under the other arithmetics of the one-kernel layer: bf16 x 3 everywhere (rounds 3-4, what
+    # PNA_AMD_POSTTRANS=bf16x3 selects) and round 5's unguarded fp16 x 2 -- and what the guard of the default did in a step
+    arith_legs, guard_info = {}, None
+    try:
+        from pna_amd import degree_groups as _DG
+        with torch.no_grad():
+            one_kernel = hasattr(layer, "_degree_grouped_path") and layer._degree_grouped_path(g, h) and _DG.fused_applies(g, g.source_features(h), F, F)
+        if one_kernel:
+            keep_arith = _DG.FUSED_ARITH
+            plan_ = _DG.plan_of(g)
+            if _DG.fused_arith() == 0:
+                _DG.guard_stats(plan_, dev, reset=True)
+                step()
+                sync()
+                handed, calls_ = _DG.guard_stats(plan_, dev)
+                guard_info = {"tiles_handed_over_to_bf16x3_per_step": handed / max(calls_, 1), "tiles": plan_.NV // 64,
+                              "note": "64-row tiles of the one-kernel layer whose outputs the fp16 x 2 floor-error bound did not certify: computed again "
+                                      "in bf16 x 3 by the second launch of the same call (pna_amd/csrc/pna_x3_split.h, DESIGN.md 4.8.17)"}
+            for name in ("bf16x3", "fp16x2"):
+                if name == keep_arith:
+                    continue
+                _DG.FUSED_ARITH = name
+                try:
+                    for _ in range(3):
+                        step()
+                    sync()
+                    t1 = time.perf_counter()
+                    for _ in range(args.steps):
+                        step()
+                    sync()
+                    arith_legs[name] = (time.perf_counter() - t1) / args.steps * 1e3
+                finally:
+                    _DG.FUSED_ARITH = keep_arith
+    except Exception as ex:   # noqa: BLE001  (never sinks the line)
+        print(f"[bench] arithmetic legs skipped: {ex}", file=sys.stderr)
+
     # ---- per-kernel timing of the dominant kernels (HIP events, this rank) ------------------------------
     csr = g.csr
     with torch.no_grad():
@@ -645,7 +690,9 @@ def main():
                 rows_g = grouped["rows_in_groups"]
                 deg_l = (csr.rowptr[1:] - csr.rowptr[:-1]).long()
                 e_g = int(deg_l[plan.perm[plan.perm >= 0].long()].sum().item())
+                from pna_amd import _lib as _plib
                 fused = {"ms_group_rows_kernel": t_fused, "ms_rest_rows_two_kernel_path": t_rest, "rows": rows_g, "edges": e_g,
+                         "arith": _plib.FD_ARITH_NAMES[call.arith],
                          "padded_rows": plan.NV, "id_records": plan.fused_tables()[2],
                          "rest_rows_beside_kernel": bool(beside), "spare_workgroups": int(call.args.spare_workgroups),
                          "tile_order": DG.FUSED_BALANCE if plan.fused_balance(PF._fused_grid(dev, int(call.args.spare_workgroups), plan.NV // 64)) is not None else "plan order",
@@ -722,8 +769,7 @@ def main():
                     "rest_rows_two_kernel_path_ms": fused["ms_rest_rows_two_kernel_path"],
                     # (three fp16 partial products per multiply since round 5 -- six bf16 ones before; the f16 pipe's dense peak is the bf16 pipe's)
                     "mfma_frac_executed_flops": 2.0 * plan.NV * (4 * F) * F / tf / (MFMA_BF16_PEAK / 3),
-                    "contraction_arith": "fp16 x 2: fp32 in / out, every operand as two fp16 terms behind a power-of-two row / column scale, three partial "
-                                         "products per multiply, fp32 accumulation (DESIGN.md 4.8.15; tower mode: bf16 x 3)",
+                    "contraction_arith": ARITH_TEXT[fused["arith"]],
                     "rest_rows_beside_kernel": fused["rest_rows_beside_kernel"], "spare_workgroups": fused["spare_workgroups"],
                     "tile_order": fused["tile_order"],
                     "full_grid": {"ms_per_launch": fused["ms_group_rows_kernel_full_grid"],
@@ -802,15 +848,18 @@ def main():
     rec = {
         "metric": f"PNA-layer fwd edges/sec (F={F}, 4 aggr x 3 scalers)", "value": value, "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" + (f" (fp32 in / out / accumulation; posttrans contraction: {fused['arith']}, see config.posttrans_arith)" if fused else ""),
+        "data": "synthetic",
         "prewarm_steps_untimed": prewarm,
         "config": {"workload": wl + f"single PNA (simple) layer fwd: 4 aggregators x 3 scalers + posttrans Linear({12 * F}->{F}) + BN + ReLU + residual",
                    "V": V, "E": E, "F": F, "aggregators": AGGREGATORS, "scalers": SCALERS,
                    "parallelism": f"dst-range shard x{world}, halo all-to-all" if world > 1 else "single GPU",
                    "x_row_pitch_floats": max(args.x_pitch, F),
-                   "posttrans_arith": ("bf16x3: fp32 in/out; each fp32 operand cut exactly into 3 bf16 terms, 6 partial products per multiply "
-                                       "on the bf16 MFMA pipe, fp32 accumulate; error vs float64 at the exact-f32 kernel's level "
-                                       "(tests/test_gpu_posttrans_x3.py)") if arith == "bf16x3" else "f32 (v_mfma_f32_16x16x4_f32)",
+                   # (the arithmetic of the path the timed step TOOK: the one-kernel layer's for its group rows, the two-kernel path's otherwise)
+                   "posttrans_arith": (ARITH_TEXT[fused["arith"]] + " -- the group rows of the one-kernel layer; the rest rows (two-kernel path): bf16x3") if fused
+                                      else ARITH_TEXT["bf16x3"] if arith == "bf16x3" else "f32 (v_mfma_f32_16x16x4_f32)",
+                   "guard": guard_info,
                    "max_in_degree": int(csr.max_degree), "halo_rows_rank0": getattr(g, "n_halo", 0),
                    "interior_rows_rank0": int(g.interior_mask().sum().item()) if world > 1 else None,
                    "local_rows_rank0": n_local, "local_edges_rank0": e_local, "partition_balance": args.balance if world > 1 else None,
@@ -827,6 +876,8 @@ def main():
                       "csr_build_once_per_graph": csr_build_ms},
         "halo_exchange": halo_rate,
         "ms_per_step_exact_f32_mfma": ms_per_step_f32, "value_exact_f32_mfma": E / (ms_per_step_f32 * 1e-3),
+        "ms_per_step_bf16x3": arith_legs.get("bf16x3"), "value_bf16x3": (E / (arith_legs["bf16x3"] * 1e-3)) if arith_legs.get("bf16x3") else None,
+        "ms_per_step_fp16x2_unguarded": arith_legs.get("fp16x2"),
         "ms_per_step_contiguous_input": ms_per_step_contig,
         "value_contiguous_input": (E / (ms_per_step_contig * 1e-3)) if ms_per_step_contig else None,
         "per_graph_setup": setup,

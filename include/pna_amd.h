@@ -26,7 +26,11 @@
 extern "C" {
 #endif
 
-#define PNA_ABI_VERSION 20 /* 20: - pna_fused_roles_{supported,image_bytes,grid,f32} (ABI 19's one-kernel layer with gather / multiply wavefront
+#define PNA_ABI_VERSION 21 /* 21: the GUARDED fp16 x 2 contraction of the one-kernel layer (round 6): + pna_fused_degree_args.{w_img_x3,
+                                  image_stride_x3, guard_ws, guard_ws_bytes, arith}, PNA_FD_ARITH_*, pna_fused_image_bytes, pna_fused_pack_f32,
+                                  pna_fused_degree_guard_bytes; the fp16 x 2 images carry a 1024-byte tail (column scales + the guard's column
+                                  thresholds); image_stride must EQUAL pna_fused_image_bytes; row scale bound in [2^14, 2^15).
+                              20: - pna_fused_roles_{supported,image_bytes,grid,f32} (ABI 19's one-kernel layer with gather / multiply wavefront
                                   roles: parity-green, 2.1-2.7x slower than pna_fused_degree_f32, never on a product path -- removed from the
                                   library in round 5; the source lives on as tools/ubench/fused_roles.hip, the result in DESIGN.md 4.9).
                                   + pna_fused_degree_args.tile_counter (dynamic tile schedule), pna_fused_degree_tile_rows.
@@ -506,19 +510,28 @@ int pna_fused_simple_f32(const pna_fused_simple_args* args, pna_stream_t stream)
  *                                                                                             for rows one lane group walks alone)
  *   y[perm[v]]  = residual[perm[v]] + act((bias + W_D(v) . a[v]) * col_scale + col_shift)   (fp32 in and out, fp32 accumulation; see ARITHMETIC)
  *
- * ARITHMETIC (round 5; rounds 3-4: the bf16x3 arithmetic of pna_posttrans_x3_f32).  Every statistic and every
- * weight enters the matrix pipe as TWO fp16 terms, x = h0 + h1 + r with h0 = fp16(x), h1 = fp16(x - h0) (round to nearest), |r| <= 2^-22 |x|,
- * and a product as three partial products (h1 w0, h0 w1, h0 w0; v_mfma_f32_16x16x32_f16, fp32 accumulation): half the matrix instructions
- * and two thirds of the weight stream of bf16x3's six products.  fp16's range is narrow, so the operands are first multiplied by powers of
- * two (exact): row v's statistics by 2^s(v), chosen in the kernel so that twice the row's largest message magnitude lies in
- * [2^13, 2^14), and column n of the weights by 2^t(n), chosen by pna_fused_degree_pack_f32 from the largest |W_D[n][k]| over k and over all images
- * (2^-t(n) rides in each image's 512-byte tail); the accumulator is multiplied by 2^-(s + t) in the bias' fma.  In tower mode the row's
- * scale also covers its own x_dst / h_self strips: it is lowered when they arrive, mid-row, and the accumulator with it (exact).  Measured against float64
- * on BASELINE configs[2] / [4] shapes: 1.25 x the error of bf16x3, a fifth of an fp32 GEMM's.  An element more than 2^28 below its row's
- * (column's) largest loses low bits, more than 2^38 below it vanishes -- absolute errors of 2^-39 of the row's largest product.
+ * ARITHMETIC (`arith`, ABI 21).  PNA_FD_ARITH_X3: every statistic and every weight as three bf16 terms, six partial products (the bf16x3
+ * arithmetic of pna_posttrans_x3_f32, rounds 3-4): componentwise fp32-accurate for operands of any dynamic range.  PNA_FD_ARITH_H2 (round 5):
+ * TWO fp16 terms, x = h0 + h1 + r with h0 = fp16(x), h1 = fp16(x - h0) (round to nearest), and three partial products (h1 w0, h0 w1, h0 w0;
+ * v_mfma_f32_16x16x32_f16, fp32 accumulation): half the matrix instructions and two thirds of the weight stream.  fp16's range is narrow, so
+ * the operands are first multiplied by powers of two (exact): row v's statistics by 2^s(v), chosen in the kernel so that twice the row's
+ * largest message magnitude lies in [2^14, 2^15), and column n of the weights by 2^t(n), chosen by the pack function from the largest
+ * |W_D[n][k]| over k and over all images into [2^13, 2^14) (2^-t(n) rides in each image's tail); the accumulator is multiplied by 2^-(s + t)
+ * in the bias' fma.  In these units |r| <= max(2^-22 |x|, 2^-25): an operand below 2^-3 -- more than 2^17 below its row's (2^16 below its
+ * column's) bound -- sits on fp16's subnormal grid with its second term and carries an ABSOLUTE error of up to 2^-25, a relative one of
+ * 2^-25 / |x|: the form is normwise-, not componentwise-accurate (a statistic 1e7 x the rest of its row with a zero weight on it: 5.6e-5
+ * relative on the outputs; at 1e13 the small statistics vanish).  PNA_FD_ARITH_GUARDED (the default) = the same fp16 x 2 launch with that
+ * FLOOR error bounded per output: the kernel adds up the exact floor errors fs(v) of a row's statistics (the part of |r| above 2^-22 |x|;
+ * zero for almost every row), the pack function those of a column's weights fw(n), and an output is certified when
+ *     |acc| >= 2^34 fs(v) + 2^35 fw(n)          (floor error <= 2^-20 |acc|: everything else of the split's error is relative term by term);
+ * a 64-row (wide shapes: 64-row) workgroup tile with an uncertified output is appended to a device-side list and a second launch computes
+ * exactly those tiles again in bf16 x 3 (no host round trip; on Gaussian features and weights nothing is handed over, the launch finds an
+ * empty list and costs ~6 us).  In tower mode the row's scale also covers its own x_dst / h_self strips: it is lowered when they arrive,
+ * mid-row, and the accumulator with it (exact).  Measured against float64 on BASELINE configs[2] / [4] shapes: 1.25 x the error of bf16x3, a
+ * fifth of an fp32 GEMM's.
  * Non-finite operands: NaN propagates; a row that holds an infinite statistic (column: an infinite weight) is non-finite in every output
  * it reaches, as in fp32 -- but its FINITE elements are scaled against FLT_MAX and may underflow, so where fp32 gives +-Inf the result
- * may be +-Inf or NaN, never finite garbage.
+ * may be +-Inf or NaN, never finite garbage (such rows are not the guard's: a non-finite accumulator certifies itself).
  *
  * The caller (pna_amd/degree_groups.py) orders the rows by in-degree into VIRTUAL rows v in [0, M):
  *   row_perm[v]   node of virtual row v, or -1 = padding (nothing is stored); M a multiple of pna_fused_degree_tile_rows(F, N) (64 or 128); every aligned block of 16
@@ -527,7 +540,8 @@ int pna_fused_simple_f32(const pna_fused_simple_args* args, pna_stream_t stream)
  *   tile_ids      n_records records of 16 int32: record (first + e)[i] = source row (row of x) of the e-th in-edge of the block's
  *                 i-th row, e in [0, D), in the row's edge order; a padding row repeats the block's first row; a block owns
  *                 max(4, round_up(D, 4)) records, the ones past D being copies of record D - 1 (D = 0: any valid row);
- *   w_img         n_img images, image_stride == pna_fused_degree_image_bytes(F, N) bytes apart (the pack function's layout), from pna_fused_degree_pack_f32:
+ *   w_img         n_img images, image_stride == pna_fused_image_bytes(F, N, tower, 0) bytes apart (the pack function's layout), from pna_fused_pack_f32
+ *                 (w_img_x3 / image_stride_x3: the bf16 x 3 images, x3 = 1):
  *                 w_ref is the Linear weight (N, n_scaler * 4F) in the reference's column order [scaler][aggregator][feature]
  *                 (pna_layer.py:192-193), scale (n_img, n_scaler) the scalers' values for image i (NULL with n_scaler = 1:
  *                 the weight itself); W_D is formed in fp32 in scaler order, like the reference's blocks.
@@ -598,9 +612,26 @@ typedef struct pna_fused_degree_args {
                            * so a workgroup that falls behind simply takes fewer tiles; tiles are started in tile_desc order
                            * device-wide.  Null: the static schedule b, b + G, b + 2 G, ...  The results do not depend on it
                            * (bit-identical). */
+  /* ABI 21 (round 6): the arithmetic of the contraction, see ARITHMETIC above */
+  const void* w_img_x3;     /* bf16 x 3 images (pna_fused_pack_f32(.., x3 = 1)), image_stride_x3 == pna_fused_image_bytes(F, N, tower, 1) apart:
+                             * PNA_FD_ARITH_GUARDED and PNA_FD_ARITH_X3; w_img / image_stride: the fp16 x 2 images (GUARDED and H2) */
+  int64_t image_stride_x3;
+  void* guard_ws;           /* PNA_FD_ARITH_GUARDED: pna_fused_degree_guard_bytes(M) bytes, 16-byte aligned, owned by the call while it runs, its first 16
+                             * bytes ZERO before the first launch (the library leaves words 0..1 zero behind every call).  int32 words: [0] tiles
+                             * handed over by the running call, [1] internal, [2] tiles handed over since the caller last zeroed it, [3] calls */
+  int64_t guard_ws_bytes;
+  int32_t arith;            /* PNA_FD_ARITH_GUARDED (0, the default) | PNA_FD_ARITH_X3 | PNA_FD_ARITH_H2 */
+  int32_t _pad5;
 } pna_fused_degree_args;
 
-int64_t pna_fused_degree_image_bytes(int32_t F, int32_t N);   /* 0 = unsupported shape */
+#define PNA_FD_ARITH_GUARDED 0 /* fp16 x 2 with the floor-error guard: tiles it cannot certify are computed again in bf16 x 3 (a second launch) */
+#define PNA_FD_ARITH_X3 1      /* bf16 x 3 everywhere: componentwise fp32-accurate for operands of any dynamic range (rounds 3-4) */
+#define PNA_FD_ARITH_H2 2      /* fp16 x 2 without the guard (round 5): operands of moderate dynamic range only; the verification instantiation */
+int64_t pna_fused_image_bytes(int32_t F, int32_t N, int32_t tower, int32_t x3);   /* bytes of one image = the stride between images; 0 = unsupported shape */
+int pna_fused_pack_f32(const float* w_ref, int64_t ldw_ref, int32_t N, int32_t F, int32_t n_scaler, const float* scale, int32_t n_img, void* img,
+                       int32_t tower, int32_t x3, pna_stream_t stream);          /* the images of either arithmetic, layer or tower mode */
+int64_t pna_fused_degree_guard_bytes(int64_t M);               /* size of pna_fused_degree_args.guard_ws for M virtual rows */
+int64_t pna_fused_degree_image_bytes(int32_t F, int32_t N);   /* = pna_fused_image_bytes(F, N, 0, 0); 0 = unsupported shape */
 int32_t pna_fused_degree_tile_rows(int32_t F, int32_t N);     /* rows of a workgroup tile for the shape (M must be a multiple; all of
                                                                   one degree and one weight image): 64, or 128 for the wide shapes when the
                                                                   library runs them as 8-wavefront workgroups; 0 = unsupported shape */

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # (PNA_AMD_LIB_PATH: another build of the same ABI -- tools/build_variant.sh, the -DPNA_AMD_EXPERIMENTS build -- for same-box A/B runs)
 LIB_PATH = os.environ.get("PNA_AMD_LIB_PATH") or os.path.join(_HERE, "lib", "libpna_amd.so")
 
-PNA_ABI_VERSION = 20
+PNA_ABI_VERSION = 21
 PNA_MAX_AGGR = 8
 PNA_MAX_SCALER = 8
 
@@ -136,7 +136,13 @@ class PnaFusedDegreeArgs(_Args):
         ("agg_out", ctypes.c_void_p), ("ld_agg", ctypes.c_int64),
         ("x_dst", ctypes.c_void_p), ("ld_xdst", ctypes.c_int64), ("h_self", ctypes.c_void_p), ("ld_h", ctypes.c_int64), ("row_post", ctypes.c_void_p),
         ("spare_workgroups", ctypes.c_int32), ("_pad4", ctypes.c_int32), ("tile_counter", ctypes.c_void_p),
+        ("w_img_x3", ctypes.c_void_p), ("image_stride_x3", ctypes.c_int64), ("guard_ws", ctypes.c_void_p), ("guard_ws_bytes", ctypes.c_int64),
+        ("arith", ctypes.c_int32), ("_pad5", ctypes.c_int32),
     ]
+
+
+FD_ARITH_GUARDED, FD_ARITH_X3, FD_ARITH_H2 = 0, 1, 2      # include/pna_amd.h PNA_FD_ARITH_*
+FD_ARITH_NAMES = {FD_ARITH_GUARDED: "fp16x2_guarded", FD_ARITH_X3: "bf16x3", FD_ARITH_H2: "fp16x2"}
 
 
 class PnaBnTailArgs(_Args):
@@ -279,6 +285,13 @@ def lib():
         L.pna_fused_tower_image_bytes.restype = ctypes.c_int64
         L.pna_fused_tower_pack_f32.argtypes = L.pna_fused_degree_pack_f32.argtypes
         L.pna_fused_tower_pack_f32.restype = ctypes.c_int
+        L.pna_fused_image_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+        L.pna_fused_image_bytes.restype = ctypes.c_int64
+        L.pna_fused_pack_f32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                                         ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+        L.pna_fused_pack_f32.restype = ctypes.c_int
+        L.pna_fused_degree_guard_bytes.argtypes = [ctypes.c_int64]
+        L.pna_fused_degree_guard_bytes.restype = ctypes.c_int64
         L.pna_fused_degree_f32.argtypes = [ctypes.POINTER(PnaFusedDegreeArgs), ctypes.c_void_p]
         L.pna_fused_degree_f32.restype = ctypes.c_int
         L.pna_posttrans_packed_floats.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,

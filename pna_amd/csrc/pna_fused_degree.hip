@@ -61,6 +61,12 @@ struct FDArgs {
   const float* xd; const float* xh; const float* row_post;   // tower layers: the rows' own projections / features, the per-row factor
   unsigned lddb, ldhb;         // row pitch of xd / xh in bytes
   int* counter;                // dynamic tile schedule (round 5): two device int32, zero at launch (claims | finished workgroups); nullptr: tile b, b + G, b + 2 G, ...
+  // the fp16 x 2 guard (round 6).  guard = {tiles handed over | workgroups of the consuming launch that have left | tiles handed over since
+  // the caller last cleared it | guarded calls}: a workgroup tile whose outputs the floor-error bound does not certify is appended to the
+  // hand-over list -- copies of its descriptors, its rows of perm (and of row_post) -- and the bf16 x 3 instantiation, launched behind this
+  // one with the list as its tile tables, computes those tiles again (k_fused_degree; nullptr: no guard).
+  int* guard; i4* g_desc; int* g_perm; float* g_post;
+  int* list_count;             // the consuming launch (ARITH 1 behind a guarded one): its tile count lives on the device (= guard of the producer)
   unsigned long long* dbg;     // experiments build only: per-wavefront phase timers
   unsigned ldb;                // row pitch of x in bytes
   unsigned ldyb, ldrb;         // row pitch of y / residual in bytes (ldrb = 0 without a residual: every load reads y's first row)
@@ -93,17 +99,14 @@ constexpr int kWavesMax = 8;
 #ifndef FD_NBUF_WIDE
 #define FD_NBUF_WIDE 6
 #endif
-// (nc: chunks of one gather pass -- a tile must have at least NBUF - 1 steps; tower: bf16 x 3 images of 15 KB, five)
-constexpr int buffers_for(int gp, int npan, int nc = 4, bool tower = true) {
-  return waves_for(gp, npan) == 8 ? 10 : tower ? 5 : npan == 2 ? FD_NBUF_WIDE : (nc * gp >= FD_NBUF_REG - 1 + 2) ? FD_NBUF_REG : 5;
+// (nc: chunks of one gather pass -- a tile must have at least NBUF - 1 steps; tower mode, and the bf16 x 3 images of 15 / 12 KB: five / six)
+constexpr int buffers_for(int gp, int npan, int nc = 4, bool tower = true, bool h2 = true) {
+  return waves_for(gp, npan) == 8 ? 10 : tower ? 5 : !h2 ? (npan == 2 ? 6 : 5) : npan == 2 ? FD_NBUF_WIDE : (nc * gp >= FD_NBUF_REG - 1 + 2) ? FD_NBUF_REG : 5;
 }
 constexpr int kChunkV = 3 * 4 * kNW;                      // 16-byte pieces of one chunk image, tower mode: [term][lane group][80 cols][8 k] bf16 x 3
 constexpr int kChunkVH = 2 * 4 * kNW;                     // ... of the layer proper (round 5): two fp16 terms (pna_x3_split.h)
-#ifndef FD_TOWER_H2
-#define FD_TOWER_H2 1                                     // tower mode on the fp16 x 2 arithmetic too (0: bf16 x 3, rounds 3-4)
-#endif
-constexpr bool kTowerH2 = FD_TOWER_H2 != 0;
-constexpr int kTailBytes = 512;                           // behind every fp16 image: 128 floats, 2^-s_n of the columns' power-of-two scales
+constexpr int kTailBytes = 1024;                          // behind every fp16 image: 128 floats, 2^-s_n of the columns' power-of-two scales, and 128
+                                                          // floats of the guard's per-column threshold (kFloorWeightScale x the column's floor error; -inf: nothing to certify)
 constexpr int kRing = 4;                                  // edge packets in the register ring
 constexpr int kNRes = kNT;                                // residual loads per lane (16 bytes each: 4 consecutive columns of one row)
 
@@ -226,9 +229,9 @@ __device__ __forceinline__ unsigned long long now() {
 // its chunks, gather 1 (the ids of the tile's edges a second time, its source rows' second half), its chunks, epilogue.  NPAN = 2:
 // 81..128 output columns as two PANELS of 64 (4 column tiles each): a step multiplies one chunk's A fragment against one panel's
 // image (12 KB: the five-buffer pipeline still fits two workgroups per CU), the fragment is formed once per chunk.
-template <int NFBF, bool HALF, bool DUMP, bool TOWER = false, bool RESPF = !DUMP && !TOWER, int GP = 1, int NPAN = 1, int WAVES = waves_for(GP, NPAN),
-          int NBUF = buffers_for(GP, NPAN, 4 * NFBF + (HALF ? 2 : 0), TOWER)>
-__global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fused_degree(const FDArgs g) {
+template <int NFBF, bool HALF, bool DUMP, bool TOWER = false, bool H2A = true, bool RESPF = !DUMP && !TOWER, int GP = 1, int NPAN = 1,
+          int WAVES = waves_for(GP, NPAN), int NBUF = buffers_for(GP, NPAN, 4 * NFBF + (HALF ? 2 : 0), TOWER, H2A)>
+__device__ __forceinline__ void fd_body(const FDArgs& g, const int t_first, const int t_stride, const int ntiles) {
   constexpr int kNBuf = NBUF, kAhead = NBUF - 1, kWaves = WAVES, kThreads = 64 * WAVES;
   static_assert(!TOWER || (NFBF == 2 && !DUMP), "tower mode: two full feature blocks (49 <= F <= 80), production only");
   static_assert((GP == 1 || (GP == 2 && !HALF && !TOWER)) && (NPAN == 1 || (NPAN == 2 && !TOWER)), "wide shapes: full blocks, no tower mode");
@@ -242,10 +245,12 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
   // half the MFMAs, two thirds of the weight stream and of the B-fragment reads of the bf16 x 3 form (six products), the same accuracy
   // class -- the row of statistics is scaled by a power of two so that its bound sits in [2^13, 2^14) (rscl below), the weights'
   // columns likewise at pack time (their 2^-s in the image's tail), the accumulator is scaled back in the epilogue.  Tower mode too
-  // (-DFD_TOWER_H2=0: bf16 x 3 as in rounds 3-4): its node panels enter the contraction as they come from memory, mid-tile, and the
+  // (H2A = false: bf16 x 3 as in rounds 3-4): its node panels enter the contraction as they come from memory, mid-tile, and the
   // row's scale is lowered to cover them when they land (panel_rescale below).
-  constexpr bool H2 = !TOWER || kTowerH2;
-  constexpr int NTERM = H2 ? 2 : 3, NPROD = H2 ? 3 : 6, NCC = H2 ? 4 : 3;
+  // H2A = false (round 6): the bf16 x 3 arithmetic of rounds 3-4 -- componentwise fp32-accurate for operands of ANY dynamic range --, the
+  // instantiation that re-computes the tiles the fp16 x 2 guard hands over (and the whole launch under PNA_FD_ARITH_X3).
+  constexpr bool H2 = H2A;
+  constexpr int NTERM = H2 ? 2 : 3, NPROD = H2 ? 3 : 6, NCC = H2 ? 5 : 3;
   using frag_t = std::conditional_t<H2, h8, bf8>;
   constexpr int CHV = NTERM * 4 * NWP;                    // 16-byte pieces of one step's image: [term][lane group][NWP cols][8 k]
   constexpr int NI = (CHV + kThreads - 1) / kThreads;     // global_load_lds instructions per wavefront per step
@@ -262,15 +267,34 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
-  const int ntiles = g.M / (kWaves * 16);
-  const int G = (int)gridDim.x;
+  const int G = t_stride;                                  // the workgroup walks tiles t_first, t_first + G, .. below ntiles (a launch: blockIdx.x, its grid)
+  const bool guard_on = H2 && g.guard != nullptr;
 
-  float* const colc = reinterpret_cast<float*>(lds + (size_t)kNBuf * CHV * 16);           // [NCC][NWA]: bias | scale | shift | (H2) 2^-s of the column
+  float* const colc = reinterpret_cast<float*>(lds + (size_t)kNBuf * CHV * 16);           // [NCC][NWA]: bias | scale | shift | (H2) 2^-s of the column | (H2) guard threshold
   for (int i = tid; i < NWA; i += kThreads) {
     colc[i] = (g.bias && i < g.N) ? g.bias[i] : 0.f;
     colc[NWA + i] = (g.col_scale && i < g.N) ? g.col_scale[i] : 1.f;
     colc[2 * NWA + i] = (g.col_shift && i < g.N) ? g.col_shift[i] : 0.f;
-    if constexpr (H2) colc[3 * NWA + i] = reinterpret_cast<const float*>(g.w_img + (size_t)NCT * CHV * 16)[i];   // (the first image's tail: the same in all)
+    if constexpr (H2) {                                                                                        // (the first image's tail: the same in all)
+      colc[3 * NWA + i] = reinterpret_cast<const float*>(g.w_img + (size_t)NCT * CHV * 16)[i];
+      colc[4 * NWA + i] = i < g.N ? reinterpret_cast<const float*>(g.w_img + (size_t)NCT * CHV * 16)[128 + i] : -INFINITY;
+    }
+  }
+  // GUARD: bit n of cmask = column tile n holds a column whose WEIGHTS have a floor error of their own (kernel-uniform; every wavefront
+  // forms it from the tail: two loads, two ballots): only those tiles' outputs need certifying for rows without a floor error
+  [[maybe_unused]] unsigned cmask = 0u;
+  if constexpr (H2) {
+    if (guard_on) {
+      const float* const cvt = reinterpret_cast<const float*>(g.w_img + (size_t)NCT * CHV * 16) + 128;
+      const unsigned long long b0 = __builtin_amdgcn_ballot_w64(lane < g.N && cvt[lane] > 0.f);
+      const unsigned long long b1 = __builtin_amdgcn_ballot_w64(lane + 64 < g.N && cvt[lane + 64] > 0.f);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) cmask |= (((b0 >> (16 * n)) & 0xffffull) ? 1u : 0u) << n | (((b1 >> (16 * n)) & 0xffffull) ? 1u : 0u) << (4 + n);
+    }
+  }
+  if (tid == 0) {                                          // the guard's two hand-over words (behind the dynamic schedule's two)
+    unsigned* const gw = reinterpret_cast<unsigned*>(lds + (size_t)kNBuf * CHV * 16 + (size_t)NCC * NWA * 4 + 8);
+    gw[0] = 0u; gw[1] = 0u;
   }
 
   f4 acc[NTA];
@@ -289,8 +313,18 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
     }
   };
 
-  int t = blockIdx.x;                                     // the workgroup's current tile
-  if (t >= ntiles) return;
+  // when a workgroup is through (also one that finds no tile): the dynamic schedule leaves its two words as it found them -- the LAST
+  // workgroup to get here (every claim of the launch has been made by then) zeroes them for the next launch on the stream, no memset
+  // node in front of every launch
+  auto finish = [&]() __attribute__((always_inline)) {
+    if (wave == 0 && lane == 0 && g.counter != nullptr &&
+        __hip_atomic_fetch_add(g.counter + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+      __hip_atomic_store(g.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(g.counter + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  int t = t_first;                                        // the workgroup's current tile
+  if (t >= ntiles) { finish(); return; }
 
   // ---- loop-carried across tiles: descriptors of this tile, of this wavefront's next tile and (in flight) of the one after;
   //      the ids of the tile's first four edges (the previous tile's last packets fetched them); the tile's rows of y ----------
@@ -326,6 +360,10 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
   bool fast_tile = false;                                 // the tile's statistics are all finite and it has in-edges (set by gather())
   int sA = 0;                                             // H2: the power of two row li's statistics are multiplied by (set by gather()) ...
   float rscl = 1.f, runs = 1.f;                           // ... 2^sA and 2^-sA
+  // the fp16 x 2 GUARD (round 6; pna_x3_split.h): fex = the lane's FLOOR error so far -- the sum over its statistics of the
+  // part of the two-term split's error that is absolute (a non-zero operand below 2^-3 in the row's units) instead of relative
+  float fex = 0.f;
+  int t_done = -1, gpar = 0;                              // the tile whose epilogue ran last, and which of the two hand-over words it used
   // The lane's strip of feature block fb starts at feature 32 fb + 8 lg (a half block: + 4 lg) -- except in the row's LAST block,
   // where a window that would reach past F slides back to end at F (round 4): no read ever leaves the row (rows of any pitch >= F,
   // the table's last row included), no statistic is ever made of padding.  A feature the slide covers twice counts once: the
@@ -367,6 +405,7 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
     const unsigned rb = (unsigned)td_cur.x * 64u;                                        // byte offset of this tile's records ...
     const unsigned rbn = P + 1 < GP ? rb : (unsigned)td_nxt.x * 64u;                     // ... and of the records the next gather starts with
     deg = D;
+    if constexpr (P == 0) fex = 0.f;
     // (tower mode: the rows of y and their factors are needed from step RSTEP on only: requested with the panels)
     if constexpr (TOWER) ld4_ws(pn, g.perm, (unsigned)((t * kWaves + wave) * 16 + li) * 4u);
     else if constexpr (P == 0) ld4_ws(pr, g.perm, (unsigned)((t * kWaves + wave) * 16 + li) * 4u);
@@ -481,7 +520,7 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
       asm volatile("ds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"((unsigned)((lane ^ 32) * 4)), "v"(m) : "memory");
       asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(o));
       const float bound = __builtin_fminf(__builtin_fmaxf(m + m, 0.0064f), 3.4028234663852886e38f);
-      const int s1 = h2_scale_exp(bound);
+      const int s1 = h2_row_scale_exp(bound);
       if constexpr (P == 0) {
         sA = s1;
       } else {
@@ -514,7 +553,7 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
     const float q0 = mul1(a, invD_), q = fma1(fnma1(D_, q0, a), invD_, q0);
     return (q == q && __builtin_fabsf(q) != INFINITY) ? q : q0;
   };
-  auto stat = [&](int fb, int j, int a, int f) __attribute__((always_inline)) -> float {
+  auto stat = [&](int fb, int j, int a, int f, int deg) __attribute__((always_inline)) -> float {   // (deg: the tile's in-degree, see split_h2_guarded)
     const float D = (float)deg, invD = 1.0f / D;
     const float s = S_[fb][j], q = Q_[fb][j];
     float r;
@@ -568,7 +607,7 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
         : "v"(s_[0]), "v"(s_[1]), "v"(q_[0]), "v"(q_[1]), "v"(D_), "v"(invD_), "v"(1e-5f));
   };
   // the eight statistics of chunk c of a FAST tile: stat_fast value by value, in wider statements
-  auto stats_fast8 = [&](auto c_c, float* v) __attribute__((always_inline)) {
+  auto stats_fast8 = [&](auto c_c, float* v, int deg) __attribute__((always_inline)) {
     constexpr int c = decltype(c_c)::value;
     const float D = (float)deg, invD = 1.0f / D;
     auto stds = [&](int fb, int j0, int n, float* o) __attribute__((always_inline)) {
@@ -633,7 +672,7 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
     asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(o));
     asm volatile("ds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"((unsigned)((lane ^ 32) * 4)), "v"(m) : "memory");
     asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(o));
-    const int sN = min(sA, h2_scale_exp(__builtin_fminf(__builtin_fmaxf(m, 1e-30f), 3.4028234663852886e38f)));
+    const int sN = min(sA, h2_row_scale_exp(__builtin_fminf(__builtin_fmaxf(m, 1e-30f), 3.4028234663852886e38f)));
     const float fac = __builtin_ldexpf(1.0f, max(sN - sA, -126));
 #pragma unroll
     for (int n = 0; n < NTA; ++n)
@@ -642,6 +681,24 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
     sA = sN;
     rscl = __builtin_ldexpf(1.0f, sA);
     runs = __builtin_ldexpf(1.0f, -sA);
+  };
+  // the two-term split of a chunk's eight values with the guard's bookkeeping: one more small chunk when any of them is non-zero and
+  // below 2^kFloorExp in the row's units (a fragment that holds +-Inf: the row is non-finite in every column it reaches -- nothing to certify)
+  // regen(x): the eight values once more, for the rare branch -- recomputed there from the running statistics (behind an opaque copy of the
+  // degree, so that hipcc does not keep the first copies alive across the split instead: eight registers at the kernel's pressure peak)
+  auto split_h2_guarded = [&](const f4 lo4, const f4 hi4, bool maybe_inf, auto regen) __attribute__((always_inline)) {
+    if constexpr (H2) {
+      if (maybe_inf && __builtin_amdgcn_ballot_w64(absmax8(lo4, hi4) == INFINITY) != 0) { split8_h2_inf(lo4, hi4, rscl, A[0], A[1]); return; }
+      int fe = 127;
+      split8_h2(lo4, hi4, rscl, A[0], A[1], fe);
+      // one of the 8 x 64 values is small (rare: ~1 % of the rows of Gaussian features): its lanes add up the floor errors exactly
+      if (__builtin_amdgcn_ballot_w64(fe <= kFloorExp) != 0) {
+        float x[8];
+        regen(x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fex += h2_floor_error(mul_1(x[j], rscl));
+      }
+    }
   };
   auto frag = [&](auto c_c, auto p_c) __attribute__((always_inline)) {
     constexpr int c = decltype(c_c)::value;               // chunk within the gather pass P
@@ -658,8 +715,9 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
         if (!halfc && p == 0 && deg <= 0) hi4[j] = 0.f;
       }
       if constexpr (H2) {                                 // (in units of the row's scale, which panel_rescale() made cover these strips)
-        if (__builtin_amdgcn_ballot_w64(absmax8(lo4, hi4) == INFINITY) != 0) split8_h2_inf(lo4, hi4, rscl, A[0], A[1]);
-        else split8_h2(lo4, hi4, rscl, A[0], A[1]);
+        split_h2_guarded(lo4, hi4, true, [&](float* x) __attribute__((always_inline)) {
+          x[0] = lo4.x; x[1] = lo4.y; x[2] = lo4.z; x[3] = lo4.w; x[4] = hi4.x; x[5] = hi4.y; x[6] = hi4.z; x[7] = hi4.w;
+        });
       } else {
         if (__builtin_amdgcn_ballot_w64(absmax8(lo4, hi4) == INFINITY) != 0) split8_inf(lo4, hi4, A[0], A[1], A[2]);
         else split8(lo4, hi4, A[0], A[1], A[2]);
@@ -668,7 +726,7 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
     }
     float v[8];
     if (!(TOWER && HALF) && fast_tile) {
-      if constexpr (c < NC) stats_fast8(c_c, v);           // (c >= NC: tower panel chunks, handled above)
+      if constexpr (c < NC) stats_fast8(c_c, v, deg);      // (c >= NC: tower panel chunks, handled above)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         int fb, sj, a, f;
@@ -679,7 +737,11 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
           if (!is_dup(P, fb, f)) g.agg_out[(size_t)((t * kWaves + wave) * 16 + li) * g.ld_agg + a * g.F + f] = v[j];
         }
       }
-      if constexpr (H2) split8_h2((f4){v[0], v[1], v[2], v[3]}, (f4){v[4], v[5], v[6], v[7]}, rscl, A[0], A[1]);
+      if constexpr (H2) split_h2_guarded((f4){v[0], v[1], v[2], v[3]}, (f4){v[4], v[5], v[6], v[7]}, false, [&](float* x) __attribute__((always_inline)) {
+        int dg = deg;
+        asm volatile("" : "+s"(dg));
+        if constexpr (c < NC) stats_fast8(c_c, x, dg);
+      });
       else split8((f4){v[0], v[1], v[2], v[3]}, (f4){v[4], v[5], v[6], v[7]}, A[0], A[1], A[2]);
       return;
     }
@@ -688,15 +750,24 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
       int fb, sj, a, f;
       if constexpr (c < 4 * NFBF) { fb = c / 4; sj = j; a = c % 4; f = feat0(P, fb) + j; }
       else { fb = NFBF; sj = j & 3; a = 2 * (c - 4 * NFBF) + (j >> 2); f = feat0(P, fb) + (j & 3); }
-      v[j] = stat(fb, sj, a, f);
+      v[j] = stat(fb, sj, a, f, deg);
       if constexpr (DUMP) {
         if (!is_dup(P, fb, f)) g.agg_out[(size_t)((t * kWaves + wave) * 16 + li) * g.ld_agg + a * g.F + f] = v[j];
       }
     }
     const f4 lo4 = (f4){v[0], v[1], v[2], v[3]}, hi4 = (f4){v[4], v[5], v[6], v[7]};
     if constexpr (H2) {
-      if (__builtin_amdgcn_ballot_w64(absmax8(lo4, hi4) == INFINITY) != 0) split8_h2_inf(lo4, hi4, rscl, A[0], A[1]);
-      else split8_h2(lo4, hi4, rscl, A[0], A[1]);
+      split_h2_guarded(lo4, hi4, true, [&](float* x) __attribute__((always_inline)) {
+        int dg = deg;
+        asm volatile("" : "+s"(dg));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          int fb, sj, a, f;
+          if constexpr (c < 4 * NFBF) { fb = c / 4; sj = j; a = c % 4; f = feat0(P, fb) + j; }
+          else { fb = NFBF; sj = j & 3; a = 2 * (c - 4 * NFBF) + (j >> 2); f = feat0(P, fb) + (j & 3); }
+          x[j] = stat(fb, sj, a, f, dg);
+        }
+      });
     } else {
       if (__builtin_amdgcn_ballot_w64(absmax8(lo4, hi4) == INFINITY) != 0) split8_inf(lo4, hi4, A[0], A[1], A[2]);
       else split8(lo4, hi4, A[0], A[1], A[2]);
@@ -705,10 +776,49 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
 
   // ---- epilogue: BatchNorm / ReLU / residual, rows scattered to node order through perm -----------------------------------
   const unsigned colc_b = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(kNBuf * CHV * 16) + (unsigned)lg * 16u;
+  // ---- the guard's hand-over (round 6) --------------------------------------------------------------------------------------------
+  // Every wavefront whose epilogue finds an output it cannot certify sets the tile's LDS word; the word is read one barrier later -- behind
+  // the first barrier of the workgroup's NEXT multiply phase, or behind the loop -- by wavefront 0, which appends the tile to the hand-over
+  // list: its position from the device-wide count, then copies of the tile's descriptors, its rows of perm and (tower mode) of row_post.
+  const unsigned gflag_b = slot_b + 8u;
+  auto collect = [&]() __attribute__((always_inline)) {
+    if (wave != 0 || t_done < 0) return;
+    unsigned f;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(f) : "v"(gflag_b + (unsigned)(gpar ^ 1) * 4u) : "memory");
+    if (__builtin_amdgcn_readfirstlane(f) == 0u) return;
+    if (lane == 0) asm volatile("ds_write_b32 %0, %1" : : "v"(gflag_b + (unsigned)(gpar ^ 1) * 4u), "v"(0u) : "memory");
+    int pos = 0;
+    if (lane == 0) pos = __hip_atomic_fetch_add(g.guard, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pos = __builtin_amdgcn_readfirstlane(pos);
+    int ln = lane;                                         // (opaque: or hipcc forms the lane addresses below ahead of the tile loop and keeps
+    asm volatile("" : "+v"(ln));                           //  them -- spilled -- through every tile for a branch that is almost never taken)
+    if (ln < kWaves) g.g_desc[(size_t)pos * kWaves + ln] = g.tdesc[(size_t)t_done * kWaves + ln];
+#pragma unroll
+    for (int i = 0; i < kWaves / 4; ++i) {
+      const size_t o = (size_t)i * 64 + ln;
+      g.g_perm[(size_t)pos * (16 * kWaves) + o] = g.perm[(size_t)t_done * (16 * kWaves) + o];
+      if constexpr (TOWER) g.g_post[(size_t)pos * (16 * kWaves) + o] = g.row_post[(size_t)t_done * (16 * kWaves) + o];
+    }
+  };
   auto epilogue = [&]() __attribute__((always_inline)) {
     const float lo = g.relu ? 0.f : -INFINITY;
     const bool leaky = g.relu == 2;
     const int row = prow();
+    // GUARD: the row's floor-error threshold from its lanes' small chunks (the row's four lanes: li + 16 k, two ds_bpermute like the bound's)
+    [[maybe_unused]] float thr_row = 0.f;
+    [[maybe_unused]] bool bad = false, thr_any = false;
+    if constexpr (H2) {
+      // (rows with a floor error are rare -- ~1 % on Gaussian features: the row sums only when the wavefront holds one)
+      if (guard_on && __builtin_amdgcn_ballot_w64(fex > 0.f) != 0) {
+        float c = fex, o;
+        asm volatile("ds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"((unsigned)((lane ^ 16) * 4)), "v"(c) : "memory");
+        c = add1(c, o);
+        asm volatile("ds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"((unsigned)((lane ^ 32) * 4)), "v"(c) : "memory");
+        c = add1(c, o);
+        thr_row = mul1(c, kFloorStatScale);
+        thr_any = true;
+      }
+    }
     if constexpr (TOWER) {
       // the residual rows were requested at the end of step RSTEP; younger than them: the weight copies of the three steps since
       asm volatile("s_waitcnt vmcnt(%5)" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]) : "n"((kAhead - 1) * NI) : "memory");
@@ -729,6 +839,19 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
       [[maybe_unused]] f4 cu;
       if constexpr (H2) {
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(cu) : "v"(colc_b), "n"(3 * NWA * 4 + n * 64) : "memory");
+        // GUARD: an output is certified when |acc| >= the row's share + the column's (pna_x3_split.h); -inf columns (padding, all-zero
+        // weights) certify anything; a NaN / Inf accumulator compares false: non-finite rows are not the guard's.  Only for the column
+        // tiles that hold a column with a floor error of its own (cmask, kernel-uniform) -- or all of them when the wavefront holds a row with one.
+        if (guard_on && (thr_any || ((cmask >> n) & 1u))) {
+          f4 cv;
+          asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(cv) : "v"(colc_b), "n"(4 * NWA * 4 + n * 64) : "memory");
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float tcv;
+            asm("v_add_f32 %0, %1, %2" : "=v"(tcv) : "v"(thr_row), "v"(cv[r]));
+            bad = bad || (__builtin_fabsf(acc[n][r]) < tcv);
+          }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cb), "+v"(cs), "+v"(ct), "+v"(cu) : : "memory");
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cb), "+v"(cs), "+v"(ct) : : "memory");
@@ -763,6 +886,10 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
           if (c0 + 2 < g.N) o[2] = z[2];
         }
       }
+    }
+    if constexpr (H2) {
+      if (guard_on && __builtin_amdgcn_ballot_w64(bad && row >= 0) != 0 && lane == 0)
+        asm volatile("ds_or_b32 %0, %1" : : "v"(gflag_b + (unsigned)gpar * 4u), "v"(1u) : "memory");
     }
   };
 
@@ -857,6 +984,9 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
     if constexpr (sp >= kAhead - 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"((kAhead - 2) * NI + young) : "memory");
     else asm volatile("s_barrier" ::: "memory");
 #endif
+    if constexpr (H2 && sg == 0) {                        // (every wavefront's epilogue of the previous tile lies behind this barrier)
+      if (guard_on) collect();
+    }
     if constexpr (TOWER && c == PWAIT) {                  // (the wait above left only the two youngest images in flight)
       static_assert(NL == 4 || NL == 5, "tower shapes");
       asm volatile("" : "+v"(rp));
@@ -951,6 +1081,7 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
         t_n3 = __builtin_amdgcn_readfirstlane(v);
         par ^= 1;
       }
+      t_done = t; gpar ^= 1;
       t = t_n1; t_n1 = t_n2; t_n2 = t_n3;
     }
     if (t >= ntiles) break;                               // (wave-uniform)
@@ -962,14 +1093,13 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
     tg += now() - t2;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the copies issued for steps that do not exist
-  // the dynamic schedule leaves its two words as it found them: the LAST workgroup to get here (every claim of the launch has been
-  // made by then) zeroes them for the next launch on the stream -- no memset node in front of every launch
-  if (dyn && wave == 0 && lane == 0) {
-    if (__hip_atomic_fetch_add(g.counter + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1) {
-      __hip_atomic_store(g.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(g.counter + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if constexpr (H2) {
+    if (guard_on) {                                        // the last tile's hand-over word: every wavefront's epilogue has written by the barrier
+      __syncthreads();
+      collect();
     }
   }
+  finish();
 #ifdef PNA_AMD_EXPERIMENTS
   if (g.dbg && lane == 0) {
     unsigned long long* d = g.dbg + ((size_t)blockIdx.x * kWaves + wave) * 8;
@@ -978,45 +1108,109 @@ __global__ __launch_bounds__(64 * WAVES, (DUMP || WAVES == 8) ? 1 : 2) void k_fu
 #endif
 }
 
+// The launches (round 6).  ARITH 0 / 2: the layer in fp16 x 2 (2: the verification instantiations) -- GUARDED when the call carries a guard
+// workspace: a tile whose outputs the floor-error bound does not certify is appended to the device-wide hand-over list.  ARITH 1: the layer
+// in bf16 x 3 -- over its own tile tables, or (g.list_count set) as the CONSUMING launch behind a guarded one: the tile tables are the list's
+// copies, the tile count lives on the device, a workgroup that finds nothing to do leaves at once (one atomic load), and the launch zeroes
+// the count behind itself.  Measured alternatives (profiles/r06_arith_ab*.log): both phases in ONE launch behind a grid barrier -- the
+// combined kernel's hot loop ran 1.9 % slower (register allocation over two bodies) and 472 workgroups polling one word slowed the last
+// gathers by another 6 %; a persistent kernel's grid barrier is also only deadlock-free while every workgroup is resident, which two such
+// launches on one device (two streams, two ranks) do not guarantee.
+template <int NFBF, bool HALF, bool DUMP, bool TOWER, int ARITH, int GP, int NPAN>
+__global__ __launch_bounds__(64 * waves_for(GP, NPAN), (DUMP || waves_for(GP, NPAN) == 8) ? 1 : 2) void k_fused_degree(const FDArgs g) {
+  const int n1 = g.M / (waves_for(GP, NPAN) * 16);
+  if constexpr (ARITH == 1) {
+    int* const gw = g.list_count;                          // {tiles handed over | workgroups that have left | handed over since cleared | guarded calls}
+    int n = n1;
+    if (gw != nullptr) {
+      n = __builtin_amdgcn_readfirstlane(__hip_atomic_load(gw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if (n == 0) {                                        // (almost always: nothing was handed over -- nobody has anything to do or to reset)
+        if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(gw + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+    }
+    if ((int)blockIdx.x < n) fd_body<NFBF, HALF, DUMP, TOWER, false, !DUMP && !TOWER, GP, NPAN>(g, (int)blockIdx.x, (int)gridDim.x, n);
+    // the last workgroup to leave zeroes the count for the next call (every workgroup has read it by then) and keeps the statistics
+    if (gw != nullptr && threadIdx.x == 0 && __hip_atomic_fetch_add(gw + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+      __hip_atomic_fetch_add(gw + 2, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(gw + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(gw, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(gw + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else {
+    fd_body<NFBF, HALF, DUMP, TOWER, true, !DUMP && !TOWER, GP, NPAN>(g, (int)blockIdx.x, (int)gridDim.x, n1);
+  }
+}
+
 // ---- weight images: W_D = sum_s scale[i][s] W_s in fp32 (scaler order), K reordered into the kernel's chunks, cut into three
 //      bf16 terms, laid out as the LDS image of every chunk: [chunk][term][lane group][80 cols][8 k] ---------------------------
 //      Tower images (tower != 0): scaler blocks of K = 5 F columns [4 F aggregators | F self panel (block 0 only)], followed by
 //      the chunks of the two node panels: x_dst against W_D,mean + W_D,max + W_D,min, h against the self panel.
 //      Wide shapes (npan = 2): [chunk][panel][term][lane group][64 cols][8 k], panel p = output columns 64 p .. 64 p + 64.
-//      Round 5, the layer proper (tower = 0): TWO fp16 terms of W_D[n][.] * 2^s_n, s_n the power of two that puts the largest |W_D[n][k]| over
+//      fp16 x 2 images (round 5): TWO fp16 terms of W_D[n][.] * 2^s_n, s_n the power of two that puts the largest |W_D[n][k]| over
 //      k and over ALL images into [2^13, 2^14) (colmax: the maxima's bit patterns, k_fused_colmax; pna_x3_split.h); images `stride`
-//      elements apart, each followed by the tail of the columns' 2^-s_n (k_fused_tails).
+//      elements apart, each followed by the tail of the columns' 2^-s_n and of the guard's per-column thresholds (k_fused_wsmall, k_fused_tails).
 __device__ __forceinline__ float colmax_bound(unsigned bits) {   // (NaN / Inf / 0 maxima: any finite positive bound will do)
   return __builtin_fminf(__builtin_fmaxf(__builtin_bit_cast(float, bits), 1e-30f), 3.4028234663852886e38f);
 }
+// W_D[n][col] = sum_s scale_s(D) W_s[n][col], scaler order (the pack kernel's, the maxima's and the small-weight count's: op for op)
+__device__ __forceinline__ float fd_combined(const float* w_ref, long ldw, int n, int col, int im, int S, int K, const float* scale) {
+  const float* row = w_ref + (long)n * ldw + col;
+  float w = scale ? scale[(long)im * S] * row[0] : row[0];
+  for (int s = 1; s < S; ++s) w = w + (scale ? scale[(long)im * S + s] * row[(long)s * K] : row[(long)s * K]);
+  return w;
+}
+// weight `col` of output column n of image im as the images hold it: col < 5 F a combined weight, beyond the x_dst panel's sum (tower)
+__device__ __forceinline__ float fd_image_weight(const float* w_ref, long ldw, int n, int col, int im, int S, int F, int tower, const float* scale) {
+  const int K = tower ? 5 * F : 4 * F;
+  if (col < 5 * F) return fd_combined(w_ref, ldw, n, col, im, S, K, scale);
+  const int f = col - 5 * F;
+  return (fd_combined(w_ref, ldw, n, f, im, S, K, scale) + fd_combined(w_ref, ldw, n, F + f, im, S, K, scale)) + fd_combined(w_ref, ldw, n, 2 * F + f, im, S, K, scale);
+}
 __global__ void k_fused_colmax(const float* w_ref, long ldw, int N, int F, int S, const float* scale, int n_img, unsigned* colmax, int tower) {
-  const int K = tower ? 5 * F : 4 * F;                    // columns of a scaler block
   const int KC = tower ? 6 * F : 4 * F;                   // weights the images hold per output column: + the x_dst panel's sums (tower)
   const long total = (long)n_img * N * KC;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int col = (int)(i % KC);
     const int n = (int)((i / KC) % N), im = (int)(i / ((long)KC * N));
-    auto combined = [&](int c_) -> float {                // (k_pack_fused_degree's, op for op)
-      const float* row = w_ref + (long)n * ldw + c_;
-      float w = scale ? scale[(long)im * S] * row[0] : row[0];
-      for (int s = 1; s < S; ++s) w = w + (scale ? scale[(long)im * S + s] * row[(long)s * K] : row[(long)s * K]);
-      return w;
-    };
-    const int f = col - 5 * F;
-    const float w = col < 5 * F ? combined(col) : (combined(f) + combined(F + f)) + combined(2 * F + f);
+    const float w = fd_image_weight(w_ref, ldw, n, col, im, S, F, tower, scale);
     atomicMax(colmax + n, __builtin_bit_cast(unsigned, __builtin_fabsf(w)));      // (|w| as bits: ordered like the floats; NaN above all)
+  }
+}
+// GUARD (round 6): wex[n] = the largest, over the images, floor error of output column n's weights -- the sum over k of the part of the
+// two-term split's error of W_D[n][k] 2^s_n that is absolute (a non-zero weight below 2^-3 in the column's units) instead of relative
+// (pna_x3_split.h::h2_floor_error), as bits (non-negative floats order like their bit patterns).  One block per (image, column).
+__global__ void k_fused_wsmall(const float* w_ref, long ldw, int N, int F, int S, const float* scale, const unsigned* colmax, unsigned* wex, int tower) {
+  const int KC = tower ? 6 * F : 4 * F;
+  const int n = blockIdx.x % N, im = blockIdx.x / N;
+  const float sc = __builtin_ldexpf(1.0f, h2_scale_exp(colmax_bound(colmax[n])));
+  __shared__ float part[128];
+  float c = 0.f;
+  for (int col = threadIdx.x; col < KC; col += blockDim.x) c += h2_floor_error(fd_image_weight(w_ref, ldw, n, col, im, S, F, tower, scale) * sc);
+  part[threadIdx.x] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < (int)blockDim.x; ++i) t += part[i];            // (fixed order: the same bits every time)
+    if (t > 0.f) atomicMax(wex + n, __builtin_bit_cast(unsigned, t));
   }
 }
 __global__ void k_fused_tails(unsigned char* img, long payload, long stride_bytes, int n_img, int N) {
   const int n = threadIdx.x;                              // 128 threads
   const unsigned bits = reinterpret_cast<const unsigned*>(img + payload)[n];
+  const float wex = __builtin_bit_cast(float, reinterpret_cast<const unsigned*>(img + payload)[128 + n]);
   const float u = n < N ? __builtin_ldexpf(1.0f, -h2_scale_exp(colmax_bound(bits))) : 1.0f;
+  // (a column without a non-zero weight, and the padding: -inf -- an exact zero certifies itself)
+  const float cv = (n < N && bits != 0u) ? wex * kFloorWeightScale : -INFINITY;
   __syncthreads();
-  for (int im = 0; im < n_img; ++im) reinterpret_cast<float*>(img + (long)im * stride_bytes + payload)[n] = u;
+  for (int im = 0; im < n_img; ++im) {
+    reinterpret_cast<float*>(img + (long)im * stride_bytes + payload)[n] = u;
+    reinterpret_cast<float*>(img + (long)im * stride_bytes + payload)[128 + n] = cv;
+  }
 }
 __global__ void k_pack_fused_degree(const float* w_ref, long ldw, int N, int F, int S, const float* scale, int n_img, unsigned short* img, int tower,
                                     int nwp, int npan, int nterm, const unsigned* colmax, long stride) {
-  const int nfull = shape_full(F), NCS = shape_chunks(F), K = tower ? 5 * F : 4 * F;
+  const int nfull = shape_full(F), NCS = shape_chunks(F);
   const int NC = NCS + (tower ? 2 * nfull + (shape_half(F) ? 1 : 0) : 0);
   const long per = (long)NC * npan * nterm * 4 * nwp * 8;
   const long total = per * n_img;
@@ -1041,14 +1235,8 @@ __global__ void k_pack_fused_degree(const float* w_ref, long ldw, int N, int F, 
     const int wl = halfb ? 4 : 8, nom = fb * 32 + lgp * wl, st = lastb ? (nom < F - wl ? nom : F - wl) : nom;
     f = st + sj;
     const bool dup = f < nom;
-    auto combined = [&](int col) -> float {               // W_D[n][col] = sum_s scale_s(D) W_s[n][col], scaler order
-      const float* row = w_ref + (long)n * ldw + col;
-      float w = scale ? scale[(long)im * S] * row[0] : row[0];
-      for (int s = 1; s < S; ++s) w = w + (scale ? scale[(long)im * S + s] * row[(long)s * K] : row[(long)s * K]);
-      return w;
-    };
     float w = 0.f;
-    if (n < N && f < F && !dup) w = a < 5 ? combined(a * F + f) : (combined(f) + combined(F + f)) + combined(2 * F + f);
+    if (n < N && f < F && !dup) w = fd_image_weight(w_ref, ldw, n, a * F + f, im, S, F, tower, scale);     // (a = 5: column 5 F + f, the x_dst panel's sum)
     if (nterm == 3) img[(long)im * stride + i % per] = weight_term(w, term);
     else img[(long)im * stride + i % per] = weight_term_h2(w * __builtin_ldexpf(1.0f, h2_scale_exp(colmax_bound(colmax[n < N ? n : 0]))), term);
   }
@@ -1058,60 +1246,74 @@ __global__ void k_pack_fused_degree(const float* w_ref, long ldw, int N, int F, 
 __host__ __device__ constexpr bool shape_wide_f(int F) { return F > 96 && F <= 128 && shape_full(F) == 4 && !shape_half(F); }
 __host__ __device__ constexpr bool shape_wide_n(int N) { return N > kNW && N <= 128; }
 
-template <int NFBF, bool HALF, bool DUMP, bool TOWER = false, int GP = 1, int NPAN = 1>
+// ARITH: 0 fp16 x 2, guarded when g.guard is set | 1 bf16 x 3 (g.list_count: the consuming launch) | 2 fp16 x 2, the verification instantiations (DUMP)
+template <int NFBF, bool HALF, bool DUMP, bool TOWER, int GP, int NPAN, int ARITH>
 int launch(const FDArgs& g, int wgs, hipStream_t st) {
-  constexpr int NWP = NPAN == 1 ? kNW : 64;
-  constexpr int NBUF = buffers_for(GP, NPAN, 4 * NFBF + (HALF ? 2 : 0), TOWER), WAVES = waves_for(GP, NPAN);
-  constexpr bool H2 = !TOWER || kTowerH2;                                                                      // (the kernel's)
-  constexpr int NTERM = H2 ? 2 : 3, NCC = H2 ? 4 : 3;
-  const size_t lds = (size_t)NBUF * (NTERM * 4 * NWP) * 16 + (size_t)(NCC * NWP * NPAN) * sizeof(float) + 16;   // (+ the two hand-over words of the dynamic schedule)
-  auto* fn = k_fused_degree<NFBF, HALF, DUMP, TOWER, !DUMP && !TOWER, GP, NPAN, WAVES, NBUF>;
+  constexpr int NWP = NPAN == 1 ? kNW : 64, NC = 4 * NFBF + (HALF ? 2 : 0), WAVES = waves_for(GP, NPAN);
+  constexpr size_t lds_h2 = (size_t)buffers_for(GP, NPAN, NC, TOWER, true) * (2 * 4 * NWP) * 16 + (size_t)(5 * NWP * NPAN) * sizeof(float) + 16;
+  constexpr size_t lds_x3 = (size_t)buffers_for(GP, NPAN, NC, TOWER, false) * (3 * 4 * NWP) * 16 + (size_t)(3 * NWP * NPAN) * sizeof(float) + 16;
+  // (+ 16: the hand-over words of the dynamic schedule and of the guard)
+  const size_t lds = ARITH == 1 ? lds_x3 : lds_h2;
+  auto* fn = k_fused_degree<NFBF, HALF, DUMP, TOWER, ARITH, GP, NPAN>;
   if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
   if (WAVES == 8) wgs = (wgs + 1) / 2;                    // (the caller counts 4-wavefront workgroups, two per CU)
   hipLaunchKernelGGL(fn, dim3((unsigned)wgs), dim3(64 * WAVES), lds, st, g);
   return 0;
 }
-template <bool DUMP>
+template <bool DUMP, int ARITH>
 int launch_shape(const FDArgs& g, int wgs, hipStream_t st) {
   const int nf = shape_full(g.F);
   const bool half = shape_half(g.F);
   if (shape_wide_f(g.F) || shape_wide_n(g.N)) {
     if (g.xd) return -2;
-    if (shape_wide_f(g.F)) return shape_wide_n(g.N) ? launch<2, false, DUMP, false, 2, 2>(g, wgs, st) : launch<2, false, DUMP, false, 2, 1>(g, wgs, st);
-    if (nf == 2 && !half) return launch<2, false, DUMP, false, 1, 2>(g, wgs, st);
+    if (shape_wide_f(g.F)) return shape_wide_n(g.N) ? launch<2, false, DUMP, false, 2, 2, ARITH>(g, wgs, st) : launch<2, false, DUMP, false, 2, 1, ARITH>(g, wgs, st);
+    if (nf == 2 && !half) return launch<2, false, DUMP, false, 1, 2, ARITH>(g, wgs, st);
     return -2;
   }
   if constexpr (!DUMP) {
-    if (g.xd) return nf != 2 ? -2 : half ? launch<2, true, false, true>(g, wgs, st) : launch<2, false, false, true>(g, wgs, st);
+    if (g.xd) return nf != 2 ? -2 : half ? launch<2, true, false, true, 1, 1, ARITH>(g, wgs, st) : launch<2, false, false, true, 1, 1, ARITH>(g, wgs, st);
   }
-  if (nf == 1 && !half) return launch<1, false, DUMP>(g, wgs, st);
-  if (nf == 1 && half) return launch<1, true, DUMP>(g, wgs, st);
-  if (nf == 2 && !half) return launch<2, false, DUMP>(g, wgs, st);
-  if (nf == 2 && half) return launch<2, true, DUMP>(g, wgs, st);
+  if (nf == 1 && !half) return launch<1, false, DUMP, false, 1, 1, ARITH>(g, wgs, st);
+  if (nf == 1 && half) return launch<1, true, DUMP, false, 1, 1, ARITH>(g, wgs, st);
+  if (nf == 2 && !half) return launch<2, false, DUMP, false, 1, 1, ARITH>(g, wgs, st);
+  if (nf == 2 && half) return launch<2, true, DUMP, false, 1, 1, ARITH>(g, wgs, st);
   return -2;
+}
+
+bool shape_ok(int F, int N) {
+  // F: 17..80 (one gather pass) or 113..128 (two passes of two full blocks; 81..112 would need unequal passes: not built);
+  // N: 4..80 (one panel of 80 columns) or 81..128 (two panels of 64), the latter with exactly two full feature blocks per pass
+  // (49 <= F <= 64 or 113..128: with a half block on top, 80 statistics + the ring + 32 accumulators + the residual spill)
+  const bool f_ok = (F >= 17 && F <= 80) || shape_wide_f(F), n_ok = (N >= 4 && N <= kNW) || shape_wide_n(N);
+  return f_ok && n_ok && !(shape_wide_n(N) && !shape_wide_f(F) && !(shape_full(F) == 2 && !shape_half(F)));
+}
+bool tower_shape_ok(int F, int N) { return F <= 80 && N <= kNW && shape_ok(F, N) && shape_full(F) == 2; }
+// bytes of one image (stride between images): x3 = 0 two fp16 terms + the tail, 1 three bf16 terms
+int64_t image_bytes(int F, int N, int tower, int x3) {
+  if (tower ? !tower_shape_ok(F, N) : !shape_ok(F, N)) return 0;
+  const int chunks = shape_chunks(F) + (tower ? 2 * shape_full(F) + (shape_half(F) ? 1 : 0) : 0);
+  const int nterm = x3 ? 3 : 2;
+  const int64_t step = shape_wide_n(N) ? 2 * (nterm * 4 * 64) : nterm * 4 * kNW;
+  return (int64_t)chunks * step * 16 + (x3 ? 0 : kTailBytes);
 }
 
 }  // namespace
 
 extern "C" int32_t pna_fused_degree_tile_rows(int32_t F, int32_t N) {
-  if (pna_fused_degree_image_bytes(F, N) == 0) return 0;
+  if (!shape_ok(F, N)) return 0;
   return 16 * waves_for(shape_wide_f(F) ? 2 : 1, shape_wide_n(N) ? 2 : 1);
 }
 
-extern "C" int64_t pna_fused_degree_image_bytes(int32_t F, int32_t N) {
-  // F: 17..80 (one gather pass) or 113..128 (two passes of two full blocks; 81..112 would need unequal passes: not built);
-  // N: 4..80 (one panel of 80 columns) or 81..128 (two panels of 64), the latter with exactly two full feature blocks per pass
-  // (49 <= F <= 64 or 113..128: with a half block on top, 80 statistics + the ring + 32 accumulators + the residual spill)
-  const bool f_ok = (F >= 17 && F <= 80) || shape_wide_f(F), n_ok = (N >= 4 && N <= kNW) || shape_wide_n(N);
-  if (!f_ok || !n_ok || (shape_wide_n(N) && !shape_wide_f(F) && !(shape_full(F) == 2 && !shape_half(F)))) return 0;
-  return (int64_t)shape_chunks(F) * (shape_wide_n(N) ? 2 * (2 * 4 * 64) : kChunkVH) * 16 + kTailBytes;
+extern "C" int64_t pna_fused_image_bytes(int32_t F, int32_t N, int32_t tower, int32_t x3) { return image_bytes(F, N, tower != 0, x3 != 0); }
+extern "C" int64_t pna_fused_degree_image_bytes(int32_t F, int32_t N) { return image_bytes(F, N, 0, 0); }
+extern "C" int64_t pna_fused_tower_image_bytes(int32_t F, int32_t N) { return image_bytes(F, N, 1, 0); }
+
+extern "C" int64_t pna_fused_degree_guard_bytes(int64_t M) {
+  // {count | finished | handed over since cleared | consuming launches | pad to 64 bytes} + descriptors (16 bytes per 16 rows) + perm + row_post
+  return M < 0 ? 0 : 64 + M + 4 * M + 4 * M;
 }
 
-static int64_t tower_image_bytes(int F, int N) {
-  if (F > 80 || N > kNW || pna_fused_degree_image_bytes(F, N) == 0 || shape_full(F) != 2) return 0;
-  return (int64_t)(shape_chunks(F) + 2 * shape_full(F) + (shape_half(F) ? 1 : 0)) * (kTowerH2 ? kChunkVH : kChunkV) * 16 + (kTowerH2 ? kTailBytes : 0);
-}
-// column maxima -> fp16 x 2 images -> tails (stream-ordered; the first image's tail is the maxima's scratch until k_fused_tails)
+// column maxima -> small-weight counts -> fp16 x 2 images -> tails (stream-ordered; the first image's tail is the scratch of both until k_fused_tails)
 static int pack_h2(const char* who, const float* w_ref, int64_t ldw, int N, int F, int S, const float* scale, int n_img, void* img, int64_t stride,
                    int tower, int nwp, int npan, hipStream_t st) {
   const int64_t payload = stride - kTailBytes;
@@ -1122,6 +1324,7 @@ static int pack_h2(const char* who, const float* w_ref, int64_t ldw, int N, int 
   const int64_t welems = (int64_t)n_img * N * (tower ? 6 : 4) * F;
   hipLaunchKernelGGL(k_fused_colmax, dim3((unsigned)((welems + 255) / 256 > 4096 ? 4096 : (welems + 255) / 256)), dim3(256), 0, st, w_ref, (long)ldw, N, F,
                      S, scale, n_img, colmax, tower);
+  hipLaunchKernelGGL(k_fused_wsmall, dim3((unsigned)(n_img * N)), dim3(128), 0, st, w_ref, (long)ldw, N, F, S, scale, (const unsigned*)colmax, colmax + 128, tower);
   hipLaunchKernelGGL(k_pack_fused_degree, dim3(blocks), dim3(256), 0, st, w_ref, (long)ldw, N, F, S, scale, n_img,
                      (unsigned short*)img, tower, nwp, npan, 2, (const unsigned*)colmax, (long)(stride / 2));
   hipLaunchKernelGGL(k_fused_tails, dim3(1), dim3(128), 0, st, (unsigned char*)img, (long)payload, (long)stride, n_img, N);
@@ -1129,46 +1332,47 @@ static int pack_h2(const char* who, const float* w_ref, int64_t ldw, int N, int 
   if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
   return PNA_OK;
 }
-extern "C" int64_t pna_fused_tower_image_bytes(int32_t F, int32_t N) { return tower_image_bytes(F, N); }
 
-extern "C" int pna_fused_tower_pack_f32(const float* w_ref, int64_t ldw, int32_t N, int32_t F, int32_t n_scaler, const float* scale,
-                                        int32_t n_img, void* img, pna_stream_t stream) {
-  if (!w_ref || !img || n_img < 1 || n_scaler < 1 || n_scaler > PNA_MAX_SCALER || tower_image_bytes(F, N) == 0 ||
-      ldw < (int64_t)n_scaler * 5 * F || (n_scaler > 1 && !scale))
-    return pna_set_error(PNA_E_INVALID, "pna_fused_tower_pack_f32: bad arguments (49 <= F <= 80, 4 <= N <= 80, ldw >= n_scaler * 5 F, scale required for n_scaler > 1)");
-  if (kTowerH2) return pack_h2("pna_fused_tower_pack_f32: hipMemsetAsync failed", w_ref, ldw, N, F, n_scaler, scale, n_img, img, tower_image_bytes(F, N), 1, kNW, 1,
-                               (hipStream_t)stream);
-  const int64_t elems = tower_image_bytes(F, N) / 2 * n_img;
+extern "C" int pna_fused_pack_f32(const float* w_ref, int64_t ldw, int32_t N, int32_t F, int32_t n_scaler, const float* scale,
+                                  int32_t n_img, void* img, int32_t tower, int32_t x3, pna_stream_t stream) {
+  const int64_t stride = image_bytes(F, N, tower != 0, x3 != 0);
+  if (!w_ref || !img || n_img < 1 || n_scaler < 1 || n_scaler > PNA_MAX_SCALER || stride == 0 ||
+      ldw < (int64_t)n_scaler * (tower ? 5 : 4) * F || (n_scaler > 1 && !scale))
+    return pna_set_error(PNA_E_INVALID, "pna_fused_pack_f32: bad arguments (pna_fused_image_bytes(F, N, tower, x3) > 0, ldw >= n_scaler * (tower ? 5 : 4) F, scale required for n_scaler > 1)");
+  const bool wide = shape_wide_n(N);
+  if (!x3) return pack_h2("pna_fused_pack_f32: hipMemsetAsync failed", w_ref, ldw, N, F, n_scaler, scale, n_img, img, stride, tower ? 1 : 0, wide ? 64 : kNW,
+                          wide ? 2 : 1, (hipStream_t)stream);
+  const int64_t elems = stride / 2 * n_img;
   const int blocks = (int)((elems + 255) / 256 > 8192 ? 8192 : (elems + 255) / 256);
   hipLaunchKernelGGL(k_pack_fused_degree, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ref, (long)ldw, N, F, n_scaler, scale, n_img,
-                     (unsigned short*)img, 1, kNW, 1, 3, (const unsigned*)nullptr, (long)(tower_image_bytes(F, N) / 2));
+                     (unsigned short*)img, tower ? 1 : 0, wide ? 64 : kNW, wide ? 2 : 1, 3, (const unsigned*)nullptr, (long)(stride / 2));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
   return PNA_OK;
 }
-
+extern "C" int pna_fused_tower_pack_f32(const float* w_ref, int64_t ldw, int32_t N, int32_t F, int32_t n_scaler, const float* scale,
+                                        int32_t n_img, void* img, pna_stream_t stream) {
+  return pna_fused_pack_f32(w_ref, ldw, N, F, n_scaler, scale, n_img, img, 1, 0, stream);
+}
 extern "C" int pna_fused_degree_pack_f32(const float* w_ref, int64_t ldw, int32_t N, int32_t F, int32_t n_scaler, const float* scale,
                                          int32_t n_img, void* img, pna_stream_t stream) {
-  if (!w_ref || !img || n_img < 1 || n_scaler < 1 || n_scaler > PNA_MAX_SCALER || pna_fused_degree_image_bytes(F, N) == 0 ||
-      ldw < (int64_t)n_scaler * 4 * F || (n_scaler > 1 && !scale))
-    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_pack_f32: bad arguments (F in 17..80 or 113..128, N in 4..128, N > 80 needs F in 49..64 or 113..128; scale required for n_scaler > 1)");
-  const bool wide = shape_wide_n(N);
-  return pack_h2("pna_fused_degree_pack_f32: hipMemsetAsync failed", w_ref, ldw, N, F, n_scaler, scale, n_img, img, pna_fused_degree_image_bytes(F, N), 0,
-                 wide ? 64 : kNW, wide ? 2 : 1, (hipStream_t)stream);
+  return pna_fused_pack_f32(w_ref, ldw, N, F, n_scaler, scale, n_img, img, 0, 0, stream);
 }
 
 extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t stream) {
   if (!p) return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: null args");
   if (int rc_ss = pna_check_struct_size("pna_fused_degree_f32", p->struct_size, sizeof(*p))) return rc_ss;
   if (p->M == 0) return PNA_OK;
-  if (!p->tile_desc || !p->tile_ids || !p->x || !p->row_perm || !p->w_img || !p->y)
-    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: tile_desc / tile_ids / x / row_perm / w_img / y must be non-null");
-  if (pna_fused_degree_image_bytes(p->F, p->N) == 0)
+  const int arith = p->arith;
+  if (arith != PNA_FD_ARITH_GUARDED && arith != PNA_FD_ARITH_X3 && arith != PNA_FD_ARITH_H2)
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: arith must be PNA_FD_ARITH_GUARDED, PNA_FD_ARITH_X3 or PNA_FD_ARITH_H2");
+  const bool need_h2 = arith != PNA_FD_ARITH_X3, need_x3 = arith != PNA_FD_ARITH_H2;
+  if (!p->tile_desc || !p->tile_ids || !p->x || !p->row_perm || !p->y || (need_h2 && !p->w_img) || (need_x3 && !p->w_img_x3))
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: tile_desc / tile_ids / x / row_perm / y and the images of the arithmetic (w_img: fp16 x 2, w_img_x3: bf16 x 3) must be non-null");
+  if (!shape_ok(p->F, p->N))
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: F in 17..80 or 113..128, N in 4..128 (N > 80 needs F in 49..64 or 113..128)");
-  const int need = shape_wide_f(p->F) ? 128 : shape_half(p->F) ? (p->F + 3) / 4 * 4 : (p->F + 7) / 8 * 8;
   // (round 4: the source rows are read through 64-bit lane addresses -- any 4-byte aligned pitch >= F, no 4 GiB / 2^24-row limit; the
-  // strips of a row's last block are 16-byte reads that may reach up to `need` floats from the row's start: the caller's storage
-  // must be readable there, which a (V, F) tensor's is for every row but the last)
+  // strips of a row's last block are 16-byte reads that end at the row's F-th float: no read leaves a row)
   if (p->ldx < p->F || ((uintptr_t)p->x & 3) != 0 || (int64_t)p->ldx * 4 >= (1ll << 31))
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: x must be 4-byte aligned with a row pitch >= F (< 2^29 floats)");
   if (p->x_rows < 1 || p->x_rows >= (1ll << 32))
@@ -1179,21 +1383,28 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
   if (p->n_records < 4 || p->n_records * 64 >= (1ll << 32))
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: tile_ids must hold 4 <= n_records < 2^26 records");
   if (p->n_nodes < 1 || p->ldy < p->N || p->n_nodes * p->ldy * 4 >= (1ll << 32) ||
-      (p->residual && (p->ld_res < p->N || p->n_nodes * p->ld_res * 4 >= (1ll << 32))) || p->image_stride <= 0)
-    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: bad n_nodes / ldy / ld_res / image_stride (y and residual must be < 4 GiB)");
+      (p->residual && (p->ld_res < p->N || p->n_nodes * p->ld_res * 4 >= (1ll << 32))))
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: bad n_nodes / ldy / ld_res (y and residual must be < 4 GiB)");
   if (p->relu < 0 || p->relu > 2) return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: relu must be 0, 1 or 2");
   if (p->spare_workgroups < 0) return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: spare_workgroups must be >= 0");
   if ((p->col_scale == nullptr) != (p->col_shift == nullptr))
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: col_scale and col_shift come together");
   if (p->agg_out && p->ld_agg < 4 * (int64_t)p->F) return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: ld_agg < 4 F");
+  if (p->agg_out && arith != PNA_FD_ARITH_H2)
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: agg_out (the verification instantiation) takes arith = PNA_FD_ARITH_H2");
   const bool tower = p->x_dst || p->h_self || p->row_post;
   if (tower) {
-    if (!p->x_dst || !p->h_self || !p->row_post || p->agg_out || tower_image_bytes(p->F, p->N) == 0)
+    if (!p->x_dst || !p->h_self || !p->row_post || p->agg_out || !tower_shape_ok(p->F, p->N))
       return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: tower mode takes x_dst, h_self and row_post together, 49 <= F <= 80, no agg_out");
     if (p->ld_xdst < p->F || ((uintptr_t)p->x_dst & 3) != 0 || p->ld_h < p->F || ((uintptr_t)p->h_self & 3) != 0 ||
         p->n_nodes >= (1 << 24) || p->n_nodes * p->ld_xdst * 4 >= (1ll << 32) || p->n_nodes * p->ld_h * 4 >= (1ll << 32))
       return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: x_dst / h_self must be 4-byte aligned (n_nodes, >= F) tables below 4 GiB and 2^24 rows");
   }
+  // the images lie exactly pna_fused_image_bytes apart: the pack functions' layout (ABI 20; a padded stride would misplace the tails)
+  if ((need_h2 && p->image_stride != image_bytes(p->F, p->N, tower, 0)) || (need_x3 && p->image_stride_x3 != image_bytes(p->F, p->N, tower, 1)))
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: image_stride / image_stride_x3 must equal pna_fused_image_bytes(F, N, tower, 0 / 1)");
+  if (arith == PNA_FD_ARITH_GUARDED && (!p->guard_ws || p->guard_ws_bytes < pna_fused_degree_guard_bytes(p->M) || ((uintptr_t)p->guard_ws & 15) != 0))
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: PNA_FD_ARITH_GUARDED needs a 16-byte aligned guard_ws of pna_fused_degree_guard_bytes(M) bytes (zero before its first use)");
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
     return pna_set_error(PNA_E_NODEVICE, "pna_fused_degree_f32: no device");
@@ -1221,7 +1432,31 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
   if (p->spare_workgroups > 0) wgs = wgs - p->spare_workgroups > cus ? wgs - p->spare_workgroups : cus;   // (never below one per CU)
   if (ntiles < wgs) wgs = ntiles;
   hipStream_t st = (hipStream_t)stream;
-  const int rc = p->agg_out ? launch_shape<true>(g, wgs, st) : launch_shape<false>(g, wgs, st);
+  int rc = 0;
+  if (arith == PNA_FD_ARITH_X3) {
+    g.w_img = (const unsigned char*)p->w_img_x3; g.img_stride = p->image_stride_x3;
+    rc = launch_shape<false, 1>(g, wgs, st);
+  } else if (p->agg_out) {
+    rc = launch_shape<true, 2>(g, wgs, st);
+  } else {
+    if (arith == PNA_FD_ARITH_GUARDED) {
+      unsigned char* ws = (unsigned char*)p->guard_ws;
+      g.guard = reinterpret_cast<int*>(ws);
+      g.g_desc = reinterpret_cast<i4*>(ws + 64);
+      g.g_perm = reinterpret_cast<int*>(ws + 64 + p->M);
+      g.g_post = reinterpret_cast<float*>(ws + 64 + 5 * p->M);
+    }
+    rc = launch_shape<false, 0>(g, wgs, st);
+    if (rc == 0 && arith == PNA_FD_ARITH_GUARDED) {
+      // the consuming launch: the SAME layer in bf16 x 3 over the tiles handed over (their count lives on the device: a grid of
+      // workgroups that almost always find nothing and leave at once)
+      FDArgs c = g;
+      c.w_img = (const unsigned char*)p->w_img_x3; c.img_stride = p->image_stride_x3;
+      c.tdesc = g.g_desc; c.perm = g.g_perm; c.row_post = tower ? g.g_post : nullptr;
+      c.counter = nullptr; c.guard = nullptr; c.list_count = g.guard;
+      rc = launch_shape<false, 1>(c, wgs, st);
+    }
+  }
   if (rc != 0) return pna_set_error(PNA_E_LAUNCH, rc == -2 ? "pna_fused_degree_f32: no instantiation for this F" : "pna_fused_degree_f32: hipFuncSetAttribute failed");
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));

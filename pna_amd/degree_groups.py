@@ -416,28 +416,43 @@ def combined_images(weight, K, row_scales, plan):
     return img, stride
 
 
-def fused_tower_images(weight, F, row_scales, plan):
+def fused_tower_images(weight, F, row_scales, plan, x3=False):
     """fused_images() for the tower mode of pna_fused_degree_f32: `weight` (N, S * 5F) in scaler blocks [4F aggregators | F self
     panel (block 0)] (functional._tower_collapsed_weights with one tower); the pack kernel appends the chunks of the two node
-    panels (pna_fused_tower_pack_f32)."""
-    return fused_images(weight, F, row_scales, plan, tower=True)
+    panels."""
+    return fused_images(weight, F, row_scales, plan, tower=True, x3=x3)
 
 
-def fused_images(weight, F, row_scales, plan, tower=False):
+def fused_arith():
+    """The arithmetic of the one-kernel layers' contraction (include/pna_amd.h PNA_FD_ARITH_*): `guarded` (default) = two fp16 terms /
+    three partial products with the floor-error guard -- tiles whose outputs it cannot certify are computed again in bf16 x 3 by a second
+    launch --; `bf16x3` = three bf16 terms / six products everywhere (rounds 3-4; also what PNA_AMD_POSTTRANS=bf16x3 selects: ADVICE r5);
+    `fp16x2` = round 5's unguarded form (opt-in: operands of moderate dynamic range only)."""
+    from . import _lib, ops
+    name = FUSED_ARITH
+    if name == "guarded" and ops.POSTTRANS_ARITH == "bf16x3":
+        name = "bf16x3"
+    try:
+        return {"guarded": _lib.FD_ARITH_GUARDED, "bf16x3": _lib.FD_ARITH_X3, "fp16x2": _lib.FD_ARITH_H2}[name]
+    except KeyError:
+        raise ValueError(f"PNA_AMD_FUSED_ARITH must be guarded, bf16x3 or fp16x2 (got {name!r})") from None
+
+
+def fused_images(weight, F, row_scales, plan, tower=False, x3=False):
     """Packed images of W_D = sum_s s_s(D) W_s for pna_fused_degree_f32 (K in the kernel's chunk order), one per degree group,
-    cached on the weight like combined_images.  The combination and the operand split (two fp16 terms behind per-column power-of-two
-    scales; tower images: three bf16 terms) happen in the pack kernel
-    (pna_fused_degree_pack_f32) from the (G, S) matrix of the groups' scaler values."""
+    cached on the weight like combined_images.  The combination and the operand split (x3=False: two fp16 terms behind per-column
+    power-of-two scales + the tail of column scales and guard thresholds; x3=True: three bf16 terms) happen in the pack kernel
+    (pna_fused_pack_f32) from the (G, S) matrix of the groups' scaler values."""
     N, G, S = weight.shape[0], plan.G, len(row_scales)
-    key = ("fused", tower, weight._version, weight.data_ptr(), str(weight.device), tuple(weight.shape), F, plan.serial, G,
+    key = ("fused", tower, x3, weight._version, weight.data_ptr(), str(weight.device), tuple(weight.shape), F, plan.serial, G,
            tuple(None if rs is None else (rs.data_ptr(), rs._version) for rs in row_scales))
     attr = "_pna_amd_fused_img"
     cache = getattr(weight, attr, None)                     # {plan serial: (key, image, stride)}: the block plans of a pipelined run
-    hit = cache.get((tower, plan.serial)) if isinstance(cache, dict) else None      # share one weight, each with its own groups
+    hit = cache.get((tower, x3, plan.serial)) if isinstance(cache, dict) else None      # share one weight, each with its own groups
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
     L = _lib.lib()
-    stride = L.pna_fused_tower_image_bytes(F, N) if tower else L.pna_fused_degree_image_bytes(F, N)
+    stride = L.pna_fused_image_bytes(F, N, 1 if tower else 0, 1 if x3 else 0)
     if stride <= 0:
         raise RuntimeError(f"pna_fused_degree: unsupported shape F={F}, N={N}")
     with torch.no_grad():
@@ -448,25 +463,69 @@ def fused_images(weight, F, row_scales, plan, tower=False):
         scale = scale.contiguous()
     img = torch.empty(G * stride // 4, dtype=torch.float32, device=weight.device)
     w = weight.detach()
-    pack = L.pna_fused_tower_pack_f32 if tower else L.pna_fused_degree_pack_f32
-    rc = pack(_lib.dev_ptr(w, torch.float32, "weight"), w.stride(0), N, F, S, _lib.dev_ptr(scale, torch.float32, "scale"),
-              G, _lib.dev_ptr(img, torch.float32, "w_img"), _lib.stream_ptr(weight.device))
-    _lib.check(rc, "pna_fused_tower_pack_f32" if tower else "pna_fused_degree_pack_f32")
+    rc = L.pna_fused_pack_f32(_lib.dev_ptr(w, torch.float32, "weight"), w.stride(0), N, F, S, _lib.dev_ptr(scale, torch.float32, "scale"),
+                              G, _lib.dev_ptr(img, torch.float32, "w_img"), 1 if tower else 0, 1 if x3 else 0, _lib.stream_ptr(weight.device))
+    _lib.check(rc, "pna_fused_pack_f32")
     try:
         if not isinstance(cache, dict):
             cache = {}
             weight._pna_amd_fused_img = cache
         if len(cache) >= 64:                                 # (plans of dropped graphs: start over rather than grow)
             cache.clear()
-        cache[(tower, plan.serial)] = (key, img, stride)
+        cache[(tower, x3, plan.serial)] = (key, img, stride)
     except AttributeError:
         pass
     return img, stride
 
 
+def bind_fused_arith(a, keep, weight, F, row_scales, plan, tower, device, verification=False):
+    """Fill the arithmetic half of a pna_fused_degree_args block: the images of the arithmetic fused_arith() selects and, for the
+    guarded form, the plan's hand-over workspace (one per (plan, stream), like the tile counters: launches on one stream are ordered).
+    `keep`: a list that keeps the tensors alive.  verification: the agg_out instantiation (fp16 x 2, unguarded)."""
+    arith = _lib.FD_ARITH_H2 if verification else fused_arith()
+    a.arith = arith
+    if arith != _lib.FD_ARITH_X3:
+        img, stride = fused_images(weight, F, row_scales, plan, tower=tower, x3=False)
+        a.w_img, a.image_stride = _lib.dev_ptr(img, torch.float32, "w_img"), stride
+        keep.append(img)
+    if arith != _lib.FD_ARITH_H2:
+        img3, stride3 = fused_images(weight, F, row_scales, plan, tower=tower, x3=True)
+        a.w_img_x3, a.image_stride_x3 = _lib.dev_ptr(img3, torch.float32, "w_img_x3"), stride3
+        keep.append(img3)
+    if arith == _lib.FD_ARITH_GUARDED:
+        ws = guard_workspace(plan, device)
+        a.guard_ws, a.guard_ws_bytes = _lib.dev_ptr(ws, torch.int32, "guard_ws"), ws.numel() * 4
+        keep.append(ws)
+    return arith
+
+
+def guard_workspace(plan, device):
+    """int32 tensor of pna_fused_degree_guard_bytes(plan.NV) bytes for the current stream: words [0..1] the running call's, [2] the tiles
+    handed over to the bf16 x 3 launch since the caller last zeroed it, [3] the calls (guard_stats)."""
+    ckey = (str(device), int(torch.cuda.current_stream(device).cuda_stream))
+    wss = plan.__dict__.setdefault("_guard_ws", {})
+    ws = wss.get(ckey)
+    if ws is None:
+        if len(wss) > 16:
+            wss.clear()
+        nb = _lib.lib().pna_fused_degree_guard_bytes(plan.NV)
+        ws = wss[ckey] = torch.zeros((nb + 3) // 4, dtype=torch.int32, device=device)
+    return ws
+
+
+def guard_stats(plan, device, reset=False):
+    """(tiles handed over to the bf16 x 3 launch, guarded calls) on the current stream since the last reset (one host read)."""
+    ws = guard_workspace(plan, device)
+    t, c = (int(v) for v in ws[2:4].tolist())
+    if reset:
+        ws[2:4].zero_()
+    return t, c
+
+
 # Load balance of the one-kernel layer (DegreePlan.fused_balance): "dynamic" (tiles claimed from a device counter, heaviest first / cheapest
 # last) | "lpt" | "cheap_last" (static schedules over a cost-balanced list) | "off" (the plan's ascending order, static)
 FUSED_BALANCE = os.environ.get("PNA_AMD_FUSED_BALANCE", "dynamic")
+FUSED_ARITH = os.environ.get("PNA_AMD_FUSED_ARITH", "guarded")   # guarded | bf16x3 | fp16x2 (fused_arith)
 FUSED_DYNAMIC_TAIL = int(os.environ.get("PNA_AMD_FUSED_DYNAMIC_TAIL", "4"))   # "dynamic": this many x G of the cheapest tiles end the list
 FUSED_TILE_COST = float(os.environ.get("PNA_AMD_FUSED_TILE_COST", "10"))   # a tile's constant cost in edge units (multiply + epilogue + control)
 OUT_PITCH_ALIGN = int(os.environ.get("PNA_AMD_OUT_PITCH_ALIGN", "32"))   # floats: row pitch of the one-kernel layers' own output (functional.out_pitch)

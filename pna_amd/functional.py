@@ -652,6 +652,8 @@ def _bind_tile_order(call, spare):
         a.spare_workgroups, a.tile_desc, a.row_perm, a.tile_counter = int(spare), hit[0], hit[1], hit[2]
         if hit[3] is not None:
             a.row_post = hit[3]
+        if hit[5] is not None:
+            a.guard_ws = hit[5]
         return
     a.spare_workgroups = int(spare)
     bal = None
@@ -682,12 +684,16 @@ def _bind_tile_order(call, spare):
                 counters.clear()
             counter = counters[ckey] = torch.zeros(2, dtype=torch.int32, device=call.y.device)
     a.tile_counter = None if counter is None else _lib.dev_ptr(counter, torch.int32, "tile_counter")
-    call._order_keep = (desc, perm, post, counter)
+    gws = None
+    if a.arith == _lib.FD_ARITH_GUARDED:                     # the guard's hand-over workspace belongs to the stream too
+        gws = DG.guard_workspace(plan, call.y.device)
+        a.guard_ws, a.guard_ws_bytes = _lib.dev_ptr(gws, torch.int32, "guard_ws"), gws.numel() * 4
+    call._order_keep = (desc, perm, post, counter, gws)
     a.tile_desc, a.row_perm = _lib.dev_ptr(desc, torch.int32, "tile_desc"), _lib.dev_ptr(perm, torch.int32, "row_perm")
     rp = None
     if post is not None and a.row_post:
         rp = a.row_post = _lib.dev_ptr(post, torch.float32, "row_post")
-    memo[mkey] = (a.tile_desc, a.row_perm, a.tile_counter, rp, call._order_keep)
+    memo[mkey] = (a.tile_desc, a.row_perm, a.tile_counter, rp, call._order_keep, a.guard_ws if gws is not None else None)
 
 
 def DG_balance_key():
@@ -723,16 +729,15 @@ class FusedTowerCall:
         else:
             self.post_g, self.post_r = plan.ones_rows(), None
         desc, ids, n_rec = plan.fused_tables()
-        img, stride = DG.fused_tower_images(Wv, Fi, scales, plan)
-        self.keep = (desc, ids, img, x_cat)
+        self.keep = [desc, ids, x_cat]
         a = _lib.PnaFusedDegreeArgs()
+        self.arith = DG.bind_fused_arith(a, self.keep, Wv, Fi, scales, plan, True, dev)
         a.tile_desc, a.tile_ids, a.n_records = _lib.dev_ptr(desc, torch.int32, "tile_desc"), _lib.dev_ptr(ids, torch.int32, "tile_ids"), n_rec
         a.x, a.ldx, a.x_rows, a.F, a.N = _lib.dev_ptr(self.x_src, torch.float32, "x_src"), x_cat.stride(0), V, Fi, N
         a.x_dst, a.ld_xdst = _lib.dev_ptr(self.x_dst, torch.float32, "x_dst"), x_cat.stride(0)
         a.h_self, a.ld_h = _lib.dev_ptr(h, torch.float32, "h"), h.stride(0)
         a.row_post = _lib.dev_ptr(self.post_g, torch.float32, "row_post")
         a.row_perm, a.M, a.n_nodes = _lib.dev_ptr(plan.perm, torch.int32, "row_perm"), plan.NV, V
-        a.w_img, a.image_stride = _lib.dev_ptr(img, torch.float32, "w_img"), stride
         a.bias = _lib.dev_ptr(d, torch.float32, "bias")
         a.col_scale, a.col_shift = _lib.dev_ptr(ones, torch.float32, "col_scale"), _lib.dev_ptr(c, torch.float32, "col_shift")
         if res is not None:
@@ -800,13 +805,12 @@ class FusedDegreeCall:
         self.y = y = torch.empty(V, out_pitch(N), dtype=torch.float32, device=h.device)[:, :N] if out is None else out
         self.cs, self.ct, self.res = cs, ct, res = _layer_tail_operands(layer, h)
         desc, ids, n_rec = plan.fused_tables()
-        img, stride = DG.fused_images(lin.weight, F, scales, plan)
-        self.keep = (desc, ids, img, lin, agg_out, h)
+        self.keep = [desc, ids, lin, agg_out, h]
         a = _lib.PnaFusedDegreeArgs()
+        self.arith = DG.bind_fused_arith(a, self.keep, lin.weight, F, scales, plan, False, h.device, verification=agg_out is not None)
         a.tile_desc, a.tile_ids, a.n_records = _lib.dev_ptr(desc, torch.int32, "tile_desc"), _lib.dev_ptr(ids, torch.int32, "tile_ids"), n_rec
         a.x, a.ldx, a.x_rows, a.F, a.N = _lib.dev_ptr(x, torch.float32, "x"), x.stride(0), x.shape[0], F, N
         a.row_perm, a.M, a.n_nodes = _lib.dev_ptr(plan.perm, torch.int32, "row_perm"), plan.NV, V
-        a.w_img, a.image_stride = _lib.dev_ptr(img, torch.float32, "w_img"), stride
         a.bias = _lib.dev_ptr(lin.bias, torch.float32, "bias")
         a.col_scale, a.col_shift = _lib.dev_ptr(cs, torch.float32, "col_scale"), _lib.dev_ptr(ct, torch.float32, "col_shift")
         if res is not None:

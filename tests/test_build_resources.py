@@ -85,7 +85,8 @@ def test_one_kernel_layer_never_touches_a_register_in_flight(tmp_path):
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
                     "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "pna_fused_degree.hip")], check=True, capture_output=True)
     names = sorted(set(re.findall(r"^(_ZN\S*k_fused_degreeI\S+?):", open(out).read(), flags=re.M)))
-    assert len(names) == 16, names                         # (4 shapes + 3 wide ones) x (production, verification) + 2 tower shapes
+    # (4 shapes + 3 wide ones) x (fp16 x 2 production, fp16 x 2 verification, bf16 x 3 production) + 2 tower shapes x (fp16 x 2, bf16 x 3)
+    assert len(names) == 25, names
     for n in names:
         kl = isa_audit.kernel_lines(out, n)
         probs = isa_audit.audit(kl)
