@@ -545,6 +545,15 @@ FUSED_OVERLAP_MIN_F = 64           # ... and so it is with few features (the cha
 FUSED_OVERLAP_MAX_REST_EDGES = 1.0 / 12   # ... and so it is when the rest rows hold more than this fraction of the group rows' edges
 
 
+def out_pitch_floats(N):
+    """Row pitch (floats) of the output the degree-grouped layers allocate (functional.out_pitch: whole 128-byte lines), at least the
+    80 / 128-column block of the grouped contraction: what the kernels' 32-bit row offsets must cover (the guard used to
+    assume 80 floats while the one-kernel layer allocates 96 for 65 <= N <= 80 -- a graph of 11.2-13.4 M nodes passed the guard and was
+    then refused by pna_fused_degree_f32)."""
+    a = max(4, int(OUT_PITCH_ALIGN))
+    return max((N + a - 1) // a * a, 80 if N <= 80 else 128)
+
+
 def fused_applies(graph, x, F, N):
     """Whether pna_fused_degree_f32 serves this call (whole-graph inference path already chosen by `applies`): a shape it is
     instantiated for and a unit-stride, 4-byte aligned source table.  Since round 4 the rows are read through 64-bit lane addresses and
@@ -568,7 +577,7 @@ def applies(graph, V, N, n_scaler, aggregators, F=None, n_edges=None, x_rows=Non
     from .graph import Graph
     from .shard import HaloGraph
     if not (ENABLED and type(graph) in (Graph, HaloGraph) and V >= MIN_ROWS and MIN_OUT <= N <= 128 and (n_scaler == 3 or (n_scaler == 2 and N >= TWO_SCALER_MIN_OUT))
-            and tuple(aggregators) == ("mean", "max", "min", "std") and V * (80 if N <= 80 else 128) * 4 < (1 << 32)):
+            and tuple(aggregators) == ("mean", "max", "min", "std") and V * out_pitch_floats(N) * 4 < (1 << 32)):
         return False
     # the gather of this path REQUIRES the hand-scheduled kernel (only it writes the plan's row order): its own preconditions
     # (pna_segreduce.hip fast_ok: dwordx4 lanes, 32-bit edge positions; since round 4 source tables beyond 2^24 rows / 4 GiB through

@@ -93,6 +93,22 @@ def test_aggregate_pitch_and_gating():
     assert not DG.applies(g, V - 1, 75, 3, aggr) and not DG.applies(g, V, 75, 3, ("mean", "max")) and not DG.applies(g, V, 129, 3, aggr)
 
 
+def test_output_pitch_bounds_the_grouped_paths_row_offsets():
+    """the one-kernel layers allocate y at a 128-byte-line pitch (N = 75 -> 96 floats); the 4 GiB guard of applies() must
+    use THAT pitch, or a graph of 11.2-13.4 M nodes with 65 <= N <= 80 is accepted here and refused by pna_fused_degree_f32."""
+    from pna_amd import functional as PF
+    for N in (40, 64, 65, 75, 80, 81, 96, 128):
+        assert DG.out_pitch_floats(N) >= PF.out_pitch(N) and DG.out_pitch_floats(N) >= (80 if N <= 80 else 128)
+    assert DG.out_pitch_floats(75) == 96 and DG.out_pitch_floats(64) == 80 and DG.out_pitch_floats(128) == 128
+    V = DG.MIN_ROWS
+    src, dst = powerlaw_graph(V, 4 * V, seed=1)
+    g = Graph(src, dst, V)
+    aggr = ("mean", "max", "min", "std")
+    lim = (1 << 32) // (96 * 4)                              # rows of 96 floats below 4 GiB
+    assert DG.applies(g, lim - 1, 75, 3, aggr) and not DG.applies(g, lim + 1, 75, 3, aggr)     # (V is only the caller's row count here)
+    assert DG.applies(g, (1 << 32) // (80 * 4) - 1, 64, 3, aggr)
+
+
 def test_plan_without_any_group():
     """No in-degree value fills a 128-row tile (a small graph): the plan is all rest rows, nothing crashes."""
     src, dst = powerlaw_graph(500, 5000, seed=1)

@@ -586,6 +586,134 @@ def test_tower_mode_fp16_scales_over_a_wide_dynamic_range(cuda_device, F):
     assert (scale > 1e3).float().mean().item() > 0.3            # (the bar bites: a third of the rows are far above the O(1) floor)
 
 
+def _tower_layer_float64(layer, g, h, snorm):
+    """PNALayer.forward (models/dgl/pna_layer.py:33-76, :130-145; eval) in float64 for every node at once, and the mass
+    sum |w_k| |a_k| of its chain of sums carried to the output (the per-element bar's floor): per edge pretrans Linear of [h_u | h_v],
+    the four aggregators, the three scalers, posttrans Linear, graph norm, eval BatchNorm, mixing Linear + LeakyReLU, residual."""
+    dev = h.device
+    V = h.shape[0]
+    csr = g.csr
+    dst = torch.repeat_interleave(torch.arange(V, device=dev), (csr.rowptr[1:] - csr.rowptr[:-1]).long())
+    src = csr.col.long()
+    deg = (csr.rowptr[1:] - csr.rowptr[:-1]).double()
+    amp, att = (t.double()[:, None] for t in g.degree_scalers(2.3))
+    towers, mix = list(layer.towers), layer.mixing_network
+    T, Fi = len(towers), towers[0].in_dim
+    outs, masses = [], []
+    for t, tw in enumerate(towers):
+        ht = (h[:, t * Fi:(t + 1) * Fi] if layer.divide_input else h).double()
+        pre, post, bn = tw.pretrans.fully_connected[0].linear, tw.posttrans.fully_connected[0].linear, tw.batchnorm_h
+        Wp, bp = pre.weight.double(), pre.bias.double()
+        m = ht[src] @ Wp[:, :Fi].t() + ht[dst] @ Wp[:, Fi:2 * Fi].t() + bp
+        dcl = deg.clamp(min=1)[:, None]
+        s1 = torch.zeros(V, Fi, dtype=torch.float64, device=dev).index_add_(0, dst, m) / dcl
+        s2 = torch.zeros(V, Fi, dtype=torch.float64, device=dev).index_add_(0, dst, m * m) / dcl
+        mx = torch.full((V, Fi), -float("inf"), dtype=torch.float64, device=dev).scatter_reduce_(0, dst[:, None].expand(-1, Fi), m, "amax")
+        mn = torch.full((V, Fi), float("inf"), dtype=torch.float64, device=dev).scatter_reduce_(0, dst[:, None].expand(-1, Fi), m, "amin")
+        a = torch.cat([s1, mx, mn, torch.sqrt(torch.relu(s2 - s1 * s1) + 1e-5)], dim=1)
+        a = torch.where((deg > 0)[:, None], a, torch.zeros_like(a))
+        cat = torch.cat([ht, a, a * amp, a * att], dim=1)
+        Wo, bo = post.weight.double(), post.bias.double()
+        z, mz = cat @ Wo.t() + bo, cat.abs() @ Wo.abs().t() + bo.abs()
+        if tw.graph_norm:
+            z, mz = z * snorm.double(), mz * snorm.double().abs()
+        if tw.batch_norm:
+            sc = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+            z, mz = (z - bn.running_mean.double()) * sc + bn.bias.double(), (mz + bn.running_mean.double().abs()) * sc.abs() + bn.bias.double().abs()
+        outs.append(z); masses.append(mz)
+    z, mz = torch.cat(outs, dim=1), torch.cat(masses, dim=1)
+    Wm, bm = mix.linear.weight.double(), mix.linear.bias.double()
+    z, mz = z @ Wm.t() + bm, mz @ Wm.abs().t() + bm.abs()
+    slope = mix.activation.negative_slope
+    y = torch.where(z >= 0, z, z * slope)
+    if layer.residual:
+        y, mz = y + h.double(), mz + h.double().abs()
+    return y, mz
+
+
+def _tower_case(cuda_device, towers, divide_input, mutate, arith, seed=41):
+    """The one-kernel tower layer under `arith` on inputs `mutate(layer, h)` has made adversarial, against float64: (worst error over the
+    per-element bar 1e-5 |ref| + 2e-6 x the chain's mass, tiles handed over, tiles)."""
+    from pna_amd import Graph, degree_groups as DG, functional as PF
+    from pna_amd.dgl.pna_layer import PNALayer
+    from pna_amd.synth import powerlaw_graph
+    V, E, F = 140_000, 1_100_000, 75
+    src, dst = powerlaw_graph(V, E, seed=seed, device=cuda_device)
+    g = Graph(src, dst, V)
+    torch.manual_seed(seed)
+    layer = PNALayer(F, F, "mean max min std", "identity amplification attenuation", {"log": torch.tensor(2.3)}, 0.0, True, True,
+                     towers=towers, divide_input=divide_input, residual=False).to(cuda_device).eval()
+    h = _features(V, F, cuda_device, seed=seed + 1)
+    snorm = torch.rand(V, 1, device=cuda_device, generator=torch.Generator(device=cuda_device).manual_seed(seed + 2)) + 0.5
+    keep = DG.FUSED_ARITH
+    with torch.no_grad():
+        for tw in layer.towers:
+            tw.batchnorm_h.running_var.uniform_(0.5, 2.0)
+            tw.batchnorm_h.running_mean.zero_(); tw.batchnorm_h.bias.zero_()
+            tw.pretrans.fully_connected[0].linear.bias.zero_(); tw.posttrans.fully_connected[0].linear.bias.zero_()
+        layer.mixing_network.linear.bias.zero_()             # (no O(1) terms anywhere in the chain: the bar is the products' alone)
+        mutate(layer, h)
+        keep_small = PF.SMALL_TOWER_ROWS
+        try:
+            DG.FUSED_ARITH, PF.SMALL_TOWER_ROWS = arith, 0         # (not the one-call kernel of molecule batches: divided input up to 262 k rows)
+            with _Knobs(fused=True, small_graphs=True):
+                assert PF.tower_layer_degree_fused_applies(layer, g, h) and not layer._small_batch_path(g, h)
+                plan = DG.plan_of(g)
+                if arith == "guarded":
+                    DG.guard_stats(plan, cuda_device, reset=True)
+                y = layer(g, h, None, snorm)
+                handed = DG.guard_stats(plan, cuda_device)[0] if arith == "guarded" else 0
+        finally:
+            DG.FUSED_ARITH, PF.SMALL_TOWER_ROWS = keep, keep_small
+        ref, mass = _tower_layer_float64(layer, g, h, snorm)
+        rows = plan.perm[plan.perm >= 0].long()
+        assert torch.isfinite(y).all()
+        tol = 1e-5 * ref.abs() + 2e-6 * mass
+        worst = ((y[rows].double() - ref[rows]).abs() / tol[rows].clamp(min=1e-300)).max().item()
+    return worst, handed, plan.NV // 64
+
+
+def _towers_apart(layer, h):
+    """Five towers over divided input, tower t's input slice 100^t x the first one's (1e8 between the extremes), and a block-structured
+    mixing network: output block t listens to tower t alone -- the collapsed image is block-diagonal over the statistics."""
+    T, Fi = len(layer.towers), layer.towers[0].in_dim
+    for t in range(T):
+        h[:, t * Fi:(t + 1) * Fi].mul_(100.0 ** t)
+    W = layer.mixing_network.linear.weight
+    Fo = W.shape[1] // T
+    mask = torch.zeros_like(W)
+    for t in range(T):
+        mask[t * (W.shape[0] // T):(t + 1) * (W.shape[0] // T), t * Fo:(t + 1) * Fo] = 1.0
+    W.mul_(mask)
+
+
+def _huge_own_feature(layer, h):
+    """One tower; the node's own feature 7 is 1e9 x the rest, with zero weight wherever it enters: pretrans (both halves) and the
+    posttrans self panel -- the row's scale must cover the huge strip (panel_rescale), the statistics sit 1e9 below it."""
+    h[:, 7].mul_(1e9)
+    tw = layer.towers[0]
+    Fi = tw.in_dim
+    tw.pretrans.fully_connected[0].linear.weight[:, [7, Fi + 7]] = 0.0
+    tw.posttrans.fully_connected[0].linear.weight[:, 7] = 0.0
+
+
+@pytest.mark.parametrize("towers,divide_input,mutate", [(5, True, _towers_apart), (1, False, _huge_own_feature)])
+def test_guarded_tower_mode_on_adversarial_inputs(cuda_device, towers, divide_input, mutate):
+    """VERDICT r5 item 1a, tower twin: block-diagonal divide_input=True images with towers 1e8 apart; a huge own feature in tower mode.
+    Guarded (default) and bf16 x 3 hold the per-element bar against float64; round 5's unguarded fp16 x 2 does not."""
+    worst_3, _, _ = _tower_case(cuda_device, towers, divide_input, mutate, "bf16x3")
+    worst_g, handed, tiles = _tower_case(cuda_device, towers, divide_input, mutate, "guarded")
+    worst_u, _, _ = _tower_case(cuda_device, towers, divide_input, mutate, "fp16x2")
+    assert worst_3 <= 1.0, worst_3
+    assert worst_g <= 1.0 and handed > 0, (worst_g, handed, tiles)
+    assert worst_u > 1.0, ("the unguarded form was expected to leave the bar here", worst_u)
+
+
+def test_guarded_tower_mode_benign(cuda_device):
+    worst_g, handed, tiles = _tower_case(cuda_device, 1, False, lambda layer, h: None, "guarded")
+    assert worst_g <= 1.0 and handed <= max(2, tiles // 100), (worst_g, handed, tiles)
+
+
 def test_source_table_beyond_4_gib_and_2_pow_24_rows(cuda_device):
     """VERDICT r3 item 3 / BASELINE configs[4] at 8 ranks: a shard's [local | halo] table has > 2^24 rows and > 4 GiB, which round 3's
     32-bit byte offsets (__umul24) could not address -- that configuration fell to the two-kernel path.  Here: the same graph twice,

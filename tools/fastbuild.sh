@@ -18,6 +18,9 @@ for f in pna_amd/csrc/*.hip; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC $OBJ/*.o -o pna_amd/lib/libpna_amd$SUF.so.tmp
+# (only the objects of sources that still exist: an object left behind by a removed .hip would otherwise be linked in -- ADVICE r5)
+objs=""
+for f in pna_amd/csrc/*.hip; do objs="$objs $OBJ/$(basename $f .hip).o"; done
+hipcc --offload-arch=gfx950 -shared -fPIC $objs -o pna_amd/lib/libpna_amd$SUF.so.tmp
 mv pna_amd/lib/libpna_amd$SUF.so.tmp pna_amd/lib/libpna_amd$SUF.so
 echo pna_amd/lib/libpna_amd$SUF.so
