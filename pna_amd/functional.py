@@ -573,6 +573,10 @@ def _tower_flat_weights(layer, towers, mix):
 
 
 _SIDE_STREAMS = {}
+# How a one-kernel layer's two halves are recorded while a hipGraph is being CAPTURED (round 6): "beside" = as in eager
+# mode (fork / join events become two branches of the graph), "behind" = one after the other on the capturing stream, whole device each,
+# "rest_first" = the same with the small launches in front.  tools/graph_replay_ab.py measures the three against the eager step.
+CAPTURE_OVERLAP = os.environ.get("PNA_AMD_CAPTURE_OVERLAP", "beside")
 
 
 def _side_stream(device):
@@ -600,7 +604,15 @@ def run_fused_call(call):
     from . import _lib
     plan = call.plan
     call.stream = _lib.stream_ptr(call.y.device)             # (the kernel goes to the stream that is current NOW, like every other launch)
-    if not plan.rest_overlap_applies(call.layer_F()):
+    overlap = plan.rest_overlap_applies(call.layer_F())
+    if overlap and CAPTURE_OVERLAP != "beside" and torch.cuda.is_current_stream_capturing():
+        overlap = False                                      # (see CAPTURE_OVERLAP)
+        if CAPTURE_OVERLAP == "rest_first":
+            call.set_spare(False)
+            call.rest_rows()
+            call.group_rows()
+            return call.y
+    if not overlap:
         call.set_spare(False)
         call.group_rows()
         return call.rest_rows()
