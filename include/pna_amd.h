@@ -547,8 +547,8 @@ int pna_fused_simple_f32(const pna_fused_simple_args* args, pna_stream_t stream)
  *                 the weight itself); W_D is formed in fp32 in scaler order, like the reference's blocks.
  * x: (x_rows, ldx) rows, 16-byte aligned, ldx % 4 == 0, ldx >= round_up(F, 8) (round_up(F, 4) when F % 32 is in 1..16),
  * x_rows < 2^24, table < 4 GiB; y and residual: n_nodes rows, each table < 4 GiB.
- * F in 17..80, or (ABI 15) 113..128 -- the features in two gather passes (BASELINE configs[4]: 128 -> 128; ldx >= 128 there);
- * N in 4..80, or (ABI 15) 81..128 -- the output columns in two panels of 64 (needs F in 49..64 or 113..128).  pna_fused_degree_image_bytes(F, N) > 0
+ * F in 17..80, or (ABI 15; 97..112 since ABI 21) 97..128 -- the features in two gather passes (BASELINE configs[4]: 128 -> 128);
+ * N in 4..80, or (ABI 15) 81..128 -- the output columns in two panels of 64 (needs F in 49..64 or 97..128).  pna_fused_degree_image_bytes(F, N) > 0
  * is the authoritative test.
  * relu: 0 none / 1 ReLU / 2 LeakyReLU(act_slope).  agg_out (nullable): (M, ld_agg) receives the
  * statistics the contraction consumed, [mean | max | min | std] x F per virtual row (verification; a slower instantiation).

@@ -113,8 +113,11 @@ constexpr int kNRes = kNT;                                // residual loads per 
 // Feature blocks of a row: NFBF full blocks of 32 features (a lane owns 8: two 16-byte loads, four chunks -- one per aggregator)
 // and, when the remainder is <= 16 features, a HALF block (a lane owns 4: one load, two chunks -- (mean | max), (min | std)).
 // F = 75: 2 full + half = 5 loads per edge, 80 running statistics, 10 chunks (three full blocks: 6 loads, 96, 12).
-__host__ __device__ constexpr int shape_full(int F) { return (F % 32 == 0 || F % 32 > 16) ? (F + 31) / 32 : F / 32; }
-__host__ __device__ constexpr bool shape_half(int F) { return F % 32 != 0 && F % 32 <= 16; }
+// (round 6: 97 <= F <= 112 count as FOUR full blocks, two gather passes of two like 113..128 -- the last block's window slides back to end
+// at F as everywhere, so only its first lane groups hold new features and the rest repeat earlier ones against zero weights: a fourth
+// block of mostly idle multiply-adds, but the layer stays ONE kernel at the hidden sizes 100 and 110 of the reference's README.)
+__host__ __device__ constexpr int shape_full(int F) { return F > 96 ? 4 : (F % 32 == 0 || F % 32 > 16) ? (F + 31) / 32 : F / 32; }
+__host__ __device__ constexpr bool shape_half(int F) { return F <= 96 && F % 32 != 0 && F % 32 <= 16; }
 __host__ __device__ constexpr int shape_chunks(int F) { return 4 * shape_full(F) + (shape_half(F) ? 2 : 0); }
 
 // ---- inline-asm loads (hipcc neither counts nor waits for them: every wait below is ours) -----------------------------------
@@ -1281,7 +1284,7 @@ int launch_shape(const FDArgs& g, int wgs, hipStream_t st) {
 }
 
 bool shape_ok(int F, int N) {
-  // F: 17..80 (one gather pass) or 113..128 (two passes of two full blocks; 81..112 would need unequal passes: not built);
+  // F: 17..80 (one gather pass) or 97..128 (two passes of two full blocks; 81..96 would need unequal passes: not built);
   // N: 4..80 (one panel of 80 columns) or 81..128 (two panels of 64), the latter with exactly two full feature blocks per pass
   // (49 <= F <= 64 or 113..128: with a half block on top, 80 statistics + the ring + 32 accumulators + the residual spill)
   const bool f_ok = (F >= 17 && F <= 80) || shape_wide_f(F), n_ok = (N >= 4 && N <= kNW) || shape_wide_n(N);
@@ -1370,7 +1373,7 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
   if (!p->tile_desc || !p->tile_ids || !p->x || !p->row_perm || !p->y || (need_h2 && !p->w_img) || (need_x3 && !p->w_img_x3))
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: tile_desc / tile_ids / x / row_perm / y and the images of the arithmetic (w_img: fp16 x 2, w_img_x3: bf16 x 3) must be non-null");
   if (!shape_ok(p->F, p->N))
-    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: F in 17..80 or 113..128, N in 4..128 (N > 80 needs F in 49..64 or 113..128)");
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: F in 17..80 or 97..128, N in 4..128 (N > 80 needs F in 49..64 or 97..128)");
   // (round 4: the source rows are read through 64-bit lane addresses -- any 4-byte aligned pitch >= F, no 4 GiB / 2^24-row limit; the
   // strips of a row's last block are 16-byte reads that end at the row's F-th float: no read leaves a row)
   if (p->ldx < p->F || ((uintptr_t)p->x & 3) != 0 || (int64_t)p->ldx * 4 >= (1ll << 31))

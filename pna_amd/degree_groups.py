@@ -452,32 +452,74 @@ def fused_arith():
         raise ValueError(f"PNA_AMD_FUSED_ARITH must be guarded, bf16x3 or fp16x2 (got {name!r})") from None
 
 
-def fused_images(weight, F, row_scales, plan, tower=False, x3=False):
+STANDARD_AGGREGATORS = ("mean", "max", "min", "std")
+# the one-kernel layer computes [mean | max | min | std]; a layer's aggregator maps onto one of those slots, `sum` onto the mean's with the
+# degree as a factor (sum = D x mean; the degree is a property of the weight image W_D like the scalers are) -- round 6, VERDICT r5 item 4
+_AGG_SLOT = {"mean": (0, False), "sum": (0, True), "max": (1, False), "min": (2, False), "std": (3, False)}
+
+
+def aggregators_fusable(aggregators):
+    """Whether the one-kernel layer can serve this aggregator list: distinct names out of mean / sum / max / min / std."""
+    a = tuple(aggregators)
+    return 0 < len(a) == len(set(a)) and all(x in _AGG_SLOT for x in a)
+
+
+def _virtual_weight(weight, F, aggregators, scale, plan, rows):
+    """(w_ref, scale') for pna_fused_pack_f32: the rows `rows` of `weight` (N, S * A * F), layer column order [scaler][aggregator][feature], as a
+    weight over the kernel's four statistics (Np, S' * 4F) with S' = S (+ S more blocks when `sum` is among the aggregators: the same scaler
+    value times the group's degree, against the mean's columns).  The standard list over all rows: the weight itself."""
+    aggs = tuple(aggregators)
+    c0, c1 = rows if rows is not None else (0, weight.shape[0])
+    if aggs == STANDARD_AGGREGATORS:
+        return weight[c0:c1], scale
+    G, S = scale.shape
+    A = len(aggs)
+    has_sum = "sum" in aggs
+    W = weight[c0:c1].detach()
+    w = torch.zeros(c1 - c0, (2 * S if has_sum else S) * 4 * F, dtype=torch.float32, device=weight.device)
+    for s_ in range(S):
+        for j, a in enumerate(aggs):
+            slot, times_deg = _AGG_SLOT[a]
+            blk = (S + s_) if times_deg else s_
+            w[:, (blk * 4 + slot) * F:(blk * 4 + slot + 1) * F] = W[:, (s_ * A + j) * F:(s_ * A + j + 1) * F]
+    if has_sum:
+        scale = torch.cat([scale, scale * plan.group_degree.to(torch.float32).view(G, 1)], dim=1)
+    return w, scale.contiguous()
+
+
+def fused_images(weight, F, row_scales, plan, tower=False, x3=False, rows=None, aggregators=STANDARD_AGGREGATORS):
     """Packed images of W_D = sum_s s_s(D) W_s for pna_fused_degree_f32 (K in the kernel's chunk order), one per degree group,
     cached on the weight like combined_images.  The combination and the operand split (x3=False: two fp16 terms behind per-column
     power-of-two scales + the tail of column scales and guard thresholds; x3=True: three bf16 terms) happen in the pack kernel
-    (pna_fused_pack_f32) from the (G, S) matrix of the groups' scaler values."""
+    (pna_fused_pack_f32) from the (G, S) matrix of the groups' scaler values.  rows = (c0, c1): the images of output columns [c0, c1) only
+    (a column panel of a layer wider than one launch takes); aggregators: the layer's list (see _virtual_weight)."""
     N, G, S = weight.shape[0], plan.G, len(row_scales)
-    key = ("fused", tower, x3, weight._version, weight.data_ptr(), str(weight.device), tuple(weight.shape), F, plan.serial, G,
+    aggs = tuple(aggregators)
+    key = ("fused", tower, x3, rows, aggs, weight._version, weight.data_ptr(), str(weight.device), tuple(weight.shape), F, plan.serial, G,
            tuple(None if rs is None else (rs.data_ptr(), rs._version) for rs in row_scales))
     attr = "_pna_amd_fused_img"
     cache = getattr(weight, attr, None)                     # {plan serial: (key, image, stride)}: the block plans of a pipelined run
-    hit = cache.get((tower, x3, plan.serial)) if isinstance(cache, dict) else None      # share one weight, each with its own groups
+    ckey = (tower, x3, rows, aggs, plan.serial)
+    hit = cache.get(ckey) if isinstance(cache, dict) else None      # share one weight, each with its own groups
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
     L = _lib.lib()
-    stride = L.pna_fused_image_bytes(F, N, 1 if tower else 0, 1 if x3 else 0)
+    Np = N if rows is None else rows[1] - rows[0]
+    stride = L.pna_fused_image_bytes(F, Np, 1 if tower else 0, 1 if x3 else 0)
     if stride <= 0:
-        raise RuntimeError(f"pna_fused_degree: unsupported shape F={F}, N={N}")
+        raise RuntimeError(f"pna_fused_degree: unsupported shape F={F}, N={Np}")
     with torch.no_grad():
         scale = torch.ones(G, S, dtype=torch.float32, device=weight.device)
         for s, rs in enumerate(row_scales):
             if rs is not None:
                 scale[:, s] = rs[plan.group_first_row]
         scale = scale.contiguous()
+        if tower:
+            w, sc = weight.detach(), scale
+        else:
+            w, sc = _virtual_weight(weight.detach(), F, aggs, scale, plan, rows)
     img = torch.empty(G * stride // 4, dtype=torch.float32, device=weight.device)
-    w = weight.detach()
-    rc = L.pna_fused_pack_f32(_lib.dev_ptr(w, torch.float32, "weight"), w.stride(0), N, F, S, _lib.dev_ptr(scale, torch.float32, "scale"),
+    rc = L.pna_fused_pack_f32(_lib.dev_ptr(w, torch.float32, "weight"), w.stride(0), Np, F, sc.shape[1], _lib.dev_ptr(sc, torch.float32, "scale"),
                               G, _lib.dev_ptr(img, torch.float32, "w_img"), 1 if tower else 0, 1 if x3 else 0, _lib.stream_ptr(weight.device))
     _lib.check(rc, "pna_fused_pack_f32")
     try:
@@ -486,24 +528,44 @@ def fused_images(weight, F, row_scales, plan, tower=False, x3=False):
             weight._pna_amd_fused_img = cache
         if len(cache) >= 64:                                 # (plans of dropped graphs: start over rather than grow)
             cache.clear()
-        cache[(tower, x3, plan.serial)] = (key, img, stride)
+        cache[ckey] = (key, img, stride)
     except AttributeError:
         pass
     return img, stride
 
 
-def bind_fused_arith(a, keep, weight, F, row_scales, plan, tower, device, verification=False):
+def fused_panels(F, N):
+    """The output-column panels [(c0, c1), ..] the one-kernel layer runs a layer of N outputs in -- one launch each, every launch its own
+    gather -- or None: one panel when pna_fused_degree_f32 is instantiated for (F, N); else up to FUSED_MAX_PANELS panels of the widest
+    instantiation F has (128 columns with exactly two full feature blocks per gather pass, else 80), cut evenly on multiples of 4."""
+    L = _lib.lib()
+    if N < 4 or L.pna_fused_degree_image_bytes(F, 4) <= 0:  # (no instantiation gathers F features)
+        return None
+    if L.pna_fused_degree_image_bytes(F, N) > 0:
+        return [(0, N)]
+    widest = 128 if L.pna_fused_degree_image_bytes(F, 128) > 0 else 80
+    n = (N + widest - 1) // widest
+    if n > FUSED_MAX_PANELS:
+        return None
+    step = ((N + n - 1) // n + 3) // 4 * 4
+    panels = [(c, min(c + step, N)) for c in range(0, N, step)]
+    if any(c1 - c0 < 4 or L.pna_fused_degree_image_bytes(F, c1 - c0) <= 0 for c0, c1 in panels):
+        return None
+    return panels
+
+
+def bind_fused_arith(a, keep, weight, F, row_scales, plan, tower, device, verification=False, rows=None, aggregators=STANDARD_AGGREGATORS):
     """Fill the arithmetic half of a pna_fused_degree_args block: the images of the arithmetic fused_arith() selects and, for the
     guarded form, the plan's hand-over workspace (one per (plan, stream), like the tile counters: launches on one stream are ordered).
     `keep`: a list that keeps the tensors alive.  verification: the agg_out instantiation (fp16 x 2, unguarded)."""
     arith = _lib.FD_ARITH_H2 if verification else fused_arith()
     a.arith = arith
     if arith != _lib.FD_ARITH_X3:
-        img, stride = fused_images(weight, F, row_scales, plan, tower=tower, x3=False)
+        img, stride = fused_images(weight, F, row_scales, plan, tower=tower, x3=False, rows=rows, aggregators=aggregators)
         a.w_img, a.image_stride = _lib.dev_ptr(img, torch.float32, "w_img"), stride
         keep.append(img)
     if arith != _lib.FD_ARITH_H2:
-        img3, stride3 = fused_images(weight, F, row_scales, plan, tower=tower, x3=True)
+        img3, stride3 = fused_images(weight, F, row_scales, plan, tower=tower, x3=True, rows=rows, aggregators=aggregators)
         a.w_img_x3, a.image_stride_x3 = _lib.dev_ptr(img3, torch.float32, "w_img_x3"), stride3
         keep.append(img3)
     if arith == _lib.FD_ARITH_GUARDED:
@@ -539,6 +601,7 @@ def guard_stats(plan, device, reset=False):
 # Load balance of the one-kernel layer (DegreePlan.fused_balance): "dynamic" (tiles claimed from a device counter, heaviest first / cheapest
 # last) | "lpt" | "cheap_last" (static schedules over a cost-balanced list) | "off" (the plan's ascending order, static)
 FUSED_BALANCE = os.environ.get("PNA_AMD_FUSED_BALANCE", "dynamic")
+FUSED_MAX_PANELS = 3       # output-column panels of one layer (fused_panels): every panel gathers again -- beyond three the ordinary path's ONE gather wins
 FUSED_ARITH = os.environ.get("PNA_AMD_FUSED_ARITH", "guarded")   # guarded | bf16x3 | fp16x2 (fused_arith)
 FUSED_DYNAMIC_TAIL = int(os.environ.get("PNA_AMD_FUSED_DYNAMIC_TAIL", "4"))   # "dynamic": this many x G of the cheapest tiles end the list
 FUSED_TILE_COST = float(os.environ.get("PNA_AMD_FUSED_TILE_COST", "10"))   # a tile's constant cost in edge units (multiply + epilogue + control)
@@ -565,16 +628,15 @@ def out_pitch_floats(N):
     assume 80 floats while the one-kernel layer allocates 96 for 65 <= N <= 80 -- a graph of 11.2-13.4 M nodes passed the guard and was
     then refused by pna_fused_degree_f32)."""
     a = max(4, int(OUT_PITCH_ALIGN))
-    return max((N + a - 1) // a * a, 80 if N <= 80 else 128)
+    return max((N + a - 1) // a * a, 80 if N <= 80 else 128 if N <= 128 else N)
 
 
-def fused_applies(graph, x, F, N):
+def fused_applies(graph, x, F, N, aggregators=STANDARD_AGGREGATORS):
     """Whether pna_fused_degree_f32 serves this call (whole-graph inference path already chosen by `applies`): a shape it is
-    instantiated for and a unit-stride, 4-byte aligned source table.  Since round 4 the rows are read through 64-bit lane addresses and
-    no read leaves a row (the last feature block's window slides back to end at F): any pitch >= F -- a CONTIGUOUS (V, F) tensor
-    included -- and tables beyond 4 GiB / 2^24 rows (a shard's [local | halo] table at BASELINE configs[4] x 8)."""
-    # F: one gather pass (17..80) or two (113..128; BASELINE configs[4]: 128 -> 128); N: one panel of 80 columns or two of 64
-    if not fused_shape_ok(x, F, N):
+    instantiated for -- N possibly in column panels -- and a unit-stride, 4-byte aligned source table.  Since round 4 the rows are read
+    through 64-bit lane addresses and no read leaves a row (the last feature block's window slides back to end at F): any pitch >= F -- a
+    CONTIGUOUS (V, F) tensor included -- and tables beyond 4 GiB / 2^24 rows (a shard's [local | halo] table at BASELINE configs[4] x 8)."""
+    if not fused_shape_ok(x, F, N) or not aggregators_fusable(aggregators):
         return False
     plan = plan_of(graph)
     return plan.G > 0 and plan.fused_tables() is not False
@@ -582,16 +644,27 @@ def fused_applies(graph, x, F, N):
 
 def fused_shape_ok(x, F, N):
     """The graph-independent half of fused_applies (a row block of shard.BlockPipeline brings its own plan)."""
-    if not FUSED or _lib.lib().pna_fused_degree_image_bytes(F, N) <= 0:
+    if not FUSED or fused_panels(F, N) is None:
         return False
     return x.dim() == 2 and x.stride(1) == 1 and x.stride(0) >= F and x.data_ptr() % 4 == 0 and x.shape[0] >= 1
 
 
+def two_kernel_applies(N, n_scaler, aggregators):
+    """The operator set / widths the two-kernel grouped path (gather in degree order + grouped contraction) is built for."""
+    return (MIN_OUT <= N <= 128 and (n_scaler == 3 or (n_scaler == 2 and N >= TWO_SCALER_MIN_OUT)) and tuple(aggregators) == STANDARD_AGGREGATORS)
+
+
 def applies(graph, V, N, n_scaler, aggregators, F=None, n_edges=None, x_rows=None):
+    """Whether a PNASimpleLayer call over `graph` takes a degree-grouped path at all: the two-kernel one (two_kernel_applies) or -- round 6 --
+    the one-kernel layer alone, which also serves one or two scalers, any distinct aggregators out of mean / sum / max / min / std and
+    outputs wider than one launch (fused_panels); which of the two runs is functional.simple_layer_degree_grouped's decision."""
     from .graph import Graph
     from .shard import HaloGraph
-    if not (ENABLED and type(graph) in (Graph, HaloGraph) and V >= MIN_ROWS and MIN_OUT <= N <= 128 and (n_scaler == 3 or (n_scaler == 2 and N >= TWO_SCALER_MIN_OUT))
-            and tuple(aggregators) == ("mean", "max", "min", "std") and V * out_pitch_floats(N) * 4 < (1 << 32)):
+    if not (ENABLED and type(graph) in (Graph, HaloGraph) and V >= MIN_ROWS and 1 <= n_scaler <= 3):
+        return False
+    two = two_kernel_applies(N, n_scaler, aggregators)
+    one = FUSED and F is not None and aggregators_fusable(aggregators) and N >= MIN_OUT and fused_panels(F, N) is not None
+    if not (two or one) or V * out_pitch_floats(N) * 4 >= (1 << 32):
         return False
     # the gather of this path REQUIRES the hand-scheduled kernel (only it writes the plan's row order): its own preconditions
     # (pna_segreduce.hip fast_ok: dwordx4 lanes, 32-bit edge positions; since round 4 source tables beyond 2^24 rows / 4 GiB through

@@ -652,6 +652,20 @@ def _fused_grid(device, spare, n_tiles64):
 
 
 def _bind_tile_order(call, spare):
+    """(see _bind_tile_order_one; a layer in several output-column panels binds every panel's argument block to the same tables)"""
+    blocks = getattr(call, "panel_args", None)
+    if not blocks or len(blocks) == 1:
+        return _bind_tile_order_one(call, spare)
+    first, first_ref = call.args, call.ref
+    _bind_tile_order_one(call, spare)
+    src = call.args
+    for a, _ in blocks[1:]:
+        a.spare_workgroups, a.tile_desc, a.row_perm, a.tile_counter = src.spare_workgroups, src.tile_desc, src.row_perm, src.tile_counter
+        a.guard_ws, a.guard_ws_bytes = src.guard_ws, src.guard_ws_bytes
+    call.args, call.ref = first, first_ref
+
+
+def _bind_tile_order_one(call, spare):
     """Point the call's argument block at the plan's tile list for the grid `spare` gives: the load-balanced order
     (DegreePlan.fused_balance) for the production instantiations of the 64-row-tile shapes, the plan's own order otherwise (the
     verification instantiation writes agg_out in plan order; the 8-wavefront build of the wide shapes has 128-row tiles)."""
@@ -798,9 +812,10 @@ def tower_layer_degree_fused(layer, graph, h, snorm_n, x_cat):
 
 
 class FusedDegreeCall:
-    """One PNASimpleLayer forward on the one-kernel path, cut into its two launches so that bench.py can time them apart:
-    `group_rows()` = pna_fused_degree_f32 (99.6 % of the benchmark graph's rows), `rest_rows()` = gather + three-block contraction
-    over the compact list of the rows no degree group holds.  Holds the argument block and every tensor it points into."""
+    """One PNASimpleLayer forward on the one-kernel path, cut into its two halves so that bench.py can time them apart:
+    `group_rows()` = pna_fused_degree_f32 (99.6 % of the benchmark graph's rows) -- one launch per output-column panel
+    (degree_groups.fused_panels: one, unless the layer is wider than an instantiation) --, `rest_rows()` = gather + three-block
+    contraction over the compact list of the rows no degree group holds.  Holds the argument blocks and every tensor they point into."""
 
     def __init__(self, layer, graph, h, x=None, out=None, agg_out=None, plan=None):
         from . import _lib, degree_groups as DG
@@ -818,19 +833,31 @@ class FusedDegreeCall:
         self.cs, self.ct, self.res = cs, ct, res = _layer_tail_operands(layer, h)
         desc, ids, n_rec = plan.fused_tables()
         self.keep = [desc, ids, lin, agg_out, h]
-        a = _lib.PnaFusedDegreeArgs()
-        self.arith = DG.bind_fused_arith(a, self.keep, lin.weight, F, scales, plan, False, h.device, verification=agg_out is not None)
-        a.tile_desc, a.tile_ids, a.n_records = _lib.dev_ptr(desc, torch.int32, "tile_desc"), _lib.dev_ptr(ids, torch.int32, "tile_ids"), n_rec
-        a.x, a.ldx, a.x_rows, a.F, a.N = _lib.dev_ptr(x, torch.float32, "x"), x.stride(0), x.shape[0], F, N
-        a.row_perm, a.M, a.n_nodes = _lib.dev_ptr(plan.perm, torch.int32, "row_perm"), plan.NV, V
-        a.bias = _lib.dev_ptr(lin.bias, torch.float32, "bias")
-        a.col_scale, a.col_shift = _lib.dev_ptr(cs, torch.float32, "col_scale"), _lib.dev_ptr(ct, torch.float32, "col_shift")
-        if res is not None:
-            a.residual, a.ld_res = _lib.dev_ptr(res, torch.float32, "residual"), res.stride(0)
-        a.y, a.ldy, a.relu = _lib.dev_ptr(y, torch.float32, "y"), y.stride(0), 1
-        if agg_out is not None:
-            a.agg_out, a.ld_agg = _lib.dev_ptr(agg_out, torch.float32, "agg_out"), agg_out.stride(0)
-        self.args, self.ref = a, ctypes.byref(a)
+        aggs = tuple(layer.aggregators)
+        panels = DG.fused_panels(F, N)
+        if panels is None or not DG.aggregators_fusable(aggs):
+            raise RuntimeError(f"pna_fused_degree: no instantiation for F={F}, N={N}, aggregators={aggs}")
+        if agg_out is not None and (len(panels) != 1 or aggs != DG.STANDARD_AGGREGATORS):
+            raise RuntimeError("pna_fused_degree: agg_out (verification) takes the four standard aggregators and a one-launch layer")
+        self.panel_args = []
+        for c0, c1 in panels:
+            a = _lib.PnaFusedDegreeArgs()
+            whole = len(panels) == 1
+            self.arith = DG.bind_fused_arith(a, self.keep, lin.weight, F, scales, plan, False, h.device, verification=agg_out is not None,
+                                             rows=None if whole else (c0, c1), aggregators=aggs)
+            a.tile_desc, a.tile_ids, a.n_records = _lib.dev_ptr(desc, torch.int32, "tile_desc"), _lib.dev_ptr(ids, torch.int32, "tile_ids"), n_rec
+            a.x, a.ldx, a.x_rows, a.F, a.N = _lib.dev_ptr(x, torch.float32, "x"), x.stride(0), x.shape[0], F, c1 - c0
+            a.row_perm, a.M, a.n_nodes = _lib.dev_ptr(plan.perm, torch.int32, "row_perm"), plan.NV, V
+            sl = lambda t: None if t is None else t[c0:c1]      # noqa: E731  (a panel's slice of a per-column vector: still unit stride)
+            a.bias = _lib.dev_ptr(sl(lin.bias), torch.float32, "bias")
+            a.col_scale, a.col_shift = _lib.dev_ptr(sl(cs), torch.float32, "col_scale"), _lib.dev_ptr(sl(ct), torch.float32, "col_shift")
+            if res is not None:
+                a.residual, a.ld_res = _lib.dev_ptr(res[:, c0:c1], torch.float32, "residual"), res.stride(0)
+            a.y, a.ldy, a.relu = _lib.dev_ptr(y[:, c0:c1], torch.float32, "y"), y.stride(0), 1
+            if agg_out is not None:
+                a.agg_out, a.ld_agg = _lib.dev_ptr(agg_out, torch.float32, "agg_out"), agg_out.stride(0)
+            self.panel_args.append((a, ctypes.byref(a)))
+        self.args, self.ref = self.panel_args[0]
         self.fn, self.check, self.stream = _lib.lib().pna_fused_degree_f32, _lib.check, _lib.stream_ptr(h.device)
         _bind_tile_order(self, 0)
 
@@ -842,7 +869,8 @@ class FusedDegreeCall:
         _bind_tile_order(self, DG.FUSED_SPARE_WGS if on else 0)
 
     def group_rows(self):
-        self.check(self.fn(self.ref, self.stream), "pna_fused_degree_f32")
+        for _, ref in self.panel_args:
+            self.check(self.fn(ref, self.stream), "pna_fused_degree_f32")
         return self.y
 
     def rest_rows(self):
@@ -879,7 +907,8 @@ def simple_layer_degree_grouped(layer, graph, h):
     from . import degree_groups as DG
     plan = DG.plan_of(graph)
     from .graph import Graph
-    if type(graph) is Graph and DG.fused_applies(graph, h, layer.in_dim, layer.out_dim):
+    aggs = tuple(layer.aggregators)
+    if type(graph) is Graph and DG.fused_applies(graph, h, layer.in_dim, layer.out_dim, aggs):
         return simple_layer_degree_fused(layer, graph, h, x=h)
     # A shard (HaloGraph).  The two-kernel path cuts its gather into the rows that read only local sources -- aggregated while
     # the halo exchange is in flight -- and the rest; the one-kernel path needs the whole [local | halo] table first.  Which one
@@ -887,11 +916,16 @@ def simple_layer_degree_grouped(layer, graph, h):
     # overlap hides next to nothing and the one-kernel layer saves a third of the compute, so: exchange, then ONE kernel over the
     # extended table (features in the shard's resident table at a 16-byte aligned pitch); with many interior rows, the overlap.
     from .shard import HaloGraph
+    two = DG.two_kernel_applies(layer.out_dim, len(layer.scalers), aggs)
     if (isinstance(graph, HaloGraph) and DG.FUSED and graph._resident(h) and graph._pending is None
-            and graph.interior_fraction() < DG.FUSED_HALO_MAX_INTERIOR):
+            and (graph.interior_fraction() < DG.FUSED_HALO_MAX_INTERIOR or not two)):
         x_ext = graph._ext[:, : h.shape[1]]
-        if DG.fused_applies(graph, x_ext, layer.in_dim, layer.out_dim):
+        if DG.fused_applies(graph, x_ext, layer.in_dim, layer.out_dim, aggs):
             return simple_layer_degree_fused(layer, graph, h, x=graph.source_features(h))
+    if not two:
+        # (an operator set / width only the one-kernel layer serves, and it does not apply to this call: PNASimpleLayer.forward
+        # catches this and takes the ordinary path)
+        raise RuntimeError("pna_amd: the hand-scheduled kernel was required (one-kernel layer) but does not apply to this call")
     return degree_grouped_posttrans(layer, graph, h, degree_grouped_aggregate(layer, graph, h, plan), plan)
 
 

@@ -776,23 +776,41 @@ def test_source_table_beyond_4_gib_and_2_pow_24_rows(cuda_device):
 # land on the two-kernel grouped path (or, beyond 128 outputs, on the ordinary kernels) visibly, not silently; and whatever ran
 # must match the oracle.  "one" = pna_fused_degree_f32 over the group rows, "two" = gather in degree order + grouped contraction,
 # "ordinary" = gather + three-block contraction in node order.
-@pytest.mark.parametrize("F,N,path", [
+@pytest.mark.parametrize("F,N,path,aggregators,scalers", [(f, n, p, "mean max min std", "identity amplification attenuation") for f, n, p in [
     (75, 75, "one"), (64, 64, "one"), (80, 80, "one"), (17, 40, "one"), (40, 72, "one"),             # one gather pass, one panel
     (128, 128, "one"), (120, 100, "one"), (113, 81, "one"), (128, 64, "one"),                        # two gather passes
     (64, 96, "one"), (50, 128, "one"),                                                               # one pass of two full blocks, two panels
-    (96, 96, "two"), (100, 100, "two"), (112, 112, "two"), (81, 64, "two"),                          # 81 <= F <= 112: unequal passes, not built
-    (75, 96, "two"), (80, 128, "two"), (40, 100, "two"),                                             # N > 80 needs exactly two full blocks per pass
+    (100, 100, "one"), (112, 112, "one"), (97, 64, "one"), (110, 110, "one"),                        # round 6: 97 <= F <= 112 as four blocks in two passes
+    (96, 96, "two"), (81, 64, "two"), (90, 90, "two"),                                               # 81 <= F <= 96: unequal passes, not built
+    (75, 96, "one"), (80, 128, "one"), (40, 100, "one"), (75, 160, "one"),                           # round 6: wider than an instantiation -> column panels, one launch each
     (16, 64, "two"),                                                                                 # F < 17
-    (75, 160, "ordinary"), (128, 192, "ordinary"),                                                   # N > 128: no grouped contraction
+    (128, 192, "one"), (75, 250, "ordinary"), (90, 160, "ordinary"),                                 # more than three panels / no gather for F: the ordinary kernels
+]] + [
+    # round 6: the operator sets of the reference's README ablations on the one-kernel layer
+    (75, 75, "one", "mean max min std", "identity"),                                                 # "PNA (no scalers)" (README.md:76-77)
+    (100, 100, "one", "mean max min std", "identity"),
+    (75, 75, "one", "mean max min std", "identity amplification"),
+    (110, 110, "one", "sum", "identity"), (100, 100, "one", "max", "identity"),                      # MPNN (sum) / (max) (README.md:91-92)
+    (75, 75, "one", "mean", "identity amplification attenuation"),
+    (64, 64, "one", "sum max", "identity attenuation"), (75, 80, "one", "mean sum max min std", "identity amplification attenuation"),
+    (75, 75, "ordinary", "mean max min var", "identity amplification attenuation"),                  # var: not a linear image of the kernel's statistics
 ])
-def test_which_path_a_shape_takes_and_that_it_matches_the_oracle(cuda_device, F, N, path):
+def test_which_path_a_shape_takes_and_that_it_matches_the_oracle(cuda_device, F, N, path, aggregators, scalers):
     from oracle import torch_oracle as O
     from pna_amd import Graph, degree_groups as DG, functional as PF
+    from pna_amd.dgl.pna_layer import PNASimpleLayer
     from pna_amd.synth import powerlaw_graph
     V, E = 6000, 48_000
     src, dst = powerlaw_graph(V, E, seed=F + N)
     g = Graph(src, dst, V).to(cuda_device)
-    layer = _layer(F, N, "cpu", residual=(F == N), seed=N)
+    torch.manual_seed(N)
+    layer = PNASimpleLayer(F, N, aggregators, scalers, {"log": torch.tensor(2.3)}, 0.0, True, F == N)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.copy_(torch.randn_like(p) / (p.shape[-1] ** 0.5 if p.dim() == 2 else 3.0))
+        layer.batchnorm_h.running_mean.normal_()
+        layer.batchnorm_h.running_var.uniform_(0.5, 2.0)
+    layer = layer.eval()
     sd = {k: v.clone() for k, v in layer.state_dict().items()}
     layer = layer.to(cuda_device)
     h = _features(V, F, cuda_device, seed=F)
@@ -802,7 +820,6 @@ def test_which_path_a_shape_takes_and_that_it_matches_the_oracle(cuda_device, F,
     PF.degree_grouped_posttrans = lambda *a, **k: (ran.append("two"), keep[1](*a, **k))[1]
     try:
         with torch.no_grad(), _Knobs(fused=True, small_graphs=True):
-            assert (_lib_image_bytes(F, N) > 0) == (path == "one")
             y = layer(g, h).cpu()
     finally:
         PF.run_fused_call, PF.degree_grouped_posttrans = keep
@@ -811,7 +828,7 @@ def test_which_path_a_shape_takes_and_that_it_matches_the_oracle(cuda_device, F,
     # a float64 std would part from BOTH at rows whose variance cancels, E[x^2] - E[x]^2), contracted in float64 -- 1e-5 relative + the
     # fp32 rounding floor of a K = 12 F sum in another order, 2e-6 x sum_k |w_k a_k| carried through BatchNorm's scale
     hc = h.cpu().contiguous()
-    agg = O.reduce_bucketed(hc[src], src, dst, V, ["mean", "max", "min", "std"], ["identity", "amplification", "attenuation"], torch.tensor(2.3)).double()
+    agg = O.reduce_bucketed(hc[src], src, dst, V, aggregators.split(), scalers.split(), torch.tensor(2.3)).double()
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     W, b = sd64["posttrans.fully_connected.0.linear.weight"], sd64["posttrans.fully_connected.0.linear.bias"]
     bn_scale = sd64["batchnorm_h.weight"] / torch.sqrt(sd64["batchnorm_h.running_var"] + 1e-5)
