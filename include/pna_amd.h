@@ -622,6 +622,12 @@ typedef struct pna_fused_degree_args {
   int64_t guard_ws_bytes;
   int32_t arith;            /* PNA_FD_ARITH_GUARDED (0, the default) | PNA_FD_ARITH_X3 | PNA_FD_ARITH_H2 */
   int32_t _pad5;
+  const float* pre_add;     /* tower mode, nullable: (n_nodes, ld_pre_add) rows, node order, added to the biased accumulator IN FRONT of the row factor:
+                             *   y = residual + act(((bias + W_D . a + .. + pre_add[perm[v]]) * row_post[v]) * col_scale + col_shift)
+                             * -- a PNALayer of T towers over the whole input (divide_input=False, models/dgl/pna_layer.py:137-139) is T launches, one per
+                             * tower's 75 message features, the partial sums carried from launch to launch (pre_add may alias y: a row is read, then written,
+                             * by the same lanes); only the last one applies bias / row factor / BatchNorm / activation / residual */
+  int64_t ld_pre_add;
 } pna_fused_degree_args;
 
 #define PNA_FD_ARITH_GUARDED 0 /* fp16 x 2 with the floor-error guard: tiles it cannot certify are computed again in bf16 x 3 (a second launch) */

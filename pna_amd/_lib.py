@@ -137,7 +137,7 @@ class PnaFusedDegreeArgs(_Args):
         ("x_dst", ctypes.c_void_p), ("ld_xdst", ctypes.c_int64), ("h_self", ctypes.c_void_p), ("ld_h", ctypes.c_int64), ("row_post", ctypes.c_void_p),
         ("spare_workgroups", ctypes.c_int32), ("_pad4", ctypes.c_int32), ("tile_counter", ctypes.c_void_p),
         ("w_img_x3", ctypes.c_void_p), ("image_stride_x3", ctypes.c_int64), ("guard_ws", ctypes.c_void_p), ("guard_ws_bytes", ctypes.c_int64),
-        ("arith", ctypes.c_int32), ("_pad5", ctypes.c_int32),
+        ("arith", ctypes.c_int32), ("_pad5", ctypes.c_int32), ("pre_add", ctypes.c_void_p), ("ld_pre_add", ctypes.c_int64),
     ]
 
 

@@ -66,6 +66,8 @@ struct FDArgs {
   // hand-over list -- copies of its descriptors, its rows of perm (and of row_post) -- and the bf16 x 3 instantiation, launched behind this
   // one with the list as its tile tables, computes those tiles again (k_fused_degree; nullptr: no guard).
   int* guard; i4* g_desc; int* g_perm; float* g_post;
+  const float* pre_add; unsigned ldpb;   // tower mode (round 6): rows added to the biased accumulator in front of the row factor (a layer of several
+                                         // towers over the whole input: one launch per tower, the partial sums carried from launch to launch)
   int* list_count;             // the consuming launch (ARITH 1 behind a guarded one): its tile count lives on the device (= guard of the producer)
   unsigned long long* dbg;     // experiments build only: per-wavefront phase timers
   unsigned ldb;                // row pitch of x in bytes
@@ -800,7 +802,7 @@ __device__ __forceinline__ void fd_body(const FDArgs& g, const int t_first, cons
     for (int i = 0; i < kWaves / 4; ++i) {
       const size_t o = (size_t)i * 64 + ln;
       g.g_perm[(size_t)pos * (16 * kWaves) + o] = g.perm[(size_t)t_done * (16 * kWaves) + o];
-      if constexpr (TOWER) g.g_post[(size_t)pos * (16 * kWaves) + o] = g.row_post[(size_t)t_done * (16 * kWaves) + o];
+      if (g.row_post != nullptr) g.g_post[(size_t)pos * (16 * kWaves) + o] = g.row_post[(size_t)t_done * (16 * kWaves) + o];
     }
   };
   auto epilogue = [&]() __attribute__((always_inline)) {
@@ -831,6 +833,18 @@ __device__ __forceinline__ void fd_body(const FDArgs& g, const int t_first, cons
       for (int n = 0; n < NTA; ++n) res[n] = reinterpret_cast<const f4u*>(rbase + res_col(n))->v;
     }
     char* const yrow = reinterpret_cast<char*>(g.y) + (size_t)(unsigned)max(row, 0) * g.ldyb;
+    // pre_add (round 6; production instantiations): the rows a launch adds to its biased accumulator in front of the row factor -- the partial
+    // sums of a layer evaluated in several launches.  Kernel-uniform; read here, not prefetched: hipcc waits for the loads with vmcnt(0),
+    // i.e. also for the weight copies in flight -- a stall only the launches that carry partial sums pay.  The layer proper (not tower mode)
+    // takes its optional row factor here too (tower mode: requested with the node panels).
+    [[maybe_unused]] const char* parow = nullptr;
+    [[maybe_unused]] float rpe = 1.f;
+    if constexpr (!DUMP) {
+      if (g.pre_add != nullptr) parow = reinterpret_cast<const char*>(g.pre_add) + (size_t)(unsigned)max(row, 0) * g.ldpb;
+      if constexpr (!TOWER) {
+        if (g.row_post != nullptr) rpe = g.row_post[(size_t)(t * kWaves + wave) * 16 + li];
+      }
+    }
 #pragma unroll
     for (int n = 0; n < NTA; ++n) {
       // the column constants of the lane's four columns, read through inline asm: an LDS read hipcc can see while a weight copy
@@ -860,13 +874,18 @@ __device__ __forceinline__ void fd_body(const FDArgs& g, const int t_first, cons
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cb), "+v"(cs), "+v"(ct) : : "memory");
       }
       float z[4];
+      [[maybe_unused]] f4 pv = (f4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (!DUMP) {
+        if (parow != nullptr) pv = fix4(n * 16 + 4 * lg, g.N, reinterpret_cast<const f4u*>(parow + res_col(n))->v);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         // (H2: the accumulator is in units of 2^(sA + s_n): back by the row's and the column's powers of two, exact, in the bias' fma)
         float v;
         if constexpr (H2) v = __builtin_fmaf(acc[n][r], runs * cu[r], cb[r]);
         else v = acc[n][r] + cb[r];
-        if constexpr (TOWER) v = v * rp;
+        if constexpr (TOWER) v = (v + pv[r]) * rp;
+        else if constexpr (!DUMP) v = (v + pv[r]) * rpe;
         v = __builtin_fmaf(v, cs[r], ct[r]);
         z[r] = v < lo ? (leaky ? v * g.slope : 0.f) : v;  // ReLU / LeakyReLU / none (lo = -inf); NaN < lo is false: NaN is kept
       }
@@ -1395,7 +1414,11 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
   if (p->agg_out && p->ld_agg < 4 * (int64_t)p->F) return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: ld_agg < 4 F");
   if (p->agg_out && arith != PNA_FD_ARITH_H2)
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: agg_out (the verification instantiation) takes arith = PNA_FD_ARITH_H2");
-  const bool tower = p->x_dst || p->h_self || p->row_post;
+  const bool tower = p->x_dst || p->h_self;                // (row_post alone: the layer proper with a row factor -- round 6)
+  if (p->pre_add && p->agg_out) return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: pre_add is not for the verification instantiation (agg_out)");
+  if (p->pre_add && (p->ld_pre_add < p->N || ((uintptr_t)p->pre_add & 3) != 0 || p->n_nodes * p->ld_pre_add * 4 >= (1ll << 32)))
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: pre_add must be a 4-byte aligned (n_nodes, >= N) table below 4 GiB");
+  if (p->row_post && !tower && p->agg_out) return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: row_post is not for the verification instantiation (agg_out)");
   if (tower) {
     if (!p->x_dst || !p->h_self || !p->row_post || p->agg_out || !tower_shape_ok(p->F, p->N))
       return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: tower mode takes x_dst, h_self and row_post together, 49 <= F <= 80, no agg_out");
@@ -1421,6 +1444,7 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
   g.agg_out = p->agg_out; g.ld_agg = p->ld_agg;
   g.xd = p->x_dst; g.xh = p->h_self; g.row_post = p->row_post; g.lddb = (unsigned)(p->ld_xdst * 4); g.ldhb = (unsigned)(p->ld_h * 4);
   g.counter = p->tile_counter;
+  g.pre_add = p->pre_add; g.ldpb = (unsigned)(p->ld_pre_add * 4);
 #ifdef PNA_AMD_EXPERIMENTS
   if (const char* e = getenv("PNA_FD_DBG_PTR")) g.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // device buffer: 8 counters per wavefront
   if (const char* e = getenv("PNA_FD_ABL")) g.abl = atoi(e);
@@ -1455,7 +1479,7 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
       // workgroups that almost always find nothing and leave at once)
       FDArgs c = g;
       c.w_img = (const unsigned char*)p->w_img_x3; c.img_stride = p->image_stride_x3;
-      c.tdesc = g.g_desc; c.perm = g.g_perm; c.row_post = tower ? g.g_post : nullptr;
+      c.tdesc = g.g_desc; c.perm = g.g_perm; c.row_post = p->row_post ? g.g_post : nullptr;
       c.counter = nullptr; c.guard = nullptr; c.list_count = g.guard;
       rc = launch_shape<false, 1>(c, wgs, st);
     }

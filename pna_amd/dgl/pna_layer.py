@@ -177,6 +177,24 @@ def _projection_cache_padded_div(towers, Fi, P):
     return hit[1], hit[2]
 
 
+def _projection_cache_padded_multi(towers, Fi, P):
+    """The SOURCE half of _projection_cache for T towers over the whole input (divide_input=False) with every tower's block padded to P
+    columns: x_src = [W_a,0 h | 0 | .. | W_a,T-1 h | 0], blocks 16-byte aligned -- the table FusedMultiTowerCall's launches read their
+    tower's 16-byte strips from (the destination half W_b h + b is linear in the row's own features: folded into the dense term)."""
+    lins = [t.pretrans.fully_connected[0].linear for t in towers]
+    key = tuple((p._version, p.data_ptr(), str(p.device)) for l in lins for p in (l.weight, l.bias)) + (P,)
+    hit = towers[0].__dict__.get("_pna_amd_proj_pad_multi")
+    if hit is None or hit[0] != key:
+        T = len(lins)
+        with torch.no_grad():
+            W = torch.zeros(T * P, Fi, dtype=lins[0].weight.dtype, device=lins[0].weight.device)
+            for t, lin in enumerate(lins):
+                W[t * P:t * P + Fi] = lin.weight[:, :Fi]
+        hit = (key, W.t().contiguous())                        # (Fi, T P): x_src = h @ it
+        towers[0].__dict__["_pna_amd_proj_pad_multi"] = hit
+    return hit[1]
+
+
 def _towers_forward(towers, graph, h, e, snorm_n, divide_input):
     """Shared body of PNATower.forward / PNALayer.forward: all towers through one gather kernel."""
     t0 = towers[0]
@@ -360,8 +378,13 @@ class PNALayer(nn.Module):
                 # (functional.tower_layer_degree_fused)
                 if T == 1:
                     Wpad, bpad = _projection_cache_padded(towers[0], Fi, PF.tower_projection_pitch(Fi))
-                else:
+                elif self.divide_input:
                     Wpad, bpad = _projection_cache_padded_div(towers, Fi, PF.tower_projection_pitch(T * Fi))
+                else:
+                    # T projections of the whole input: one launch per tower over its own block of the projection table
+                    # (the library GEMM: 400 output columns from K = 75 -- measured 0.99 ms against the contraction kernels' 1.06 / 1.21 at 1 M rows)
+                    Wt = _projection_cache_padded_multi(towers, Fi, PF.tower_projection_pitch(Fi))
+                    return PF.tower_layer_degree_fused_multi(self, graph, h, snorm_n, torch.mm(h, Wt))
                 return PF.tower_layer_degree_fused(self, graph, h, snorm_n, PF.linear_act(h, Wpad, bpad))
             if self.divide_input:
                 W = torch.stack([t.pretrans.fully_connected[0].linear.weight for t in towers])

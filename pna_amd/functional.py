@@ -532,20 +532,29 @@ def tower_projection_pitch(Fi):
 
 
 def tower_layer_degree_fused_applies(layer, graph, h):
-    """Whether the grouped tower path runs its group rows through pna_fused_degree_f32's tower mode: ONE gather of 49..80
-    message features, at most 80 outputs, features the kernel can read in 16-byte pieces.  That is a layer with one tower, or --
-    round 5 -- T towers with divide_input=True (models/dgl/pna_layer.py:133-136: tower t sees the input slice [t Fi, (t+1) Fi), so
-    all towers' messages together are in_dim = T Fi wide: ONE gather over the block-diagonal projection, and the collapsed
-    posttrans . BatchNorm . mixing weight is dense anyway).  T towers with divide_input=False have T DIFFERENT projections of the
-    whole input (T x in_dim message features per edge, T gathers' worth of bytes): they stay on the two-kernel path."""
+    """Whether the grouped tower path runs its group rows through pna_fused_degree_f32's tower mode: gathers of 49..80 message
+    features, at most 80 outputs, features the kernel can read in 16-byte pieces.  That is a layer with one tower; T towers with
+    divide_input=True (round 5; models/dgl/pna_layer.py:133-136: tower t sees the input slice [t Fi, (t+1) Fi), so all towers' messages
+    together are in_dim = T Fi wide: ONE gather over the block-diagonal projection, and the collapsed posttrans . BatchNorm . mixing
+    weight is dense anyway); and -- round 6 -- T towers with divide_input=False (:137-139: T DIFFERENT projections of the whole input,
+    T x in_dim message features per edge): one launch per tower over its own 49..80 projected features, the partial sums carried from
+    launch to launch (FusedMultiTowerCall)."""
     from . import degree_groups as DG
     towers = list(layer.towers)
-    Fe = len(towers) * towers[0].in_dim                    # message features per edge, all towers
-    if not (DG.FUSED and (len(towers) == 1 or layer.divide_input) and 49 <= Fe <= 80 and layer.in_dim == Fe and 4 <= layer.out_dim <= 80):
+    T, Fi = len(towers), towers[0].in_dim
+    if not DG.FUSED or not 4 <= layer.out_dim <= 80:
         return False
-    if not DG.fused_applies(graph, h, Fe, layer.out_dim):
+    if T == 1 or layer.divide_input:
+        Fe = T * Fi                                        # message features per edge, all towers
+        if not (49 <= Fe <= 80 and layer.in_dim == Fe and DG.fused_applies(graph, h, Fe, layer.out_dim)):
+            return False
+        return h.shape[0] * 2 * tower_projection_pitch(Fe) * 4 < (1 << 32)
+    if not (49 <= Fi <= 80 and layer.in_dim == Fi and T <= FUSED_MAX_TOWER_PASSES and DG.fused_applies(graph, h, Fi, layer.out_dim)):
         return False
-    return h.shape[0] * 2 * tower_projection_pitch(Fe) * 4 < (1 << 32)
+    return h.shape[0] * 2 * T * tower_projection_pitch(Fi) * 4 < (1 << 32)
+
+
+FUSED_MAX_TOWER_PASSES = 8     # towers of a divide_input=False layer the one-kernel path takes (one launch -- one gather -- per tower)
 
 
 def _tower_flat_weights(layer, towers, mix):
@@ -604,6 +613,8 @@ def run_fused_call(call):
     from . import _lib
     plan = call.plan
     call.stream = _lib.stream_ptr(call.y.device)             # (the kernel goes to the stream that is current NOW, like every other launch)
+    if hasattr(call, "prologue"):
+        call.prologue()                                      # (what BOTH halves read: in front of the fork)
     overlap = plan.rest_overlap_applies(call.layer_F())
     if overlap and CAPTURE_OVERLAP != "beside" and torch.cuda.is_current_stream_capturing():
         overlap = False                                      # (see CAPTURE_OVERLAP)
@@ -801,6 +812,175 @@ class FusedTowerCall:
             ops.posttrans(agg[:, :K], K, self.Wv, rest_scales, self.d, out=self.y, row_post=self.post_r, col_scale=self.ones, col_shift=self.c,
                           leaky_slope=self.slope, residual=self.res, row_perm=plan.perm_rest, n_out=N)
         return self.y
+
+
+def _tower_pass_weights(layer, towers, mix):
+    """The collapsed weight of a divide_input=False layer (_tower_collapsed_weights: scaler blocks [C_1,s | .. | C_T,s | h panel (block 0)])
+    cut for FusedMultiTowerCall: per tower the weight of its statistics, (N, S * 4 Fi) in scaler blocks [mean | max | min | std] -- the
+    layer-proper format --, and ONE dense weight for everything that is linear in the row's own features h_v:
+        mean / max / min of (a_u + b_v) = those of a_u, + b_v;  b_v = W_b,t h_v + beta_t   (models/dgl/pna_layer.py:35-40: the pretrans Linear)
+        =>  dst term = sum_s scale_s(D_v) [deg_v > 0] (M_s h_v + beta_s),   M_s = sum_t (C_t,s^mean + C_t,s^max + C_t,s^min) W_b,t,
+                                                                            beta_s = sum_t (C_t,s^mean + C_t,s^max + C_t,s^min) beta_t
+    and the self panel W_self h_v: (N, in_dim + S in_dim) = [W_self | M_0 | .. | M_S-1], the layout of functional.posttrans with h_self = agg = h.
+    Formed in float64, rounded once.  Cached on the layer."""
+    Wv, d, c, ones, K = _tower_collapsed_weights(layer, towers, mix, False)
+    hit = layer.__dict__.get("_pna_amd_pass_w")
+    if hit is not None and hit[0] is Wv:
+        return hit[1:]
+    T, Fi = len(towers), towers[0].in_dim
+    S = Wv.shape[1] // K
+    N = Wv.shape[0]
+    with torch.no_grad():
+        Ws = []
+        for t in range(T):
+            W = torch.empty(N, S * 4 * Fi, dtype=torch.float32, device=Wv.device)
+            for s_ in range(S):
+                W[:, s_ * 4 * Fi:(s_ + 1) * 4 * Fi] = Wv[:, s_ * K + t * 4 * Fi:s_ * K + (t + 1) * 4 * Fi]
+            Ws.append(W.contiguous())
+        Wd = torch.zeros(N, (1 + S) * Fi, dtype=torch.float64, device=Wv.device)
+        Wd[:, :Fi] = Wv[:, T * 4 * Fi:T * 4 * Fi + Fi].double()
+        beta = torch.zeros(S, N, dtype=torch.float64, device=Wv.device)
+        for t, tw in enumerate(towers):
+            lin = tw.pretrans.fully_connected[0].linear
+            Wb, bt = lin.weight[:, Fi:2 * Fi].double(), (lin.bias.double() if lin.bias is not None else torch.zeros(Fi, dtype=torch.float64, device=Wv.device))
+            for s_ in range(S):
+                Ct = Wv[:, s_ * K + t * 4 * Fi:s_ * K + (t + 1) * 4 * Fi].double()
+                Wsum = Ct[:, :Fi] + Ct[:, Fi:2 * Fi] + Ct[:, 2 * Fi:3 * Fi]
+                Wd[:, (1 + s_) * Fi:(2 + s_) * Fi] += Wsum @ Wb
+                beta[s_] += Wsum @ bt
+        # the rest rows (two-kernel path over their compact list): scaler blocks [the towers' aggregator columns | an N-column panel], the
+        # panel the identity in block 0 (the identity scaler's) and zero elsewhere -- it carries the row's dense term, copied behind the
+        # statistics of a_u in the aggregate buffer
+        Ka = T * 4 * Fi
+        Wr = torch.zeros(N, S * (Ka + N), dtype=torch.float32, device=Wv.device)
+        for s_ in range(S):
+            Wr[:, s_ * (Ka + N):s_ * (Ka + N) + Ka] = Wv[:, s_ * K:s_ * K + Ka]
+        Wr[:, Ka:Ka + N] = torch.eye(N, dtype=torch.float32, device=Wv.device)
+    res = (Ws, Wd.float().contiguous(), beta.float().contiguous(), Wr.contiguous(), d, c, ones)
+    layer.__dict__["_pna_amd_pass_w"] = (Wv,) + res
+    return res
+
+
+class FusedMultiTowerCall:
+    """One PNALayer forward with T towers over the WHOLE input (divide_input=False; models/dgl/pna_layer.py:137-139; eval) on the one-kernel
+    path (round 6).  Every tower has its own projection of the input -- T x Fi message features per edge -- and a wavefront
+    cannot hold T x 80 running statistics: the layer is one dense launch over the rows' own features (everything linear in h_v: the
+    destination terms of all towers and the self panel, _tower_pass_weights) and T launches of pna_fused_degree_f32 -- the LAYER-PROPER
+    instantiation, no node panels --, launch t gathering tower t's Fi features out of the (V, T P) source projection and adding
+    W_t a_t to the partial sums of the launches before it (pna_fused_degree_args.pre_add); the last one applies bias, graph norm, the
+    collapsed BatchNorm / mixing constants, LeakyReLU and the residual.  The aggregates never reach HBM; what does is T x 2 x 4 N bytes per
+    row of partial sums.  `rest_rows()`: the rows no degree group holds, all towers at once on the two-kernel path."""
+
+    def __init__(self, layer, graph, h, snorm_n, x_src):
+        from . import _lib, degree_groups as DG
+        from .dgl.pna_layer import _row_scales
+        import ctypes
+        towers, mix = list(layer.towers), layer.mixing_network
+        t0 = towers[0]
+        T, Fi, V, dev = len(towers), t0.in_dim, h.shape[0], h.device
+        P = x_src.shape[1] // T
+        self.layer, self.graph, self.plan, self.t0, self.T, self.Fi, self.P = layer, graph, DG.plan_of(graph), t0, T, Fi, P
+        plan = self.plan
+        Ws, self.Wd, self.beta, self.Wr, self.d, self.c, self.ones = _tower_pass_weights(layer, towers, mix)
+        d, c, ones = self.d, self.c, self.ones
+        N = Ws[0].shape[0]
+        self.x_src, self.h = x_src, h
+        self.scales = scales = _row_scales(graph, t0.scalers, t0.avg_d, dev)
+        self.y = y = torch.empty(V, out_pitch(N), dtype=torch.float32, device=dev)[:, :N]
+        self.part = part = torch.empty(V, out_pitch(N), dtype=torch.float32, device=dev)[:, :N]
+        self.res = res = h if layer.residual else None
+        self.slope = float(mix.activation.negative_slope)
+        if t0.graph_norm and snorm_n is not None:
+            post = snorm_n.reshape(-1).to(torch.float32)[plan.perm_all().long()]
+            self.post_g, self.post_r = post[:plan.NV].contiguous(), post[plan.NV:].contiguous()
+        else:
+            self.post_g, self.post_r = plan.ones_rows(), None
+        # the scalers of the dense term: zero for rows without in-edges (DGL leaves their aggregate -- the destination term with it -- at zero)
+        hit = plan.__dict__.setdefault("_masked_scales", {})
+        mkey = tuple(None if r is None else r.data_ptr() for r in scales)
+        if mkey not in hit:
+            if len(hit) > 8:
+                hit.clear()
+            live = (plan._deg > 0).to(torch.float32)
+            ms = [live if r is None else (r * live).contiguous() for r in scales]
+            hit[mkey] = (ms, torch.stack(ms, dim=1).contiguous())
+        self.mscales, self.mscale_mat = hit[mkey]
+        desc, ids, n_rec = plan.fused_tables()
+        self.keep = [desc, ids, x_src, Ws]
+        blocks = []
+        for t in range(T):
+            last = t == T - 1
+            a = _lib.PnaFusedDegreeArgs()
+            self.arith = DG.bind_fused_arith(a, self.keep, Ws[t], Fi, scales, plan, False, dev)
+            a.tile_desc, a.tile_ids, a.n_records = _lib.dev_ptr(desc, torch.int32, "tile_desc"), _lib.dev_ptr(ids, torch.int32, "tile_ids"), n_rec
+            xs = x_src[:, t * P:t * P + Fi]
+            a.x, a.ldx, a.x_rows, a.F, a.N = _lib.dev_ptr(xs, torch.float32, "x_src"), x_src.stride(0), V, Fi, N
+            a.row_perm, a.M, a.n_nodes = _lib.dev_ptr(plan.perm, torch.int32, "row_perm"), plan.NV, V
+            a.pre_add, a.ld_pre_add = _lib.dev_ptr(part, torch.float32, "pre_add"), part.stride(0)
+            if last:
+                a.row_post = _lib.dev_ptr(self.post_g, torch.float32, "row_post")
+                a.bias = _lib.dev_ptr(d, torch.float32, "bias")
+                a.col_scale, a.col_shift = _lib.dev_ptr(ones, torch.float32, "col_scale"), _lib.dev_ptr(c, torch.float32, "col_shift")
+                if res is not None:
+                    a.residual, a.ld_res = _lib.dev_ptr(res, torch.float32, "residual"), res.stride(0)
+                a.y, a.ldy, a.relu, a.act_slope = _lib.dev_ptr(y, torch.float32, "y"), y.stride(0), 2, self.slope
+            else:                                            # a partial sum: no bias, no factor, no activation
+                a.y, a.ldy, a.relu = _lib.dev_ptr(part, torch.float32, "y"), part.stride(0), 0
+            blocks.append((a, ctypes.byref(a)))
+        self.launch_order = blocks
+        self.panel_args = [blocks[-1]] + blocks[:-1]         # (_bind_tile_order: the primary block is the one whose row_post follows the tile order)
+        self.args, self.ref = blocks[-1]
+        self.fn, self.check, self.stream = _lib.lib().pna_fused_degree_f32, _lib.check, _lib.stream_ptr(dev)
+        _bind_tile_order(self, 0)
+
+    def layer_F(self):
+        return self.Fi
+
+    def set_spare(self, on):
+        from . import degree_groups as DG
+        _bind_tile_order(self, DG.FUSED_SPARE_WGS if on else 0)
+
+    def dense_term(self):
+        """part = W_self h + sum_s scale_s [deg > 0] (M_s h + beta_s): one contraction launch over the rows' own features + a rank-S update."""
+        h, Fi = _unit_stride(self.h), self.Fi
+        ops.posttrans(h, Fi, self.Wd, self.mscales, None, h, out=self.part)
+        self.part.add_(self.mscale_mat @ self.beta)
+        return self.part
+
+    def prologue(self):
+        """What both halves read: the dense term of every row (run_fused_call launches it in front of the fork)."""
+        self.dense_term()
+
+    def group_rows(self):
+        for _, ref in self.launch_order:
+            self.check(self.fn(ref, self.stream), "pna_fused_degree_f32")
+        return self.y
+
+    def rest_rows(self):
+        plan, graph, t0, T, Fi, P = self.plan, self.graph, self.t0, self.T, self.Fi, self.P
+        if plan.NR:
+            from . import degree_groups as DG
+            from .dgl.pna_layer import _avg_log_value
+            N, Ka = self.Wr.shape[0], T * 4 * Fi
+            K = Ka + N
+            items, hout, hs = plan.rest_items(graph)
+            agg = torch.empty(plan.NRp, DG.agg_pitch(K), dtype=torch.float32, device=self.y.device)
+            csr = graph.csr
+            # statistics of a_u alone, all towers (the destination term is in the dense term, like the group rows')
+            ops.segreduce(csr.rowptr, csr.col, self.x_src, Fi, t0.aggregators, (None,), n_tower=T, tower_stride_in=P,
+                          out=agg, tower_stride_out=4 * Fi, heavy=hs, workspace=graph.workspace, items=items, heavy_out=hout,
+                          tune=dict(generic=2, rows_per_group=DG.REST_ROWS_PER_GROUP))
+            ops.pack_rows(self.part, plan.perm_all()[plan.NV:], out=agg[:, Ka:K])
+            rest_scales = plan.rest_scales(tuple(t0.scalers) + (_avg_log_value(t0.avg_d),), self.scales)
+            ops.posttrans(agg[:, :K], K, self.Wr, rest_scales, self.d, out=self.y, row_post=self.post_r, col_scale=self.ones, col_shift=self.c,
+                          leaky_slope=self.slope, residual=self.res, row_perm=plan.perm_rest, n_out=N)
+        return self.y
+
+
+def tower_layer_degree_fused_multi(layer, graph, h, snorm_n, x_src):
+    """PNALayer.forward (eval, T towers, divide_input=False) after the node-level SOURCE projection x_src = [W_a,0 h | .. | W_a,T-1 h]
+    (blocks of tower_projection_pitch columns): FusedMultiTowerCall."""
+    return run_fused_call(FusedMultiTowerCall(layer, graph, h, snorm_n, x_src))
 
 
 def tower_layer_degree_fused(layer, graph, h, snorm_n, x_cat):

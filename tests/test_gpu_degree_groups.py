@@ -235,8 +235,10 @@ def test_grouped_tower_layer_vs_reference_golden(cuda_device, name, path):
     g = Graph(a["src"].long(), a["dst"].long(), meta["N"], meta["sizes"]).to(cuda_device)
     h, snorm = a["h"].to(cuda_device), a["snorm_n"].to(cuda_device)
     one = path == "one-kernel"
-    if one and not ((meta["towers"] == 1 or meta["divide_input"]) and 49 <= meta["in_dim"] <= 80 and meta["out_dim"] <= 80):
-        pytest.skip("the one-kernel tower layer takes ONE gather of 49..80 message features: one tower, or T towers with divide_input")
+    if one and not (49 <= meta["in_dim"] <= 80 and meta["out_dim"] <= 80):
+        # (one tower, T towers with divide_input -- ONE gather of in_dim message features -- or, round 6, T towers over the whole input:
+        # one launch per tower, FusedMultiTowerCall)
+        pytest.skip("the one-kernel tower layer takes gathers of 49..80 message features")
     if one:
         h = _pitched(h)                                   # (pitch 75 rows are not 16-byte aligned: the path would decline)
     keep = (DG.ENABLED, DG.MIN_ROWS, DG.MIN_OUT, PF.SMALL_TOWER_ROWS, DG.FUSED)
