@@ -464,50 +464,54 @@ def aggregators_fusable(aggregators):
     return 0 < len(a) == len(set(a)) and all(x in _AGG_SLOT for x in a)
 
 
-def _virtual_weight(weight, F, aggregators, scale, plan, rows):
+def _virtual_weight(weight, F, aggregators, scale, plan, rows, feats=None):
     """(w_ref, scale') for pna_fused_pack_f32: the rows `rows` of `weight` (N, S * A * F), layer column order [scaler][aggregator][feature], as a
-    weight over the kernel's four statistics (Np, S' * 4F) with S' = S (+ S more blocks when `sum` is among the aggregators: the same scaler
-    value times the group's degree, against the mean's columns).  The standard list over all rows: the weight itself."""
+    weight over the kernel's four statistics of the features `feats` = (f0, f1), (Np, S' * 4 Fp) with Fp = f1 - f0 and S' = S (+ S more
+    blocks when `sum` is among the aggregators: the same scaler value times the group's degree, against the mean's columns).  The standard
+    list over all rows and features: the weight itself."""
     aggs = tuple(aggregators)
     c0, c1 = rows if rows is not None else (0, weight.shape[0])
-    if aggs == STANDARD_AGGREGATORS:
+    f0, f1 = feats if feats is not None else (0, F)
+    if aggs == STANDARD_AGGREGATORS and (f0, f1) == (0, F):
         return weight[c0:c1], scale
     G, S = scale.shape
-    A = len(aggs)
+    A, Fp = len(aggs), f1 - f0
     has_sum = "sum" in aggs
     W = weight[c0:c1].detach()
-    w = torch.zeros(c1 - c0, (2 * S if has_sum else S) * 4 * F, dtype=torch.float32, device=weight.device)
+    w = torch.zeros(c1 - c0, (2 * S if has_sum else S) * 4 * Fp, dtype=torch.float32, device=weight.device)
     for s_ in range(S):
         for j, a in enumerate(aggs):
             slot, times_deg = _AGG_SLOT[a]
             blk = (S + s_) if times_deg else s_
-            w[:, (blk * 4 + slot) * F:(blk * 4 + slot + 1) * F] = W[:, (s_ * A + j) * F:(s_ * A + j + 1) * F]
+            w[:, (blk * 4 + slot) * Fp:(blk * 4 + slot + 1) * Fp] = W[:, (s_ * A + j) * F + f0:(s_ * A + j) * F + f1]
     if has_sum:
         scale = torch.cat([scale, scale * plan.group_degree.to(torch.float32).view(G, 1)], dim=1)
     return w, scale.contiguous()
 
 
-def fused_images(weight, F, row_scales, plan, tower=False, x3=False, rows=None, aggregators=STANDARD_AGGREGATORS):
+def fused_images(weight, F, row_scales, plan, tower=False, x3=False, rows=None, aggregators=STANDARD_AGGREGATORS, feats=None):
     """Packed images of W_D = sum_s s_s(D) W_s for pna_fused_degree_f32 (K in the kernel's chunk order), one per degree group,
     cached on the weight like combined_images.  The combination and the operand split (x3=False: two fp16 terms behind per-column
     power-of-two scales + the tail of column scales and guard thresholds; x3=True: three bf16 terms) happen in the pack kernel
     (pna_fused_pack_f32) from the (G, S) matrix of the groups' scaler values.  rows = (c0, c1): the images of output columns [c0, c1) only
-    (a column panel of a layer wider than one launch takes); aggregators: the layer's list (see _virtual_weight)."""
+    (a column panel of a layer wider than one launch takes); feats = (f0, f1): over the statistics of the features [f0, f1) only (a
+    feature panel of a layer with more features than one launch gathers); aggregators: the layer's list (see _virtual_weight)."""
     N, G, S = weight.shape[0], plan.G, len(row_scales)
     aggs = tuple(aggregators)
-    key = ("fused", tower, x3, rows, aggs, weight._version, weight.data_ptr(), str(weight.device), tuple(weight.shape), F, plan.serial, G,
+    key = ("fused", tower, x3, rows, feats, aggs, weight._version, weight.data_ptr(), str(weight.device), tuple(weight.shape), F, plan.serial, G,
            tuple(None if rs is None else (rs.data_ptr(), rs._version) for rs in row_scales))
     attr = "_pna_amd_fused_img"
     cache = getattr(weight, attr, None)                     # {plan serial: (key, image, stride)}: the block plans of a pipelined run
-    ckey = (tower, x3, rows, aggs, plan.serial)
+    ckey = (tower, x3, rows, feats, aggs, plan.serial)
     hit = cache.get(ckey) if isinstance(cache, dict) else None      # share one weight, each with its own groups
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
     L = _lib.lib()
     Np = N if rows is None else rows[1] - rows[0]
-    stride = L.pna_fused_image_bytes(F, Np, 1 if tower else 0, 1 if x3 else 0)
+    Fp = F if feats is None else feats[1] - feats[0]
+    stride = L.pna_fused_image_bytes(Fp, Np, 1 if tower else 0, 1 if x3 else 0)
     if stride <= 0:
-        raise RuntimeError(f"pna_fused_degree: unsupported shape F={F}, N={Np}")
+        raise RuntimeError(f"pna_fused_degree: unsupported shape F={Fp}, N={Np}")
     with torch.no_grad():
         scale = torch.ones(G, S, dtype=torch.float32, device=weight.device)
         for s, rs in enumerate(row_scales):
@@ -517,9 +521,9 @@ def fused_images(weight, F, row_scales, plan, tower=False, x3=False, rows=None, 
         if tower:
             w, sc = weight.detach(), scale
         else:
-            w, sc = _virtual_weight(weight.detach(), F, aggs, scale, plan, rows)
+            w, sc = _virtual_weight(weight.detach(), F, aggs, scale, plan, rows, feats)
     img = torch.empty(G * stride // 4, dtype=torch.float32, device=weight.device)
-    rc = L.pna_fused_pack_f32(_lib.dev_ptr(w, torch.float32, "weight"), w.stride(0), Np, F, sc.shape[1], _lib.dev_ptr(sc, torch.float32, "scale"),
+    rc = L.pna_fused_pack_f32(_lib.dev_ptr(w, torch.float32, "weight"), w.stride(0), Np, Fp, sc.shape[1], _lib.dev_ptr(sc, torch.float32, "scale"),
                               G, _lib.dev_ptr(img, torch.float32, "w_img"), 1 if tower else 0, 1 if x3 else 0, _lib.stream_ptr(weight.device))
     _lib.check(rc, "pna_fused_pack_f32")
     try:
@@ -534,10 +538,7 @@ def fused_images(weight, F, row_scales, plan, tower=False, x3=False, rows=None, 
     return img, stride
 
 
-def fused_panels(F, N):
-    """The output-column panels [(c0, c1), ..] the one-kernel layer runs a layer of N outputs in -- one launch each, every launch its own
-    gather -- or None: one panel when pna_fused_degree_f32 is instantiated for (F, N); else up to FUSED_MAX_PANELS panels of the widest
-    instantiation F has (128 columns with exactly two full feature blocks per gather pass, else 80), cut evenly on multiples of 4."""
+def _column_panels(F, N):
     L = _lib.lib()
     if N < 4 or L.pna_fused_degree_image_bytes(F, 4) <= 0:  # (no instantiation gathers F features)
         return None
@@ -554,18 +555,42 @@ def fused_panels(F, N):
     return panels
 
 
-def bind_fused_arith(a, keep, weight, F, row_scales, plan, tower, device, verification=False, rows=None, aggregators=STANDARD_AGGREGATORS):
+def fused_panels(F, N):
+    """The launches [(f0, f1, c0, c1), ..] the one-kernel layer runs a layer of F features and N outputs in, or None.  One launch when
+    pna_fused_degree_f32 is instantiated for (F, N).  A layer WIDER than an instantiation: up to FUSED_MAX_PANELS output-column panels
+    [c0, c1) of the widest instantiation F has (128 columns with exactly two full feature blocks per gather pass, else 80), cut evenly
+    on multiples of 4 -- every panel its own gather.  A layer with MORE FEATURES than an instantiation gathers (81 <= F <= 96: the
+    statistics of different features never meet before the contraction): feature panels [0, 64) and [64, F), the second launch adding
+    its share to the first's partial sums (pna_fused_degree_args.pre_add) and applying the epilogue -- round 6, hidden sizes 90 / 95 of the
+    reference's README.  Launch order = list order: within a column panel the feature panels follow one another."""
+    cols = _column_panels(F, N)
+    if cols is not None:
+        return [(0, F, c0, c1) for c0, c1 in cols]
+    if not 81 <= F <= 96:
+        return None
+    out = []
+    for f0, f1 in ((0, 64), (64, F)):
+        cols = _column_panels(f1 - f0, N)
+        if cols is None:
+            return None
+        out.append([(f0, f1, c0, c1) for c0, c1 in cols])
+    if len(out[0]) + len(out[1]) > 2 * FUSED_MAX_PANELS:
+        return None
+    return out[0] + out[1]            # (all of the first feature panel's launches, then the second's: those read the partial sums)
+
+
+def bind_fused_arith(a, keep, weight, F, row_scales, plan, tower, device, verification=False, rows=None, aggregators=STANDARD_AGGREGATORS, feats=None):
     """Fill the arithmetic half of a pna_fused_degree_args block: the images of the arithmetic fused_arith() selects and, for the
     guarded form, the plan's hand-over workspace (one per (plan, stream), like the tile counters: launches on one stream are ordered).
     `keep`: a list that keeps the tensors alive.  verification: the agg_out instantiation (fp16 x 2, unguarded)."""
     arith = _lib.FD_ARITH_H2 if verification else fused_arith()
     a.arith = arith
     if arith != _lib.FD_ARITH_X3:
-        img, stride = fused_images(weight, F, row_scales, plan, tower=tower, x3=False, rows=rows, aggregators=aggregators)
+        img, stride = fused_images(weight, F, row_scales, plan, tower=tower, x3=False, rows=rows, aggregators=aggregators, feats=feats)
         a.w_img, a.image_stride = _lib.dev_ptr(img, torch.float32, "w_img"), stride
         keep.append(img)
     if arith != _lib.FD_ARITH_H2:
-        img3, stride3 = fused_images(weight, F, row_scales, plan, tower=tower, x3=True, rows=rows, aggregators=aggregators)
+        img3, stride3 = fused_images(weight, F, row_scales, plan, tower=tower, x3=True, rows=rows, aggregators=aggregators, feats=feats)
         a.w_img_x3, a.image_stride_x3 = _lib.dev_ptr(img3, torch.float32, "w_img_x3"), stride3
         keep.append(img3)
     if arith == _lib.FD_ARITH_GUARDED:

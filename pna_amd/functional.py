@@ -1020,20 +1020,30 @@ class FusedDegreeCall:
         if agg_out is not None and (len(panels) != 1 or aggs != DG.STANDARD_AGGREGATORS):
             raise RuntimeError("pna_fused_degree: agg_out (verification) takes the four standard aggregators and a one-launch layer")
         self.panel_args = []
-        for c0, c1 in panels:
+        whole = len(panels) == 1
+        last_f0 = panels[-1][0]                               # (the feature panel whose launches apply the epilogue)
+        self.part = None
+        if any(f0 != last_f0 for f0, _, _, _ in panels):      # feature panels: partial sums between the launches
+            self.part = torch.empty(V, out_pitch(N), dtype=torch.float32, device=h.device)[:, :N]
+        for f0, f1, c0, c1 in panels:
             a = _lib.PnaFusedDegreeArgs()
-            whole = len(panels) == 1
+            final, first = f0 == last_f0, f0 == 0
             self.arith = DG.bind_fused_arith(a, self.keep, lin.weight, F, scales, plan, False, h.device, verification=agg_out is not None,
-                                             rows=None if whole else (c0, c1), aggregators=aggs)
+                                             rows=None if whole else (c0, c1), aggregators=aggs, feats=None if (f0, f1) == (0, F) else (f0, f1))
             a.tile_desc, a.tile_ids, a.n_records = _lib.dev_ptr(desc, torch.int32, "tile_desc"), _lib.dev_ptr(ids, torch.int32, "tile_ids"), n_rec
-            a.x, a.ldx, a.x_rows, a.F, a.N = _lib.dev_ptr(x, torch.float32, "x"), x.stride(0), x.shape[0], F, c1 - c0
+            a.x, a.ldx, a.x_rows, a.F, a.N = _lib.dev_ptr(x[:, f0:f1], torch.float32, "x"), x.stride(0), x.shape[0], f1 - f0, c1 - c0
             a.row_perm, a.M, a.n_nodes = _lib.dev_ptr(plan.perm, torch.int32, "row_perm"), plan.NV, V
             sl = lambda t: None if t is None else t[c0:c1]      # noqa: E731  (a panel's slice of a per-column vector: still unit stride)
-            a.bias = _lib.dev_ptr(sl(lin.bias), torch.float32, "bias")
-            a.col_scale, a.col_shift = _lib.dev_ptr(sl(cs), torch.float32, "col_scale"), _lib.dev_ptr(sl(ct), torch.float32, "col_shift")
-            if res is not None:
-                a.residual, a.ld_res = _lib.dev_ptr(res[:, c0:c1], torch.float32, "residual"), res.stride(0)
-            a.y, a.ldy, a.relu = _lib.dev_ptr(y[:, c0:c1], torch.float32, "y"), y.stride(0), 1
+            if not first:
+                a.pre_add, a.ld_pre_add = _lib.dev_ptr(self.part[:, c0:c1], torch.float32, "pre_add"), self.part.stride(0)
+            if final:
+                a.bias = _lib.dev_ptr(sl(lin.bias), torch.float32, "bias")
+                a.col_scale, a.col_shift = _lib.dev_ptr(sl(cs), torch.float32, "col_scale"), _lib.dev_ptr(sl(ct), torch.float32, "col_shift")
+                if res is not None:
+                    a.residual, a.ld_res = _lib.dev_ptr(res[:, c0:c1], torch.float32, "residual"), res.stride(0)
+                a.y, a.ldy, a.relu = _lib.dev_ptr(y[:, c0:c1], torch.float32, "y"), y.stride(0), 1
+            else:                                            # a partial sum: no bias, no BatchNorm, no activation, no residual
+                a.y, a.ldy, a.relu = _lib.dev_ptr(self.part[:, c0:c1], torch.float32, "y"), self.part.stride(0), 0
             if agg_out is not None:
                 a.agg_out, a.ld_agg = _lib.dev_ptr(agg_out, torch.float32, "agg_out"), agg_out.stride(0)
             self.panel_args.append((a, ctypes.byref(a)))

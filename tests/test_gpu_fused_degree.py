@@ -781,16 +781,17 @@ def test_source_table_beyond_4_gib_and_2_pow_24_rows(cuda_device):
     (128, 128, "one"), (120, 100, "one"), (113, 81, "one"), (128, 64, "one"),                        # two gather passes
     (64, 96, "one"), (50, 128, "one"),                                                               # one pass of two full blocks, two panels
     (100, 100, "one"), (112, 112, "one"), (97, 64, "one"), (110, 110, "one"),                        # round 6: 97 <= F <= 112 as four blocks in two passes
-    (96, 96, "two"), (81, 64, "two"), (90, 90, "two"),                                               # 81 <= F <= 96: unequal passes, not built
+    (96, 96, "one"), (81, 64, "one"), (90, 90, "one"), (95, 95, "one"),                              # round 6: 81 <= F <= 96 as feature panels [0, 64) + [64, F), partial sums between the launches
     (75, 96, "one"), (80, 128, "one"), (40, 100, "one"), (75, 160, "one"),                           # round 6: wider than an instantiation -> column panels, one launch each
     (16, 64, "two"),                                                                                 # F < 17
-    (128, 192, "one"), (75, 250, "ordinary"), (90, 160, "ordinary"),                                 # more than three panels / no gather for F: the ordinary kernels
+    (128, 192, "one"), (90, 160, "one"), (75, 250, "ordinary"),                                      # more than three panels: the ordinary kernels
 ]] + [
     # round 6: the operator sets of the reference's README ablations on the one-kernel layer
     (75, 75, "one", "mean max min std", "identity"),                                                 # "PNA (no scalers)" (README.md:76-77)
     (100, 100, "one", "mean max min std", "identity"),
     (75, 75, "one", "mean max min std", "identity amplification"),
     (110, 110, "one", "sum", "identity"), (100, 100, "one", "max", "identity"),                      # MPNN (sum) / (max) (README.md:91-92)
+    (95, 95, "one", "mean max min std", "identity"), (90, 90, "one", "mean max min std", "identity"),  # "PNA (no scalers)" at its hidden sizes (README.md:76-77)
     (75, 75, "one", "mean", "identity amplification attenuation"),
     (64, 64, "one", "sum max", "identity attenuation"), (75, 80, "one", "mean sum max min std", "identity amplification attenuation"),
     (75, 75, "ordinary", "mean max min var", "identity amplification attenuation"),                  # var: not a linear image of the kernel's statistics
