@@ -625,8 +625,10 @@ typedef struct pna_fused_degree_args {
   const float* pre_add;     /* tower mode, nullable: (n_nodes, ld_pre_add) rows, node order, added to the biased accumulator IN FRONT of the row factor:
                              *   y = residual + act(((bias + W_D . a + .. + pre_add[perm[v]]) * row_post[v]) * col_scale + col_shift)
                              * -- a PNALayer of T towers over the whole input (divide_input=False, models/dgl/pna_layer.py:137-139) is T launches, one per
-                             * tower's 75 message features, the partial sums carried from launch to launch (pre_add may alias y: a row is read, then written,
-                             * by the same lanes); only the last one applies bias / row factor / BatchNorm / activation / residual */
+                             * tower's 75 message features, the partial sums carried from launch to launch; only the last one applies bias / row factor /
+                             * BatchNorm / activation / residual.  pre_add must NOT alias y under PNA_FD_ARITH_GUARDED: the second launch computes
+                             * a handed-over tile again from the same pre_add rows.  Also taken by the layer proper (with row_post as its
+                             * optional row factor): a layer in feature panels, FusedMultiTowerCall's launches */
   int64_t ld_pre_add;
 } pna_fused_degree_args;
 

@@ -489,6 +489,31 @@ def _virtual_weight(weight, F, aggregators, scale, plan, rows, feats=None):
     return w, scale.contiguous()
 
 
+def virtual_layer_weight(weight, F, aggregators, S):
+    """The layer's posttrans weight (N, S * A * F) over the FOUR standard statistics (+ a fifth block, sum = D x mean, when `sum` is among
+    the aggregators), for the contraction of the rest rows -- their gather is the hand-scheduled kernel's: the standard four only --:
+    (N, S * Kv), scaler blocks of Kv = 4F or 5F columns [mean | max | min | std (| sum)].  Cached on the weight."""
+    aggs = tuple(aggregators)
+    key = ("virt", aggs, S, weight._version, weight.data_ptr(), tuple(weight.shape))
+    hit = getattr(weight, "_pna_amd_virtual", None)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    A = len(aggs)
+    Kv = (5 if "sum" in aggs else 4) * F
+    with torch.no_grad():
+        W = weight.detach()
+        w = torch.zeros(W.shape[0], S * Kv, dtype=torch.float32, device=W.device)
+        for s_ in range(S):
+            for j, a in enumerate(aggs):
+                slot = 4 if a == "sum" else _AGG_SLOT[a][0]
+                w[:, s_ * Kv + slot * F:s_ * Kv + (slot + 1) * F] = W[:, (s_ * A + j) * F:(s_ * A + j + 1) * F]
+    try:
+        weight._pna_amd_virtual = (key, w, Kv)
+    except AttributeError:
+        pass
+    return w, Kv
+
+
 def fused_images(weight, F, row_scales, plan, tower=False, x3=False, rows=None, aggregators=STANDARD_AGGREGATORS, feats=None):
     """Packed images of W_D = sum_s s_s(D) W_s for pna_fused_degree_f32 (K in the kernel's chunk order), one per degree group,
     cached on the weight like combined_images.  The combination and the operand split (x3=False: two fp16 terms behind per-column

@@ -359,21 +359,34 @@ def _layer_tail_operands(layer, h):
 
 def _rest_posttrans(layer, graph, agg_rest, plan, scales, y, cs, ct, res):
     """The rows no degree group holds (rare degrees, hub rows): the ordinary three-block contraction over their compact list
-    `agg_rest` ((plan.NRp, 4F), virtual order), rows scattered to node order."""
+    `agg_rest` ((plan.NRp, 4F): the four STANDARD statistics, virtual order; (plan.NRp, 5F) with room for a fifth block when the layer
+    aggregates `sum`), rows scattered to node order.  A layer with another aggregator list (round 6) contracts against its weight
+    re-expressed over those statistics (degree_groups.virtual_layer_weight); the sum block = in-degree x mean is formed here."""
+    from . import degree_groups as DG
     F, N = layer.in_dim, layer.out_dim
-    K = len(layer.aggregators) * F
+    K = 4 * F
     lin = layer.posttrans.fully_connected[0].linear
     from .dgl.pna_layer import _avg_log_value
     rest_scales = plan.rest_scales(tuple(layer.scalers) + (_avg_log_value(layer.avg_d),), scales)
-    if N <= 80 and len(scales) == 3:
-        ops.posttrans(agg_rest, K, lin.weight, rest_scales, lin.bias, out=y, col_scale=cs, col_shift=ct, relu=True, residual=res,
+    weight = lin.weight
+    if tuple(layer.aggregators) != DG.STANDARD_AGGREGATORS:
+        weight, K = DG.virtual_layer_weight(lin.weight, F, layer.aggregators, len(scales))
+        if K == 5 * F:
+            deg = plan.__dict__.get("_rest_deg")
+            if deg is None:
+                deg = torch.zeros(max(plan.NRp, 1), 1, dtype=torch.float32, device=y.device)
+                deg[:plan.NR, 0] = plan._deg[plan.rest_rows].to(torch.float32)
+                deg = plan.__dict__["_rest_deg"] = deg[:plan.NRp]
+            torch.mul(agg_rest[:, :F], deg, out=agg_rest[:, 4 * F:5 * F])
+    if N <= 80 and len(rest_scales) == 3:
+        ops.posttrans(agg_rest, K, weight, rest_scales, lin.bias, out=y, col_scale=cs, col_shift=ct, relu=True, residual=res,
                       row_perm=plan.perm_rest, n_out=N)
     else:
         # 128-column block (three blocks x three weight buffers do not fit the LDS) or another scaler count (no grouped
         # instantiation): the few rest rows take the ordinary kernel over their compact list and are scattered by index (three
         # small torch kernels)
         rr = plan.rest_rows
-        y_r = ops.posttrans(agg_rest[:plan.NR], K, lin.weight, [None if r is None else r[:plan.NR] for r in rest_scales],
+        y_r = ops.posttrans(agg_rest[:plan.NR], K, weight, [None if r is None else r[:plan.NR] for r in rest_scales],
                             lin.bias, col_scale=cs, col_shift=ct, relu=True, residual=None if res is None else res.index_select(0, rr),
                             arith="bf16x3")
         y.index_copy_(0, rr, y_r)
@@ -887,7 +900,10 @@ class FusedMultiTowerCall:
         self.x_src, self.h = x_src, h
         self.scales = scales = _row_scales(graph, t0.scalers, t0.avg_d, dev)
         self.y = y = torch.empty(V, out_pitch(N), dtype=torch.float32, device=dev)[:, :N]
+        # partial sums ping-pong between two buffers: a launch never writes the rows it reads -- the guard's second launch computes a
+        # handed-over tile AGAIN from the same pre_add rows (in place it would add the tile's share twice: found by tools/fuzz_fused.py)
         self.part = part = torch.empty(V, out_pitch(N), dtype=torch.float32, device=dev)[:, :N]
+        self.part2 = torch.empty(V, out_pitch(N), dtype=torch.float32, device=dev)[:, :N] if T > 1 else None
         self.res = res = h if layer.residual else None
         self.slope = float(mix.activation.negative_slope)
         if t0.graph_norm and snorm_n is not None:
@@ -916,7 +932,8 @@ class FusedMultiTowerCall:
             xs = x_src[:, t * P:t * P + Fi]
             a.x, a.ldx, a.x_rows, a.F, a.N = _lib.dev_ptr(xs, torch.float32, "x_src"), x_src.stride(0), V, Fi, N
             a.row_perm, a.M, a.n_nodes = _lib.dev_ptr(plan.perm, torch.int32, "row_perm"), plan.NV, V
-            a.pre_add, a.ld_pre_add = _lib.dev_ptr(part, torch.float32, "pre_add"), part.stride(0)
+            src_buf, dst_buf = (part, self.part2) if t % 2 == 0 else (self.part2, part)
+            a.pre_add, a.ld_pre_add = _lib.dev_ptr(src_buf, torch.float32, "pre_add"), src_buf.stride(0)
             if last:
                 a.row_post = _lib.dev_ptr(self.post_g, torch.float32, "row_post")
                 a.bias = _lib.dev_ptr(d, torch.float32, "bias")
@@ -925,7 +942,7 @@ class FusedMultiTowerCall:
                     a.residual, a.ld_res = _lib.dev_ptr(res, torch.float32, "residual"), res.stride(0)
                 a.y, a.ldy, a.relu, a.act_slope = _lib.dev_ptr(y, torch.float32, "y"), y.stride(0), 2, self.slope
             else:                                            # a partial sum: no bias, no factor, no activation
-                a.y, a.ldy, a.relu = _lib.dev_ptr(part, torch.float32, "y"), part.stride(0), 0
+                a.y, a.ldy, a.relu = _lib.dev_ptr(dst_buf, torch.float32, "y"), dst_buf.stride(0), 0
             blocks.append((a, ctypes.byref(a)))
         self.launch_order = blocks
         self.panel_args = [blocks[-1]] + blocks[:-1]         # (_bind_tile_order: the primary block is the one whose row_post follows the tile order)
@@ -1068,11 +1085,12 @@ class FusedDegreeCall:
         if plan.NR:
             from . import degree_groups as DG
             F = layer.in_dim
-            K = len(layer.aggregators) * F
+            K = 4 * F                                        # (the four standard statistics whatever the layer's list: _rest_posttrans)
+            Kb = 5 * F if "sum" in layer.aggregators else K  # (+ room for the sum block)
             items, hout, hs = plan.rest_items(graph)
-            agg = torch.empty(plan.NRp, DG.agg_pitch(K), dtype=torch.float32, device=self.y.device)[:, :K]
+            agg = torch.empty(plan.NRp, DG.agg_pitch(Kb), dtype=torch.float32, device=self.y.device)[:, :Kb]
             csr = graph.csr
-            ops.segreduce(csr.rowptr, csr.col, _unit_stride(self.x), F, layer.aggregators, (None,), tower_stride_in=F, out=agg,
+            ops.segreduce(csr.rowptr, csr.col, _unit_stride(self.x), F, DG.STANDARD_AGGREGATORS, (None,), tower_stride_in=F, out=agg[:, :K],
                           heavy=hs, workspace=graph.workspace, items=items, heavy_out=hout,
                           tune=dict(generic=2, rows_per_group=DG.REST_ROWS_PER_GROUP))
             _rest_posttrans(layer, graph, agg, plan, self.scales, self.y, self.cs, self.ct, self.res)
