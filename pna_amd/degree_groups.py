@@ -640,11 +640,15 @@ def guard_workspace(plan, device):
 
 
 def guard_stats(plan, device, reset=False):
-    """(tiles handed over to the bf16 x 3 launch, guarded calls) on the current stream since the last reset (one host read)."""
-    ws = guard_workspace(plan, device)
-    t, c = (int(v) for v in ws[2:4].tolist())
-    if reset:
-        ws[2:4].zero_()
+    """(tiles handed over to the bf16 x 3 launch, guarded calls) of this plan on `device` since the last reset, over ALL its workspaces -- one
+    per stream a call was bound on (a captured hipGraph's calls own the capture stream's) -- one host read per workspace."""
+    t = c = 0
+    for (dev, _), ws in plan.__dict__.get("_guard_ws", {}).items():
+        if dev == str(device):
+            a, b = (int(v) for v in ws[2:4].tolist())
+            t, c = t + a, c + b
+            if reset:
+                ws[2:4].zero_()
     return t, c
 
 

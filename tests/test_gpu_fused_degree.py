@@ -291,6 +291,45 @@ def test_guarded_contraction_other_instantiations_adversarial(cuda_device, F, N)
     assert worst_u > 1.0, worst_u
 
 
+def test_guard_hands_over_inside_a_replayed_hipgraph_and_leaves_its_words_zero(cuda_device):
+    """The guard needs no host round trip: captured once (pna_amd.capture.GraphedForward), the layer is replayed on a benign input and on an
+    adversarial one written into the same static buffer -- the second replay hands its tiles to the bf16 x 3 launch and equals the eager,
+    guarded result bit for bit; afterwards the working words of the guard block and the dynamic schedule's counter pair are zero (ADVICE r5:
+    a launch that left them non-zero would make every later launch on the plan skip tiles)."""
+    from pna_amd import Graph, degree_groups as DG
+    from pna_amd.capture import GraphedForward
+    from pna_amd.synth import powerlaw_graph
+    V, E, F = 140_000, 1_100_000, 75
+    src, dst = powerlaw_graph(V, E, seed=77, device=cuda_device)
+    g = Graph(src, dst, V)
+    layer = _layer(F, F, cuda_device, residual=True, seed=78)
+    h = _features(V, F, cuda_device, seed=79)
+    with torch.no_grad():
+        lin = layer.posttrans.fully_connected[0].linear
+        lin.weight[:, [s_ * 4 * F + a * F + 7 for s_ in range(3) for a in range(4)]] = 0.0
+        with _Knobs(fused=True, small_graphs=True):
+            assert DG.fused_applies(g, h, F, F)
+            plan = DG.plan_of(g)
+            gf = GraphedForward(lambda x: layer(g, x), h, alias_inputs=True)
+            DG.guard_stats(plan, cuda_device, reset=True)
+            gf.graph.replay()
+            y_benign = gf.static_out.clone()
+            handed_benign = DG.guard_stats(plan, cuda_device, reset=True)[0]
+            h[:, 7].mul_(1e9)                                   # the static input, in place: feature 7 (zero weight) dwarfs the row
+            gf.graph.replay()
+            y_adv = gf.static_out.clone()
+            handed_adv = DG.guard_stats(plan, cuda_device)[0]
+            y_eager = layer(g, h)
+            for ws in plan.__dict__["_guard_ws"].values():
+                assert ws[:2].tolist() == [0, 0], ws[:4].tolist()
+            for c in plan.__dict__.get("_tile_counters", {}).values():
+                assert c.tolist() == [0, 0], c.tolist()
+    assert handed_benign <= 2 and handed_adv > 0.5 * (plan.NV // 64), (handed_benign, handed_adv)
+    assert torch.equal(y_adv, y_eager)
+    live = plan.perm[plan.perm >= 0].long()
+    assert (y_adv[live][:, :7] - y_benign[live][:, :7]).abs().max().item() <= 1e-4 * y_benign.abs().max().item()   # (feature 7 has no weight: only its own residual column moves)
+
+
 def test_guard_leaves_benign_inputs_on_the_fast_path(cuda_device):
     """Gaussian features and weights (the benchmark's input class), ReLU-like features with exact zeros, and a constant feature six decades
     below the others: the guard hands over at most a few tiles in a thousand / a few per cent -- and holds the bar either way."""

@@ -7,6 +7,7 @@ import collections
 import csv
 import glob
 import os
+import re
 import sys
 
 O = sys.argv[1]
@@ -16,7 +17,11 @@ for p in glob.glob(os.path.join(O, "*", "**", "*counter_collection.csv"), recurs
     label = os.path.relpath(p, O).split(os.sep)[0].rsplit("_", 1)[0]
     for r in csv.DictReader(open(p)):
         if sub in r["Kernel_Name"] and int(r["Grid_Size"]) > 60000:
-            agg[(label, r["Counter_Name"], r["Grid_Size"])].append(float(r["Counter_Value"]))
+            # (round 6: a guarded call is two launches of the same grid -- k_fused_degree<.., ARITH = 0, ..> and its consuming
+            # launch <.., ARITH = 1, ..> --: kept apart by the template arguments)
+            m = re.search(r"<([^>]*)>", r["Kernel_Name"])
+            tag = label + (" <" + m.group(1).replace(" ", "") + ">" if m else "")
+            agg[(tag, r["Counter_Name"], r["Grid_Size"])].append(float(r["Counter_Value"]))
 for k in sorted(agg):
     v = sorted(agg[k])
-    print(f"{k[0]:28s} {k[1]:36s} grid {k[2]:8s} median {v[len(v) // 2]:16.1f}  n={len(v)}")
+    print(f"{k[0]:44s} {k[1]:36s} grid {k[2]:8s} median {v[len(v) // 2]:16.1f}  n={len(v)}")
