@@ -337,6 +337,18 @@ typedef struct pna_segreduce_bwd_pull_args {
   int32_t run_rowprep;   /* != 0: `table` is a WORKSPACE; the call runs the rowprep pass itself (table, base->grad_dst and the ranks in one sweep) */
   uint16_t* ranks;
   int64_t ld_rank;
+  /* round 6 (ABI 21), optional: the pull over PER-EDGE rows.  edge_rows != NULL: a (n_edges, ld_edge >= F) workspace; the call first walks the
+   * FORWARD work list `items` (n_items records {row, beg, end, slot}, pna_segreduce_args.work_items) and writes, in CSR order,
+   *     P[e] = R1[v] + [e = argmax[v]] G_max[v] + [e = argmin[v]] G_min[v]        and R2[v] into table (V, ld_table >= F),
+   * then pulls per out-edge P[pos_t[j]] and R2[col_t[j]] (pos_t: position of every transposed edge in the forward CSR): 2 x 4F bytes per
+   * edge instead of 20F + ranks; the same additions in the same order: bit-identical gradients.  One tower, no dst_term, aggr[] = mean, std,
+   * max, min (any order); rank_t / ranks / run_rowprep are not used. */
+  float* edge_rows;
+  int64_t ld_edge;
+  const int32_t* pos_t;
+  const int32_t* items;
+  int32_t n_items;
+  int32_t _pad_e;
 } pna_segreduce_bwd_pull_args;
 int pna_segreduce_bwd_pull_f32(const pna_segreduce_bwd_pull_args* args, pna_stream_t stream);
 

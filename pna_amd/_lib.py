@@ -121,6 +121,8 @@ class PnaSegreduceBwdPullArgs(_Args):
         ("struct_size", ctypes.c_uint32), ("_abi_reserved", ctypes.c_uint32),
         ("base", ctypes.c_void_p), ("table", ctypes.c_void_p), ("ld_table", ctypes.c_int64), ("col_t", ctypes.c_void_p), ("rank_t", ctypes.c_void_p),
         ("items_t", ctypes.c_void_p), ("n_items_t", ctypes.c_int32), ("run_rowprep", ctypes.c_int32), ("ranks", ctypes.c_void_p), ("ld_rank", ctypes.c_int64),
+        ("edge_rows", ctypes.c_void_p), ("ld_edge", ctypes.c_int64), ("pos_t", ctypes.c_void_p), ("items", ctypes.c_void_p),
+        ("n_items", ctypes.c_int32), ("_pad_e", ctypes.c_int32),
     ]
 
 

@@ -313,7 +313,23 @@ def _backward_pull(graph, x, dst_term, ident, amx, amn, gagg, aggs, all_aggs, T,
               and x.stride(1) == 1 and os.environ.get("PNA_AMD_BWD_ARGS", "pull") == "pull")
     if packed_rows is not None and not ranked:
         raise RuntimeError("_backward_pull: packed_rows (in place) needs the ranked pull")
-    if ranked and (PULL_PACKED or packed_rows is not None):
+    # round 6: the pull over PER-EDGE rows (pna_segreduce_bwd_pull_args.edge_rows): one tower, no destination term, the four standard
+    # aggregators -- PNASimpleLayer's backward.  2 x 4F bytes per out-edge instead of 20F + ranks; bit-identical gradients.
+    edge_mode = (ranked and PULL_EDGE_ROWS and T == 1 and dst_term is None and set(aggs) == {"mean", "std", "max", "min"} and not need_d
+                 and csr.col.numel() * ((F + 15) // 16 * 16) * 4 < (1 << 36))
+    if edge_mode:
+        b.stat_node_of, b.stat_rows = None, 0               # (the per-edge pass walks the FORWARD work list: a node's statistics through row_of)
+        # rows at a 64-byte aligned pitch (F = 75: 80 floats): a 300-byte row then lies on exactly three 128-byte lines wherever it starts
+        # (at the packed pitch of 76 floats: 3.4 on average, and the writer's last sector of a row is shared with the next row's first)
+        Fp = (F + 15) // 16 * 16
+        E_ = csr.col.numel()
+        flat = graph.__dict__.get("_pna_amd_edge_rows")     # (3.2 GB at C3: kept on the graph like the packed pull rows, sized for the widest layer seen)
+        if flat is None or flat.numel() < (E_ + V) * Fp or flat.device != dev:
+            flat = graph.__dict__["_pna_amd_edge_rows"] = torch.empty(max((E_ + V) * Fp, 1), dtype=torch.float32, device=dev)
+        P = flat[:E_ * Fp].view(E_, Fp)
+        table = flat[E_ * Fp:(E_ + V) * Fp].view(V, Fp)       # R2: its own (V, Fp) table behind the edge rows
+        ranks = None
+    elif ranked and (PULL_PACKED or packed_rows is not None):
         # one row [R1 | R2 | G_max | G_min | 16-bit ranks] per node at a 128-byte aligned pitch: an out-edge of the pull reads 12 cache
         # lines at F = 75 instead of ~14.7 for three separate pieces (pna_segreduce_bwd_pull_f32, packed rows).  packed_rows: the
         # caller's buffer, whose first 4 T F columns ARE gagg (aggs = mean, std, max, min): rowprep works in place
@@ -347,7 +363,7 @@ def _backward_pull(graph, x, dst_term, ident, amx, amn, gagg, aggs, all_aggs, T,
             gx = torch.empty(x.shape[0], TF, dtype=torch.float32, device=dev)
             if hs.n_heavy > 0:
                 gx.index_fill_(0, hs.heavy_rows.long(), 0.0)  # hub sources: their segments add atomically
-            if ranks is None:
+            if ranks is None and not edge_mode:
                 ranks = torch.empty(V, 2 * TF, dtype=torch.int16, device=dev)
             b.x, b.ldx = _lib.dev_ptr(x, torch.float32, "x"), x.stride(0)
             b.grad_x, b.ld_gx = _lib.dev_ptr(gx, torch.float32, "grad_x"), gx.stride(0)
@@ -356,7 +372,16 @@ def _backward_pull(graph, x, dst_term, ident, amx, amn, gagg, aggs, all_aggs, T,
             q.table, q.ld_table = _lib.dev_ptr(table, torch.float32, "table"), table.stride(0)
             q.col_t, q.rank_t = _lib.dev_ptr(tcsr.col, torch.int32, "col_t"), _lib.dev_ptr(rank_t, torch.int32, "rank_t")
             q.items_t, q.n_items_t, q.run_rowprep = _lib.dev_ptr(items, torch.int32, "items_t"), items.shape[0], 1
-            q.ranks, q.ld_rank = _lib.dev_ptr(ranks, torch.int16, "ranks"), ranks.stride(0)
+            if edge_mode:
+                pos_t = getattr(gT, "_pna_amd_pos_t", None)       # position of every transposed edge in the forward CSR
+                if pos_t is None:
+                    pos_t = gT._pna_amd_pos_t = tcsr.eid.to(torch.int32).contiguous()
+                fitems = graph.work_items()
+                q.edge_rows, q.ld_edge = _lib.dev_ptr(P, torch.float32, "edge_rows"), P.stride(0)
+                q.pos_t = _lib.dev_ptr(pos_t, torch.int32, "pos_t")
+                q.items, q.n_items = _lib.dev_ptr(fitems, torch.int32, "items"), fitems.shape[0]
+            else:
+                q.ranks, q.ld_rank = _lib.dev_ptr(ranks, torch.int16, "ranks"), ranks.stride(0)
             rc = _lib.lib().pna_segreduce_bwd_pull_f32(ctypes.byref(q), _lib.stream_ptr(dev))
             _lib.check(rc, "pna_segreduce_bwd_pull_f32")
             if x.shape[1] != TF:
@@ -389,6 +414,7 @@ def M_rows(t):
     return t.shape[0]
 
 
+PULL_EDGE_ROWS = os.environ.get("PNA_AMD_PULL_EDGE_ROWS", "1") != "0"   # 0: the ranked pull of rounds 3-5 (R1 | R2 | G_max | G_min | ranks per out-edge)
 PULL_PACKED = os.environ.get("PNA_AMD_PULL_PACKED", "1") != "0"   # 0: table, aggregate gradient and ranks as three separate rows (round 3)
 DW_KERNEL = os.environ.get("PNA_AMD_DW_KERNEL", "1") != "0"    # 0: the library route (slab-batched GEMM) for the weight gradient
 DW_GROUPED = os.environ.get("PNA_AMD_DW_GROUPED", "1") != "0"  # 0: per-row scalers (three scaled copies of gy inside the kernel)

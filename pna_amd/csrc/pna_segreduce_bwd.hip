@@ -526,6 +526,129 @@ __global__ __launch_bounds__(kBlock) void k_bwd_pull(const LArgs a) {
   }
 }
 
+// ---- round 6: the pull over PER-EDGE rows ------------------------------------------------------------------------------------
+// The ranked pull above reads, per out-edge (u -> v), R1 | R2 | G_max | G_min of v and two rank rows: 1 568 bytes at F = 75, of which the
+// max / min part (G rows + ranks: 900 bytes) only decides which ONE in-edge of v per feature receives G_max / G_min.  Here that decision is
+// taken where it is cheap -- on the destination's side, walking v's in-edges in sequence (the forward work list) --:
+//     P[e] = R1[v] + [e = argmax[v]] G_max[v] + [e = argmin[v]] G_min[v]        one F-float row per edge, written in CSR order
+// and the pull reads per out-edge P[position of the edge] and R2[v]: 2 x 4F bytes.  The same additions in the same order as the ranked pull
+// (t = R1; t += max term; t += min term; s1 += t; s2 += R2): bit-identical gradients.  One tower, no destination term (PNASimpleLayer).
+struct EArgs {
+  const int32_t* items; const int32_t* rowptr; const int32_t* row_of;
+  const float* gmean; const float* gstd; const float* gmax; const float* gmin; const float* mean; const float* stdv;
+  const int32_t* amx; const int32_t* amn;
+  float* r2; float* P;
+  long ld_g, ld_stat, ld_arg, ld_r2, ld_p;
+  int n_items, F, L, G;
+};
+__global__ __launch_bounds__(kBlock) void k_bwd_edge_rows(const EArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = lane / a.L;
+  if (grp >= a.G) return;
+  const int c = lane - grp * a.L;
+  const int nchunks = (a.F + 3) / 4;
+  if (c >= nchunks) return;
+  const int off = min(c * 4, a.F - 4);
+  const long item = ((long)blockIdx.x * kWaves + wave) * a.G + grp;
+  if (item >= a.n_items) return;
+  const i4 rec = reinterpret_cast<const i4*>(a.items)[item];
+  const int row = rec.x, beg = rec.y, end = rec.z;
+  const int rbeg = a.rowptr[row];
+  const float D = (float)(a.rowptr[row + 1] - rbeg);
+  const long vs = a.row_of ? (long)a.row_of[row] : (long)row;
+  struct __attribute__((packed, aligned(4))) i4u { i4 v; };
+  auto ld = [](const float* p) -> f4 { return reinterpret_cast<const f4u*>(p)->v; };
+  const f4 zero = {0.f, 0.f, 0.f, 0.f};
+  f4 r1 = zero, cvar = zero, gmx = zero, gmn = zero;
+  i4 ex = {-1, -1, -1, -1}, en = ex;
+  if (D > 0.f) {
+    const size_t og = (size_t)row * a.ld_g + off, os = (size_t)vs * a.ld_stat + off, oa = (size_t)vs * a.ld_arg + off;
+    const f4 gm = ld(a.gmean + og), gd = ld(a.gstd + og), sd = ld(a.stdv + os), mean = ld(a.mean + os);
+    gmx = ld(a.gmax + og); gmn = ld(a.gmin + og);
+    ex = reinterpret_cast<const i4u*>(a.amx + oa)->v; en = reinterpret_cast<const i4u*>(a.amn + oa)->v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                           // (k_bwd_rowprep4's arithmetic, op by op)
+      const float base = gm[q] / D;
+      const float vr = sd[q] * sd[q] - 1e-5f;
+      const float gs = 0.f + gd[q] / (2.f * sd[q]);
+      cvar[q] = vr > 0.f ? gs * (2.f / D) : 0.f;
+      r1[q] = base + cvar[q] * (0.f - mean[q]);
+    }
+  }
+  if (beg == rbeg) reinterpret_cast<f4u*>(a.r2 + (size_t)row * a.ld_r2 + off)->v = cvar;      // (a hub row's first segment writes the row's R2)
+  for (int e = beg; e < end; ++e) {
+    f4 t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v = r1[q];
+      v = v + (ex[q] == e ? gmx[q] : 0.f);
+      v = v + (en[q] == e ? gmn[q] : 0.f);
+      t[q] = v;
+    }
+    reinterpret_cast<f4u*>(a.P + (size_t)e * a.ld_p + off)->v = t;
+  }
+}
+
+struct LArgs2 {
+  const int32_t* items; const int32_t* col_t; const int32_t* pos_t;
+  const float* P; const float* r2; const float* x; float* gx;
+  long ld_p, ld_r2, ldx, ld_gx;
+  int n_items, F, L, G;
+};
+template <int U>
+__global__ __launch_bounds__(kBlock) void k_bwd_pull_rows(const LArgs2 a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = lane / a.L;
+  if (grp >= a.G) return;
+  const int c = lane - grp * a.L;
+  const int nchunks = (a.F + 3) / 4;
+  const bool lane_ok = c < nchunks;
+  const int off = min(min(c, nchunks - 1) * 4, a.F - 4);
+  const long item = ((long)blockIdx.x * kWaves + wave) * a.G + grp;
+  if (item >= a.n_items) return;
+  const i4 rec = reinterpret_cast<const i4*>(a.items)[item];
+  const int row = rec.x, beg = rec.y, end = rec.z, slot = rec.w;
+  f4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  for (int e = beg; e < end; e += U) {
+    int v[U], ps[U];
+    f4 pr[U], r2[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = min(e + u, end - 1);
+      v[u] = a.col_t[j];
+      ps[u] = a.pos_t[j];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      pr[u] = reinterpret_cast<const f4u*>(a.P + (size_t)ps[u] * a.ld_p + off)->v;
+      r2[u] = reinterpret_cast<const f4u*>(a.r2 + (size_t)v[u] * a.ld_r2 + off)->v;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (e + u < end) {                                    // (group-uniform)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          s1[q] = s1[q] + pr[u][q];
+          s2[q] = s2[q] + r2[u][q];
+        }
+      }
+    }
+  }
+  if (!lane_ok) return;
+  const f4 xu = reinterpret_cast<const f4u*>(a.x + (size_t)row * a.ldx + off)->v;
+  f4 res;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) res[q] = s1[q] + xu[q] * s2[q];
+  float* o = a.gx + (size_t)row * a.ld_gx + off;
+  if (slot < 0) {
+    reinterpret_cast<f4u*>(o)->v = res;                     // (a row's last, overlapping window recomputes the same values)
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (off + q >= c * 4) unsafeAtomicAdd(o + q, res[q]);   // hub segment: every column once (the last window overlaps its neighbour)
+  }
+}
+
 int fill_pull_args(const pna_segreduce_bwd_args* p, PArgs& k, const char* who) {
   memset(&k, 0, sizeof(k));
   if (!p) return pna_set_error(PNA_E_INVALID, "null args");
@@ -631,10 +754,38 @@ extern "C" int pna_segreduce_bwd_pull_f32(const pna_segreduce_bwd_pull_args* q, 
   if (p->V == 0 || q->n_items_t == 0) return PNA_OK;
   const int T = k.T, F = p->F, TF = T * F;
   if (!k.g[PNA_AGG_MAX] || !k.g[PNA_AGG_MIN] || !p->argmax || !p->argmin || !k.has_var || F < 4 || F > 256 || !p->x || !p->grad_x || !q->table ||
-      !q->col_t || !q->rank_t || !q->items_t || !q->ranks || q->ld_table < 2 * TF || q->ld_rank < 2 * TF || p->ldx < TF || p->ld_gx < TF || q->n_items_t < 0)
+      !q->col_t || !q->items_t || p->ldx < TF || p->ld_gx < TF || q->n_items_t < 0 ||
+      (!q->edge_rows && (!q->rank_t || !q->ranks || q->ld_table < 2 * TF || q->ld_rank < 2 * TF)))
     return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_pull_f32: needs max + min + std/var among aggr[], argmax / argmin, x, grad_x, the rowprep table "
                                         "(ld >= 2 T F), the transposed graph (col_t, rank_t, items_t), a ranks workspace (ld >= 2 T F) and 4 <= F <= 256");
   hipStream_t st = (hipStream_t)stream;
+  if (q->edge_rows) {
+    // round 6: per-edge rows (see k_bwd_edge_rows): table = the (V, ld_table >= F) rows of R2
+    if (T != 1 || p->dst_term || !k.g[PNA_AGG_MEAN] || !k.g[PNA_AGG_STD] || k.g[PNA_AGG_SUM] || k.g[PNA_AGG_VAR] || !p->stdv || !q->pos_t || !q->items ||
+        q->n_items < 0 || q->ld_edge < F || q->ld_table < F || p->stat_node_of)
+      return pna_set_error(PNA_E_INVALID, "pna_segreduce_bwd_pull_f32: edge_rows needs one tower, no dst_term, aggr[] = mean / std / max / min, pos_t, the forward "
+                                          "work list (items), ld_edge >= F and ld_table >= F");
+    EArgs e;
+    memset(&e, 0, sizeof(e));
+    e.items = q->items; e.rowptr = p->rowptr; e.row_of = p->stat_row_of;
+    e.gmean = k.g[PNA_AGG_MEAN]; e.gstd = k.g[PNA_AGG_STD]; e.gmax = k.g[PNA_AGG_MAX]; e.gmin = k.g[PNA_AGG_MIN]; e.mean = p->mean; e.stdv = p->stdv;
+    e.amx = p->argmax; e.amn = p->argmin; e.r2 = const_cast<float*>(q->table); e.P = q->edge_rows;
+    e.ld_g = p->ld_g; e.ld_stat = p->ld_stat; e.ld_arg = p->ld_arg; e.ld_r2 = q->ld_table; e.ld_p = q->ld_edge;
+    e.n_items = q->n_items; e.F = F;
+    e.L = (F + 3) / 4 > 64 ? 64 : (F + 3) / 4; e.G = 64 / e.L;
+    const long groups = (long)kWaves * e.G;
+    if (q->n_items > 0)
+      hipLaunchKernelGGL(k_bwd_edge_rows, dim3((unsigned)((q->n_items + groups - 1) / groups)), dim3(kBlock), 0, st, e);
+    LArgs2 a;
+    memset(&a, 0, sizeof(a));
+    a.items = q->items_t; a.col_t = q->col_t; a.pos_t = q->pos_t; a.P = q->edge_rows; a.r2 = q->table; a.x = p->x; a.gx = p->grad_x;
+    a.ld_p = q->ld_edge; a.ld_r2 = q->ld_table; a.ldx = p->ldx; a.ld_gx = p->ld_gx;
+    a.n_items = q->n_items_t; a.F = F; a.L = e.L; a.G = e.G;
+    hipLaunchKernelGGL((k_bwd_pull_rows<4>), dim3((unsigned)((q->n_items_t + groups - 1) / groups)), dim3(kBlock), 0, st, a);
+    hipError_t er = hipGetLastError();
+    if (er != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(er));
+    return PNA_OK;
+  }
   const long n = (long)p->V * TF;
   // PACKED rows (round 4): ld_table >= 5 T F and ranks == table + 4 T F floats -- one row [R1 | R2 | G_max | G_min | ranks] per node,
   // 20 T F bytes contiguous: an out-edge touches 12 cache lines at F = 75 (pitch 1536 B) instead of ~14.7 for the three separate

@@ -69,7 +69,9 @@ alg = {
     "k_segreduce_fast": ("forward gather with arg tracking: E (4F + 4) read; V (16F aggregate + 8F arg indices) written", E * (4 * F + 4) + V * 24 * F),
     "k_posttrans_x3": ("forward contraction (V (16F + 4F) read, 4N written) + d agg = gy W^T (V 4N read, 16F written): two launches", V * (20 * F + 4 * N) + V * (4 * N + 16 * F)),
     "k_bwd_rowprep": ("rowprep + ranks, packed rows: V (16F d agg + 8F mean / std + 8F arg indices) read; V (16F R1 | R2 | G_max | G_min + 4F ranks) written", V * 52 * F),
-    "k_bwd_pull": ("pull over the transposed graph: per out-edge R1 | R2 (8F), G_max | G_min (8F), two 16-bit rank rows (4F), the id and its rank (8); V (4F x + 4F grad) per row", E * (20 * F + 8) + V * 8 * F),
+    "k_bwd_pull<": ("pull over the transposed graph (rounds 3-5): per out-edge R1 | R2 (8F), G_max | G_min (8F), two 16-bit rank rows (4F), the id and its rank (8); V (4F x + 4F grad) per row", E * (20 * F + 8) + V * 8 * F),
+    "k_bwd_edge_rows": ("round 6, per-edge rows: V (16F d agg + 8F mean / std + 8F arg indices) read; E x 4F edge rows + V x 4F R2 written", V * 36 * F + E * 4 * F),
+    "k_bwd_pull_rows": ("round 6, pull over the edge rows: per out-edge the edge's row (4F) + R2 of its destination (4F) + the id and the position (8); V (4F x + 4F grad) per row", E * (8 * F + 8) + V * 8 * F),
     "k_posttrans_dw_grouped(": ("weight gradient in degree-plan order: V (4N gy + 16F aggregate + 4F h) read once", V * (4 * N + 20 * F)),
     "k_posttrans_dw(": ("weight gradient with per-row scalers: gy read by three column thirds", V * (12 * N + 20 * F)),
     "k_bn_apply": ("BatchNorm tail forward + backward element-wise passes", V * 4 * N * 3 + V * 4 * N * 3),
