@@ -675,8 +675,26 @@ def _fused_grid(device, spare, n_tiles64):
     return max(1, min(wgs, n_tiles64))
 
 
+DEBUG_COUNTERS = os.environ.get("PNA_AMD_DEBUG_COUNTERS", "0") == "1"   # host-side check (one sync per launch) that the tile counter pair and the
+# guard's working words are zero in front of a launch of the one-kernel layer: a launch that left them non-zero would make every later launch
+# on the plan skip tiles silently
+
+
+def _check_working_words(call):
+    keep = getattr(call, "_order_keep", None)
+    if keep is None:
+        return
+    torch.cuda.current_stream(call.y.device).synchronize()
+    for name, t in (("tile_counter", keep[3]), ("guard workspace", keep[4])):
+        if t is not None and t[:2].tolist() != [0, 0]:
+            raise RuntimeError(f"pna_amd: the {name} of this plan / stream is {t[:2].tolist()} in front of a launch (expected [0, 0]): an earlier launch "
+                               "was aborted or ran on another stream than it was bound on")
+
+
 def _bind_tile_order(call, spare):
     """(see _bind_tile_order_one; a layer in several output-column panels binds every panel's argument block to the same tables)"""
+    if DEBUG_COUNTERS and getattr(call, "_order_keep", None) is not None:
+        _check_working_words(call)
     blocks = getattr(call, "panel_args", None)
     if not blocks or len(blocks) == 1:
         return _bind_tile_order_one(call, spare)
