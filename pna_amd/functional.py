@@ -920,8 +920,15 @@ class FusedMultiTowerCall:
         self.y = y = torch.empty(V, out_pitch(N), dtype=torch.float32, device=dev)[:, :N]
         # partial sums ping-pong between two buffers: a launch never writes the rows it reads -- the guard's second launch computes a
         # handed-over tile AGAIN from the same pre_add rows (in place it would add the tile's share twice: found by tools/fuzz_fused.py)
-        self.part = part = torch.empty(V, out_pitch(N), dtype=torch.float32, device=dev)[:, :N]
+        self._part_full = torch.empty(V, out_pitch(N), dtype=torch.float32, device=dev)
+        self.part = part = self._part_full[:, :N]
         self.part2 = torch.empty(V, out_pitch(N), dtype=torch.float32, device=dev)[:, :N] if T > 1 else None
+        bp = layer.__dict__.get("_pna_amd_beta_pad")          # beta padded to the buffer's pitch: the rank-S update runs in place on the whole buffer
+        if bp is None or bp[0] is not self.beta or bp[1].shape[1] != out_pitch(N):
+            padded = torch.zeros(self.beta.shape[0], out_pitch(N), dtype=torch.float32, device=dev)
+            padded[:, :N] = self.beta
+            bp = layer.__dict__["_pna_amd_beta_pad"] = (self.beta, padded)
+        self.beta_pad = bp[1]
         self.res = res = h if layer.residual else None
         self.slope = float(mix.activation.negative_slope)
         if t0.graph_norm and snorm_n is not None:
@@ -979,7 +986,7 @@ class FusedMultiTowerCall:
         """part = W_self h + sum_s scale_s [deg > 0] (M_s h + beta_s): one contraction launch over the rows' own features + a rank-S update."""
         h, Fi = _unit_stride(self.h), self.Fi
         ops.posttrans(h, Fi, self.Wd, self.mscales, None, h, out=self.part)
-        self.part.add_(self.mscale_mat @ self.beta)
+        torch.addmm(self._part_full, self.mscale_mat, self.beta_pad, out=self._part_full)   # (+= [deg > 0] scale_s beta_s; the padding columns stay unread)
         return self.part
 
     def prologue(self):
