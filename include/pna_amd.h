@@ -870,6 +870,19 @@ int pna_collate_csr_i32(const int32_t* src, const int32_t* dst, int64_t n_edges,
 int pna_pack_rows_f32(const float* x, int64_t ldx, const int32_t* idx, int64_t n, int32_t F, float* out, int64_t ldo,
                       pna_stream_t stream);
 
+/* ---- node-level projection with a wide output (ABI 21) ------------------------------------------------------------------
+ * replaces: the source half of `self.pretrans` of every tower of a PNALayer whose towers all read the whole input
+ * (models/dgl/pna_layer.py:137-139 divide_input=False; models/dgl/pna_layer.py:36-44 pretrans_edges), factorised to node level:
+ *
+ *   y[m, 0:N] = sum_k x[m, k] w[n, k]            x (M, K) fp32, 4 <= K <= 128;  w (N, K) row-major (nn.Linear's layout), N <= 512
+ *
+ * fp32 operands, exact fp32 products (v_mfma_f32_16x16x4_f32), fp32 accumulation: an fp32 GEMM up to the order of the sum.  The whole
+ * weight stays in LDS (16 ceil(K / 16) x (80 ceil(N / 80) + 4) floats <= 160 KB, else PNA_E_INVALID), x is read once and every row
+ * of y is written once, whatever N -- the product is bound by its output stream.  Columns [N, ldy) of y are left alone.
+ */
+int pna_project_f32(const float* x, int64_t ldx, int64_t M, int32_t K, const float* w, int64_t ldw, int32_t N, float* y, int64_t ldy,
+                    pna_stream_t stream);
+
 /* ---- the tail of PNASimpleLayer's TRAINING forward, and its backward (ABI 18) ----------------------------------------
  * replaces: models/dgl/pna_layer.py:207-213 in training mode -- `h = self.batchnorm_h(h)` (nn.BatchNorm1d, batch statistics),
  * `h = F.relu(h)`, `h = h_in + h` -- and their autograd nodes:

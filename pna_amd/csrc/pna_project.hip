@@ -1,0 +1,195 @@
+// pna_project.hip -- node-level projection with a WIDE output: y = x W^T, x (M, K <= 128) fp32, W (N, K), N up to 512 columns.
+// Implements pna_project_f32 of include/pna_amd.h.
+//
+// Where it is used: a PNALayer with T towers over the whole input (models/dgl/pna_layer.py:137-139) factorises its pretrans Linear to
+// node level -- x_src = h [W_a,0 | .. | W_a,T-1]^T, T x 80 output columns from K = 75 inputs (pna_amd/functional.py::FusedMultiTowerCall).
+// That product WRITES 1.6 GB from 0.3 GB at C3 and has 60 GFLOP: it is bound by its output stream.  The contraction kernels of this
+// library cut N into 80-column blocks and read x once per block (5 x 0.3 GB on top of the 1.6: 1.07 / 1.21 ms), the library GEMM does no
+// better (0.99 ms).  Here a workgroup keeps the WHOLE weight in LDS (K x N fp32: 126 KB at 75 x 400, one workgroup per CU), reads its 128
+// rows of x once and writes every output row as whole 64-byte pieces.
+//
+// v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation: the result is an fp32 GEMM's up to the summation order), computed
+// TRANSPOSED like the one-kernel layer's contraction: the weight fragment is the A operand (lane (i, g): column 16 n + i, k = g), the rows'
+// the B operand (lane (i, g): row i, k = g), so lane (i, g) ends up with columns 16 n + 4 g .. + 4 of row i -- one 16-byte store.  K is
+// consumed 16 at a time: lane (i, g) loads x[row i][16 c + 4 g .. + 4) with one dwordx4 and step s of the chunk multiplies physical
+// k = 16 c + 4 g + s (a permutation of the summation order that both operands agree on); the row's last window slides back to end at K and is
+// realigned (pna_x3::fix4): no read leaves a row of any pitch >= K, nothing is made of padding.
+//
+// Measured (1 M rows, K = 75, N = 400; tools/ubench/project_variants.sh, profiles/r06_project_variants.txt): 0.70 ms against the library
+// GEMM's 1.03.  Its parts alone: the MFMA stream without stores 0.56-0.59 ms (without the LDS reads too: 0.53 -- 120 TFLOP/s of the
+// 157 fp32 MFMA peak, the clock under this load), loads + stores without one MFMA 0.50 (a CU issues 16-byte stores at ~12 B/clk: 7.4 TB/s for
+// the chip even into L2).  256 / 512 / 1024 threads and weights prefetched one K chunk ahead in registers: within 2 % of each other.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pna_amd.h"
+#include "pna_internal.h"
+#include "pna_x3_split.h"
+
+namespace {
+
+using pna_x3::f4;
+using pna_x3::f4u;
+using pna_x3::fix4;
+
+#ifndef PNA_PROJECT_BLOCK
+#define PNA_PROJECT_BLOCK 512
+#endif
+constexpr int kBlock = PNA_PROJECT_BLOCK, kWaves = kBlock / 64, kRowsWG = 16 * kWaves;     // 2 wavefronts per SIMD: one's stores under the other's MFMAs
+
+struct JArgs {
+  const float* x; const float* w; float* y;
+  long ldx, ldw, ldy;
+  int M, K, N, NP;                                          // NP: LDS row pitch of the weight image (floats)
+};
+
+// NCH: 16-wide chunks of K (= ceil(K / 16): compile time, so that the row's windows are all in flight at once and nothing in the MFMA loop
+// is conditional); NTT: 16-column tiles per pass (the accumulators live in registers; the LDS image holds whole passes, zero beyond N)
+template <int NCH, int NTT>
+__global__ __launch_bounds__(kBlock) void k_project(const JArgs g) {
+  extern __shared__ float lds[];                            // [16 NCH][NP]: w^T, zero beyond K / N
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  constexpr int Kp = NCH * 16;
+  for (int i = tid; i < Kp * g.NP; i += kBlock) lds[i] = 0.f;
+  __syncthreads();
+  for (int i0 = tid; i0 < g.N * g.K; i0 += 4 * kBlock) {    // consecutive threads: consecutive k of one column (coalesced reads of w)
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = min(i0 + u * kBlock, g.N * g.K - 1), n = i / g.K;
+      v[u] = g.w[(long)n * g.ldw + (i - n * g.K)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = min(i0 + u * kBlock, g.N * g.K - 1), n = i / g.K;
+      lds[(i - n * g.K) * g.NP + n] = v[u];
+    }
+  }
+  __syncthreads();
+  const int npass = (g.N + 16 * NTT - 1) / (16 * NTT);
+  const long stride = (long)gridDim.x * kRowsWG;
+  long row0 = ((long)blockIdx.x * kWaves + wave) * 16;
+  if (row0 >= g.M) return;
+  // the row's K values: one 16-byte window per chunk (at 16 c + 4 lg); the last chunk's slides back to end at K and is realigned.
+  // Requested by hand (asm) and waited for by hand: s_waitcnt vmcnt counts loads and stores in ONE order, and the compiler's own wait for
+  // windows requested at the top of a tile drains every store of that tile first (measured: the launch 0.70 ms, 0.49 of it without a
+  // single MFMA).  Here the next tile's windows are requested before the LAST pass's MFMAs and taken after them, before its stores:
+  // the wait leaves nothing younger than one pass of MFMAs (>= 1.3 us) outstanding.
+  f4 raw[NCH];
+  auto fetch = [&](long r0) {
+    const float* const xr = g.x + min(r0 + li, (long)g.M - 1) * g.ldx;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const float* const a = xr + max(0, min(16 * c + 4 * lg, g.K - 4));
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[c]) : "v"(a) : "memory");
+    }
+  };
+  const float* const wl = lds + (size_t)(4 * lg) * g.NP + li;
+  f4 xa[NCH];
+  auto take = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      asm volatile("" : "+v"(raw[c]));                         // (the values exist from here on: nothing that reads them moves above the wait)
+      xa[c] = c + 1 < NCH ? raw[c] : fix4(16 * c + 4 * lg, g.K, raw[c]);
+    }
+  };
+  const int nfull = g.N >> 4, nrem = g.N & 15;
+  f4 acc[NTT];
+  auto mfmas = [&](int p) {
+#pragma unroll
+    for (int n = 0; n < NTT; ++n) acc[n] = (f4){0.f, 0.f, 0.f, 0.f};
+    const float* const wp = wl + p * (16 * NTT);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float* const wr = wp + (size_t)(16 * c + s) * g.NP;
+#pragma unroll
+        for (int n = 0; n < NTT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[16 * n], xa[c][s], acc[n], 0, 0, 0);
+      }
+    }
+  };
+  auto stores = [&](int p, float* o, bool live) {
+#pragma unroll
+    for (int n = 0; n < NTT; ++n) {
+      const int t = p * NTT + n;                               // (wave-uniform: whole tiles take one 16-byte store per lane)
+      if (t < nfull) {
+        if (live) { f4u w; w.v = acc[n]; *reinterpret_cast<f4u*>(o + t * 16) = w; }
+      } else if (t == nfull && nrem && live) {
+        for (int r = 0; r < 4; ++r)
+          if (4 * lg + r < nrem) o[t * 16 + r] = acc[n][r];
+      }
+    }
+  };
+  fetch(row0);
+  take();
+  for (; row0 < g.M; row0 += stride) {
+    float* const o = g.y + (row0 + li) * g.ldy + 4 * lg;
+    const bool live = row0 + li < g.M;
+    for (int p = 0; p + 1 < npass; ++p) {
+      mfmas(p);
+      stores(p, o, live);
+    }
+    fetch(row0 + stride);                                     // (clamped to the last row: never out of bounds, unused past the end)
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(npass - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    f4 last[NTT];
+#pragma unroll
+    for (int n = 0; n < NTT; ++n) last[n] = acc[n];
+    take();
+#pragma unroll
+    for (int n = 0; n < NTT; ++n) acc[n] = last[n];
+    stores(npass - 1, o, live);
+  }
+}
+
+constexpr int kNTT = 5;
+
+template <int NCH>
+hipError_t launch_project(const JArgs& g, unsigned grid, size_t lds, hipStream_t stream) {
+  auto* fn = k_project<NCH, kNTT>;
+  hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lds, stream, g);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int pna_project_f32(const float* x, int64_t ldx, int64_t M, int32_t K, const float* w, int64_t ldw, int32_t N, float* y, int64_t ldy,
+                               pna_stream_t stream) {
+  if (M == 0) return PNA_OK;
+  if (!x || !w || !y || M < 0 || M >= (1ll << 31) || K < 4 || K > 128 || N < 1 || N > 512 || ldx < K || ldw < K || ldy < N ||
+      ((uintptr_t)x & 3) || ((uintptr_t)y & 3))
+    return pna_set_error(PNA_E_INVALID, "pna_project_f32: 4 <= K <= 128, 1 <= N <= 512, ldx >= K, ldw >= K, ldy >= N, 4-byte aligned x / y");
+  const int nch = (K + 15) / 16, Kp = nch * 16;
+  // pitch: whole passes of 16-column tiles + 4: one read takes 16 consecutive columns of the rows k, k + 4, k + 8, k + 12 (the four lane
+  // groups), which 4 x pitch = 16 (mod 64) floats apart puts on 64 different banks
+  const int NP = (N + 16 * kNTT - 1) / (16 * kNTT) * (16 * kNTT) + 4;
+  const size_t lds = (size_t)Kp * NP * sizeof(float);
+  if (lds > 160 * 1024)
+    return pna_set_error(PNA_E_INVALID, "pna_project_f32: the weight (16 ceil(K / 16) x (80 ceil(N / 80) + 4) floats) must fit 160 KB of LDS");
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return pna_set_error(PNA_E_NODEVICE, "pna_project_f32: no device");
+  JArgs g;
+  g.x = x; g.w = w; g.y = y; g.ldx = ldx; g.ldw = ldw; g.ldy = ldy; g.M = (int)M; g.K = K; g.N = N; g.NP = NP;
+  const long wgs_needed = (M + kRowsWG - 1) / kRowsWG;
+  const unsigned grid = (unsigned)(wgs_needed < cus ? wgs_needed : cus);      // persistent: the weight image is loaded once per workgroup
+  hipError_t e = hipSuccess;
+  switch (nch) {
+    case 1: e = launch_project<1>(g, grid, lds, (hipStream_t)stream); break;
+    case 2: e = launch_project<2>(g, grid, lds, (hipStream_t)stream); break;
+    case 3: e = launch_project<3>(g, grid, lds, (hipStream_t)stream); break;
+    case 4: e = launch_project<4>(g, grid, lds, (hipStream_t)stream); break;
+    case 5: e = launch_project<5>(g, grid, lds, (hipStream_t)stream); break;
+    case 6: e = launch_project<6>(g, grid, lds, (hipStream_t)stream); break;
+    case 7: e = launch_project<7>(g, grid, lds, (hipStream_t)stream); break;
+    default: e = launch_project<8>(g, grid, lds, (hipStream_t)stream); break;
+  }
+  if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
+  return PNA_OK;
+}

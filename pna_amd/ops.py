@@ -439,6 +439,20 @@ def pack_rows(x: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = 
     return out
 
 
+def project(x: torch.Tensor, K: int, weight: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = x[:, :K] weight^T with weight (N <= 512, K <= 128) in nn.Linear's layout (pna_project_f32): exact fp32 products, the weight
+    resident in LDS, x read once and out written once -- the node-level source projection of all the towers of a PNALayer at once."""
+    N = weight.shape[0]
+    if weight.shape[1] != K or weight.stride(1) != 1:
+        raise ValueError("project: weight must be (N, K) with unit inner stride")
+    if out is None:
+        out = torch.empty(x.shape[0], N, dtype=torch.float32, device=x.device)
+    rc = _lib.lib().pna_project_f32(_lib.dev_ptr(x, torch.float32, "x"), _ld(x), x.shape[0], K, _lib.dev_ptr(weight, torch.float32, "weight"),
+                                    weight.stride(0), N, _lib.dev_ptr(out, torch.float32, "out"), _ld(out), _lib.stream_ptr(x.device))
+    _lib.check(rc, "pna_project_f32")
+    return out
+
+
 def posttrans_towers(agg: torch.Tensor, K: int, weights: Sequence[torch.Tensor], row_scales: Sequence[Optional[torch.Tensor]],
                      biases: Optional[torch.Tensor], h: Optional[torch.Tensor], h_shared: bool, out: torch.Tensor,
                      row_post: Optional[torch.Tensor] = None, col_scale: Optional[torch.Tensor] = None,
