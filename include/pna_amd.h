@@ -883,6 +883,20 @@ int pna_pack_rows_f32(const float* x, int64_t ldx, const int32_t* idx, int64_t n
 int pna_project_f32(const float* x, int64_t ldx, int64_t M, int32_t K, const float* w, int64_t ldw, int32_t N, float* y, int64_t ldy,
                     pna_stream_t stream);
 
+/* The scaled form (ABI 21): the part of a multi-tower PNALayer that is linear in the row's OWN features -- the destination half of every
+ * tower's pretrans (models/dgl/pna_layer.py:36-44: mean / max / min of (a_u + b_v) = those of a_u, + b_v), through the scalers
+ * (models/dgl/scalers.py:11-26) and the collapsed posttrans . mixing weight, plus the self panel of posttrans (pna_layer.py:69-72):
+ *
+ *   y[m, n] = [self_block] sum_k x[m, k] w[n, k]  +  sum_{s < n_scaled} scales[m, s] (sum_k x[m, k] w[n, (self_block + s) K + k] + beta[s, n])
+ *
+ * w (N <= 80, blocks x K) row-major, blocks = self_block + n_scaled in 1..4 (four: K <= 80) side by side along a row; scales (M, n_scaled) (zero for a row
+ * without in-edges); beta (n_scaled, N) nullable.  Same arithmetic and residency as pna_project_f32; one pass, every block's accumulators
+ * in registers, the combination lane-local.  pna_amd/functional.py::FusedMultiTowerCall.dense_term is the caller.
+ */
+int pna_project_scaled_f32(const float* x, int64_t ldx, int64_t M, int32_t K, const float* w, int64_t ldw, int32_t N, int32_t n_scaled,
+                           int32_t self_block, const float* scales, int64_t ld_scales, const float* beta /* nullable */, int64_t ld_beta,
+                           float* y, int64_t ldy, pna_stream_t stream);
+
 /* ---- the tail of PNASimpleLayer's TRAINING forward, and its backward (ABI 18) ----------------------------------------
  * replaces: models/dgl/pna_layer.py:207-213 in training mode -- `h = self.batchnorm_h(h)` (nn.BatchNorm1d, batch statistics),
  * `h = F.relu(h)`, `h = h_in + h` -- and their autograd nodes:

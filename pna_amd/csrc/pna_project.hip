@@ -146,6 +146,141 @@ __global__ __launch_bounds__(kBlock) void k_project(const JArgs g) {
   }
 }
 
+// ---- the scaled form: y = [x W_0^T] + sum_s r_s (x W_s^T + beta_s), every block of the weight resident, ONE pass ---------------------
+// The dense term of the multi-tower layer (pna_amd/functional.py::FusedMultiTowerCall.dense_term): the row's own features against the self
+// panel and the S collapsed destination-term blocks, each scaled by the row's degree scaler.  A lane holds the same 4 columns of every block
+// (tile j of block b = accumulator 5 b + j), so the combination is lane-local; beta sits behind the weight image in LDS.
+struct SArgs {
+  const float* x; const float* w; const float* scales; const float* beta; float* y;
+  long ldx, ldw, lds_, ldb, ldy;
+  int M, K, N, S, self;
+};
+
+constexpr int kPanel = 80, kTPP = kPanel / 16;              // columns (tiles) of one block in the image: N <= 80
+
+template <int NCH, int NPAN>
+__global__ __launch_bounds__(kBlock) void k_project_scaled(const SArgs g) {
+  extern __shared__ float lds[];                            // [16 NCH][NP]: block b's w^T at columns 80 b; then beta [S][80]
+  constexpr int NP = NPAN * kPanel + 4, Kp = NCH * 16, NT = NPAN * kTPP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  float* const lbeta = lds + Kp * NP;
+  for (int i = tid; i < Kp * NP + 3 * kPanel; i += kBlock) lds[i] = 0.f;
+  __syncthreads();
+  const int KW = NPAN * g.K;                                // the weight's row: NPAN blocks of K
+  for (int i0 = tid; i0 < g.N * KW; i0 += 4 * kBlock) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = min(i0 + u * kBlock, g.N * KW - 1), n = i / KW;
+      v[u] = g.w[(long)n * g.ldw + (i - n * KW)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = min(i0 + u * kBlock, g.N * KW - 1), n = i / KW, kk = i - n * KW, b = kk / g.K;
+      lds[(kk - b * g.K) * NP + b * kPanel + n] = v[u];
+    }
+  }
+  if (g.beta)
+    for (int i = tid; i < g.S * g.N; i += kBlock) lbeta[(i / g.N) * kPanel + i % g.N] = g.beta[(long)(i / g.N) * g.ldb + i % g.N];
+  __syncthreads();
+  const long stride = (long)gridDim.x * kRowsWG;
+  long row0 = ((long)blockIdx.x * kWaves + wave) * 16;
+  if (row0 >= g.M) return;
+  f4 raw[NCH], xa[NCH];
+  auto fetch = [&](long r0) {
+    const float* const xr = g.x + min(r0 + li, (long)g.M - 1) * g.ldx;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const float* const a = xr + max(0, min(16 * c + 4 * lg, g.K - 4));
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[c]) : "v"(a) : "memory");
+    }
+  };
+  auto take = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      asm volatile("" : "+v"(raw[c]));
+      xa[c] = c + 1 < NCH ? raw[c] : fix4(16 * c + 4 * lg, g.K, raw[c]);
+    }
+  };
+  const float* const wl = lds + (size_t)(4 * lg) * NP + li;
+  const int nfull = g.N >> 4, nrem = g.N & 15;
+  fetch(row0);
+  take();
+  for (; row0 < g.M; row0 += stride) {
+    const long row = min(row0 + li, (long)g.M - 1);
+    const bool live = row0 + li < g.M;
+    float rs[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (q < g.S) rs[q] = g.scales[row * g.lds_ + q];
+    fetch(row0 + stride);
+    __builtin_amdgcn_sched_barrier(0);
+    f4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float* const wr = wl + (size_t)(16 * c + s) * NP;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[16 * t], xa[c][s], acc[t], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // y = [block 0] + sum_q r_q (block self + q, + beta_q): in this order, every operation rounded once (no contraction)
+    f4 out[kTPP];
+#pragma unroll
+    for (int j = 0; j < kTPP; ++j) {
+      out[j] = g.self ? acc[j] : (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        if (q < NPAN && q < g.S) {                            // block self + q (S + self = NPAN: both candidates are compile-time indices)
+          const f4 bq = *reinterpret_cast<const f4*>(lbeta + q * kPanel + 16 * j + 4 * lg);
+          const f4 a = g.self ? acc[(q + 1 < NPAN ? q + 1 : NPAN - 1) * kTPP + j] : acc[q * kTPP + j];
+          out[j] = out[j] + rs[q] * (a + bq);
+        }
+      }
+    }
+    take();
+    if (live) {
+      float* const o = g.y + row * g.ldy + 4 * lg;
+#pragma unroll
+      for (int j = 0; j < kTPP; ++j) {
+        if (j < nfull) {
+          f4u w; w.v = out[j]; *reinterpret_cast<f4u*>(o + j * 16) = w;
+        } else if (j == nfull && nrem) {
+          for (int r = 0; r < 4; ++r)
+            if (4 * lg + r < nrem) o[j * 16 + r] = out[j][r];
+        }
+      }
+    }
+  }
+}
+
+template <int NCH, int NPAN>
+hipError_t launch_scaled2(const SArgs& g, unsigned grid, size_t lds, hipStream_t stream) {
+  auto* fn = k_project_scaled<NCH, NPAN>;
+  hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lds, stream, g);
+  return hipGetLastError();
+}
+
+template <int NCH>
+hipError_t launch_scaled(const SArgs& g, int npan, unsigned grid, size_t lds, hipStream_t stream) {
+  switch (npan) {
+    case 1: return launch_scaled2<NCH, 1>(g, grid, lds, stream);
+    case 2: return launch_scaled2<NCH, 2>(g, grid, lds, stream);
+    case 3: return launch_scaled2<NCH, 3>(g, grid, lds, stream);
+    default:
+      if constexpr (NCH <= 5) return launch_scaled2<NCH, 4>(g, grid, lds, stream);   // (four blocks' accumulators + six chunks of windows: over the register budget)
+      return hipErrorInvalidValue;
+  }
+}
+
 constexpr int kNTT = 5;
 
 template <int NCH>
@@ -189,6 +324,46 @@ extern "C" int pna_project_f32(const float* x, int64_t ldx, int64_t M, int32_t K
     case 6: e = launch_project<6>(g, grid, lds, (hipStream_t)stream); break;
     case 7: e = launch_project<7>(g, grid, lds, (hipStream_t)stream); break;
     default: e = launch_project<8>(g, grid, lds, (hipStream_t)stream); break;
+  }
+  if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
+  return PNA_OK;
+}
+
+extern "C" int pna_project_scaled_f32(const float* x, int64_t ldx, int64_t M, int32_t K, const float* w, int64_t ldw, int32_t N, int32_t n_scaled,
+                                      int32_t self_block, const float* scales, int64_t ld_scales, const float* beta, int64_t ld_beta, float* y,
+                                      int64_t ldy, pna_stream_t stream) {
+  if (M == 0) return PNA_OK;
+  const int npan = n_scaled + (self_block ? 1 : 0);
+  if (!x || !w || !y || M < 0 || M >= (1ll << 31) || K < 4 || K > 128 || N < 1 || N > kPanel || n_scaled < 0 || n_scaled > 3 || npan < 1 || ldx < K ||
+      ldw < (int64_t)npan * K || ldy < N || (n_scaled && (!scales || ld_scales < n_scaled)) || (beta && ld_beta < N) || ((uintptr_t)x & 3) ||
+      ((uintptr_t)y & 3))
+    return pna_set_error(PNA_E_INVALID,
+                         "pna_project_scaled_f32: 4 <= K <= 128, 1 <= N <= 80, n_scaled <= 3, at least one block, ldx >= K, ldw >= blocks x K, ldy >= N, "
+                         "ld_scales >= n_scaled, ld_beta >= N");
+  const int nch = (K + 15) / 16, Kp = nch * 16;
+  if (npan == 4 && nch > 5) return pna_set_error(PNA_E_INVALID, "pna_project_scaled_f32: four blocks need K <= 80 (the accumulators' register budget)");
+  const size_t lds = ((size_t)Kp * (npan * kPanel + 4) + 3 * kPanel) * sizeof(float);
+  if (lds > 160 * 1024)
+    return pna_set_error(PNA_E_INVALID, "pna_project_scaled_f32: the weight (16 ceil(K / 16) x (80 blocks + 4) floats) must fit 160 KB of LDS");
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return pna_set_error(PNA_E_NODEVICE, "pna_project_scaled_f32: no device");
+  SArgs g;
+  g.x = x; g.w = w; g.scales = scales; g.beta = beta; g.y = y;
+  g.ldx = ldx; g.ldw = ldw; g.lds_ = ld_scales; g.ldb = ld_beta; g.ldy = ldy;
+  g.M = (int)M; g.K = K; g.N = N; g.S = n_scaled; g.self = self_block ? 1 : 0;
+  const long wgs_needed = (M + kRowsWG - 1) / kRowsWG;
+  const unsigned grid = (unsigned)(wgs_needed < cus ? wgs_needed : cus);
+  hipError_t e = hipSuccess;
+  switch (nch) {
+    case 1: e = launch_scaled<1>(g, npan, grid, lds, (hipStream_t)stream); break;
+    case 2: e = launch_scaled<2>(g, npan, grid, lds, (hipStream_t)stream); break;
+    case 3: e = launch_scaled<3>(g, npan, grid, lds, (hipStream_t)stream); break;
+    case 4: e = launch_scaled<4>(g, npan, grid, lds, (hipStream_t)stream); break;
+    case 5: e = launch_scaled<5>(g, npan, grid, lds, (hipStream_t)stream); break;
+    case 6: e = launch_scaled<6>(g, npan, grid, lds, (hipStream_t)stream); break;
+    case 7: e = launch_scaled<7>(g, npan, grid, lds, (hipStream_t)stream); break;
+    default: e = launch_scaled<8>(g, npan, grid, lds, (hipStream_t)stream); break;
   }
   if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
   return PNA_OK;

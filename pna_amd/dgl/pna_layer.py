@@ -25,6 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import functional as PF
+from .. import ops
 from ..graph import Graph
 from ..layers import MLP, FCLayer
 from .aggregators import AGGREGATORS
@@ -190,9 +191,9 @@ def _projection_cache_padded_multi(towers, Fi, P):
             W = torch.zeros(T * P, Fi, dtype=lins[0].weight.dtype, device=lins[0].weight.device)
             for t, lin in enumerate(lins):
                 W[t * P:t * P + Fi] = lin.weight[:, :Fi]
-        hit = (key, W.t().contiguous())                        # (Fi, T P): x_src = h @ it
+        hit = (key, W.t().contiguous(), W)                     # (Fi, T P): x_src = h @ it; (T P, Fi): pna_project_f32's layout
         towers[0].__dict__["_pna_amd_proj_pad_multi"] = hit
-    return hit[1]
+    return hit[1], hit[2]
 
 
 def _towers_forward(towers, graph, h, e, snorm_n, divide_input):
@@ -381,10 +382,12 @@ class PNALayer(nn.Module):
                 elif self.divide_input:
                     Wpad, bpad = _projection_cache_padded_div(towers, Fi, PF.tower_projection_pitch(T * Fi))
                 else:
-                    # T projections of the whole input: one launch per tower over its own block of the projection table
-                    # (the library GEMM: 400 output columns from K = 75 -- measured 0.99 ms against the contraction kernels' 1.06 / 1.21 at 1 M rows)
-                    Wt = _projection_cache_padded_multi(towers, Fi, PF.tower_projection_pitch(Fi))
-                    return PF.tower_layer_degree_fused_multi(self, graph, h, snorm_n, torch.mm(h, Wt))
+                    # T projections of the whole input: one launch per tower over its own block of the projection table.  The table itself:
+                    # pna_project_f32 (the weight resident in LDS, h read once: 0.70 ms at 1 M rows x 75 -> 400 columns against the library
+                    # GEMM's 1.03 and the contraction kernels' 1.06 / 1.21), the library GEMM where the weight does not fit the LDS
+                    Wt, Wn = _projection_cache_padded_multi(towers, Fi, PF.tower_projection_pitch(Fi))
+                    x_src = ops.project(h, Fi, Wn) if ops.project_applies(h, Fi, Wn.shape[0]) else torch.mm(h, Wt)
+                    return PF.tower_layer_degree_fused_multi(self, graph, h, snorm_n, x_src)
                 return PF.tower_layer_degree_fused(self, graph, h, snorm_n, PF.linear_act(h, Wpad, bpad))
             if self.divide_input:
                 W = torch.stack([t.pretrans.fully_connected[0].linear.weight for t in towers])

@@ -892,6 +892,9 @@ def _tower_pass_weights(layer, towers, mix):
     return res
 
 
+DENSE_TERM_RESIDENT = True          # FusedMultiTowerCall.dense_term through pna_project_scaled_f32 where it applies (False: contraction + rank-S update)
+
+
 class FusedMultiTowerCall:
     """One PNALayer forward with T towers over the WHOLE input (divide_input=False; models/dgl/pna_layer.py:137-139; eval) on the one-kernel
     path (round 6).  Every tower has its own projection of the input -- T x Fi message features per edge -- and a wavefront
@@ -985,6 +988,9 @@ class FusedMultiTowerCall:
     def dense_term(self):
         """part = W_self h + sum_s scale_s [deg > 0] (M_s h + beta_s): one contraction launch over the rows' own features + a rank-S update."""
         h, Fi = _unit_stride(self.h), self.Fi
+        if DENSE_TERM_RESIDENT and ops.project_scaled_applies(h, Fi, self.Wd.shape[0], 1 + len(self.mscales)):
+            # every block of the weight resident in LDS, h read once, beta inside (0.66 -> 0.3 ms at 1 M rows: tools/multi_tower_time.py)
+            return ops.project_scaled(h, Fi, self.Wd, self.mscale_mat, self.beta, True, out=self.part)
         ops.posttrans(h, Fi, self.Wd, self.mscales, None, h, out=self.part)
         torch.addmm(self._part_full, self.mscale_mat, self.beta_pad, out=self._part_full)   # (+= [deg > 0] scale_s beta_s; the padding columns stay unread)
         return self.part

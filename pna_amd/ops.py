@@ -439,6 +439,12 @@ def pack_rows(x: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = 
     return out
 
 
+def project_applies(x: torch.Tensor, K: int, N: int) -> bool:
+    """pna_project_f32's domain: 4 <= K <= 128, N <= 512, the weight image (16 ceil(K / 16) x (80 ceil(N / 80) + 4) floats) within 160 KB of LDS."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and 4 <= K <= 128 and 1 <= N <= 512
+            and (K + 15) // 16 * 16 * ((N + 79) // 80 * 80 + 4) * 4 <= 160 * 1024)
+
+
 def project(x: torch.Tensor, K: int, weight: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = x[:, :K] weight^T with weight (N <= 512, K <= 128) in nn.Linear's layout (pna_project_f32): exact fp32 products, the weight
     resident in LDS, x read once and out written once -- the node-level source projection of all the towers of a PNALayer at once."""
@@ -450,6 +456,31 @@ def project(x: torch.Tensor, K: int, weight: torch.Tensor, out: Optional[torch.T
     rc = _lib.lib().pna_project_f32(_lib.dev_ptr(x, torch.float32, "x"), _ld(x), x.shape[0], K, _lib.dev_ptr(weight, torch.float32, "weight"),
                                     weight.stride(0), N, _lib.dev_ptr(out, torch.float32, "out"), _ld(out), _lib.stream_ptr(x.device))
     _lib.check(rc, "pna_project_f32")
+    return out
+
+
+def project_scaled_applies(x: torch.Tensor, K: int, N: int, blocks: int) -> bool:
+    """pna_project_scaled_f32's domain: N <= 80, 1..4 blocks (four: K <= 80), the image of all blocks within 160 KB of LDS."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and 4 <= K <= 128 and 1 <= N <= 80 and 1 <= blocks <= 4
+            and (blocks < 4 or K <= 80) and ((K + 15) // 16 * 16 * (80 * blocks + 4) + 240) * 4 <= 160 * 1024)
+
+
+def project_scaled(x: torch.Tensor, K: int, weight: torch.Tensor, scales: Optional[torch.Tensor], beta: Optional[torch.Tensor], self_block: bool,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = [x W_0^T] + sum_s scales[:, s] (x W_s^T + beta[s]) with weight (N <= 80, blocks x K) = [W_self | W_0 | ..] side by side
+    (pna_project_scaled_f32): exact fp32 products, every block resident in LDS, x read once."""
+    N = weight.shape[0]
+    S = 0 if scales is None else scales.shape[1]
+    if weight.shape[1] != (S + int(self_block)) * K or weight.stride(1) != 1 or (scales is not None and scales.stride(1) != 1):
+        raise ValueError("project_scaled: weight must be (N, blocks x K), scales (M, S), both with unit inner stride")
+    if out is None:
+        out = torch.empty(x.shape[0], N, dtype=torch.float32, device=x.device)
+    rc = _lib.lib().pna_project_scaled_f32(
+        _lib.dev_ptr(x, torch.float32, "x"), _ld(x), x.shape[0], K, _lib.dev_ptr(weight, torch.float32, "weight"), weight.stride(0), N, S, int(self_block),
+        None if scales is None else _lib.dev_ptr(scales, torch.float32, "scales"), 0 if scales is None else scales.stride(0),
+        None if beta is None else _lib.dev_ptr(beta, torch.float32, "beta"), 0 if beta is None else beta.stride(0),
+        _lib.dev_ptr(out, torch.float32, "out"), _ld(out), _lib.stream_ptr(x.device))
+    _lib.check(rc, "pna_project_scaled_f32")
     return out
 
 

@@ -54,3 +54,51 @@ def test_projection_rejects_what_it_cannot_hold():
         ops.project(x, 128, torch.randn(512, 128, device="cuda"))       # 128 x 516 floats > 160 KB of LDS
     with pytest.raises(Exception):
         ops.project(x[:, :3], 3, torch.randn(8, 3, device="cuda"))      # K < 4
+
+
+def _scaled_case(M, K, N, S, self_block, with_beta=True, ldy=None, seed=0):
+    from pna_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    B = S + int(self_block)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, B * K, generator=g) * 0.3
+    scales = torch.rand(M, S, generator=g) * 3 if S else None
+    if S and M > 3:
+        scales[3] = 0.0                                           # a row without in-edges
+    beta = torch.randn(S, N, generator=g) if (S and with_beta) else None
+    ldy = ldy or N
+    yb = torch.full((M, ldy), 7.0, device="cuda")
+    y = ops.project_scaled(x.cuda(), K, w.cuda(), None if scales is None else scales.cuda(), None if beta is None else beta.cuda(), self_block, out=yb[:, :N])
+    xd, wd = x.double(), w.double()
+    ref = torch.zeros(M, N, dtype=torch.float64)
+    floor = torch.zeros(M, N, dtype=torch.float64)
+    b0 = 0
+    if self_block:
+        ref += xd @ wd[:, :K].t(); floor += xd.abs() @ wd[:, :K].abs().t(); b0 = 1
+    for s in range(S):
+        blk = wd[:, (b0 + s) * K:(b0 + s + 1) * K]
+        t = xd @ blk.t() + (beta[s].double() if beta is not None else 0.0)
+        ref += scales[:, s:s + 1].double() * t
+        floor += scales[:, s:s + 1].double() * (xd.abs() @ blk.abs().t() + (beta[s].abs().double() if beta is not None else 0.0))
+    err = ((y.cpu().double() - ref).abs() / floor.clamp(min=1e-300)).max().item() if M else 0.0
+    assert err <= 1e-6, (M, K, N, S, self_block, err)
+    assert (yb[:, N:] == 7.0).all()
+
+
+@pytest.mark.parametrize("M,K,N,S,self_block", [(1000, 75, 75, 3, True), (4097, 75, 75, 3, False), (130, 75, 80, 2, True), (17, 16, 16, 1, False),
+                                                (300, 128, 64, 2, True), (255, 100, 33, 3, False), (513, 80, 80, 3, True), (64, 5, 3, 1, True),
+                                                (200, 40, 50, 0, True), (0, 75, 75, 3, True), (1, 4, 1, 3, True)])
+def test_scaled_projection_matches_float64(M, K, N, S, self_block):
+    _scaled_case(M, K, N, S, self_block)
+
+
+def test_scaled_projection_without_beta_and_into_a_pitched_buffer():
+    _scaled_case(777, 75, 75, 3, True, with_beta=False, ldy=80)
+
+
+def test_scaled_projection_rejects_four_blocks_beyond_its_register_budget():
+    from pna_amd import ops
+    x = torch.randn(8, 96, device="cuda")
+    assert not ops.project_scaled_applies(x, 96, 75, 4) and ops.project_scaled_applies(x[:, :75], 75, 75, 4)
+    with pytest.raises(Exception):
+        ops.project_scaled(x, 96, torch.randn(75, 4 * 96, device="cuda"), torch.rand(8, 3, device="cuda"), None, True)

@@ -34,16 +34,20 @@ def ev(fn, n=10):
 
 with torch.no_grad():
     towers = list(layer.towers)
-    Wt = PL._projection_cache_padded_multi(towers, F, PF.tower_projection_pitch(F))
+    Wt, Wn = PL._projection_cache_padded_multi(towers, F, PF.tower_projection_pitch(F))
     Wpad, bpad = Wt.t().contiguous(), torch.zeros(Wt.shape[1], device=dev)
     out = {"layer_ms": ev(lambda: layer(g, h, None, sn)), "projection_torch_mm_ms": ev(lambda: torch.mm(h, Wt)),
            "projection_x3_kernel_ms": ev(lambda: PF.linear_act(h, Wpad, bpad))}
     x_src = torch.mm(h, Wt)
     from pna_amd import ops
+    out["projection_resident_weight_kernel_ms"] = ev(lambda: ops.project(h, F, Wn))
     out["projection_f32_mfma_kernel_ms"] = ev(lambda: ops.posttrans(h, F, Wpad, [None], bpad, arith="f32"))
     call = PF.FusedMultiTowerCall(layer, g, h, sn, x_src)
     call.set_spare(False)
     out["dense_term_ms"] = ev(call.dense_term)
+    PF.DENSE_TERM_RESIDENT = False
+    out["dense_term_contraction_and_rank_update_ms"] = ev(call.dense_term)
+    PF.DENSE_TERM_RESIDENT = True
     out["five_launches_ms"] = ev(call.group_rows)
     one = call.launch_order[0][1]
     out["first_launch_ms"] = ev(lambda: call.check(call.fn(one, call.stream), "x"))
