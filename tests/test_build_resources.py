@@ -24,6 +24,8 @@ CSRC = os.path.join(ROOT, "pna_amd", "csrc")
                                                                                         "k_segreduce_fastILi4ELb1ELb0ELb0ELi1E": 104, "k_segreduce_fastILi4ELb1ELb0ELb0ELi2E": 104}),
                                           ("pna_posttrans.hip", {}), ("pna_pack.hip", {}), ("pna_tower_fused.hip", {}), ("pna_fused.hip", {}),
                                           ("pna_segreduce_bwd.hip", {}),
+                                          # the resident-weight projections: one 8-wavefront workgroup per CU (126 KB of LDS), 256 registers each
+                                          ("pna_project.hip", {"k_project": 256}),
                                           # the weight-gradient kernels: two 4-wavefront workgroups / one 8-wavefront workgroup per CU
                                           ("pna_posttrans_dw.hip", {"k_posttrans_dw": 256}),
                                           # the one-kernel layer: two 4-wavefront workgroups per CU (the production instantiations: DUMP = false)
@@ -93,5 +95,27 @@ def test_one_kernel_layer_never_touches_a_register_in_flight(tmp_path):
         assert not probs, (n, probs[:5])
         # ... nor hands an inline-asm memory instruction an SGPR (a base pointer) that a VALU instruction -- the v_readlane_b32 of
         # an SGPR-spill reload -- wrote fewer than five wait states before: hipcc's hazard recognizer does not look inside inline asm
+        haz = isa_audit.sgpr_hazards(kl)
+        assert not haz, (n, haz[:5])
+
+
+def test_resident_weight_projection_never_touches_a_register_in_flight(tmp_path):
+    """pna_project.hip requests the next tile's row windows through inline asm one tile ahead and waits with its own s_waitcnt: the same
+    replay (tools/isa_audit.py) over every instantiation of both kernels."""
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_audit
+    out = str(tmp_path / "pj.s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+                    "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "pna_project.hip")], check=True, capture_output=True)
+    names = sorted(set(re.findall(r"^(_ZN\S*k_project\S+?):", open(out).read(), flags=re.M)))
+    assert len(names) == 8 + 8 * 3 + 5, names                    # K chunks 1..8 x (plain, 1..3 blocks) + four blocks at <= 5 chunks
+    for n in names:
+        kl = isa_audit.kernel_lines(out, n)
+        probs = isa_audit.audit(kl)
+        assert not probs, (n, probs[:5])
         haz = isa_audit.sgpr_hazards(kl)
         assert not haz, (n, haz[:5])
