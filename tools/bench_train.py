@@ -48,13 +48,25 @@ def timed(fn, n=20, warmup=12, repeats=2):
     return best
 
 
+gy_next = torch.randn(V, F, device=dev)
+
+
+def step_given_gy():
+    """The same step with the output's gradient GIVEN (what the next layer's backward hands this one), instead of made by a loss over
+    the layer's own (V, F) output: `out.sum().backward()` costs a (V, F) reduction and a (V, F) fill of ones that no layer inside a
+    network pays."""
+    h.grad = None
+    layer.zero_grad(set_to_none=True)
+    layer(g, h).backward(gy_next)
+
+
 def fwd_only():
     with torch.no_grad():
         layer(g, h)
 
 
 res = {"workload": "C3 PNASimpleLayer, train mode (batch-stat BatchNorm), V=1M E=10M F=75",
-       "fwd_bwd_ms": timed(step), "fwd_train_mode_nograd_ms": timed(fwd_only)}
+       "fwd_bwd_ms": timed(step), "fwd_bwd_given_output_gradient_ms": timed(step_given_gy), "fwd_train_mode_nograd_ms": timed(fwd_only)}
 from torch.profiler import profile, ProfilerActivity  # noqa: E402
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
     step()
