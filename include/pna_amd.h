@@ -897,6 +897,20 @@ int pna_project_scaled_f32(const float* x, int64_t ldx, int64_t M, int32_t K, co
                            int32_t self_block, const float* scales, int64_t ld_scales, const float* beta /* nullable */, int64_t ld_beta,
                            float* y, int64_t ldy, pna_stream_t stream);
 
+/* The grouped form (ABI 21): one weight per DEGREE GROUP of a degree plan, rows through the plan's permutation --
+ *
+ *   y[node, 0:N] = sum_k x[node, k] w_groups[g][n, k]        node = row_perm[v] (-1: padding, skipped), g = tile_group[v / 128], v in [0, M)
+ *
+ * the backward's d agg = gy W_D^T of a PNASimpleLayer in training (autograd of models/dgl/pna_layer.py:197-206): every scaler is a function
+ * of the in-degree alone (models/dgl/scalers.py:7-19), so for the rows of one degree the three scaler blocks collapse into one 4F x N
+ * matrix.  w_groups: n_groups dense (N, K) matrices group_stride FLOATS apart; M a multiple of 128.  A workgroup walks a contiguous piece of
+ * the tiles and refills its LDS image when the group changes: list the tiles sorted by group (they are independent -- any order of
+ * (128 entries of row_perm, one entry of tile_group) pairs is the same product).
+ * Same arithmetic and limits as pna_project_f32.  Rows of y that no virtual row names are left alone.
+ */
+int pna_project_grouped_f32(const float* x, int64_t ldx, int64_t x_rows, int32_t K, const float* w_groups, int64_t group_stride, int32_t n_groups,
+                            int32_t N, const int32_t* row_perm, int64_t M, const int32_t* tile_group, float* y, int64_t ldy, pna_stream_t stream);
+
 /* ---- the tail of PNASimpleLayer's TRAINING forward, and its backward (ABI 18) ----------------------------------------
  * replaces: models/dgl/pna_layer.py:207-213 in training mode -- `h = self.batchnorm_h(h)` (nn.BatchNorm1d, batch statistics),
  * `h = F.relu(h)`, `h = h_in + h` -- and their autograd nodes:

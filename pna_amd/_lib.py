@@ -266,6 +266,10 @@ def lib():
                                              ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                              ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
         L.pna_project_scaled_f32.restype = ctypes.c_int
+        L.pna_project_grouped_f32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
+                                              ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                              ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+        L.pna_project_grouped_f32.restype = ctypes.c_int
         L.pna_fused_simple_f32.argtypes = [ctypes.POINTER(PnaFusedSimpleArgs), ctypes.c_void_p]
         L.pna_fused_simple_f32.restype = ctypes.c_int
         L.pna_fused_degree_image_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32]

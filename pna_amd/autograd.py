@@ -414,6 +414,7 @@ def M_rows(t):
     return t.shape[0]
 
 
+DAGG_GROUPED = os.environ.get("PNA_AMD_DAGG_GROUPED", "1") != "0"     # 0: d agg = gy W^T as the three-block bf16 x 3 contraction (rounds 3-5)
 PULL_EDGE_ROWS = os.environ.get("PNA_AMD_PULL_EDGE_ROWS", "1") != "0"   # 0: the ranked pull of rounds 3-5 (R1 | R2 | G_max | G_min | ranks per out-edge)
 PULL_PACKED = os.environ.get("PNA_AMD_PULL_PACKED", "1") != "0"   # 0: table, aggregate gradient and ranks as three separate rows (round 3)
 DW_KERNEL = os.environ.get("PNA_AMD_DW_KERNEL", "1") != "0"    # 0: the library route (slab-batched GEMM) for the weight gradient
@@ -492,7 +493,23 @@ class SimpleLayerPlanFn(torch.autograd.Function):
             if flat is None or flat.numel() < V * pitch or flat.device != gy.device:
                 flat = plan.__dict__["_pull_rows"] = torch.empty(V * pitch, dtype=torch.float32, device=gy.device)
             packed = flat[:V * pitch].view(V, pitch)
-            g_agg = ops.posttrans(gy, N, wt, scales, None, arith="bf16x3", out=packed[:, :K])
+            if DAGG_GROUPED and plan.G and ops.project_applies(gy, N, K) and plan.NV % 128 == 0:
+                # rows of the degree groups: ONE combined 4F x N weight per group (W_D^T = sum_s scale_s(D) W_s^T: a third of the
+                # multiply-adds), resident in LDS, exact fp32 products (pna_project_grouped_f32); the three-block contraction took 1.11 ms
+                # at C3.  The few rows no group holds: the three-block contraction over their compact list.
+                with torch.no_grad():
+                    sc = plan.group_scaler_values(scales)                                                  # (G, S)
+                    wb = weight.reshape(N, S, K).index_select(2, order)                                     # (N, S, 4F) in the packed order
+                    wg = torch.einsum("gs,nsk->gkn", sc, wb).contiguous()                                  # (G, 4F, N) = W_D^T per group
+                perm_g, group_g = plan.tiles_by_group()
+                g_agg = ops.project_grouped(gy, N, wg, perm_g, group_g, out=packed[:, :K])
+                if plan.NR:
+                    rest = plan.rest_rows
+                    g_rest = ops.posttrans(gy.index_select(0, rest), N, wt, [None if r is None else r.index_select(0, rest) for r in scales], None,
+                                           arith="bf16x3")
+                    g_agg.index_copy_(0, rest, g_rest)
+            else:
+                g_agg = ops.posttrans(gy, N, wt, scales, None, arith="bf16x3", out=packed[:, :K])
             g_h, _ = _backward_pull(graph, x, None, agg, amx, amn, g_agg, ["mean", "std", "max", "min"], aggs, 1, F, True, False,
                                     row_of=plan.vmap32(), packed_rows=packed, node_of=plan.node_of_rows())
         return g_h, g_w, g_b, None, None

@@ -18,7 +18,8 @@
 // Measured (1 M rows, K = 75, N = 400; tools/ubench/project_variants.sh, profiles/r06_project_variants.txt): 0.70 ms against the library
 // GEMM's 1.03.  Its parts alone: the MFMA stream without stores 0.56-0.59 ms (without the LDS reads too: 0.53 -- 120 TFLOP/s of the
 // 157 fp32 MFMA peak, the clock under this load), loads + stores without one MFMA 0.50 (a CU issues 16-byte stores at ~12 B/clk: 7.4 TB/s for
-// the chip even into L2).  256 / 512 / 1024 threads and weights prefetched one K chunk ahead in registers: within 2 % of each other.
+// the chip even into L2).  256 / 512 / 1024 threads, weights prefetched one K chunk ahead in registers, the windows requested at the top of a
+// tile and waited for with the tile's 25 stores still in flight (a counted vmcnt): all within 2 % of each other.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -281,6 +282,154 @@ hipError_t launch_scaled(const SArgs& g, int npan, unsigned grid, size_t lds, hi
   }
 }
 
+// ---- the grouped form: one weight per DEGREE GROUP, rows through the degree plan's permutation ------------------------------------------
+// y[node, 0:N] = x[node, 0:K] W_g^T for node = row_perm[v], g = tile_group[v / 128]: the backward's d agg = gy W_D^T of a PNASimpleLayer in
+// training (pna_amd/autograd.py::SimpleLayerPlanFn.backward) -- every scaler is a function of the in-degree alone, so the three scaler blocks
+// of a degree group's rows collapse into ONE 75 x 300 weight (a third of the multiply-adds of the three-block contraction, which took
+// 1.11 ms at C3).  A workgroup walks a contiguous piece of the tiles and refills its LDS image only when the group changes: the caller lists
+// the tiles sorted by group (tiles are independent: any order of (row_perm, tile_group) pairs is the same product).
+struct GArgs {
+  const float* x; const float* w; float* y;
+  const int* perm; const int* tile_group;
+  long ldx, ldy, wstride;                                    // wstride: floats between two groups' (N, K) matrices
+  int ntiles, K, N, NP;
+};
+
+template <int NCH, int NTT>
+__global__ __launch_bounds__(kBlock) void k_project_grouped(const GArgs g) {
+  static_assert(kBlock == 512, "one 128-row tile of the degree plan per workgroup pass: 8 wavefronts x 16 rows");
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  constexpr int Kp = NCH * 16;
+  const int per = (g.ntiles + gridDim.x - 1) / gridDim.x;
+  const int s0 = blockIdx.x * per, s1 = min(s0 + per, g.ntiles);
+  if (s0 >= s1) return;                                     // (whole workgroups: no barrier is left waiting)
+  for (int i = tid; i < Kp * g.NP; i += kBlock) lds[i] = 0.f;
+  const int npass = (g.N + 16 * NTT - 1) / (16 * NTT);
+  const int nfull = g.N >> 4, nrem = g.N & 15;
+  auto fill = [&](int grp) {                                // (between two barriers: nobody reads the image meanwhile)
+    const float* const w = g.w + (size_t)grp * g.wstride;
+    for (int i0 = tid; i0 < g.N * g.K; i0 += 4 * kBlock) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = w[min(i0 + u * kBlock, g.N * g.K - 1)];      // (group matrices are dense (N, K) rows)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = min(i0 + u * kBlock, g.N * g.K - 1), n = i / g.K;
+        lds[(i - n * g.K) * g.NP + n] = v[u];
+      }
+    }
+  };
+  // node of this lane's row in tile s (-1: padding) and the tile's group, requested by hand TWO / ONE tiles ahead as VECTOR loads: they land by
+  // the `vmcnt(0)` of the tile before.  (As scalar loads in the loop they would sit in lgkmcnt in front of every wait for an LDS read.)
+  int node_a, node_b, grp_v;                                  // tiles s + 1 and s + 2 while tile s is multiplied; group of tile s + 1
+  auto ask_node = [&](int s, int& dst) {
+    const int* const p = g.perm + (size_t)min(s, s1 - 1) * 128 + wave * 16 + li;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+  };
+  auto ask_group = [&](int s) {
+    const int* const p = g.tile_group + min(s, s1 - 1);
+    asm volatile("global_load_dword %0, %1, off" : "=v"(grp_v) : "v"(p) : "memory");
+  };
+  f4 raw[NCH], xa[NCH];
+  auto fetch = [&](int node) {
+    const float* const xr = g.x + (long)max(node, 0) * g.ldx;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const float* const a = xr + max(0, min(16 * c + 4 * lg, g.K - 4));
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[c]) : "v"(a) : "memory");
+    }
+  };
+  auto take = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      asm volatile("" : "+v"(raw[c]));
+      xa[c] = c + 1 < NCH ? raw[c] : fix4(16 * c + 4 * lg, g.K, raw[c]);
+    }
+  };
+  const float* const wl = lds + (size_t)(4 * lg) * g.NP + li;
+  f4 acc[NTT];
+  auto mfmas = [&](int p) {
+#pragma unroll
+    for (int n = 0; n < NTT; ++n) acc[n] = (f4){0.f, 0.f, 0.f, 0.f};
+    const float* const wp = wl + p * (16 * NTT);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float* const wr = wp + (size_t)(16 * c + s) * g.NP;
+#pragma unroll
+        for (int n = 0; n < NTT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[16 * n], xa[c][s], acc[n], 0, 0, 0);
+      }
+    }
+  };
+  auto stores = [&](int p, float* o, bool live) {
+#pragma unroll
+    for (int n = 0; n < NTT; ++n) {
+      const int t = p * NTT + n;
+      if (t < nfull) {
+        if (live) { f4u w; w.v = acc[n]; *reinterpret_cast<f4u*>(o + t * 16) = w; }
+      } else if (t == nfull && nrem && live) {
+        for (int r = 0; r < 4; ++r)
+          if (4 * lg + r < nrem) o[t * 16 + r] = acc[n][r];
+      }
+    }
+  };
+  int node;
+  ask_node(s0, node);
+  ask_group(s0);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(node), "+v"(grp_v) : : "memory");
+  int grp = __builtin_amdgcn_readfirstlane(grp_v);
+  ask_node(s0 + 1, node_a);
+  ask_group(s0 + 1);
+  fetch(node);
+  take();                                                     // (node_a and the next group have landed too)
+  asm volatile("" : "+v"(node_a), "+v"(grp_v));
+  int cur = -1;
+  for (int s = s0; s < s1; ++s) {
+    if (grp != cur) {                                         // (workgroup-uniform)
+      __syncthreads();
+      fill(grp);
+      __syncthreads();
+      cur = grp;
+    }
+    grp = __builtin_amdgcn_readfirstlane(grp_v);              // tile s + 1's
+    float* const o = g.y + (long)max(node, 0) * g.ldy + 4 * lg;
+    const bool live = node >= 0;
+    for (int p = 0; p + 1 < npass; ++p) {
+      mfmas(p);
+      stores(p, o, live);
+    }
+    ask_node(s + 2, node_b);
+    ask_group(s + 2);
+    fetch(node_a);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(npass - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    f4 last[NTT];
+#pragma unroll
+    for (int n = 0; n < NTT; ++n) last[n] = acc[n];
+    take();
+    asm volatile("" : "+v"(node_b), "+v"(grp_v));
+#pragma unroll
+    for (int n = 0; n < NTT; ++n) acc[n] = last[n];
+    stores(npass - 1, o, live);
+    node = node_a;
+    node_a = node_b;
+  }
+}
+
+template <int NCH>
+hipError_t launch_grouped(const GArgs& g, unsigned grid, size_t lds, hipStream_t stream) {
+  auto* fn = k_project_grouped<NCH, 5>;
+  hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lds, stream, g);
+  return hipGetLastError();
+}
+
 constexpr int kNTT = 5;
 
 template <int NCH>
@@ -364,6 +513,41 @@ extern "C" int pna_project_scaled_f32(const float* x, int64_t ldx, int64_t M, in
     case 6: e = launch_scaled<6>(g, npan, grid, lds, (hipStream_t)stream); break;
     case 7: e = launch_scaled<7>(g, npan, grid, lds, (hipStream_t)stream); break;
     default: e = launch_scaled<8>(g, npan, grid, lds, (hipStream_t)stream); break;
+  }
+  if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
+  return PNA_OK;
+}
+
+extern "C" int pna_project_grouped_f32(const float* x, int64_t ldx, int64_t x_rows, int32_t K, const float* w_groups, int64_t group_stride,
+                                       int32_t n_groups, int32_t N, const int32_t* row_perm, int64_t M, const int32_t* tile_group,
+                                       float* y, int64_t ldy, pna_stream_t stream) {
+  if (M == 0) return PNA_OK;
+  if (!x || !w_groups || !y || !row_perm || !tile_group || M < 0 || M % 128 || M >= (1ll << 31) || x_rows < 1 || K < 4 || K > 128 || N < 1 ||
+      N > 512 || n_groups < 1 || group_stride < (int64_t)N * K || ldx < K || ldy < N || ((uintptr_t)x & 3) || ((uintptr_t)y & 3))
+    return pna_set_error(PNA_E_INVALID,
+                         "pna_project_grouped_f32: M a multiple of 128, 4 <= K <= 128, 1 <= N <= 512, group_stride >= N K, ldx >= K, ldy >= N");
+  const int nch = (K + 15) / 16, Kp = nch * 16;
+  const int NP = (N + 79) / 80 * 80 + 4;
+  const size_t lds = (size_t)Kp * NP * sizeof(float);
+  if (lds > 160 * 1024)
+    return pna_set_error(PNA_E_INVALID, "pna_project_grouped_f32: a group's weight (16 ceil(K / 16) x (80 ceil(N / 80) + 4) floats) must fit 160 KB of LDS");
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return pna_set_error(PNA_E_NODEVICE, "pna_project_grouped_f32: no device");
+  GArgs g;
+  g.x = x; g.w = w_groups; g.y = y; g.perm = row_perm; g.tile_group = tile_group;
+  g.ldx = ldx; g.ldy = ldy; g.wstride = group_stride; g.ntiles = (int)(M / 128); g.K = K; g.N = N; g.NP = NP;
+  const unsigned grid = (unsigned)(g.ntiles < cus ? g.ntiles : cus);
+  hipError_t e = hipSuccess;
+  switch (nch) {
+    case 1: e = launch_grouped<1>(g, grid, lds, (hipStream_t)stream); break;
+    case 2: e = launch_grouped<2>(g, grid, lds, (hipStream_t)stream); break;
+    case 3: e = launch_grouped<3>(g, grid, lds, (hipStream_t)stream); break;
+    case 4: e = launch_grouped<4>(g, grid, lds, (hipStream_t)stream); break;
+    case 5: e = launch_grouped<5>(g, grid, lds, (hipStream_t)stream); break;
+    case 6: e = launch_grouped<6>(g, grid, lds, (hipStream_t)stream); break;
+    case 7: e = launch_grouped<7>(g, grid, lds, (hipStream_t)stream); break;
+    default: e = launch_grouped<8>(g, grid, lds, (hipStream_t)stream); break;
   }
   if (e != hipSuccess) return pna_set_error(PNA_E_LAUNCH, hipGetErrorString(e));
   return PNA_OK;

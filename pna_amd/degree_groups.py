@@ -268,6 +268,23 @@ class DegreePlan:
         self.__dict__["_dw_tables"] = (n_wgs, out)
         return out
 
+    def tiles_by_group(self):
+        """(row_perm, tile_group) of the plan's tiles listed SORTED BY degree group (stable): int32 [NV], int32 [NV / 128] -- what
+        pna_project_grouped_f32 walks, its workgroups refilling their weight image only when the group changes (the plan's own tile order
+        may interleave low and high degrees)."""
+        hit = self.__dict__.get("_tiles_by_group")
+        if hit is None:
+            order = torch.sort(self.tile_image.long(), stable=True).indices
+            hit = self.__dict__["_tiles_by_group"] = (self.perm.view(-1, TILE)[order].reshape(-1).contiguous(),
+                                                      self.tile_image[order].to(torch.int32).contiguous())
+        return hit
+
+    def group_scaler_values(self, row_scales):
+        """(G, S) fp32: the value of every scaler on the rows of every degree group (None = the identity scaler: 1)."""
+        cols = [torch.ones(self.G, dtype=torch.float32, device=self.perm.device) if rs is None else rs[self.group_first_row].to(torch.float32)
+                for rs in row_scales]
+        return torch.stack(cols, dim=1)
+
     def vmap32(self):
         """int32 [V]: row of the plan-ordered aggregate buffer that holds node v (pna_segreduce_args.out_row_of)."""
         return self._vmap

@@ -484,6 +484,21 @@ def project_scaled(x: torch.Tensor, K: int, weight: torch.Tensor, scales: Option
     return out
 
 
+def project_grouped(x: torch.Tensor, K: int, w_groups: torch.Tensor, row_perm: torch.Tensor, tile_group: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[node] = x[node, :K] w_groups[g]^T for node = row_perm[v], g = tile_group[v // 128] (pna_project_grouped_f32): w_groups (G, N, K)
+    contiguous, one matrix per degree group of a degree plan; rows of `out` that no virtual row names are left alone.  List the tiles sorted
+    by group (DegreePlan.tiles_by_group): a workgroup refills its weight image only when the group changes."""
+    G, N = w_groups.shape[0], w_groups.shape[1]
+    if w_groups.shape[2] != K or not w_groups.is_contiguous():
+        raise ValueError("project_grouped: w_groups must be a contiguous (G, N, K) tensor")
+    rc = _lib.lib().pna_project_grouped_f32(
+        _lib.dev_ptr(x, torch.float32, "x"), _ld(x), x.shape[0], K, _lib.dev_ptr(w_groups, torch.float32, "w_groups"), N * K, G, N,
+        _lib.dev_ptr(row_perm, torch.int32, "row_perm"), row_perm.numel(), _lib.dev_ptr(tile_group, torch.int32, "tile_group"),
+        _lib.dev_ptr(out, torch.float32, "out"), _ld(out), _lib.stream_ptr(x.device))
+    _lib.check(rc, "pna_project_grouped_f32")
+    return out
+
+
 def posttrans_towers(agg: torch.Tensor, K: int, weights: Sequence[torch.Tensor], row_scales: Sequence[Optional[torch.Tensor]],
                      biases: Optional[torch.Tensor], h: Optional[torch.Tensor], h_shared: bool, out: torch.Tensor,
                      row_post: Optional[torch.Tensor] = None, col_scale: Optional[torch.Tensor] = None,

@@ -112,7 +112,7 @@ def test_resident_weight_projection_never_touches_a_register_in_flight(tmp_path)
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
                     "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "pna_project.hip")], check=True, capture_output=True)
     names = sorted(set(re.findall(r"^(_ZN\S*k_project\S+?):", open(out).read(), flags=re.M)))
-    assert len(names) == 8 + 8 * 3 + 5, names                    # K chunks 1..8 x (plain, 1..3 blocks) + four blocks at <= 5 chunks
+    assert len(names) == 8 + 8 * 3 + 5 + 8, names                # K chunks 1..8 x (plain, 1..3 blocks, grouped) + four blocks at <= 5 chunks
     for n in names:
         kl = isa_audit.kernel_lines(out, n)
         probs = isa_audit.audit(kl)

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import torch_oracle as O
-from pna_amd import Graph, functional as PF
+from pna_amd import Graph, functional as PF, ops
 from pna_amd.dgl.pna_layer import PNALayer, PNASimpleLayer
 
 pytestmark = pytest.mark.gpu
@@ -492,6 +492,39 @@ def test_simple_layer_training_step_in_degree_plan_order(cuda_device, monkeypatc
     else:
         off = ((gh1 - gh0).abs() > 1e-4 * gh0.abs().max()).float().mean().item()
         assert off <= 1e-3 and rel(gw1, gw0) <= 2e-3 and rel(gb1, gb0) <= 2e-3, (off, rel(gw1, gw0), rel(gb1, gb0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,E,F", [(40_000, 400_000, 75), (30_000, 240_000, 20)])
+def test_grouped_aggregate_gradient_against_the_three_block_contraction(cuda_device, monkeypatch, V, E, F):
+    """d agg = gy W_D^T with one combined weight per degree group (pna_project_grouped_f32, round 6) against the three-block bf16 x 3
+    contraction of rounds 3-5 inside the same plan-order backward: same forward, same gy -- the input gradient differs by the two
+    contractions' rounding only (no ReLU decision depends on it)."""
+    from pna_amd import autograd as AG, degree_groups as DG
+    from pna_amd.synth import powerlaw_graph
+    monkeypatch.setattr(DG, "MIN_ROWS", 1)
+    monkeypatch.setattr(DG, "MIN_OUT", 1)
+    src, dst = powerlaw_graph(V, E, seed=29)
+    keep = dst >= 50
+    g = Graph(src[keep], dst[keep], V).to(cuda_device)
+    avg = {"log": float(torch.log(g.in_degrees().float() + 1).mean())}
+    res = {}
+    for grouped in (True, False):
+        monkeypatch.setattr(AG, "DAGG_GROUPED", grouped)
+        torch.manual_seed(0)
+        layer = PNASimpleLayer(F, F, "mean max min std", "identity amplification attenuation", avg, 0.0, True, True).to(cuda_device).train()
+        h = torch.randn(V, F, generator=torch.Generator().manual_seed(1)).to(cuda_device).requires_grad_(True)
+        calls = []
+        real = ops.project_grouped
+        monkeypatch.setattr(ops, "project_grouped", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        out = layer(g, h)
+        (out * torch.linspace(0.5, 1.5, F, device=cuda_device)).sum().backward()
+        monkeypatch.setattr(ops, "project_grouped", real)
+        assert bool(calls) == grouped
+        res[grouped] = (out.detach(), h.grad.clone(), layer.posttrans.fully_connected[0].linear.weight.grad.clone())
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][2], res[False][2])
+    gh1, gh0 = res[True][1], res[False][1]
+    assert (gh1 - gh0).abs().max().item() <= 2e-5 * gh0.abs().max().item(), (gh1 - gh0).abs().max().item() / gh0.abs().max().item()
 
 
 def test_simple_layer_training_step_in_degree_plan_order_vs_the_float64_oracle(cuda_device, monkeypatch):

@@ -102,3 +102,33 @@ def test_scaled_projection_rejects_four_blocks_beyond_its_register_budget():
     assert not ops.project_scaled_applies(x, 96, 75, 4) and ops.project_scaled_applies(x[:, :75], 75, 75, 4)
     with pytest.raises(Exception):
         ops.project_scaled(x, 96, torch.randn(75, 4 * 96, device="cuda"), torch.rand(8, 3, device="cuda"), None, True)
+
+
+@pytest.mark.parametrize("V,K,N,G,seed", [(5000, 75, 300, 7, 0), (1000, 16, 80, 3, 1), (3000, 75, 75, 1, 2), (777, 33, 130, 12, 3), (20000, 75, 300, 40, 4)])
+def test_grouped_projection_matches_float64(V, K, N, G, seed):
+    """pna_project_grouped_f32: virtual rows in 128-row tiles, each tile with its group's weight, -1 padding rows, rows that no virtual
+    row names left alone, tiles listed in group order or as they come."""
+    from pna_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    ntiles = (V + 127) // 128 + 3
+    tile_group = torch.randint(0, G, (ntiles,), generator=g, dtype=torch.int32)
+    perm = torch.full((ntiles * 128,), -1, dtype=torch.int32)
+    named = torch.randperm(V, generator=g)[:V - V // 10]                       # a tenth of the nodes are named by no virtual row
+    slots = torch.randperm(ntiles * 128, generator=g)[:named.numel()]
+    perm[slots] = named.to(torch.int32)
+    x = torch.randn(V, K, generator=g)
+    w = torch.randn(G, N, K, generator=g) * 0.3
+    order = torch.sort(tile_group.long(), stable=True).indices
+    for by_group in (True, False):                                               # tiles listed sorted by group, or as they come
+        pm, tg = (perm.view(-1, 128)[order].reshape(-1), tile_group[order]) if by_group else (perm, tile_group)
+        y = torch.full((V, N + 5), 7.0, device="cuda")
+        ops.project_grouped(x.cuda(), K, w.cuda(), pm.contiguous().cuda(), tg.contiguous().cuda(), out=y[:, :N])
+        y = y.cpu()
+        grp = torch.full((V,), -1, dtype=torch.long)
+        grp[perm[slots].long()] = tile_group[(slots // 128)].long()
+        ref = torch.einsum("vk,vnk->vn", x[named].double(), w[grp[named]].double())
+        floor = torch.einsum("vk,vnk->vn", x[named].abs().double(), w[grp[named]].abs().double())
+        err = ((y[named, :N].double() - ref).abs() / floor).max().item()
+        assert err <= 1e-6, err
+        untouched = torch.ones(V, dtype=torch.bool); untouched[named] = False
+        assert (y[untouched] == 7.0).all() and (y[:, N:] == 7.0).all()

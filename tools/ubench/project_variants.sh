@@ -1,7 +1,7 @@
 #!/bin/bash
 # build: tools/ubench/project_variants.sh build     run (on the GPU box): tools/ubench/project_variants.sh run
 cd "$(dirname "$0")/../.."
-V=("b512:-DPNA_PROJECT_BLOCK=512" "b512ns:-DPNA_PROJECT_BLOCK=512 -DPNA_PROJECT_NOSTORE" "b1024ns:-DPNA_PROJECT_BLOCK=1024 -DPNA_PROJECT_NOSTORE" "b512nsnl:-DPNA_PROJECT_BLOCK=512 -DPNA_PROJECT_NOSTORE -DPNA_PROJECT_NOLDS" "b512nl:-DPNA_PROJECT_BLOCK=512 -DPNA_PROJECT_NOLDS" "b256nsnl:-DPNA_PROJECT_BLOCK=256 -DPNA_PROJECT_NOSTORE -DPNA_PROJECT_NOLDS")
+V=("b512:-DPNA_PROJECT_BLOCK=512")     # (other block sizes: before pna_project_grouped_f32 tied the file to 8-wavefront workgroups -- profiles/r06_project_variants.txt)
 mkdir -p pna_amd/lib/pv
 for v in "${V[@]}"; do
   name=${v%%:*}; flags=${v#*:}
