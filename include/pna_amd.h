@@ -642,6 +642,11 @@ typedef struct pna_fused_degree_args {
                              * a handed-over tile again from the same pre_add rows.  Also taken by the layer proper (with row_post as its
                              * optional row factor): a layer in feature panels, FusedMultiTowerCall's launches */
   int64_t ld_pre_add;
+  int32_t y_cols_writable;  /* 0 (= N), or N <= y_cols_writable <= min(ldy, 16 ceil(N / 16)): the columns of a row of y the kernel may WRITE; the ones
+                             * behind N receive zeros.  With the padding of its own output buffer writable, a row of N = 75 floats is ten whole
+                             * 32-byte sectors (no partially written sector for the memory side to complete by reading it first) and the row's last
+                             * window one 16-byte store instead of three scalar ones.  Never set it for a y that is a view of wider rows. */
+  int32_t _pad6;
 } pna_fused_degree_args;
 
 #define PNA_FD_ARITH_GUARDED 0 /* fp16 x 2 with the floor-error guard: tiles it cannot certify are computed again in bf16 x 3 (a second launch) */

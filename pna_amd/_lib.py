@@ -140,6 +140,7 @@ class PnaFusedDegreeArgs(_Args):
         ("spare_workgroups", ctypes.c_int32), ("_pad4", ctypes.c_int32), ("tile_counter", ctypes.c_void_p),
         ("w_img_x3", ctypes.c_void_p), ("image_stride_x3", ctypes.c_int64), ("guard_ws", ctypes.c_void_p), ("guard_ws_bytes", ctypes.c_int64),
         ("arith", ctypes.c_int32), ("_pad5", ctypes.c_int32), ("pre_add", ctypes.c_void_p), ("ld_pre_add", ctypes.c_int64),
+        ("y_cols_writable", ctypes.c_int32), ("_pad6", ctypes.c_int32),
     ]
 
 

@@ -73,6 +73,7 @@ struct FDArgs {
   unsigned ldb;                // row pitch of x in bytes
   unsigned ldyb, ldrb;         // row pitch of y / residual in bytes (ldrb = 0 without a residual: every load reads y's first row)
   int F, M, N, relu;
+  int ncw;                     // columns of a row of y the kernel may write (>= N; zeros behind N)
   float slope;
   int abl;                     // experiments build only: parts skipped for timing (bit 0 MFMAs, 1 fragment maths after the first chunk,
 };                             // 2 the fold, 3 the y stores, 4 the B-fragment reads, 7 the weight copies, 8 gather from row 0): results are then meaningless
@@ -896,13 +897,16 @@ __device__ __forceinline__ void fd_body(const FDArgs& g, const int t_first, cons
 #pragma unroll
         for (int j = 0; j < 4; ++j) z[j] = rr[j] + z[j];
       }
-      if (row >= 0 && c0 < g.N && !FD_ABL(3)) {
+      // (ncw >= N: the columns of a row the caller lets the kernel write -- y_cols_writable; the ones behind N receive zeros, so that a row
+      //  of N = 75 floats is ten whole 32-byte sectors instead of nine and a half, and its last window one 16-byte store instead of three scalar ones)
+      if (row >= 0 && c0 < g.ncw && !FD_ABL(3)) {
         float* const o = reinterpret_cast<float*>(yrow + (unsigned)c0 * 4u);
-        if (c0 + 4 <= g.N) {
-          f4u w; w.v = (f4){z[0], z[1], z[2], z[3]};
+        if (c0 + 4 <= g.ncw) {
+          f4u w; w.v = (f4){z[0], c0 + 1 < g.N ? z[1] : 0.f, c0 + 2 < g.N ? z[2] : 0.f, c0 + 3 < g.N ? z[3] : 0.f};
+          if (c0 >= g.N) w.v.x = 0.f;
           if (FD_ABL(5)) __builtin_nontemporal_store(w.v, reinterpret_cast<f4a4*>(o));
           else *reinterpret_cast<f4u*>(o) = w;
-        } else {                                          // the row's last, partial window
+        } else if (c0 < g.N) {                            // the row's last, partial window
           o[0] = z[0];
           if (c0 + 1 < g.N) o[1] = z[1];
           if (c0 + 2 < g.N) o[2] = z[2];
@@ -1408,6 +1412,8 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
       (p->residual && (p->ld_res < p->N || p->n_nodes * p->ld_res * 4 >= (1ll << 32))))
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: bad n_nodes / ldy / ld_res (y and residual must be < 4 GiB)");
   if (p->relu < 0 || p->relu > 2) return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: relu must be 0, 1 or 2");
+  if (p->y_cols_writable != 0 && (p->y_cols_writable < p->N || p->y_cols_writable > p->ldy || p->y_cols_writable > (p->N + 15) / 16 * 16))
+    return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: y_cols_writable must be 0 or in [N, min(ldy, 16 ceil(N / 16))]");
   if (p->spare_workgroups < 0) return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: spare_workgroups must be >= 0");
   if ((p->col_scale == nullptr) != (p->col_shift == nullptr))
     return pna_set_error(PNA_E_INVALID, "pna_fused_degree_f32: col_scale and col_shift come together");
@@ -1441,6 +1447,7 @@ extern "C" int pna_fused_degree_f32(const pna_fused_degree_args* p, pna_stream_t
   g.bias = p->bias; g.col_scale = p->col_scale; g.col_shift = p->col_shift; g.residual = p->residual; g.y = p->y;
   g.ldyb = (unsigned)(p->ldy * 4); g.ldrb = p->residual ? (unsigned)(p->ld_res * 4) : 0u;
   g.M = (int)p->M; g.N = p->N; g.relu = p->relu; g.slope = p->relu == 2 ? p->act_slope : 0.f;
+  g.ncw = p->y_cols_writable > p->N ? (int)p->y_cols_writable : p->N;
   g.agg_out = p->agg_out; g.ld_agg = p->ld_agg;
   g.xd = p->x_dst; g.xh = p->h_self; g.row_post = p->row_post; g.lddb = (unsigned)(p->ld_xdst * 4); g.ldhb = (unsigned)(p->ld_h * 4);
   g.counter = p->tile_counter;

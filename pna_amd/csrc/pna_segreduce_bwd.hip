@@ -533,6 +533,9 @@ __global__ __launch_bounds__(kBlock) void k_bwd_pull(const LArgs a) {
 //     P[e] = R1[v] + [e = argmax[v]] G_max[v] + [e = argmin[v]] G_min[v]        one F-float row per edge, written in CSR order
 // and the pull reads per out-edge P[position of the edge] and R2[v]: 2 x 4F bytes.  The same additions in the same order as the ranked pull
 // (t = R1; t += max term; t += min term; s1 += t; s2 += R2): bit-identical gradients.  One tower, no destination term (PNASimpleLayer).
+#ifndef PNA_EDGE_ROWS_WHOLE
+#define PNA_EDGE_ROWS_WHOLE 1          // (0: rows written through the load windows -- the A/B build of tools/fastbuild.sh _nowhole -DPNA_EDGE_ROWS_WHOLE=0)
+#endif
 struct EArgs {
   const int32_t* items; const int32_t* rowptr; const int32_t* row_of;
   const float* gmean; const float* gstd; const float* gmax; const float* gmin; const float* mean; const float* stdv;
@@ -547,8 +550,13 @@ __global__ __launch_bounds__(kBlock) void k_bwd_edge_rows(const EArgs a) {
   if (grp >= a.G) return;
   const int c = lane - grp * a.L;
   const int nchunks = (a.F + 3) / 4;
-  if (c >= nchunks) return;
-  const int off = min(c * 4, a.F - 4);
+  // whole_rows (L = ld_p / 4 lanes): every lane stores the 16 ALIGNED bytes at column 4 c, the row's padding columns included (zeros) -- an edge
+  // row is then ld_p x 4 contiguous, fully written bytes.  With the windows of the loads (the last one slid back to end at F) a 300-byte row
+  // of pitch 320 left 20 bytes unwritten: one partially written 32-byte sector per edge, which the memory side completes by reading it first.
+  const bool whole_rows = a.L > nchunks;
+  if (c >= nchunks && !whole_rows) return;
+  const int off = min(min(c, nchunks - 1) * 4, a.F - 4);
+  const int sc = whole_rows ? c * 4 : off, sd_ = sc - off;   // store column; how far the load window sits below it (0..3; >= 4: pure padding)
   const long item = ((long)blockIdx.x * kWaves + wave) * a.G + grp;
   if (item >= a.n_items) return;
   const i4 rec = reinterpret_cast<const i4*>(a.items)[item];
@@ -575,7 +583,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_edge_rows(const EArgs a) {
       r1[q] = base + cvar[q] * (0.f - mean[q]);
     }
   }
-  if (beg == rbeg) reinterpret_cast<f4u*>(a.r2 + (size_t)row * a.ld_r2 + off)->v = cvar;      // (a hub row's first segment writes the row's R2)
+  if (beg == rbeg && c < nchunks) reinterpret_cast<f4u*>(a.r2 + (size_t)row * a.ld_r2 + off)->v = cvar;      // (a hub row's first segment writes the row's R2)
   for (int e = beg; e < end; ++e) {
     f4 t;
 #pragma unroll
@@ -585,7 +593,17 @@ __global__ __launch_bounds__(kBlock) void k_bwd_edge_rows(const EArgs a) {
       v = v + (en[q] == e ? gmn[q] : 0.f);
       t[q] = v;
     }
-    reinterpret_cast<f4u*>(a.P + (size_t)e * a.ld_p + off)->v = t;
+    if (whole_rows) {                                        // the window's values moved up to the store column, zeros behind column F
+      f4 o;
+      o.x = sd_ == 0 ? t.x : sd_ == 1 ? t.y : sd_ == 2 ? t.z : sd_ == 3 ? t.w : 0.f;
+      o.y = sd_ == 0 ? t.y : sd_ == 1 ? t.z : sd_ == 2 ? t.w : 0.f;
+      o.z = sd_ == 0 ? t.z : sd_ == 1 ? t.w : 0.f;
+      o.w = sd_ == 0 ? t.w : 0.f;
+      o.x = sc < a.F ? o.x : 0.f; o.y = sc + 1 < a.F ? o.y : 0.f; o.z = sc + 2 < a.F ? o.z : 0.f; o.w = sc + 3 < a.F ? o.w : 0.f;
+      *reinterpret_cast<f4*>(a.P + (size_t)e * a.ld_p + sc) = o;
+    } else {
+      reinterpret_cast<f4u*>(a.P + (size_t)e * a.ld_p + off)->v = t;
+    }
   }
 }
 
@@ -772,7 +790,12 @@ extern "C" int pna_segreduce_bwd_pull_f32(const pna_segreduce_bwd_pull_args* q, 
     e.amx = p->argmax; e.amn = p->argmin; e.r2 = const_cast<float*>(q->table); e.P = q->edge_rows;
     e.ld_g = p->ld_g; e.ld_stat = p->ld_stat; e.ld_arg = p->ld_arg; e.ld_r2 = q->ld_table; e.ld_p = q->ld_edge;
     e.n_items = q->n_items; e.F = F;
-    e.L = (F + 3) / 4 > 64 ? 64 : (F + 3) / 4; e.G = 64 / e.L;
+    e.L = (F + 3) / 4 > 64 ? 64 : (F + 3) / 4;
+    // whole rows (k_bwd_edge_rows): the pitch a multiple of 4 floats, at most 2 chunks of padding, the buffer 16-byte aligned, as many groups per wavefront
+    if (PNA_EDGE_ROWS_WHOLE && q->ld_edge % 4 == 0 && q->ld_edge / 4 > e.L && q->ld_edge / 4 <= e.L + 2 && q->ld_edge / 4 <= 64 && ((uintptr_t)q->edge_rows & 15) == 0 &&
+        64 / (int)(q->ld_edge / 4) == 64 / e.L)
+      e.L = (int)(q->ld_edge / 4);
+    e.G = 64 / e.L;
     const long groups = (long)kWaves * e.G;
     if (q->n_items > 0)
       hipLaunchKernelGGL(k_bwd_edge_rows, dim3((unsigned)((q->n_items + groups - 1) / groups)), dim3(kBlock), 0, st, e);

@@ -665,6 +665,18 @@ def out_pitch(N):
     return (N + a - 1) // a * a
 
 
+def own_buffer_cols(pitch, c0, c1, N):
+    """pna_fused_degree_args.y_cols_writable for the column panel [c0, c1) of a row of N columns in a buffer THIS module allocated at `pitch`
+    floats (out_pitch): the last panel may write zeros into the row's padding up to the next multiple of 16 columns -- whole 32-byte
+    sectors and one 16-byte store for the row's last window (WRITE_PADDING = False: off, for A/B runs)."""
+    if not WRITE_PADDING or c1 != N:
+        return 0
+    return max(c1 - c0, min(pitch - c0, (c1 - c0 + 15) // 16 * 16))
+
+
+WRITE_PADDING = os.environ.get("PNA_AMD_WRITE_PADDING", "1") != "0"
+
+
 def _fused_grid(device, spare, n_tiles64):
     """Workgroups pna_fused_degree_f32 launches for the 4-wavefront shapes (pna_fused_degree.hip: two per CU, less the spare ones, never
     below one per CU, never more than tiles)."""
@@ -811,6 +823,7 @@ class FusedTowerCall:
         if res is not None:
             a.residual, a.ld_res = _lib.dev_ptr(res, torch.float32, "residual"), res.stride(0)
         a.y, a.ldy, a.relu, a.act_slope = _lib.dev_ptr(y, torch.float32, "y"), y.stride(0), 2, self.slope
+        a.y_cols_writable = own_buffer_cols(y.stride(0), 0, N, N)
         self.args, self.ref = a, ctypes.byref(a)
         self.fn, self.check, self.stream = _lib.lib().pna_fused_degree_f32, _lib.check, _lib.stream_ptr(dev)
         _bind_tile_order(self, 0)
@@ -969,8 +982,10 @@ class FusedMultiTowerCall:
                 if res is not None:
                     a.residual, a.ld_res = _lib.dev_ptr(res, torch.float32, "residual"), res.stride(0)
                 a.y, a.ldy, a.relu, a.act_slope = _lib.dev_ptr(y, torch.float32, "y"), y.stride(0), 2, self.slope
+                a.y_cols_writable = own_buffer_cols(y.stride(0), 0, N, N)
             else:                                            # a partial sum: no bias, no factor, no activation
                 a.y, a.ldy, a.relu = _lib.dev_ptr(dst_buf, torch.float32, "y"), dst_buf.stride(0), 0
+                a.y_cols_writable = own_buffer_cols(dst_buf.stride(0), 0, N, N)
             blocks.append((a, ctypes.byref(a)))
         self.launch_order = blocks
         self.panel_args = [blocks[-1]] + blocks[:-1]         # (_bind_tile_order: the primary block is the one whose row_post follows the tile order)
@@ -1090,8 +1105,11 @@ class FusedDegreeCall:
                 if res is not None:
                     a.residual, a.ld_res = _lib.dev_ptr(res[:, c0:c1], torch.float32, "residual"), res.stride(0)
                 a.y, a.ldy, a.relu = _lib.dev_ptr(y[:, c0:c1], torch.float32, "y"), y.stride(0), 1
+                if out is None:
+                    a.y_cols_writable = own_buffer_cols(y.stride(0), c0, c1, N)
             else:                                            # a partial sum: no bias, no BatchNorm, no activation, no residual
                 a.y, a.ldy, a.relu = _lib.dev_ptr(self.part[:, c0:c1], torch.float32, "y"), self.part.stride(0), 0
+                a.y_cols_writable = own_buffer_cols(self.part.stride(0), c0, c1, N)
             if agg_out is not None:
                 a.agg_out, a.ld_agg = _lib.dev_ptr(agg_out, torch.float32, "agg_out"), agg_out.stride(0)
             self.panel_args.append((a, ctypes.byref(a)))
