@@ -21,6 +21,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
                   layer, timed on this box's host cores on a bounded sample (rank 0, N=1 only)
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -447,6 +448,8 @@ def main():
         # the same untimed pre-conditioning as the one-layer line below (first calls: plans, weight images; then the device's
         # sustained clock state): without it 3 + 10 steps of 4 layers measured 0.80 / 0.98 / 1.28 ms per layer on three boxes
         prewarm_l = 0
+        gc.collect()
+        gc.disable()                                           # (see the one-layer loop below)
         if not args.no_prewarm:
             for _ in range(2):
                 step_l()
@@ -462,6 +465,7 @@ def main():
             step_l()
         sync()
         dt = time.perf_counter() - t0
+        gc.enable()
         if world > 1:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -483,6 +487,13 @@ def main():
     # for the device to reach its sustained clock state: measured on one box, W = 5 / K = 20 gave 0.899 ms/step, W = 50 0.838, K = 200
     # 0.841 -- the first ~50 steps after an idle phase run 7 % slower.  The timed region below is still exactly K steps after W
     # warm-up steps, bracketed by barrier + synchronize.
+    # The interpreter's cyclic garbage collector stays out of the pre-conditioning, W and K steps (collected in front of them, re-enabled after -- what `timeit` does):
+    # a full collection of this process' ~1 M objects takes ~47 ms, and WHICH step it lands on depends on the number of objects allocated
+    # so far -- `python bench.py` without arguments had it inside the 20 timed steps (2.5-3.9 ms per step reported for 0.72 ms steps), any
+    # argument moved it out (found in round 6 with PNA_BENCH_STEP_TIMES=1: one step of 47.65 ms, the other 59 of 0.84-0.91).  Collected IN FRONT of
+    # the pre-conditioning steps: the collection itself leaves the device idle for those 47 ms, and the first steps after an idle phase run slower.
+    gc.collect()
+    gc.disable()
     prewarm = 0
     if not args.no_prewarm:
         for _ in range(2):                                     # (first calls: degree plan, weight images, allocator)
@@ -503,11 +514,17 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    if os.environ.get("PNA_BENCH_STEP_TIMES") == "1":            # diagnosis only: every step synchronised and timed on its own (to stderr)
+        ts = []
+        for _ in range(3 * args.steps):
+            t_ = time.perf_counter(); step(); sync(); ts.append(round((time.perf_counter() - t_) * 1e3, 3))
+        print("[bench] per-step ms:", ts, file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
     dt = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
