@@ -254,3 +254,36 @@ def test_fused_balance_is_a_permutation_of_tiles_round_by_round(graph_and_plan):
         assert plan.fused_balance(8) is None
     finally:
         DG.FUSED_BALANCE = keep
+
+
+def test_tiles_by_group_lists_every_tile_once_with_its_group(graph_and_plan):
+    """DegreePlan.tiles_by_group (round 6: what pna_project_grouped_f32 walks): the plan's 128-row tiles re-listed sorted by degree group --
+    the same (rows, group) pairs, every tile once, groups non-decreasing; group_scaler_values: one scaler value per group, the value of
+    any of the group's rows."""
+    g, plan = graph_and_plan
+    perm_g, group_g = plan.tiles_by_group()
+    nt = plan.NV // DG.TILE
+    assert perm_g.numel() == plan.NV and group_g.numel() == nt
+    assert bool((group_g[1:] >= group_g[:-1]).all())
+    own = sorted((tuple(plan.perm.view(nt, DG.TILE)[t].tolist()), int(plan.tile_image[t])) for t in range(nt))
+    listed = sorted((tuple(perm_g.view(nt, DG.TILE)[t].tolist()), int(group_g[t])) for t in range(nt))
+    assert own == listed
+    deg = g.in_degrees().float()
+    amp = torch.log(deg + 1) / 1.7
+    sc = plan.group_scaler_values([None, amp])
+    assert sc.shape == (plan.G, 2) and bool((sc[:, 0] == 1).all())
+    for t in range(nt):                                                                       # every live row of a tile carries its group's value
+        rows = perm_g.view(nt, DG.TILE)[t]
+        rows = rows[rows >= 0].long()
+        assert bool((amp[rows] == sc[int(group_g[t]), 1]).all())
+
+
+def test_own_buffer_cols_only_pads_the_last_panel_of_an_own_buffer(monkeypatch):
+    """functional.own_buffer_cols (pna_fused_degree_args.y_cols_writable): zeros may be written behind column N only by the row's LAST column
+    panel, up to the next multiple of 16 columns and never beyond the pitch; an inner panel, or the switch off: 0 (= N)."""
+    from pna_amd import functional as PF
+    assert PF.own_buffer_cols(96, 0, 75, 75) == 80 and PF.own_buffer_cols(76, 0, 75, 75) == 76 and PF.own_buffer_cols(96, 0, 80, 80) == 80
+    assert PF.own_buffer_cols(160, 0, 64, 150) == 0                                          # an inner panel: the next columns are another panel's
+    assert PF.own_buffer_cols(160, 128, 150, 150) == 32 and PF.own_buffer_cols(152, 128, 150, 150) == 24
+    monkeypatch.setattr(PF, "WRITE_PADDING", False)
+    assert PF.own_buffer_cols(96, 0, 75, 75) == 0

@@ -520,6 +520,53 @@ def test_fused_entry_point_rejects_bad_arguments(cuda_device):
     a.arith = _lib.FD_ARITH_GUARDED
     assert L.pna_fused_degree_f32(ctypes.byref(a), None) == -1 and b"guard_ws" in L.pna_last_error()
     assert L.pna_fused_degree_guard_bytes(64) == 64 + 9 * 64
+    # ABI 21, y_cols_writable: 0, or between N and min(ldy, 16 ceil(N / 16))
+    a.arith = _lib.FD_ARITH_H2
+    for bad in (74, 81, 96):
+        a.y_cols_writable = bad
+        assert L.pna_fused_degree_f32(ctypes.byref(a), None) == -1 and b"y_cols_writable" in L.pna_last_error(), bad
+
+
+@pytest.mark.parametrize("F,N", [(75, 75), (40, 72), (64, 96), (128, 100), (20, 13)])
+def test_rows_of_the_layers_own_output_buffer_are_written_as_whole_sectors(cuda_device, F, N, monkeypatch):
+    """pna_fused_degree_args.y_cols_writable (round 6): into the padding of the buffer the layer allocates itself the kernel writes ZEROS up to
+    the next multiple of 16 columns -- same bits in the N columns as without, nothing beyond the writable columns; a caller's own `out` (rows
+    of exactly N floats here) is never padded."""
+    from pna_amd import Graph, functional as PF
+    from pna_amd.synth import powerlaw_graph
+    V, E = 140_000, 1_000_000
+    src, dst = powerlaw_graph(V, E, seed=9, device=cuda_device)
+    g = Graph(src, dst, V)
+    layer = _layer(F, N, cuda_device, seed=5, residual=F == N)
+    h = _features(V, F, cuda_device, seed=3)
+    marks = {}
+    real_empty = torch.empty
+
+    def marked_empty(*size, **kw):                              # the layer's buffers start as 7.0 everywhere: what the kernel leaves alone stays 7.0
+        t = real_empty(*size, **kw)
+        if t.dtype == torch.float32 and t.dim() == 2 and t.shape[0] == V:
+            t.fill_(7.0)
+        return t
+    with torch.no_grad(), _Knobs(fused=True, small_graphs=True):
+        out = {}
+        for pad in (True, False):
+            monkeypatch.setattr(PF, "WRITE_PADDING", pad)
+            monkeypatch.setattr(torch, "empty", marked_empty)
+            call = PF.FusedDegreeCall(layer, g, h)
+            monkeypatch.setattr(torch, "empty", real_empty)
+            call.set_spare(False)
+            call.group_rows()
+            call.rest_rows()
+            torch.cuda.synchronize()
+            out[pad] = (call.y.clone(), torch.as_strided(call.y, (V, call.y.stride(0)), (call.y.stride(0), 1)).clone(), call.plan)
+    assert torch.equal(out[True][0], out[False][0])
+    full, plan = out[True][1], out[True][2]
+    pitch, w = full.shape[1], min(full.shape[1], (N + 15) // 16 * 16)
+    rows = plan.perm[plan.perm >= 0].long()                     # the rows of the degree groups: the one-kernel launch's
+    assert bool((full[rows][:, N:w] == 0).all()) and bool((full[rows][:, w:] == 7.0).all())
+    assert bool((out[False][1][:, N:] == 7.0).all())
+    if plan.NR:                                                  # the rest rows (two-kernel path) leave their padding alone
+        assert bool((full[plan.rest_rows.long()][:, N:] == 7.0).all())
 
 
 def test_tower_mode_rows_vs_float64_and_100_identical_runs_at_full_size(cuda_device, c3):
