@@ -1193,14 +1193,22 @@ __device__ __forceinline__ float fd_image_weight(const float* w_ref, long ldw, i
   const int f = col - 5 * F;
   return (fd_combined(w_ref, ldw, n, f, im, S, K, scale) + fd_combined(w_ref, ldw, n, F + f, im, S, K, scale)) + fd_combined(w_ref, ldw, n, 2 * F + f, im, S, K, scale);
 }
+// One block per (image, column): the block's maximum first, ONE atomic per block (round 6: an atomic per weight -- 1.4 M of them onto 75
+// addresses for the benchmark layer's 63 images -- took 5.6 ms of the 7.3 ms image pack).
 __global__ void k_fused_colmax(const float* w_ref, long ldw, int N, int F, int S, const float* scale, int n_img, unsigned* colmax, int tower) {
   const int KC = tower ? 6 * F : 4 * F;                   // weights the images hold per output column: + the x_dst panel's sums (tower)
-  const long total = (long)n_img * N * KC;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int col = (int)(i % KC);
-    const int n = (int)((i / KC) % N), im = (int)(i / ((long)KC * N));
-    const float w = fd_image_weight(w_ref, ldw, n, col, im, S, F, tower, scale);
-    atomicMax(colmax + n, __builtin_bit_cast(unsigned, __builtin_fabsf(w)));      // (|w| as bits: ordered like the floats; NaN above all)
+  const int n = blockIdx.x % N, im = blockIdx.x / N;
+  __shared__ unsigned part[128];
+  unsigned m = 0u;
+  for (int col = threadIdx.x; col < KC; col += blockDim.x) {
+    const unsigned b = __builtin_bit_cast(unsigned, __builtin_fabsf(fd_image_weight(w_ref, ldw, n, col, im, S, F, tower, scale)));
+    m = b > m ? b : m;                                     // (|w| as bits: ordered like the floats; NaN above all)
+  }
+  part[threadIdx.x] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < (int)blockDim.x; ++i) m = part[i] > m ? part[i] : m;
+    if (m != 0u) atomicMax(colmax + n, m);
   }
 }
 // GUARD (round 6): wex[n] = the largest, over the images, floor error of output column n's weights -- the sum over k of the part of the
@@ -1347,9 +1355,7 @@ static int pack_h2(const char* who, const float* w_ref, int64_t ldw, int N, int 
   const int blocks = (int)((elems + 255) / 256 > 8192 ? 8192 : (elems + 255) / 256);
   unsigned* const colmax = reinterpret_cast<unsigned*>((unsigned char*)img + payload);
   if (hipMemsetAsync(colmax, 0, kTailBytes, st) != hipSuccess) return pna_set_error(PNA_E_LAUNCH, who);
-  const int64_t welems = (int64_t)n_img * N * (tower ? 6 : 4) * F;
-  hipLaunchKernelGGL(k_fused_colmax, dim3((unsigned)((welems + 255) / 256 > 4096 ? 4096 : (welems + 255) / 256)), dim3(256), 0, st, w_ref, (long)ldw, N, F,
-                     S, scale, n_img, colmax, tower);
+  hipLaunchKernelGGL(k_fused_colmax, dim3((unsigned)(n_img * N)), dim3(128), 0, st, w_ref, (long)ldw, N, F, S, scale, n_img, colmax, tower);
   hipLaunchKernelGGL(k_fused_wsmall, dim3((unsigned)(n_img * N)), dim3(128), 0, st, w_ref, (long)ldw, N, F, S, scale, (const unsigned*)colmax, colmax + 128, tower);
   hipLaunchKernelGGL(k_pack_fused_degree, dim3(blocks), dim3(256), 0, st, w_ref, (long)ldw, N, F, S, scale, n_img,
                      (unsigned short*)img, tower, nwp, npan, 2, (const unsigned*)colmax, (long)(stride / 2));
