@@ -584,6 +584,28 @@ __global__ __launch_bounds__(kBlock) void k_bwd_edge_rows(const EArgs a) {
     }
   }
   if (beg == rbeg && c < nchunks) reinterpret_cast<f4u*>(a.r2 + (size_t)row * a.ld_r2 + off)->v = cvar;      // (a hub row's first segment writes the row's R2)
+  if (whole_rows) {
+    // the window's values moved up to the store column ONCE, in front of the edge loop (zeros / no arg index behind column F): the loop is
+    // two compares, two selects and two additions per column and one aligned 16-byte store
+    auto upf = [&](f4 t, int q) { const int j = q + sd_; return (j < 4 && sc + q < a.F) ? (j == 0 ? t.x : j == 1 ? t.y : j == 2 ? t.z : t.w) : 0.f; };
+    auto upi = [&](i4 t, int q) { const int j = q + sd_; return (j < 4 && sc + q < a.F) ? (j == 0 ? t.x : j == 1 ? t.y : j == 2 ? t.z : t.w) : -1; };
+    const f4 r1s = {upf(r1, 0), upf(r1, 1), upf(r1, 2), upf(r1, 3)}, gxs = {upf(gmx, 0), upf(gmx, 1), upf(gmx, 2), upf(gmx, 3)},
+             gns = {upf(gmn, 0), upf(gmn, 1), upf(gmn, 2), upf(gmn, 3)};
+    const i4 exs = {upi(ex, 0), upi(ex, 1), upi(ex, 2), upi(ex, 3)}, ens = {upi(en, 0), upi(en, 1), upi(en, 2), upi(en, 3)};
+    float* pe = a.P + (size_t)beg * a.ld_p + sc;
+    for (int e = beg; e < end; ++e, pe += a.ld_p) {
+      f4 t;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v = r1s[q];
+        v = v + (exs[q] == e ? gxs[q] : 0.f);
+        v = v + (ens[q] == e ? gns[q] : 0.f);
+        t[q] = v;
+      }
+      *reinterpret_cast<f4*>(pe) = t;
+    }
+    return;
+  }
   for (int e = beg; e < end; ++e) {
     f4 t;
 #pragma unroll
@@ -593,17 +615,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_edge_rows(const EArgs a) {
       v = v + (en[q] == e ? gmn[q] : 0.f);
       t[q] = v;
     }
-    if (whole_rows) {                                        // the window's values moved up to the store column, zeros behind column F
-      f4 o;
-      o.x = sd_ == 0 ? t.x : sd_ == 1 ? t.y : sd_ == 2 ? t.z : sd_ == 3 ? t.w : 0.f;
-      o.y = sd_ == 0 ? t.y : sd_ == 1 ? t.z : sd_ == 2 ? t.w : 0.f;
-      o.z = sd_ == 0 ? t.z : sd_ == 1 ? t.w : 0.f;
-      o.w = sd_ == 0 ? t.w : 0.f;
-      o.x = sc < a.F ? o.x : 0.f; o.y = sc + 1 < a.F ? o.y : 0.f; o.z = sc + 2 < a.F ? o.z : 0.f; o.w = sc + 3 < a.F ? o.w : 0.f;
-      *reinterpret_cast<f4*>(a.P + (size_t)e * a.ld_p + sc) = o;
-    } else {
-      reinterpret_cast<f4u*>(a.P + (size_t)e * a.ld_p + off)->v = t;
-    }
+    reinterpret_cast<f4u*>(a.P + (size_t)e * a.ld_p + off)->v = t;
   }
 }
 
